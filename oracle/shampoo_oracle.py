@@ -1,0 +1,343 @@
+"""CPU oracle for the Shampoo preconditioner-compute hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain NumPy float32 *restatement* of the reference algorithm
+(google-research/precondition, ``precondition/distributed_shampoo.py``, cited
+below as ``DS:<line>``).  It exists so that the HIP kernels can be checked
+against something that follows the reference line by line.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it; the product package (``precondition_amd``) never does and fails loudly if
+its HIP library is missing.
+
+Parity pin: ``tools/gen_golden.py`` runs the reference's own source (imported
+from /root/reference over a NumPy stand-in for jax) on seeded inputs and
+stores inputs+outputs under ``tests/golden/``; at generation time this oracle
+is asserted to agree **bit for bit** with those outputs on the generating
+machine (same NumPy/OpenBLAS op sequence), and ``tests/test_oracle_golden.py``
+re-checks it against the committed vectors to a tight tolerance on any machine
+(OpenBLAS picks different kernels per CPU, so bits may differ elsewhere).
+Third-party arithmetic the reference delegates to jax/XLA (dot, eigh) is
+*unpinned* upstream (pyproject.toml:17-28 lists a bare "jax"); here it is
+NumPy/OpenBLAS/LAPACK float32.
+
+Everything is float32 because ``_MAT_INV_PTH_ROOT_DTYPE = jnp.float64``
+(DS:38) silently degrades to float32 unless jax_enable_x64 is set (DS:35-38),
+which neither the library nor its tests do.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+_EPSILON = 1e-25  # DS:41
+
+
+# ---------------------------------------------------------------------------
+# DS:595-652 power_iteration
+# ---------------------------------------------------------------------------
+def power_iteration(matrix, num_iters=100, error_tolerance=1e-6,
+                    padding_start=None):
+  """Returns (v, s, iters_run).  Follows DS:625-652 statement by statement."""
+  matrix = np.asarray(matrix, dtype=F32)
+  n = matrix.shape[-1]
+  # DS:642-646: fixed seed; note uniform(size=n) is a prefix of uniform(size=m>n).
+  v_0 = np.random.RandomState(1729).uniform(-1.0, 1.0, n).astype(F32)
+  if padding_start is not None:
+    v_0 = v_0 * (np.arange(n, dtype=np.int32) < padding_start).astype(F32)
+  i = 0
+  new_v = v_0
+  s = F32(0.0)
+  run_step = True
+  while i < num_iters and run_step:  # DS:627-629
+    new_v = new_v / np.linalg.norm(new_v)  # DS:634
+    s_v = np.einsum("ij,j->i", matrix, new_v)  # DS:636
+    s_new = np.einsum("i,i->", new_v, s_v)  # DS:637
+    run_step = bool(np.abs(s_new - s) > error_tolerance)  # DS:639
+    i, new_v, s = i + 1, s_v, F32(s_new)
+  v_out = new_v / np.linalg.norm(new_v)  # DS:651
+  return v_out, s, i
+
+
+# ---------------------------------------------------------------------------
+# DS:655-678 mat_power
+# ---------------------------------------------------------------------------
+def mat_power(mat_m, p):
+  """M^p by binary powering with the reference's multiplication order.
+
+  The reference multiplies ``mat @ power`` (DS:671) starting from ``power=I``
+  and squares ``mat`` once more than needed (DS:674); ``X @ I`` is exact in
+  float32 and the trailing square is unused, so both are skipped here without
+  changing a single bit of the result.
+  """
+  mat = np.asarray(mat_m, dtype=F32)
+  power = None
+  i = int(p)
+  while i > 0:
+    if i % 2 == 1:
+      power = mat if power is None else np.matmul(mat, power)
+    i //= 2
+    if i > 0:
+      mat = np.matmul(mat, mat)
+  if power is None:  # p == 0
+    power = np.eye(mat.shape[0], dtype=F32)
+  return power
+
+
+def mat_power_products(p):
+  """Number of n^3 products mat_power *needs* for exponent p."""
+  p = int(p)
+  return int(np.floor(np.log2(p))) + bin(p).count("1") - 1 if p > 0 else 0
+
+
+def newton_products_per_iter(p):
+  """c(p) of SURVEY §8d: mat_power products + M update + H update."""
+  return mat_power_products(p) + 2
+
+
+# ---------------------------------------------------------------------------
+# DS:702-940 matrix_inverse_pth_root (coupled Newton branch)
+# ---------------------------------------------------------------------------
+def matrix_inverse_pth_root(matrix, p, num_iters=100, ridge_epsilon=1e-6,
+                            error_tolerance=1e-6, relative_matrix_epsilon=True,
+                            padding_start=None):
+  """Returns (root float32 [n,n], metrics dict of python floats)."""
+  matrix = np.array(matrix, dtype=F32)  # DS:773
+  n = matrix.shape[0]
+  assert matrix.shape == (n, n)
+  p = int(p)
+  alpha = F32(-1.0 / p)  # DS:774
+  identity = np.eye(n, dtype=F32)  # DS:775
+  if padding_start is not None:  # DS:777-783
+    ix = (np.arange(n, dtype=np.int32) < padding_start).astype(F32)
+    matrix = matrix * ix[np.newaxis, :]
+    matrix = matrix * ix[:, np.newaxis]
+    identity = identity * ix
+  if relative_matrix_epsilon:  # DS:814-828
+    _, max_ev, _ = power_iteration(matrix, 100, 1e-6, padding_start)
+  else:
+    max_ev = F32(1.0)
+  ridge = F32(F32(ridge_epsilon) * np.maximum(F32(max_ev), F32(_EPSILON)))  # DS:830
+  max_error_ratio = F32(1.2)  # DS:834
+  one_minus_alpha = F32(1) - alpha
+
+  # DS:860 init_outer_state = (0, identity, 1000.0, 100, 1.0, True)
+  tries = 0
+  resultant = identity
+  error = F32(1000.0)
+  iters = 100
+  error_ratio = F32(1.0)
+  failed = True
+  with np.errstate(all="ignore"):
+    while failed and tries < 6:  # DS:862-864
+      damped = matrix + (ridge * F32(10**tries)) * identity  # DS:869
+      z = F32(1 + p) / (F32(2) * np.linalg.norm(damped))  # DS:870
+      mat_m = damped * z  # DS:871
+      err = np.max(np.abs(mat_m - identity))  # DS:872
+      mat_h = identity * np.power(z, F32(1.0 / p))  # DS:873
+      old_mat_h = mat_h
+      it = 0
+      ratio = F32(1.0)
+      # DS:836-848
+      while it < num_iters and err > error_tolerance and ratio < max_error_ratio:
+        mat_m_i = one_minus_alpha * identity + alpha * mat_m  # DS:844
+        new_mat_m = np.matmul(mat_power(mat_m_i, p), mat_m)  # DS:845
+        new_mat_h = np.matmul(mat_h, mat_m_i)  # DS:846
+        new_err = np.max(np.abs(new_mat_m - identity))  # DS:847
+        ratio = F32(new_err / err)
+        it, mat_m, old_mat_h, mat_h, err = it + 1, new_mat_m, mat_h, new_mat_h, new_err
+      error = F32(np.max(np.abs(mat_m - identity)))  # DS:878
+      is_converged = F32(1.0) if ratio < max_error_ratio else F32(0.0)  # DS:879
+      resultant = is_converged * mat_h + (F32(1) - is_converged) * old_mat_h  # DS:880
+      tries, iters, error_ratio = tries + 1, it, ratio
+      failed = bool(error > 0.05)  # DS:858,882 (NaN > 0.05 is False)
+  if padding_start is not None and padding_start == 0:  # DS:930-937
+    resultant = np.zeros_like(resultant)
+    error = F32(0.0)
+  metrics = dict(
+      inverse_pth_root_errors=float(error),
+      inverse_pth_root_iters=float(iters),
+      final_error_ratio=float(error_ratio),
+      max_eigen_value=float(max_ev),
+      total_retries=float(tries),
+  )
+  return resultant.astype(F32), metrics
+
+
+# ---------------------------------------------------------------------------
+# DS:943-1030 matrix_inverse_pth_root_eigh
+# ---------------------------------------------------------------------------
+def matrix_inverse_pth_root_eigh(matrix, p, ridge_epsilon=1e-6,
+                                 error_tolerance=1e-6,
+                                 relative_matrix_epsilon=True,
+                                 padding_start=None):
+  matrix = np.array(matrix, dtype=F32)
+  n = matrix.shape[0]
+  alpha = F32(-1.0 / int(p))
+  identity = np.eye(n, dtype=F32)
+  ix = None
+  if padding_start is not None:  # DS:989-994
+    ix = (np.arange(n, dtype=np.int32) < padding_start).astype(F32)
+    matrix = matrix * ix[np.newaxis, :]
+    matrix = matrix * ix[:, np.newaxis]
+    identity = identity * ix
+  if relative_matrix_epsilon:  # DS:995-1001 (note: tolerance = error_tolerance)
+    _, max_ev, _ = power_iteration(matrix, 100, error_tolerance, padding_start)
+  else:
+    max_ev = F32(1.0)
+  ridge = F32(F32(ridge_epsilon) * np.maximum(F32(max_ev), F32(error_tolerance)))  # DS:1005
+  regularized = matrix + ridge * identity  # DS:1006
+  if np.all(np.isfinite(regularized)):
+    e, u = np.linalg.eigh(regularized)  # DS:1007 (LAPACK ssyevd, ascending)
+  else:  # all-padding block: max_ev is 0/0; XLA yields NaNs where LAPACK raises
+    e, u = np.full(n, np.nan, F32), np.full((n, n), np.nan, F32)
+  e = e.astype(F32)
+  u = u.astype(F32)
+  if ix is not None:
+    e = e * ix[::-1]  # DS:1010
+  with np.errstate(all="ignore"):
+    inv_e = np.where(e == 0.0, F32(0.0),
+                     np.power(np.maximum(e, ridge), alpha)).astype(F32)  # DS:1012
+  root = u * np.sqrt(inv_e)  # DS:1015
+  # separate buffers force plain sgemm (NumPy would otherwise pick ssyrk for
+  # X @ X.T, which rounds differently from a general dot)
+  val = np.matmul(root, np.array(root.T))  # DS:1016
+  recovered_e = np.matmul(np.array(u.T),
+                          np.matmul(regularized, u))  # DS:1017
+  eig_error = recovered_e - np.diag(e)  # DS:1018
+  if ix is not None:
+    eig_error = eig_error * ix[::-1]  # DS:1020
+  error = F32(np.max(np.abs(eig_error)))  # DS:1021
+  if padding_start is not None and padding_start == 0:  # DS:1024-1028
+    val = np.zeros_like(val)
+    error = F32(0.0)
+  metrics = dict(
+      inverse_pth_root_errors=float(error),
+      inverse_pth_root_iters=0.0,
+      final_error_ratio=0.0,
+      max_eigen_value=0.0,  # DS:1022: only the error field is populated
+      total_retries=0.0,
+  )
+  return val.astype(F32), metrics
+
+
+# ---------------------------------------------------------------------------
+# DS:1440-1470 gram_weighted_update ; DS:2635-2636 weights
+# ---------------------------------------------------------------------------
+def gram_weighted_update(old_stats, g, axis, w1, w2):
+  g = np.asarray(g, dtype=F32)
+  axes = [i for i in range(g.ndim) if i != axis]
+  # second operand is a separate buffer so NumPy uses sgemm, not ssyrk
+  gram = np.tensordot(g, np.array(g), axes=(axes, axes))  # DS:1469
+  return (F32(w1) * np.asarray(old_stats, F32) + F32(w2) * gram).astype(F32)  # DS:1470
+
+
+def stats_weights(beta2):
+  """DS:2635-2636: w1 = beta2, w2 = 1 if beta2 == 1 else 1 - beta2."""
+  w1 = beta2
+  w2 = beta2 if beta2 == 1.0 else 1.0 - beta2
+  return w1, w2
+
+
+# ---------------------------------------------------------------------------
+# DS:1324-1350 pad_square_matrix ; DS:1827-1846 batch/unbatch ;
+# DS:2816-3010 _pmap_compute_preconditioners (numerical part only)
+# ---------------------------------------------------------------------------
+def pad_square_matrix(mat, max_size):
+  mat = np.asarray(mat)
+  rows, cols = mat.shape
+  if rows != cols:
+    raise ValueError("Must have rows == cols, instead got "
+                     f"rows={rows}, cols={cols}")
+  if cols > max_size:
+    raise ValueError("Must have cols <= max_size. Instead got "
+                     f"cols={cols}, max_size={max_size}.")
+  if rows == max_size:
+    return mat
+  out = np.zeros((max_size, max_size), dtype=mat.dtype)
+  out[:rows, :rows] = mat
+  idx = np.arange(rows, max_size)
+  out[idx, idx] = 1
+  return out
+
+
+def compute_preconditioners_reference_order(statistics, exponents,
+                                            prev_preconditioners, num_devices,
+                                            ridge_epsilon=1e-6,
+                                            relative_matrix_epsilon=True,
+                                            inverse_failure_threshold=0.1,
+                                            eigh=False):
+  """Emulates DS:2816-2950 for ``num_devices`` replicas on one host.
+
+  Every statistic is padded to ``max_size`` (DS:2841-2843), the list is padded
+  with identities / exponent 1 / padding_start 0 to a multiple of
+  ``num_devices`` (DS:2844-2850), replica r computes the contiguous chunk
+  ``[r*b, (r+1)*b)`` (DS:2862-2873, ``batch``), results are concatenated in
+  replica order (``all_gather`` + ``unbatch``, DS:2876-2879), cropped to the
+  original shape and selected against the previous preconditioner on NaN /
+  error >= threshold (DS:2936-2950).
+
+  Returns (new_preconditioners, metrics_list (incl. the padding entries),
+  owner_rank per padded index).
+  """
+  num_statistics = len(statistics)
+  if num_statistics == 0:
+    return [], [], []
+  max_size = max(s.shape[0] for s in statistics)
+  packed = [pad_square_matrix(np.asarray(s, F32), max_size) for s in statistics]
+  to_pad = -num_statistics % num_devices
+  packed += [np.eye(max_size, dtype=F32) for _ in range(to_pad)]
+  exps = list(exponents) + [1] * to_pad
+  paddings = [s.shape[0] for s in statistics] + [0] * to_pad
+  n_total = len(packed)
+  b = n_total // num_devices
+  roots, metrics, owners = [None] * n_total, [None] * n_total, [None] * n_total
+  fn = matrix_inverse_pth_root_eigh if eigh else matrix_inverse_pth_root
+  for r in range(num_devices):
+    for j in range(r * b, (r + 1) * b):
+      roots[j], metrics[j] = fn(
+          packed[j], exps[j], ridge_epsilon=ridge_epsilon,
+          relative_matrix_epsilon=relative_matrix_epsilon,
+          padding_start=paddings[j])
+      owners[j] = r
+  new_p = []
+  for j in range(num_statistics):
+    err = metrics[j]["inverse_pth_root_errors"]
+    n = statistics[j].shape[0]
+    if np.isnan(err) or err >= inverse_failure_threshold:
+      new_p.append(np.asarray(prev_preconditioners[j], F32))
+    else:
+      new_p.append(roots[j][:n, :n])
+  return new_p, metrics, owners
+
+
+# ---------------------------------------------------------------------------
+# CPU-baseline helper for bench.py: the reference's *executed* op sequence.
+# ---------------------------------------------------------------------------
+def newton_root_reference_opcount(matrix, p, ridge_epsilon=1e-6,
+                                  padding_start=None):
+  """Same result as matrix_inverse_pth_root but executes the reference's
+  redundant products too (the ``@ I`` and the unused trailing square of
+  DS:670-674), so that its wall time is the reference's CPU op sequence.
+  Used only as bench.py's ``cpu_baseline`` (kind "port")."""
+  eye_cache = {}
+
+  def ref_mat_power(mat, p):
+    n = mat.shape[0]
+    if n not in eye_cache:
+      eye_cache[n] = np.eye(n, dtype=F32)
+    power = eye_cache[n]
+    i = int(p)
+    while i > 0:
+      if i % 2 == 1:
+        power = np.matmul(mat, power)
+      i //= 2
+      mat = np.matmul(mat, mat)
+    return power
+
+  global mat_power
+  saved = mat_power
+  mat_power = ref_mat_power
+  try:
+    return matrix_inverse_pth_root(matrix, p, ridge_epsilon=ridge_epsilon,
+                                   padding_start=padding_start)
+  finally:
+    mat_power = saved

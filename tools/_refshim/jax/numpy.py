@@ -1,0 +1,159 @@
+"""`jax.numpy` stand-in: NumPy with x64-off dtype semantics (dev-only)."""
+import numpy as _np
+
+from _shimcore import ShimArray, asarray, canon_dtype, wrap, _unwrap
+
+ndarray = ShimArray
+float32 = _np.float32
+float64 = _np.float32  # jax_enable_x64 is off in the reference's tests/library
+float16 = _np.float16
+int32 = _np.int32
+int64 = _np.int32
+int16 = _np.int16
+int8 = _np.int8
+uint8 = _np.uint8
+bool_ = _np.bool_
+newaxis = None
+inf = _np.inf
+pi = _np.pi
+
+
+class _BF16:  # placeholder so `== jnp.bfloat16` comparisons work
+  pass
+
+
+bfloat16 = _BF16
+
+
+def dtype(x):
+  return canon_dtype(x)
+
+
+def array(x, dtype=None):
+  return asarray(x, dtype)
+
+
+def _dt(kw):
+  if "dtype" in kw:
+    kw["dtype"] = canon_dtype(kw["dtype"])
+  return kw
+
+
+def eye(n, m=None, k=0, dtype=float32):
+  return wrap(_np.eye(int(n), None if m is None else int(m), k,
+                      dtype=canon_dtype(dtype)))
+
+
+def zeros(shape, dtype=float32):
+  return wrap(_np.zeros(_unwrap(shape), dtype=canon_dtype(dtype)))
+
+
+def ones(shape, dtype=float32):
+  return wrap(_np.ones(_unwrap(shape), dtype=canon_dtype(dtype)))
+
+
+def zeros_like(x, dtype=None):
+  return wrap(_np.zeros_like(_unwrap(asarray(x)), dtype=canon_dtype(dtype)))
+
+
+def ones_like(x, dtype=None):
+  return wrap(_np.ones_like(_unwrap(asarray(x)), dtype=canon_dtype(dtype)))
+
+
+def arange(*a, **kw):
+  kw = _dt(kw)
+  r = _np.arange(*_unwrap(a), **kw)
+  return wrap(r)
+
+
+def _drop_precision(f):
+
+  def g(*a, precision=None, **kw):
+    del precision
+    return wrap(f(*[_unwrap(asarray(x)) if not isinstance(x, (str, list, tuple))
+                    else _unwrap(x) for x in a], **_unwrap(kw)))
+
+  return g
+
+
+matmul = _drop_precision(_np.matmul)
+dot = _drop_precision(_np.dot)
+
+
+def einsum(spec, *ops, precision=None):
+  del precision
+  return wrap(_np.einsum(spec, *[_unwrap(asarray(o)) for o in ops]))
+
+
+def tensordot(a, b, axes=2, precision=None):
+  del precision
+  return wrap(_np.tensordot(_unwrap(asarray(a)), _unwrap(asarray(b)),
+                            axes=_unwrap(axes)))
+
+
+def _generic(name):
+  f = getattr(_np, name)
+
+  def g(*a, **kw):
+    a = [_unwrap(x) for x in a]
+    kw = _dt({k: _unwrap(v) for k, v in kw.items()})
+    return wrap(f(*a, **kw))
+
+  g.__name__ = name
+  return g
+
+
+for _n in [
+    "where", "stack", "max", "min", "abs", "diag", "sqrt", "maximum", "minimum",
+    "sum", "concatenate", "square", "flip", "reshape", "logical_or",
+    "logical_and", "logical_not", "isnan", "squeeze", "power", "transpose",
+    "roll", "pad", "mean", "any", "all", "trace", "sign", "round", "repeat",
+    "moveaxis", "log", "log1p", "expm1", "exp", "greater", "expand_dims",
+    "cumsum", "argsort", "sort", "isfinite", "clip", "outer", "tril", "triu",
+    "allclose", "full", "diagonal", "less", "equal", "broadcast_to", "floor",
+    "ceil", "prod", "take", "argmax", "argmin", "linspace", "multiply", "add",
+    "subtract", "divide", "negative", "float_power", "cumprod", "nan_to_num",
+]:
+  globals()[_n] = _generic(_n)
+
+
+def split(x, indices_or_sections, axis=0):
+  ios = _unwrap(indices_or_sections)
+  if isinstance(ios, _np.ndarray):
+    ios = [int(v) for v in ios]
+  return [wrap(p) for p in _np.split(_unwrap(asarray(x)), ios, axis=axis)]
+
+
+class _Linalg:
+
+  @staticmethod
+  def norm(x, ord=None, axis=None, keepdims=False):
+    return wrap(_np.linalg.norm(_unwrap(asarray(x)), ord=ord, axis=axis,
+                                keepdims=keepdims))
+
+  @staticmethod
+  def eigh(x):
+    a = _unwrap(asarray(x))
+    if not _np.all(_np.isfinite(a)):  # XLA returns NaNs, LAPACK raises
+      return (wrap(_np.full(a.shape[:-1], _np.nan, a.dtype)),
+              wrap(_np.full(a.shape, _np.nan, a.dtype)))
+    w, v = _np.linalg.eigh(a)
+    return wrap(w), wrap(v)
+
+  @staticmethod
+  def eigvalsh(x):
+    return wrap(_np.linalg.eigvalsh(_unwrap(asarray(x))))
+
+  @staticmethod
+  def svd(x, full_matrices=True, compute_uv=True, hermitian=False):
+    r = _np.linalg.svd(_unwrap(asarray(x)), full_matrices=full_matrices,
+                       compute_uv=compute_uv, hermitian=hermitian)
+    return wrap(tuple(r)) if isinstance(r, tuple) else wrap(r)
+
+  @staticmethod
+  def qr(x, mode="reduced"):
+    r = _np.linalg.qr(_unwrap(asarray(x)), mode=mode)
+    return wrap(tuple(r)) if isinstance(r, tuple) else wrap(r)
+
+
+linalg = _Linalg()

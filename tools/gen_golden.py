@@ -1,0 +1,456 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/* by running the REFERENCE'S OWN SOURCE here.
+
+Dev-container only.  Imports ``precondition.distributed_shampoo`` from
+/root/reference over the NumPy stand-in for jax in tools/_refshim (jax is not
+installed in this image), runs it on seeded inputs and writes inputs + outputs
+as small fixtures.  Nothing of the reference is copied: fixtures are data.
+
+While generating, every numerical case is also run through oracle/ and the
+two are required to agree bit for bit on this machine (same NumPy/OpenBLAS op
+sequence); the flag is stored in each fixture as ``oracle_bitexact_at_gen``.
+
+Usage:  python tools/gen_golden.py            (writes tests/golden/)
+"""
+import json
+import os
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "_refshim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import scipy.stats  # noqa: E402
+
+import jax.numpy as jnp  # noqa: E402  (the shim)
+import precondition.distributed_shampoo as ds  # noqa: E402  (the reference)
+from oracle import shampoo_oracle as orc  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+F32 = np.float32
+
+
+def npy(x):
+  a = np.asarray(x)
+  assert a.dtype != np.float64 and a.dtype != np.int64, a.dtype
+  return np.array(a)
+
+
+def metrics_vec(m):
+  """[error, iters, final_error_ratio, max_ev, total_retries] as float32."""
+  fields = ("inverse_pth_root_errors", "inverse_pth_root_iters",
+            "final_error_ratio", "max_eigen_value", "total_retries")
+  for f in fields:
+    assert np.asarray(getattr(m, f)).dtype == np.float32, f
+  return np.array([float(np.asarray(getattr(m, f))) for f in fields], F32)
+
+
+def metrics_vec_oracle(m):
+  return np.array([m["inverse_pth_root_errors"], m["inverse_pth_root_iters"],
+                   m["final_error_ratio"], m["max_eigen_value"],
+                   m["total_retries"]], F32)
+
+
+# ---------------------------------------------------------------------------
+# input builders (all seeded; also used verbatim by tests via the stored arrays)
+# ---------------------------------------------------------------------------
+def wishart(n, k, seed):
+  g = np.random.default_rng(seed).standard_normal((n, k)).astype(F32)
+  return (g @ g.T).astype(F32)
+
+
+def spectrum_matrix(n, cond, seed, scale=1.0):
+  """Haar Q, eigenvalues cond^{-i/(n-1)} (DST:348-365 style)."""
+  q = scipy.stats.ortho_group.rvs(n, random_state=seed)
+  e = cond ** (-np.arange(n) / (n - 1))
+  a = (q * e) @ q.T * scale
+  a = (a + a.T) / 2
+  return a.astype(F32)
+
+
+def bitexact(a, b):
+  a, b = np.asarray(a), np.asarray(b)
+  return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(
+      a.view(np.uint32) if a.dtype == F32 else a,
+      b.view(np.uint32) if b.dtype == F32 else b)
+
+
+def gen_newton():
+  cases = []
+
+  def add(name, a, p, ridge=1e-6, padding_start=None, rel=True, full=True):
+    cases.append(dict(name=name, a=a, p=p, ridge=ridge,
+                      padding_start=padding_start, rel=rel, full=full))
+
+  add("cfg1_wishart128_p4", wishart(128, 512, 0), 4)
+  for k, cond in enumerate([1e2, 1e3, 1e4, 1e5, 1e6, 1e7]):
+    add(f"dst348_cond1e{k+2}_n16_p4", spectrum_matrix(16, cond, 100 + k), 4,
+        ridge=1e-12)
+  for p in (2, 4, 6, 8):
+    add(f"spec24_cond1e3_p{p}", spectrum_matrix(24, 1e3, 7), p)
+    add(f"wishart64_p{p}", wishart(64, 256, 11 + p), p)
+  add("p3_odd_exponent_n20", spectrum_matrix(20, 50.0, 5), 3)
+  add("p1_identity_exponent_n12", spectrum_matrix(12, 10.0, 6), 1)
+  # DST:367-398 padding cases: sz in {4, 32}, cond 1e3, scaled by 1e-3.
+  for sz in (4, 32):
+    a = spectrum_matrix(sz, 1e3, 200 + sz, scale=1e-3)
+    add(f"dst367_unpadded_n{sz}", a, 4, ridge=1e-3)
+    add(f"dst367_padded_n{sz}", orc.pad_square_matrix(a, 2 * sz), 4,
+        ridge=1e-3, padding_start=sz)
+  add("dst400_all_padding_n10", np.eye(10, dtype=F32), 4, padding_start=0)
+  # rank-1 4x4 (what DST:93-96's [2,2] params produce after merge_small_dims):
+  g = np.array([3., 4., 5., 6.], F32)
+  add("rank1_n4_p2_fails_6_retries",
+      (F32(1e-6) * np.eye(4, dtype=F32) + F32(0.001) * np.outer(g, g)).astype(F32), 2)
+  add("rank_deficient_n48_p4", wishart(48, 12, 3), 4)
+  add("square_wishart_n96_p4", wishart(96, 96, 4), 4)
+  add("absolute_eps_n32_p4", wishart(32, 64, 9), 4, rel=False, ridge=1e-4)
+  add("ragged200_wishart_p2", wishart(200, 800, 21), 2)
+  add("wishart256_p4", wishart(256, 1024, 22), 4)
+  add("padded_197_in_256_p4", orc.pad_square_matrix(wishart(197, 768, 23), 256),
+      4, padding_start=197)
+  add("zeros_n8_p4", np.zeros((8, 8), F32), 4)
+  add("cfg2_sample_wishart512_p4", wishart(512, 2048, 1234), 4, full=True)
+  add("headline_sample_wishart1024_p4", wishart(1024, 4096, 1024), 4, full=False)
+
+  out = {}
+  index = []
+  probe = np.random.default_rng(99).standard_normal((1024, 8)).astype(F32)
+  for c in cases:
+    a = c["a"]
+    kw = dict(ridge_epsilon=c["ridge"], relative_matrix_epsilon=c["rel"],
+              padding_start=c["padding_start"])
+    with np.errstate(all="ignore"):
+      h, m = ds.matrix_inverse_pth_root(jnp.array(a), c["p"], **kw)
+    h = npy(h)
+    assert h.dtype == F32
+    mv = metrics_vec(m)
+    ho, mo = orc.matrix_inverse_pth_root(a, c["p"], **kw)
+    mvo = metrics_vec_oracle(mo)
+    bx = bitexact(h, ho) and np.array_equal(mv, mvo, equal_nan=True)
+    print(f"{c['name']:40s} n={a.shape[0]:5d} p={c['p']} err={mv[0]:.3e} "
+          f"iters={mv[1]:.0f} ratio={mv[2]:.3f} maxev={mv[3]:.5g} "
+          f"tries={mv[4]:.0f} oracle_bitexact={bx}")
+    assert bx, c["name"]
+    nm = c["name"]
+    n = a.shape[0]
+    if c["full"]:
+      out[nm + "__a"] = a
+      out[nm + "__root"] = h
+    else:
+      # large case: input is regenerated from its seed by the test; the output
+      # is pinned by 8 probe products and its Frobenius norm.
+      out[nm + "__root_probe"] = (h @ probe[:n]).astype(F32)
+      out[nm + "__root_fro"] = np.array(np.linalg.norm(h.astype(np.float64)))
+      out[nm + "__root_diag"] = np.diag(h).copy()
+    out[nm + "__metrics"] = mv
+    index.append(dict(name=nm, n=int(n), p=int(c["p"]), ridge=c["ridge"],
+                      rel=bool(c["rel"]),
+                      padding_start=c["padding_start"], full=bool(c["full"]),
+                      oracle_bitexact_at_gen=bool(bx)))
+  out["probe"] = probe
+  np.savez_compressed(os.path.join(OUT, "newton_root.npz"), **out)
+  with open(os.path.join(OUT, "newton_root_index.json"), "w") as f:
+    json.dump(index, f, indent=1)
+
+
+def gen_power_iteration_and_matpower():
+  out = {}
+  idx = []
+  mats = {
+      "wishart128": wishart(128, 512, 0),
+      "spec16_1e4": spectrum_matrix(16, 1e4, 1),
+      "wishart200": wishart(200, 800, 21),
+      "diag_sep_n8": np.diag(np.array([5, 1, .5, .2, .1, .05, .02, .01], F32)),
+  }
+  for nm, a in mats.items():
+    v, s = ds.power_iteration(jnp.array(a))
+    vo, so, it = orc.power_iteration(a)
+    assert bitexact(npy(v), vo) and bitexact(npy(s), np.asarray(so)), nm
+    out[f"pi_{nm}__a"] = a
+    out[f"pi_{nm}__v"] = npy(v)
+    out[f"pi_{nm}__s"] = npy(s)
+    out[f"pi_{nm}__iters"] = np.array(it, np.int32)
+    idx.append(nm)
+    print(f"power_iteration {nm}: s={float(s):.6f} iters={it}")
+  # padded power iteration (prefix property of the seeded v0)
+  a = orc.pad_square_matrix(wishart(40, 160, 2), 64)
+  ix = (np.arange(64) < 40).astype(F32)
+  am = a * ix[None] * ix[:, None]
+  v, s = ds.power_iteration(jnp.array(am), padding_start=40)
+  vo, so, it = orc.power_iteration(am, padding_start=40)
+  assert bitexact(npy(v), vo) and bitexact(npy(s), np.asarray(so))
+  out["pi_padded40in64__a"] = am
+  out["pi_padded40in64__v"] = npy(v)
+  out["pi_padded40in64__s"] = npy(s)
+  out["pi_padded40in64__iters"] = np.array(it, np.int32)
+  for p in (1, 2, 3, 4, 5, 6, 7, 8):
+    m = spectrum_matrix(12, 5.0, 30 + p)
+    r = npy(ds.mat_power(jnp.array(m), p))
+    assert bitexact(r, orc.mat_power(m, p)), p
+    out[f"mp_p{p}__m"] = m
+    out[f"mp_p{p}__r"] = r
+  np.savez_compressed(os.path.join(OUT, "power_iter_matpower.npz"), **out)
+
+
+def gen_eigh():
+  out = {}
+  idx = []
+  cases = [
+      ("wishart64_p2", wishart(64, 256, 13), 2, None),
+      ("spec24_cond1e3_p4", spectrum_matrix(24, 1e3, 7), 4, None),
+      ("wishart128_p2", wishart(128, 512, 0), 2, None),
+      ("padded20in32_p2", orc.pad_square_matrix(wishart(20, 80, 3), 32), 2, 20),
+      ("all_padding_n10", np.eye(10, dtype=F32), 2, 0),
+      ("ragged200_p2", wishart(200, 800, 21), 2, None),
+  ]
+  for nm, a, p, ps in cases:
+    h, m = ds.matrix_inverse_pth_root(jnp.array(a), p, ridge_epsilon=1e-6,
+                                      padding_start=ps, eigh=True)
+    h = npy(h)
+    err = float(np.asarray(m.inverse_pth_root_errors))
+    ho, mo = orc.matrix_inverse_pth_root_eigh(a, p, padding_start=ps)
+    bx = bitexact(h, ho) and np.float32(err) == np.float32(
+        mo["inverse_pth_root_errors"])
+    print(f"eigh {nm}: err={err:.3e} oracle_bitexact={bx}")
+    assert bx, nm
+    out[nm + "__a"] = a
+    out[nm + "__root"] = h
+    out[nm + "__err"] = np.array(err, F32)
+    idx.append(dict(name=nm, p=p, padding_start=ps))
+  np.savez_compressed(os.path.join(OUT, "eigh_root.npz"), **out)
+  with open(os.path.join(OUT, "eigh_root_index.json"), "w") as f:
+    json.dump(idx, f, indent=1)
+
+
+def gen_gram():
+  out = {}
+  rng = np.random.default_rng(5)
+  cases = {
+      "g2d_24x40": rng.standard_normal((24, 40)).astype(F32),
+      "g2d_130x70": rng.standard_normal((130, 70)).astype(F32),
+      "g3d_6x10x8": rng.standard_normal((6, 10, 8)).astype(F32),
+      "g1d_33": rng.standard_normal((33,)).astype(F32),
+  }
+  for nm, g in cases.items():
+    out[nm + "__g"] = g
+    for axis in range(g.ndim):
+      old = wishart(g.shape[axis], 2 * g.shape[axis], 50 + axis)
+      for (w1, w2) in [(0.999, 0.001), (1.0, 1.0), (0.9, 0.1)]:
+        # w2 as the reference derives it (DS:2635-2636): float32 scalar
+        r = npy(ds.gram_weighted_update(jnp.array(old), jnp.array(g), axis,
+                                        w1, jnp.array(w2, jnp.float32)))
+        ro = orc.gram_weighted_update(old, g, axis, w1, w2)
+        assert bitexact(r, ro), (nm, axis, w1)
+        key = f"{nm}__ax{axis}__w{w1}"
+        out[key + "__old"] = old
+        out[key + "__new"] = r
+  np.savez_compressed(os.path.join(OUT, "gram_update.npz"), **out)
+
+
+# ---------------------------------------------------------------------------
+# bookkeeping (bit-exact integer tables)
+# ---------------------------------------------------------------------------
+VIT_B_SHAPES = (
+    [[16, 16, 3, 768], [768], [1, 1, 768], [1, 197, 768]] +
+    [[768], [768], [768, 12, 64], [12, 64], [768, 12, 64], [12, 64],
+     [768, 12, 64], [12, 64], [12, 64, 768], [768], [768], [768],
+     [768, 3072], [3072], [3072, 768], [768]] +
+    [[768], [768], [768, 1000], [1000]])
+
+MISC_SHAPES = [
+    [1, 2, 512, 1, 2048, 1, 3, 4], [1, 2, 768, 1, 2048], [1, 1, 1], [],
+    [2500], [5000, 3], [4097, 8], [2, 2], [2, 5], [6, 3], [1024, 1024],
+    [1025, 1023], [3, 3, 64, 128], [7, 7, 512, 512], [4096, 4096], [4097],
+    [30522, 768], [1], [8, 8, 8, 8, 8], [129, 257, 3],
+]
+
+
+class _P:  # shape-only stand-in for a parameter
+
+  def __init__(self, shape):
+    self.shape = tuple(shape)
+
+
+def gen_bookkeeping():
+  rec = dict(merge_small_dims=[], block_partitioner=[], preconditioner=[],
+             pad_square_matrix=[], batch_unbatch=[])
+  for shape in VIT_B_SHAPES + MISC_SHAPES:
+    for max_dim in (1024, 4096, 128):
+      rec["merge_small_dims"].append(
+          dict(shape=list(shape), max_dim=max_dim,
+               out=[int(x) for x in ds.merge_small_dims(list(shape), max_dim)]))
+  k = 0
+  for shape in [[2500], [5, 7], [130, 70], [256, 300], [6, 10, 8], [33, 2, 65],
+                [64, 64], [1, 197, 96]]:
+    for bs in (32, 64, 128, 1024, 0):
+      x = np.random.default_rng(1000 + k).standard_normal(shape).astype(F32)
+      bp = ds.BlockPartitioner(jnp.array(x), bs)
+      parts = bp.partition(jnp.array(x))
+      merged = npy(bp.merge_partitions(parts))
+      assert np.array_equal(merged, x)
+      rec["block_partitioner"].append(
+          dict(shape=shape, block_size=bs, seed=1000 + k,
+               split_sizes=[[int(v) for v in s] for s in bp.split_sizes()],
+               part_shapes=[list(p.shape) for p in parts],
+               # first/last element + float64 sum as a content fingerprint
+               part_first=[float(np.asarray(p).ravel()[0]) for p in parts],
+               part_last=[float(np.asarray(p).ravel()[-1]) for p in parts],
+               part_sum=[float(np.asarray(p, np.float64).sum()) for p in parts]))
+      k += 1
+
+  for shape in VIT_B_SHAPES + MISC_SHAPES:
+    if len(shape) == 0:
+      continue
+    for bs, msb in ((1024, 4096), (128, 1024)):
+      for best_effort in (True, False):
+        for ptype in (ds.PreconditionerType.ALL, ds.PreconditionerType.INPUT,
+                      ds.PreconditionerType.OUTPUT):
+          for rank in (0, 4):
+            if int(np.prod(shape)) > 5_000_000 or (bs == 128 and
+                                                   int(np.prod(shape)) > 700_000):
+              continue
+            param = jnp.zeros(shape, jnp.float32)
+            pc = ds.Preconditioner(param, bs, msb, best_effort, ptype, rank)
+            rec["preconditioner"].append(
+                dict(shape=list(shape), block_size=bs, merge_block=msb,
+                     best_effort=best_effort, ptype=int(ptype), rank=rank,
+                     transformed=[int(v) for v in pc._transformed_shape],
+                     shapes=[[int(a), int(b)] for a, b in
+                             pc.shapes_for_preconditioners()],
+                     exponent=int(pc.exponent_for_preconditioner()),
+                     should=[bool(v) for v in pc.should_precondition_dims()]))
+  for k, ms in ((3, 5), (5, 5), (1, 4), (4, 7)):
+    m = (np.arange(k * k, dtype=F32).reshape(k, k) + 1)
+    rec["pad_square_matrix"].append(
+        dict(k=k, max_size=ms, out=npy(ds.pad_square_matrix(jnp.array(m), ms)).tolist()))
+  for n, d in ((8, 1), (8, 2), (8, 4), (8, 8), (6, 3), (400, 8)):
+    x = [jnp.array(np.full((2, 2), i, F32)) for i in range(n)]
+    b = ds.batch(x, d)
+    u = ds.unbatch(b)
+    rec["batch_unbatch"].append(
+        dict(n=n, num_devices=d, batched_shape=list(b.shape),
+             owner_of=[int(np.asarray(b)[r, j, 0, 0]) for r in range(d)
+                       for j in range(b.shape[1])],
+             unbatched_order=[int(np.asarray(v).ravel()[0]) for v in u]))
+  with open(os.path.join(OUT, "bookkeeping.json"), "w") as f:
+    json.dump(rec, f)
+  print("bookkeeping:", {k: len(v) for k, v in rec.items()})
+
+
+# ---------------------------------------------------------------------------
+# end-to-end optimizer goldens
+# ---------------------------------------------------------------------------
+def gen_e2e():
+  out = {}
+  index = []
+  rng = np.random.default_rng(1234)
+  init_small = (np.array([[1., 3.], [2., 4.]], F32),
+                np.array([[3., 4.], [3., 4.]], F32))
+  grads_small = (np.array([[3., 4.], [5., 6.]], F32),
+                 np.array([[1., 3.], [2., 1.]], F32))
+
+  def tree(shapes, seed):
+    r = np.random.default_rng(seed)
+    return tuple(r.standard_normal(s).astype(F32) for s in shapes)
+
+  shapes_a = ([40, 24], [24], [6, 10, 8], [70, 33])
+  configs = [
+      ("dst_small_default", init_small, None, dict(block_size=32,
+       preconditioning_compute_steps=2), 8, "same"),
+      ("tree_a_bs32_sgd", tree(shapes_a, 1), None, dict(
+          block_size=32, preconditioning_compute_steps=2,
+          start_preconditioning_step=2), 7, "fresh"),
+      ("tree_a_bs16_rmsprop_beta2", tree(shapes_a, 2), None, dict(
+          block_size=16, beta2=0.9, graft_type=ds.GraftingType.RMSPROP_NORMALIZED,
+          preconditioning_compute_steps=1, start_preconditioning_step=1,
+          weight_decay=0.01, nesterov=False), 5, "fresh"),
+      ("tree_a_bs64_adagrad_stats2", tree(shapes_a, 3), None, dict(
+          block_size=64, graft_type=ds.GraftingType.ADAGRAD,
+          statistics_compute_steps=2, preconditioning_compute_steps=2,
+          start_preconditioning_step=3, moving_average_for_momentum=True,
+          decoupled_weight_decay=True, weight_decay=0.001), 6, "fresh"),
+      ("tree_a_eigh", tree(shapes_a, 4), None, dict(
+          block_size=32, preconditioning_compute_steps=2,
+          start_preconditioning_step=2, eigh=True), 5, "fresh"),
+      # INPUT/OUTPUT types assert on rank-1 (merged) params in the reference
+      # (DS:1621), so this tree keeps every param rank >= 2 after merging.
+      ("tree_b_input_only", tree(([40, 24], [70, 33], [6, 10, 8]), 5), None, dict(
+          block_size=32, preconditioning_compute_steps=1,
+          start_preconditioning_step=1, merge_small_dims_block_size=32,
+          precondtioner_type=ds.PreconditionerType.INPUT,
+          graft_type=ds.GraftingType.SQRT_N, exponent_override=3), 4, "fresh"),
+  ]
+  for name, params, _, kw, steps, gmode in configs:
+    lr = 0.1
+    opt = ds.distributed_shampoo(lr, batch_axis_name=None, **kw)
+    p_j = tuple(jnp.array(p) for p in params)
+    st = opt.init(p_j)
+    grs = []
+    ups = []
+    gr_rng = np.random.default_rng(zlib.crc32(name.encode()))
+    for t in range(steps):
+      if gmode == "same":
+        g = grads_small
+      else:
+        g = tuple((gr_rng.standard_normal(p.shape) * (1 + 0.1 * t)).astype(F32)
+                  for p in params)
+      with np.errstate(all="ignore"):
+        upd, st = opt.update(tuple(jnp.array(x) for x in g), st, p_j)
+      grs.append(g)
+      ups.append(tuple(npy(u) for u in upd))
+      for u in upd:
+        assert np.asarray(u).dtype == F32
+    for i, p in enumerate(params):
+      out[f"{name}__param{i}"] = p
+      for t in range(steps):
+        out[f"{name}__grad{i}_t{t}"] = grs[t][i]
+        out[f"{name}__upd{i}_t{t}"] = ups[t][i]
+      s = st.stats[i]
+      for j, x in enumerate(s.statistics):
+        out[f"{name}__stat{i}_{j}"] = npy(x)
+      for j, x in enumerate(s.preconditioners):
+        out[f"{name}__precond{i}_{j}"] = npy(x)
+      if len(s.statistics):
+        tm = s.training_metrics
+        out[f"{name}__metrics{i}"] = np.stack([
+            npy(tm.inverse_pth_root_errors), npy(tm.inverse_pth_root_iters),
+            npy(tm.final_error_ratio), npy(tm.max_eigen_value),
+            npy(tm.total_retries)], axis=1)
+      out[f"{name}__momentum{i}"] = npy(s.momentum.to_float())
+      out[f"{name}__diag_momentum{i}"] = npy(s.diagonal_momentum.to_float())
+      dsf = s.diagonal_statistics.to_float()
+      if not (isinstance(dsf, list) and not dsf):
+        out[f"{name}__diag_stats{i}"] = npy(dsf)
+    kw_json = {k: (int(v) if isinstance(v, (ds.GraftingType,
+                                            ds.PreconditionerType)) else v)
+               for k, v in kw.items()}
+    index.append(dict(name=name, n_params=len(params), steps=steps, lr=lr,
+                      kwargs=kw_json, count=int(np.asarray(st.count))))
+    print(f"e2e {name}: {steps} steps, last upd[0][:3]="
+          f"{ups[-1][0].ravel()[:3]}")
+  np.savez_compressed(os.path.join(OUT, "e2e.npz"), **out)
+  with open(os.path.join(OUT, "e2e_index.json"), "w") as f:
+    json.dump(index, f, indent=1)
+
+
+if __name__ == "__main__":
+  which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e"]
+  if "newton" in which:
+    gen_newton()
+  if "pi" in which:
+    gen_power_iteration_and_matpower()
+  if "eigh" in which:
+    gen_eigh()
+  if "gram" in which:
+    gen_gram()
+  if "book" in which:
+    gen_bookkeeping()
+  if "e2e" in which:
+    gen_e2e()
+  print("golden fixtures written to", OUT)
