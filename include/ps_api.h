@@ -1,0 +1,180 @@
+/*
+ * ps_api.h — C-ABI of libprecondition_amd.so (MI355X / gfx950).
+ *
+ * The reference (google-research/precondition, precondition/distributed_shampoo.py,
+ * "DS:<line>" below) has no FFI: its preconditioner-compute path is jnp/lax calls
+ * lowered by XLA.  These entry points are what a binding at the reference's three
+ * internal seams would call:
+ *
+ *   (i)   gram_weighted_update(old, g, axis, w1, w2)            DS:1440-1470,
+ *         called from Preconditioner.updated_statistics_from_grad DS:1588
+ *         -> ps_stats_update_f32 / ps_stats_update_grouped_f32
+ *   (ii)  _matrix_inverse_pth_root_vmap(xs, ps, padding_starts)  DS:2742-2744
+ *         = vmap(matrix_inverse_pth_root DS:702-940 | _eigh DS:943-1030)
+ *         -> ps_newton_root_batched_f32 / ps_eigh_root_batched_f32
+ *         (with power_iteration DS:595-652 -> ps_power_iteration_batched_f32 and
+ *          mat_power DS:655-678 -> ps_mat_power_f32 also exposed, since the
+ *          reference's tests call them directly)
+ *   (iii) jax.lax.all_gather DS:2876-2877 -> done by the host with RCCL through
+ *         torch.distributed (plumbing); no entry point here.
+ *
+ * Conventions
+ *   - Plain C, no torch/HIP types in signatures: streams are passed as void*
+ *     (hipStream_t), device memory as raw pointers.  All matrices are float32,
+ *     row-major, leading dimension in elements.
+ *   - Every function returns 0 on success, a negative PS_E* code for an invalid
+ *     argument, or a positive hipError_t passed through.  Nothing throws or aborts.
+ *   - The caller owns every device buffer, including workspace; sizes come from
+ *     the *_workspace_bytes functions.  No hidden device allocation happens inside
+ *     a compute call (a few KB of pinned host memory are allocated once per
+ *     process for convergence flags).
+ *   - Calls are stream-ordered.  ps_newton_root_batched_f32 additionally polls a
+ *     pinned convergence flag (one event wait per Newton iteration, lagging the
+ *     GPU by one iteration) because iteration counts are data dependent
+ *     (DS:836-848, 862-864); all other entry points only enqueue work.
+ *   - Numerical failure is data, not an error (DS:2936-2950): it is reported in
+ *     the metrics table and the function still returns 0.
+ */
+#ifndef PS_API_H_
+#define PS_API_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_VERSION 100 /* 0.1.0 */
+
+enum {
+  PS_OK = 0,
+  PS_EINVAL = -1,     /* bad pointer / size / exponent */
+  PS_EWORKSPACE = -2, /* workspace too small */
+  PS_EUNSUPPORTED = -3,
+  PS_EINTERNAL = -4
+};
+
+/* Columns of the per-block metrics table written by the root functions.
+ * 0..4 are the reference's TrainingMetrics fields (DS:338-351, 902-907). */
+enum {
+  PS_M_ERROR = 0,        /* inverse_pth_root_errors : max|M - I| of the last try */
+  PS_M_ITERS = 1,        /* inverse_pth_root_iters  : inner iterations of the last try */
+  PS_M_ERROR_RATIO = 2,  /* final_error_ratio */
+  PS_M_MAX_EV = 3,       /* max_eigen_value (power iteration) */
+  PS_M_RETRIES = 4,      /* total_retries = number of tries (>=1) */
+  PS_M_TOTAL_ITERS = 5,  /* inner iterations summed over all tries (for FLOP accounting) */
+  PS_M_POWER_ITERS = 6,  /* power-iteration steps executed */
+  PS_M_RESERVED = 7,
+  PS_METRICS_STRIDE = 8
+};
+
+int ps_version(void);
+const char* ps_error_string(int code);
+
+/* v0 of power_iteration: first n values of
+ * numpy.random.RandomState(1729).uniform(-1, 1, n).astype(float32) (DS:642-643),
+ * reproduced with a built-in MT19937 so the library needs no NumPy. Host buffer. */
+int ps_power_iteration_v0(int n, float* out_host);
+
+/* ---- statistics: S <- w1*S + w2*tensordot(g, g, all axes but `axis`) ----------
+ * Replaces gram_weighted_update DS:1468-1470.  The Gram matrix of a gradient
+ * block along one axis is a sum over `nseg` segments of X_s X_s^T, where X_s is
+ * the [d, k] matrix whose element (i, kk) lives at
+ *     layout 0 ("k-contiguous"):  g[s*seg_stride + i*ld + kk]
+ *     layout 1 ("d-contiguous"):  g[s*seg_stride + kk*ld + i]
+ * which covers every axis of a (strided view of a) 2-D or 3-D block without a
+ * copy: for a row-major [m, n] block with leading dimension L, axis 0 is
+ * {layout 0, d=m, k=n, ld=L, nseg=1} and axis 1 is {layout 1, d=n, k=m, ld=L,
+ * nseg=1}; the middle axis of a [b0,b1,b2] view with strides (s0,s1,1) is
+ * {layout 0, d=b1, k=b2, ld=s1, nseg=b0, seg_stride=s0}.
+ * stat_out may alias stat_in (in-place).  desc is a HOST array; all pointers
+ * inside are device pointers.  One launch per layout covers the whole
+ * Python-unrolled loop of DS:1582-1590. */
+typedef struct {
+  const float* g;
+  int32_t layout; /* 0 or 1 */
+  int32_t d;      /* statistic is [d, d] */
+  int32_t k;      /* contraction length per segment */
+  int32_t nseg;   /* >= 1 */
+  int64_t ld;
+  int64_t seg_stride;
+  const float* stat_in;
+  float* stat_out;
+  int64_t lds;    /* leading dimension of stat_in / stat_out */
+} ps_stats_desc;
+
+size_t ps_stats_update_grouped_workspace_bytes(const ps_stats_desc* desc, int count);
+int ps_stats_update_grouped_f32(void* stream, const ps_stats_desc* desc, int count,
+                                float w1, float w2, void* workspace,
+                                size_t workspace_bytes);
+
+/* Convenience form for one row-major [rows, cols] matrix (leading dimension ldg):
+ * axis 0: S is [rows,rows] (+= g g^T);  axis 1: S is [cols,cols] (+= g^T g).
+ * Needs no workspace (the task table is passed by value). */
+int ps_stats_update_f32(void* stream, const float* g, int64_t rows, int64_t cols,
+                        int64_t ldg, int axis, const float* stat_in,
+                        float* stat_out, int64_t lds, float w1, float w2);
+
+/* ---- power iteration (DS:595-652), batched ------------------------------------
+ * a[b]: device pointer to an [n[b], n[b]] matrix (ld = lda[b]); padding_start may
+ * be NULL (no padding) or per-block values (rows/cols >= it are treated as zero).
+ * out_lambda[b] (device) receives s of the last executed step, out_iters[b]
+ * (device, may be NULL) the number of steps executed.  out_v (device, may be
+ * NULL) receives the normalised vector, n_max floats per block.  Host arrays:
+ * a, n, lda, padding_start. */
+size_t ps_power_iteration_workspace_bytes(int batch, const int32_t* n);
+int ps_power_iteration_batched_f32(void* stream, const float* const* a,
+                                   const int32_t* n, const int32_t* lda,
+                                   const int32_t* padding_start, int batch,
+                                   int num_iters, float error_tolerance,
+                                   float* out_lambda, int32_t* out_iters,
+                                   float* out_v, int32_t ldv, void* workspace,
+                                   size_t workspace_bytes);
+
+/* ---- mat_power (DS:655-678): out = m^p, same multiplication order ------------ */
+size_t ps_mat_power_workspace_bytes(int n, int p);
+int ps_mat_power_f32(void* stream, const float* m, int n, int ldm, int p,
+                     float* out, int ldo, void* workspace, size_t workspace_bytes);
+
+/* ---- batched inverse p-th root, coupled Newton (DS:702-940 under vmap) -------
+ * Host arrays of length batch: a (device pointers), n, lda, p, padding_start
+ * (NULL = none), out (device pointers), ldo.  metrics: device, [batch][8] floats.
+ * Semantics per block equal matrix_inverse_pth_root(a, p, num_iters, ridge_epsilon,
+ * error_tolerance, relative_matrix_epsilon, padding_start=...): power iteration
+ * for the relative epsilon, <=6 tries with ridge*10^i, inner loop while
+ * it<num_iters && err>tol && ratio<1.2, previous H returned if the last step
+ * diverged, all-padding blocks forced to 0.  n == 1 returns the closed form
+ * (the reference raises there, DS:850-855/907).
+ * iters_executed_host (may be NULL): total Newton steps the host loop enqueued. */
+size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
+                                      const int32_t* p,
+                                      const int32_t* padding_start);
+int ps_newton_root_batched_f32(void* stream, const float* const* a,
+                               const int32_t* n, const int32_t* lda,
+                               const int32_t* p, const int32_t* padding_start,
+                               int batch, int num_iters, float ridge_epsilon,
+                               float error_tolerance, int relative_matrix_epsilon,
+                               float* const* out, const int32_t* ldo,
+                               float* metrics, void* workspace,
+                               size_t workspace_bytes, int32_t* iters_executed_host);
+
+/* ---- batched inverse p-th root by symmetric eigendecomposition (DS:943-1030) - */
+size_t ps_eigh_root_workspace_bytes(int batch, const int32_t* n);
+int ps_eigh_root_batched_f32(void* stream, const float* const* a, const int32_t* n,
+                             const int32_t* lda, const int32_t* p,
+                             const int32_t* padding_start, int batch,
+                             float ridge_epsilon, float error_tolerance,
+                             int relative_matrix_epsilon, float* const* out,
+                             const int32_t* ldo, float* metrics, void* workspace,
+                             size_t workspace_bytes);
+
+/* ---- plain batched product C = A*B (n^3), exposed for tests / roofline probes - */
+int ps_gemm_nn_f32(void* stream, const float* a, const float* b, float* c, int m,
+                   int n, int k, int lda, int ldb, int ldc, int batch,
+                   int64_t stride_a, int64_t stride_b, int64_t stride_c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PS_API_H_ */

@@ -1,0 +1,111 @@
+"""ctypes binding of libprecondition_amd.so (the C-ABI in include/ps_api.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or
+``make -C precondition_amd/csrc``).  There is no CPU fallback: if the shared
+object is missing, or a compute entry point is called without a GPU, this
+module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprecondition_amd.so")
+
+PS_METRICS_STRIDE = 8
+(PS_M_ERROR, PS_M_ITERS, PS_M_ERROR_RATIO, PS_M_MAX_EV, PS_M_RETRIES,
+ PS_M_TOTAL_ITERS, PS_M_POWER_ITERS, PS_M_RESERVED) = range(8)
+
+
+class PsError(RuntimeError):
+  pass
+
+
+class StatsDesc(C.Structure):
+  """Mirror of ps_stats_desc."""
+  _fields_ = [
+      ("g", C.c_void_p),
+      ("layout", C.c_int32),
+      ("d", C.c_int32),
+      ("k", C.c_int32),
+      ("nseg", C.c_int32),
+      ("ld", C.c_int64),
+      ("seg_stride", C.c_int64),
+      ("stat_in", C.c_void_p),
+      ("stat_out", C.c_void_p),
+      ("lds", C.c_int64),
+  ]
+
+
+# name -> (restype, argtypes); every symbol include/ps_api.h declares.
+_SIGNATURES = {
+    "ps_version": (C.c_int, []),
+    "ps_error_string": (C.c_char_p, [C.c_int]),
+    "ps_power_iteration_v0": (C.c_int, [C.c_int, C.c_void_p]),
+    "ps_stats_update_grouped_workspace_bytes":
+        (C.c_size_t, [C.POINTER(StatsDesc), C.c_int]),
+    "ps_stats_update_grouped_f32":
+        (C.c_int, [C.c_void_p, C.POINTER(StatsDesc), C.c_int, C.c_float,
+                   C.c_float, C.c_void_p, C.c_size_t]),
+    "ps_stats_update_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                   C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                   C.c_float]),
+    "ps_power_iteration_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p]),
+    "ps_power_iteration_batched_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "ps_mat_power_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ps_mat_power_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                   C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "ps_newton_root_workspace_bytes":
+        (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ps_newton_root_batched_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                   C.c_void_p]),
+    "ps_eigh_root_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p]),
+    "ps_eigh_root_batched_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ps_gemm_nn_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                   C.c_int64, C.c_int64, C.c_int64]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+  return sorted(_SIGNATURES)
+
+
+def lib():
+  """Loads the shared library (once). Raises PsError if it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise PsError(
+          f"{LIB_PATH} not found: build it with `python -c 'import "
+          "__graft_entry__ as g; g.build()'` or `make -C precondition_amd/csrc`."
+          " There is no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+      fn = getattr(l, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = l
+  return _lib
+
+
+def check(code, what):
+  if code != 0:
+    msg = lib().ps_error_string(code)
+    raise PsError(f"{what} failed with code {code}: "
+                  f"{msg.decode() if msg else '?'}")

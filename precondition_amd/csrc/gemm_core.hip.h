@@ -1,0 +1,285 @@
+// gemm_core.hip.h — 128x128 output-tile float32 GEMM core for gfx950 (MI355X).
+//
+// One workgroup = 256 threads = 4 wavefronts (64 lanes each) arranged 2x2; each
+// wavefront owns a 64x64 sub-tile as 2x2 accumulators of
+// v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain, 64 cycles/SIMD).
+// Operands are staged global -> registers -> LDS (double buffered, one barrier
+// per K-tile); the global loads for K-tile t+1 are issued before the MFMAs of
+// tile t and written to the other LDS buffer after them.
+//
+// Two LDS images, chosen by how the operand lies in memory so that staging never
+// transposes:
+//   KC ("k-contiguous", element (mn,k) at p[mn*ld + k]):  LDS [128][BK+4];
+//       a lane reads 4 consecutive k with one ds_read_b128 (conflict-free: row
+//       stride 20 or 36 dwords walks all 64 banks in a 16-lane group).
+//   MC ("mn-contiguous", element (mn,k) at p[k*ld + mn]):  LDS [BK][128+4];
+//       a lane reads one dword per k (consecutive lanes, consecutive banks).
+// Inside every 8-deep k-chunk the k order is permuted (lane half h consumes
+// k = 8c+4h+s at MFMA step s) identically for A and B, which only changes the
+// summation order of the exact-f32 chain.
+//
+// Replaces the XLA dot at DS:671,674,845,846 (Newton products) and DS:1469
+// (statistics Gram matrix) of the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE = 128;      // BM = BN
+constexpr int NTHREADS = 256;  // 4 wavefronts
+
+enum Layout { KC = 0, MC = 1 };
+
+// Pointers that come out of descriptor tables in memory are generic ("flat") to
+// the compiler; flat loads count on lgkmcnt as well as vmcnt and so would
+// serialise with the LDS fragment reads.  Everything we touch through such
+// pointers is device global memory: say so.
+#define PS_GLOBAL __attribute__((address_space(1)))
+__device__ inline f32x4 gload4(const float* p) {
+  return *(const f32x4 PS_GLOBAL*)(p);
+}
+__device__ inline float gload1(const float* p) { return *(const float PS_GLOBAL*)(p); }
+__device__ inline void gstore1(float* p, float v) { *(float PS_GLOBAL*)(p) = v; }
+
+template <int BK>
+struct SmemCfg {
+  static constexpr int KC_LD = BK + 4;
+  static constexpr int MC_LD = TILE + 4;
+  static constexpr int KC_SIZE = TILE * KC_LD;
+  static constexpr int MC_SIZE = BK * MC_LD;
+  static constexpr int OP_SIZE = KC_SIZE > MC_SIZE ? KC_SIZE : MC_SIZE;
+  static constexpr int STAGE_SIZE = 2 * OP_SIZE;    // A + B
+  static constexpr int TOTAL = 2 * STAGE_SIZE;      // double buffered (floats)
+};
+
+struct Operand {
+  const float* p;
+  int ld;
+  int mn0;   // first row (A) / column (B) of this tile
+  int MN;    // logical extent along mn (guarded loads only)
+  int K;     // logical extent along k  (guarded loads only)
+  bool vec;  // 16-byte vector loads are legal (base and ld aligned)
+};
+
+// ---- global -> registers ---------------------------------------------------
+template <int LAYOUT, int BK, bool GUARD>
+struct TileLoader {
+  static constexpr int NV = (TILE * BK / 4) / NTHREADS;  // float4 per thread
+  static_assert(NV >= 1, "BK too small");
+
+  __device__ static inline void coords(int v, int tid, int& mn, int& k) {
+    const int f = tid + NTHREADS * v;
+    if (LAYOUT == KC) {
+      mn = f / (BK / 4);
+      k = (f % (BK / 4)) * 4;
+    } else {
+      k = f / (TILE / 4);
+      mn = (f % (TILE / 4)) * 4;
+    }
+  }
+
+  __device__ static inline void load(const Operand& op, int k0, int tid,
+                                     f32x4 (&r)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      int mn, k;
+      coords(v, tid, mn, k);
+      const int gmn = op.mn0 + mn;
+      const int gk = k0 + k;
+      if (LAYOUT == KC) {
+        const float* src = op.p + (int64_t)gmn * op.ld + gk;
+        if (!GUARD) {
+          r[v] = gload4(src);
+        } else {
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          if (gmn < op.MN) {
+            if (op.vec && gk + 3 < op.K) {
+              t = gload4(src);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (gk + e < op.K) t[e] = gload1(src + e);
+            }
+          }
+          r[v] = t;
+        }
+      } else {
+        const float* src = op.p + (int64_t)gk * op.ld + gmn;
+        if (!GUARD) {
+          r[v] = gload4(src);
+        } else {
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          if (gk < op.K) {
+            if (op.vec && gmn + 3 < op.MN) {
+              t = gload4(src);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (gmn + e < op.MN) t[e] = gload1(src + e);
+            }
+          }
+          r[v] = t;
+        }
+      }
+    }
+  }
+
+  // registers -> LDS image
+  __device__ static inline void store(float* s, int tid, const f32x4 (&r)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      int mn, k;
+      coords(v, tid, mn, k);
+      float* dst = (LAYOUT == KC) ? s + mn * SmemCfg<BK>::KC_LD + k
+                                  : s + k * SmemCfg<BK>::MC_LD + mn;
+      *reinterpret_cast<f32x4*>(dst) = r[v];
+    }
+  }
+};
+
+// ---- LDS -> fragments -> MFMA for one K-tile --------------------------------
+template <int LA, int LB, int BK>
+__device__ inline void compute_ktile(const float* sA, const float* sB,
+                                     f32x16 (&acc)[2][2], int wm, int wn,
+                                     int lane) {
+  const int i = lane & 31;
+  const int h = lane >> 5;
+#pragma unroll
+  for (int c = 0; c < BK / 8; ++c) {
+    float a[2][4], b[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (LA == KC) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
+            sA + (wm * 64 + t * 32 + i) * SmemCfg<BK>::KC_LD + 8 * c + 4 * h);
+        a[t][0] = v[0]; a[t][1] = v[1]; a[t][2] = v[2]; a[t][3] = v[3];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          a[t][s] = sA[(8 * c + 4 * h + s) * SmemCfg<BK>::MC_LD + wm * 64 + t * 32 + i];
+      }
+      if (LB == KC) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
+            sB + (wn * 64 + t * 32 + i) * SmemCfg<BK>::KC_LD + 8 * c + 4 * h);
+        b[t][0] = v[0]; b[t][1] = v[1]; b[t][2] = v[2]; b[t][3] = v[3];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          b[t][s] = sB[(8 * c + 4 * h + s) * SmemCfg<BK>::MC_LD + wn * 64 + t * 32 + i];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+    }
+  }
+}
+
+// ---- whole K loop for one 128x128 tile --------------------------------------
+// A supplies rows (mn = m), B supplies columns (mn = n).  Kext is the k range to
+// cover (rounded up to BK internally; unguarded callers must have zero padding
+// there).  smem must hold SmemCfg<BK>::TOTAL floats.  Ends with a barrier, so
+// smem may be reused by the caller's epilogue.
+__device__ inline void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+}
+
+// Accumulating form: acc += A * B over k in [0, Kext).
+template <int LA, int LB, int BK, bool GUARD>
+__device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int Kext,
+                                       float* smem, f32x16 (&acc)[2][2]) {
+  using LdA = TileLoader<LA, BK, GUARD>;
+  using LdB = TileLoader<LB, BK, GUARD>;
+  constexpr int OPS = SmemCfg<BK>::OP_SIZE;
+  constexpr int STG = SmemCfg<BK>::STAGE_SIZE;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wm = wave >> 1;
+  const int wn = wave & 1;
+
+  const int nk = (Kext + BK - 1) / BK;
+  f32x4 ra[LdA::NV], rb[LdB::NV];
+  LdA::load(A, 0, tid, ra);
+  LdB::load(B, 0, tid, rb);
+  LdA::store(smem, tid, ra);
+  LdB::store(smem + OPS, tid, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    float* cur = smem + (kt & 1) * STG;
+    float* nxt = smem + ((kt + 1) & 1) * STG;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      LdA::load(A, (kt + 1) * BK, tid, ra);
+      LdB::load(B, (kt + 1) * BK, tid, rb);
+    }
+    compute_ktile<LA, LB, BK>(cur, cur + OPS, acc, wm, wn, lane);
+    if (more) {
+      LdA::store(nxt, tid, ra);
+      LdB::store(nxt + OPS, tid, rb);
+    }
+    __syncthreads();
+  }
+}
+
+template <int LA, int LB, int BK, bool GUARD>
+__device__ inline void gemm_tile(const Operand& A, const Operand& B, int Kext,
+                                 float* smem, f32x16 (&acc)[2][2]) {
+  zero_acc(acc);
+  gemm_tile_accum<LA, LB, BK, GUARD>(A, B, Kext, smem, acc);
+}
+
+// Accumulator element -> (row, col) inside the 128x128 tile (C/D layout of the
+// 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+__device__ inline int acc_row(int wm, int tm, int r, int lane) {
+  return wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+__device__ inline int acc_col(int wn, int tn, int lane) {
+  return wn * 64 + tn * 32 + (lane & 31);
+}
+
+// Bijective XCD-aware remap: consecutive logical tiles share an XCD (workgroups
+// are dealt round-robin over the 8 XCDs), so the tiles of one matrix block reuse
+// its operand panels out of one L2.  Speed only; any placement is correct.
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+// NaN-propagating max of |x| on bit patterns (jnp.max returns NaN if any NaN).
+__device__ inline unsigned abs_bits(float x) {
+  return __float_as_uint(x) & 0x7fffffffu;
+}
+
+__device__ inline unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__device__ inline float wave_sum_f32(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace psk

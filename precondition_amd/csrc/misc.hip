@@ -1,0 +1,165 @@
+// misc.hip — version/error strings, the seeded v0 of power_iteration, a plain
+// batched product and mat_power (reference: DS:642-643, DS:655-678).
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "gemm_core.hip.h"
+
+using namespace psk;
+
+extern "C" int ps_version(void) { return PS_VERSION; }
+
+extern "C" const char* ps_error_string(int code) {
+  switch (code) {
+    case PS_OK: return "ok";
+    case PS_EINVAL: return "invalid argument";
+    case PS_EWORKSPACE: return "workspace too small";
+    case PS_EUNSUPPORTED: return "unsupported size or exponent";
+    case PS_EINTERNAL: return "internal error";
+    default:
+      return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+// numpy.random.RandomState(1729).uniform(-1.0, 1.0, n).astype(float32):
+// MT19937 seeded with init_genrand(1729); each double is built from two 32-bit
+// draws, (a>>5, b>>6) -> (a*2^26 + b) / 2^53; uniform = low + (high-low)*u.
+extern "C" int ps_power_iteration_v0(int n, float* out) {
+  if (n < 0 || (n > 0 && !out)) return PS_EINVAL;
+  uint32_t mt[624];
+  mt[0] = 1729u;
+  for (int i = 1; i < 624; ++i)
+    mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  int pos = 624;
+  auto next = [&]() -> uint32_t {
+    if (pos >= 624) {
+      for (int k = 0; k < 624; ++k) {
+        uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+        mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      pos = 0;
+    }
+    uint32_t y = mt[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  };
+  for (int i = 0; i < n; ++i) {
+    const uint32_t a = next() >> 5, b = next() >> 6;
+    const double u = (a * 67108864.0 + b) / 9007199254740992.0;
+    out[i] = (float)(-1.0 + 2.0 * u);
+  }
+  return PS_OK;
+}
+
+namespace psk {
+
+constexpr int GBK = 16;
+
+// C[b] = A[b] * B[b], row-major, any sizes / alignment (guarded loads).
+__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(
+    const float* a, const float* b, float* c, int M, int N, int K, int lda, int ldb,
+    int ldc, int64_t sa, int64_t sb, int64_t sc, int tiles_m, int tiles_n, int veca,
+    int vecb) {
+  __shared__ __align__(16) float smem[SmemCfg<GBK>::TOTAL];
+  const int per = tiles_m * tiles_n;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int bi = t / per, tm = (t % per) / tiles_n, tn = t % tiles_n;
+  Operand A{a + bi * sa, lda, tm * TILE, M, K, veca != 0};
+  Operand B{b + bi * sb, ldb, tn * TILE, N, K, vecb != 0};
+  f32x16 acc[2][2];
+  gemm_tile<KC, MC, GBK, true>(A, B, K, smem, acc);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* C = c + bi * sc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tm * TILE + acc_row(wm, i, r, lane);
+        const int col = tn * TILE + acc_col(wn, j, lane);
+        if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[i][j][r];
+      }
+}
+
+}  // namespace psk
+
+static bool vec_ok(const float* p, int ld, int64_t stride) {
+  return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0) && (stride % 4 == 0);
+}
+
+extern "C" int ps_gemm_nn_f32(void* stream, const float* a, const float* b, float* c,
+                              int m, int n, int k, int lda, int ldb, int ldc, int batch,
+                              int64_t stride_a, int64_t stride_b, int64_t stride_c) {
+  if (!a || !b || !c || m < 1 || n < 1 || k < 1 || batch < 1 || lda < k || ldb < n ||
+      ldc < n)
+    return PS_EINVAL;
+  const int tm = (m + TILE - 1) / TILE, tn = (n + TILE - 1) / TILE;
+  const int64_t grid = (int64_t)tm * tn * batch;
+  if (grid > 0x7fffffff) return PS_EUNSUPPORTED;
+  hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, a, b, c, m, n, k, lda, ldb, ldc, stride_a,
+                     stride_b, stride_c, tm, tn, vec_ok(a, lda, stride_a) ? 1 : 0,
+                     vec_ok(b, ldb, stride_b) ? 1 : 0);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// mat_power: the reference's loop (DS:663-677) with the exact "@ I" skipped.
+extern "C" size_t ps_mat_power_workspace_bytes(int n, int p) {
+  if (n < 1 || p < 0) return 0;
+  int bits = 0;
+  for (int i = p; i > 0; i >>= 1) ++bits;
+  return (size_t)(2 * bits + 2) * n * n * sizeof(float) + 1024;
+}
+
+extern "C" int ps_mat_power_f32(void* stream, const float* m, int n, int ldm, int p,
+                                float* out, int ldo, void* workspace,
+                                size_t workspace_bytes) {
+  if (!m || !out || n < 1 || p < 0 || ldm < n || ldo < n) return PS_EINVAL;
+  if (workspace_bytes < ps_mat_power_workspace_bytes(n, p) || !workspace)
+    return PS_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  psh::Arena ar(workspace, workspace_bytes);
+  const size_t sq = (size_t)n * n;
+  const float* mat = m;
+  int ldmat = ldm;
+  const float* power = nullptr;
+  int ldpow = n;
+  int i = p;
+  while (i > 0) {
+    if (i & 1) {
+      if (!power) { power = mat; ldpow = ldmat; }
+      else {
+        float* t = ar.take<float>(sq);
+        int rc = ps_gemm_nn_f32(stream, mat, power, t, n, n, n, ldmat, ldpow, n, 1, 0, 0, 0);
+        if (rc) return rc;
+        power = t; ldpow = n;
+      }
+    }
+    i >>= 1;
+    if (i > 0) {
+      float* t = ar.take<float>(sq);
+      int rc = ps_gemm_nn_f32(stream, mat, mat, t, n, n, n, ldmat, ldmat, n, 1, 0, 0, 0);
+      if (rc) return rc;
+      mat = t; ldmat = n;
+    }
+  }
+  if (!power) {  // p == 0: identity
+    std::vector<float> eye(sq, 0.f);
+    for (int r = 0; r < n; ++r) eye[(size_t)r * n + r] = 1.f;
+    PS_HIP(hipMemcpy2DAsync(out, (size_t)ldo * 4, eye.data(), (size_t)n * 4, (size_t)n * 4,
+                            n, hipMemcpyHostToDevice, st));
+    PS_HIP(hipStreamSynchronize(st));
+    return PS_OK;
+  }
+  PS_HIP(hipMemcpy2DAsync(out, (size_t)ldo * 4, power, (size_t)ldpow * 4, (size_t)n * 4, n,
+                          hipMemcpyDeviceToDevice, st));
+  return PS_OK;
+}

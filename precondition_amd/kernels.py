@@ -1,0 +1,300 @@
+"""Torch-tensor front end of the C-ABI (include/ps_api.h).
+
+Torch is plumbing here: it owns device memory and the current HIP stream; all
+arithmetic happens in libprecondition_amd.so.  Function names and argument
+meaning follow the reference's public helpers
+(precondition/distributed_shampoo.py: power_iteration DS:595, mat_power DS:655,
+matrix_inverse_pth_root DS:702, gram_weighted_update DS:1440).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import StatsDesc, check, lib
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+  if not t.is_cuda:
+    raise _lib.PsError(
+        f"{what}: expected a tensor on an MI355X device, got {t.device}; "
+        "precondition_amd has no CPU path.")
+  if t.dtype != torch.float32:
+    raise TypeError(f"{what}: expected float32, got {t.dtype}")
+
+
+def _stream() -> int:
+  return torch.cuda.current_stream().cuda_stream
+
+
+def _i32(xs) -> np.ndarray:
+  return np.ascontiguousarray(np.asarray(xs, dtype=np.int32))
+
+
+def _ptrs(ts: Sequence[torch.Tensor]) -> np.ndarray:
+  return np.ascontiguousarray(
+      np.asarray([t.data_ptr() for t in ts], dtype=np.uint64))
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+  return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _as_2d_ld(t: torch.Tensor) -> int:
+  """Leading dimension of a row-major 2-D view (last stride must be 1)."""
+  assert t.dim() == 2
+  if t.shape[1] > 1 and t.stride(1) != 1:
+    raise ValueError("matrix rows must be contiguous")
+  return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
+
+
+# ---------------------------------------------------------------------------
+# inverse p-th root
+# ---------------------------------------------------------------------------
+def matrix_inverse_pth_root_batched(
+    matrices: Sequence[torch.Tensor],
+    ps: Sequence[int],
+    padding_starts: Optional[Sequence[int]] = None,
+    num_iters: int = 100,
+    ridge_epsilon: float = 1e-6,
+    error_tolerance: float = 1e-6,
+    relative_matrix_epsilon: bool = True,
+    eigh: bool = False,
+    out: Optional[Sequence[torch.Tensor]] = None,
+) -> Tuple[List[torch.Tensor], torch.Tensor]:
+  """vmap(matrix_inverse_pth_root) over independent blocks (DS:2742-2744).
+
+  Returns (roots, metrics[batch, 8]); metrics columns are the PS_M_* indices
+  (0..4 = TrainingMetrics fields of DS:902-907).  Blocks may differ in size.
+  """
+  batch = len(matrices)
+  if batch == 0:
+    return [], torch.empty((0, _lib.PS_METRICS_STRIDE), dtype=torch.float32)
+  dev = matrices[0].device
+  for m in matrices:
+    _require_gpu(m, "matrix_inverse_pth_root")
+    if m.dim() != 2 or m.shape[0] != m.shape[1]:
+      raise ValueError(f"expected square matrices, got {tuple(m.shape)}")
+  n = _i32([m.shape[0] for m in matrices])
+  lda = _i32([_as_2d_ld(m) for m in matrices])
+  p = _i32(list(ps))
+  pad = None if padding_starts is None else _i32(list(padding_starts))
+  if out is None:
+    out = [torch.empty((int(k), int(k)), dtype=torch.float32, device=dev)
+           for k in n]
+  ldo = _i32([_as_2d_ld(o) for o in out])
+  a_ptrs, o_ptrs = _ptrs(matrices), _ptrs(out)
+  metrics = torch.empty((batch, _lib.PS_METRICS_STRIDE), dtype=torch.float32,
+                        device=dev)
+  L = lib()
+  pad_ptr = None if pad is None else pad.ctypes.data
+  if eigh:
+    nbytes = L.ps_eigh_root_workspace_bytes(batch, n.ctypes.data)
+    ws = _workspace(nbytes, dev)
+    rc = L.ps_eigh_root_batched_f32(
+        _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
+        p.ctypes.data, pad_ptr, batch, ridge_epsilon, error_tolerance,
+        int(relative_matrix_epsilon), o_ptrs.ctypes.data, ldo.ctypes.data,
+        metrics.data_ptr(), ws.data_ptr(), ws.numel())
+    check(rc, "ps_eigh_root_batched_f32")
+  else:
+    nbytes = L.ps_newton_root_workspace_bytes(batch, n.ctypes.data,
+                                              p.ctypes.data, pad_ptr)
+    if nbytes == 0:
+      raise _lib.PsError("ps_newton_root_workspace_bytes: unsupported exponent")
+    ws = _workspace(nbytes, dev)
+    iters = C.c_int32(0)
+    rc = L.ps_newton_root_batched_f32(
+        _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
+        p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
+        error_tolerance, int(relative_matrix_epsilon), o_ptrs.ctypes.data,
+        ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
+        C.addressof(iters))
+    check(rc, "ps_newton_root_batched_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  return list(out), metrics
+
+
+def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
+                    error_tolerance: float = 1e-6,
+                    padding_start: Optional[int] = None):
+  """DS:595-652.  Returns (eigenvector, eigenvalue) as device tensors."""
+  _require_gpu(matrix, "power_iteration")
+  n = int(matrix.shape[-1])
+  dev = matrix.device
+  na, lda = _i32([n]), _i32([_as_2d_ld(matrix)])
+  pad = None if padding_start is None else _i32([padding_start])
+  lam = torch.empty(1, dtype=torch.float32, device=dev)
+  its = torch.empty(1, dtype=torch.int32, device=dev)
+  v = torch.zeros((1, n), dtype=torch.float32, device=dev)
+  L = lib()
+  ws = _workspace(L.ps_power_iteration_workspace_bytes(1, na.ctypes.data), dev)
+  a_ptrs = _ptrs([matrix])
+  rc = L.ps_power_iteration_batched_f32(
+      _stream(), a_ptrs.ctypes.data, na.ctypes.data, lda.ctypes.data,
+      None if pad is None else pad.ctypes.data, 1, num_iters, error_tolerance,
+      lam.data_ptr(), its.data_ptr(), v.data_ptr(), n, ws.data_ptr(), ws.numel())
+  check(rc, "ps_power_iteration_batched_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  return v[0], lam[0]
+
+
+def power_iteration_batched(matrices: Sequence[torch.Tensor], num_iters=100,
+                            error_tolerance=1e-6, padding_starts=None):
+  """Returns (lambda[batch], iters[batch])."""
+  batch = len(matrices)
+  dev = matrices[0].device
+  for m in matrices:
+    _require_gpu(m, "power_iteration")
+  n = _i32([m.shape[0] for m in matrices])
+  lda = _i32([_as_2d_ld(m) for m in matrices])
+  pad = None if padding_starts is None else _i32(list(padding_starts))
+  lam = torch.empty(batch, dtype=torch.float32, device=dev)
+  its = torch.empty(batch, dtype=torch.int32, device=dev)
+  L = lib()
+  ws = _workspace(L.ps_power_iteration_workspace_bytes(batch, n.ctypes.data), dev)
+  a_ptrs = _ptrs(matrices)
+  rc = L.ps_power_iteration_batched_f32(
+      _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
+      None if pad is None else pad.ctypes.data, batch, num_iters,
+      error_tolerance, lam.data_ptr(), its.data_ptr(), None, 0, ws.data_ptr(),
+      ws.numel())
+  check(rc, "ps_power_iteration_batched_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  return lam, its
+
+
+def mat_power(mat_m: torch.Tensor, p: int) -> torch.Tensor:
+  """DS:655-678: M^p with the reference's multiplication order."""
+  _require_gpu(mat_m, "mat_power")
+  n = int(mat_m.shape[0])
+  out = torch.empty((n, n), dtype=torch.float32, device=mat_m.device)
+  L = lib()
+  ws = _workspace(L.ps_mat_power_workspace_bytes(n, int(p)), mat_m.device)
+  rc = L.ps_mat_power_f32(_stream(), mat_m.data_ptr(), n, _as_2d_ld(mat_m),
+                          int(p), out.data_ptr(), n, ws.data_ptr(), ws.numel())
+  check(rc, "ps_mat_power_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  return out
+
+
+def matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+  """Plain float32 product on the MFMA core ([m,k] @ [k,n] or batched 3-D)."""
+  _require_gpu(a, "matmul")
+  _require_gpu(b, "matmul")
+  if a.dim() == 2:
+    a3, b3 = a.unsqueeze(0), b.unsqueeze(0)
+  else:
+    a3, b3 = a, b
+  a3, b3 = a3.contiguous(), b3.contiguous()
+  bt, m, k = a3.shape
+  n = b3.shape[2]
+  c = torch.empty((bt, m, n), dtype=torch.float32, device=a.device)
+  rc = lib().ps_gemm_nn_f32(_stream(), a3.data_ptr(), b3.data_ptr(),
+                            c.data_ptr(), m, n, k, k, n, n, bt, m * k, k * n,
+                            m * n)
+  check(rc, "ps_gemm_nn_f32")
+  return c[0] if a.dim() == 2 else c
+
+
+# ---------------------------------------------------------------------------
+# statistics
+# ---------------------------------------------------------------------------
+def gram_desc(g: torch.Tensor, axis: int, stat_in: torch.Tensor,
+              stat_out: torch.Tensor):
+  """Builds the ps_stats_desc for tensordot(g, g, all axes but `axis`).
+
+  Returns (desc, keepalive).  2-D and 3-D (strided) blocks are addressed in
+  place; higher ranks or exotic strides are made contiguous first and viewed
+  as [outer, d, inner].
+  """
+  keep = [g, stat_in, stat_out]
+  nd = g.dim()
+  if nd == 0:
+    raise ValueError("scalar gradients have no Gram matrix")
+
+  def contiguous_3d(t):
+    t = t.contiguous()
+    keep.append(t)
+    outer = int(np.prod(t.shape[:axis], dtype=np.int64)) if axis > 0 else 1
+    inner = int(np.prod(t.shape[axis + 1:], dtype=np.int64)) if axis < nd - 1 else 1
+    return t, outer, int(t.shape[axis]), inner
+
+  d = StatsDesc()
+  ok_inplace = nd <= 3 and (g.stride(nd - 1) == 1 or g.shape[nd - 1] == 1)
+  if nd == 1:
+    # [d]: Gram is the outer product; layout 1 with k = 1.
+    gg = g.contiguous()
+    keep.append(gg)
+    d.g, d.layout, d.d, d.k, d.nseg, d.ld, d.seg_stride = (
+        gg.data_ptr(), 1, int(gg.shape[0]), 1, 1, int(gg.shape[0]), 0)
+  elif nd == 2 and ok_inplace:
+    m, n = int(g.shape[0]), int(g.shape[1])
+    ld = _as_2d_ld(g)
+    if axis == 0:
+      d.g, d.layout, d.d, d.k, d.nseg, d.ld, d.seg_stride = (
+          g.data_ptr(), 0, m, n, 1, ld, 0)
+    else:
+      d.g, d.layout, d.d, d.k, d.nseg, d.ld, d.seg_stride = (
+          g.data_ptr(), 1, n, m, 1, ld, 0)
+  elif nd == 3 and ok_inplace and g.stride(2) == 1:
+    b0, b1, b2 = (int(x) for x in g.shape)
+    s0, s1 = int(g.stride(0)), int(g.stride(1))
+    if axis == 0:    # k = (j, c): segments over j
+      d.g, d.layout, d.d, d.k, d.nseg, d.ld, d.seg_stride = (
+          g.data_ptr(), 0, b0, b2, b1, s0, s1)
+    elif axis == 1:  # k = (a, c): segments over a
+      d.g, d.layout, d.d, d.k, d.nseg, d.ld, d.seg_stride = (
+          g.data_ptr(), 0, b1, b2, b0, s1, s0)
+    else:            # k = (a, j): segments over a, rows j
+      d.g, d.layout, d.d, d.k, d.nseg, d.ld, d.seg_stride = (
+          g.data_ptr(), 1, b2, b1, b0, s1, s0)
+  else:
+    t, outer, dd, inner = contiguous_3d(g)
+    if inner == 1:
+      d.g, d.layout, d.d, d.k, d.nseg, d.ld, d.seg_stride = (
+          t.data_ptr(), 1, dd, outer, 1, dd, 0)
+    else:
+      d.g, d.layout, d.d, d.k, d.nseg, d.ld, d.seg_stride = (
+          t.data_ptr(), 0, dd, inner, outer, inner, dd * inner)
+  d.stat_in, d.stat_out = stat_in.data_ptr(), stat_out.data_ptr()
+  d.lds = _as_2d_ld(stat_out)
+  assert _as_2d_ld(stat_in) == d.lds or stat_in.shape[0] == 1
+  return d, keep
+
+
+def stats_update_grouped(items, w1: float, w2: float):
+  """items: list of (g_block, axis, stat_in, stat_out). One launch per layout."""
+  if not items:
+    return
+  dev = items[0][0].device
+  descs = (StatsDesc * len(items))()
+  keep = []
+  for i, (g, axis, sin, sout) in enumerate(items):
+    _require_gpu(g, "gram_weighted_update")
+    _require_gpu(sin, "gram_weighted_update")
+    d, k = gram_desc(g, axis, sin, sout)
+    descs[i] = d
+    keep.append(k)
+  L = lib()
+  ws = _workspace(L.ps_stats_update_grouped_workspace_bytes(descs, len(items)), dev)
+  rc = L.ps_stats_update_grouped_f32(_stream(), descs, len(items), float(w1),
+                                     float(w2), ws.data_ptr(), ws.numel())
+  check(rc, "ps_stats_update_grouped_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  del keep
+
+
+def gram_weighted_update(old_stats: torch.Tensor, g: torch.Tensor, axis: int,
+                         w1: float, w2: float, precision=None) -> torch.Tensor:
+  """DS:1440-1470: w1 * old_stats + w2 * tensordot(g, g, axes != axis)."""
+  del precision  # always full float32 (exact-f32 MFMA)
+  _require_gpu(g, "gram_weighted_update")
+  old = old_stats.contiguous()
+  out = torch.empty_like(old)
+  stats_update_grouped([(g, axis, old, out)], w1, w2)
+  return out
