@@ -169,6 +169,18 @@ int ps_eigh_root_batched_f32(void* stream, const float* const* a, const int32_t*
                              const int32_t* ldo, float* metrics, void* workspace,
                              size_t workspace_bytes);
 
+/* ---- optional per-kernel timing of the Newton driver (bench/roofline only) ----
+ * When enabled, ps_newton_root_batched_f32 brackets every product-stage launch
+ * with a pair of HIP events on the caller's stream and, before returning,
+ * accumulates their elapsed times (this makes the call synchronous).
+ * ps_profile_get: total milliseconds and launch count of newton_stage_kernel,
+ * milliseconds of the power-iteration launches, and of everything else the
+ * call enqueued (init/control/copy-out), since the last ps_profile_reset. */
+int ps_profile_enable(int on);
+int ps_profile_reset(void);
+int ps_profile_get(double* stage_ms, int64_t* stage_launches, double* power_iter_ms,
+                   double* other_ms);
+
 /* ---- plain batched product C = A*B (n^3), exposed for tests / roofline probes - */
 int ps_gemm_nn_f32(void* stream, const float* a, const float* b, float* c, int m,
                    int n, int k, int lda, int ldb, int ldc, int batch,

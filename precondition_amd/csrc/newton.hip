@@ -507,6 +507,48 @@ size_t carve(const Plan& pl, Arena& ar, WsLayout* lo) {
   return ar.off;
 }
 
+struct Profile {
+  bool on = false;
+  double stage_ms = 0, pi_ms = 0, other_ms = 0;
+  int64_t stage_launches = 0;
+};
+Profile g_prof;
+
+// Event pairs recorded on the caller's stream; resolved after the call.
+struct ProfRun {
+  struct Span { hipEvent_t a, b; int kind; };  // kind 0 stage, 1 power iter, 2 other
+  std::vector<Span> spans;
+  bool active;
+  hipStream_t st;
+  explicit ProfRun(hipStream_t s) : active(g_prof.on), st(s) {}
+  void begin(int kind) {
+    if (!active) return;
+    Span sp; sp.kind = kind;
+    if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) { active = false; return; }
+    (void)hipEventRecord(sp.a, st);
+    spans.push_back(sp);
+  }
+  void end() {
+    if (!active || spans.empty()) return;
+    (void)hipEventRecord(spans.back().b, st);
+  }
+  void finish() {
+    if (spans.empty()) return;
+    (void)hipStreamSynchronize(st);
+    for (auto& sp : spans) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+        if (sp.kind == 0) { g_prof.stage_ms += ms; g_prof.stage_launches += 1; }
+        else if (sp.kind == 1) g_prof.pi_ms += ms;
+        else g_prof.other_ms += ms;
+      }
+      (void)hipEventDestroy(sp.a);
+      (void)hipEventDestroy(sp.b);
+    }
+    spans.clear();
+  }
+};
+
 HostStatus* pinned_status() {
   static HostStatus* st = nullptr;
   if (!st) {
@@ -637,7 +679,9 @@ extern "C" int ps_newton_root_batched_f32(
   // staged synchronously by the runtime, but do not rely on it).
   PS_HIP(hipStreamSynchronize(st));
 
+  ProfRun prof(st);
   // ---- power iteration -> ridge epsilon --------------------------------------
+  prof.begin(1);
   if (relative_matrix_epsilon) {
     hipLaunchKernelGGL(fill_v0_kernel, dim3(batch), dim3(256), 0, st, lo.pis, lo.v0,
                        batch);
@@ -646,6 +690,7 @@ extern "C" int ps_newton_root_batched_f32(
     hipLaunchKernelGGL(pi_final_kernel, dim3(batch), dim3(256), 0, st, lo.pis, 100,
                        (float*)nullptr, (int*)nullptr, (float*)nullptr, 0);
   }
+  prof.end();
   hipLaunchKernelGGL(newton_setup_kernel, dim3((batch + 255) / 256), dim3(256), 0, st,
                      lo.blocks, lo.pis, batch, ridge_epsilon, relative_matrix_epsilon);
   PS_LAUNCH_CHECK();
@@ -664,17 +709,21 @@ extern "C" int ps_newton_root_batched_f32(
       HostStatus* slot = &status[g % 64];
       slot->gen = -1;
       if (need_init) {
+        prof.begin(2);
         hipLaunchKernelGGL(newton_init1_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
                            lo.init_tiles);
         hipLaunchKernelGGL(newton_init2_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
                            lo.init_tiles);
         hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.blocks,
                            batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr);
+        prof.end();
       }
       for (int s = 0; s < pl.nstages; ++s) {
         const int nt = (int)pl.stage_tiles[s].size();
+        prof.begin(0);
         hipLaunchKernelGGL(newton_stage_kernel, dim3(nt), dim3(256), 0, st, lo.blocks,
                            lo.tasks[s], lo.tiles[s], nt);
+        prof.end();
       }
       hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.blocks,
                          batch, 1, num_iters, error_tolerance, g, slot);
@@ -695,10 +744,27 @@ extern "C" int ps_newton_root_batched_f32(
     (void)hipEventDestroy(ev[1]);
     if (rc) return rc;
   }
+  prof.begin(2);
   hipLaunchKernelGGL(newton_final_kernel, dim3(batch, 32), dim3(256), 0, st, lo.blocks,
                      metrics);
+  prof.end();
   PS_LAUNCH_CHECK();
+  prof.finish();
   if (iters_executed_host) *iters_executed_host = executed;
+  return PS_OK;
+}
+
+extern "C" int ps_profile_enable(int on) { g_prof.on = on != 0; return PS_OK; }
+extern "C" int ps_profile_reset(void) {
+  g_prof.stage_ms = g_prof.pi_ms = g_prof.other_ms = 0; g_prof.stage_launches = 0;
+  return PS_OK;
+}
+extern "C" int ps_profile_get(double* stage_ms, int64_t* stage_launches,
+                              double* power_iter_ms, double* other_ms) {
+  if (stage_ms) *stage_ms = g_prof.stage_ms;
+  if (stage_launches) *stage_launches = g_prof.stage_launches;
+  if (power_iter_ms) *power_iter_ms = g_prof.pi_ms;
+  if (other_ms) *other_ms = g_prof.other_ms;
   return PS_OK;
 }
 
