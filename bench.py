@@ -75,7 +75,7 @@ class Workload:
         padding_starts=[self.n] * self.nb, out=list(self.roots.unbind(0)))
     if self.world > 1:
       import torch.distributed as dist
-      dist.all_gather_into_tensor(self.gathered, self.roots)
+      dist.all_gather_into_tensor(self.gathered.view(-1), self.roots.view(-1))
 
   def flops(self):
     """Algorithmic FLOPs of the last step on this rank."""

@@ -144,8 +144,9 @@ int ps_mat_power_f32(void* stream, const float* m, int n, int ldm, int p,
  * error_tolerance, relative_matrix_epsilon, padding_start=...): power iteration
  * for the relative epsilon, <=6 tries with ridge*10^i, inner loop while
  * it<num_iters && err>tol && ratio<1.2, previous H returned if the last step
- * diverged, all-padding blocks forced to 0.  n == 1 returns the closed form
- * (the reference raises there, DS:850-855/907).
+ * diverged, all-padding blocks forced to 0.  A 1x1 block runs the same iteration
+ * (as it does in the reference whenever it is padded to max_size, DS:2841-2843;
+ * the reference's unpadded matrix_size == 1 branch raises, DS:850-855/907).
  * iters_executed_host (may be NULL): total Newton steps the host loop enqueued. */
 size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
                                       const int32_t* p,
@@ -181,10 +182,14 @@ int ps_profile_reset(void);
 int ps_profile_get(double* stage_ms, int64_t* stage_launches, double* power_iter_ms,
                    double* other_ms);
 
-/* ---- plain batched product C = A*B (n^3), exposed for tests / roofline probes - */
-int ps_gemm_nn_f32(void* stream, const float* a, const float* b, float* c, int m,
-                   int n, int k, int lda, int ldb, int ldc, int batch,
-                   int64_t stride_a, int64_t stride_b, int64_t stride_c);
+/* ---- plain batched product C = op(A) * op(B), row-major ------------------------
+ * transa = 0: A is [m,k] (lda >= k);  transa = 1: A is stored [k,m] (lda >= m).
+ * transb = 0: B is [k,n] (ldb >= n);  transb = 1: B is stored [n,k] (ldb >= k).
+ * Used for the reference's preconditioned_grad contraction
+ * tensordot(g, P, axes=[[0],[0]]) (DS:1707; transa = 1) and by tests. */
+int ps_gemm_f32(void* stream, int transa, int transb, const float* a, const float* b,
+                float* c, int m, int n, int k, int lda, int ldb, int ldc, int batch,
+                int64_t stride_a, int64_t stride_b, int64_t stride_c);
 
 #ifdef __cplusplus
 }

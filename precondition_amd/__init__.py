@@ -7,3 +7,20 @@ ShampooState surface.  All arithmetic runs in hand-written HIP kernels for
 gfx950 (libprecondition_amd.so, C-ABI in include/ps_api.h).
 """
 __version__ = "0.1.0"
+
+from .blocking import (BlockPartitioner, Preconditioner, batch, merge_small_dims,
+                       pad_square_matrix, pad_vector, unbatch)
+from .distributed_shampoo import (distributed_shampoo,
+                                  preconditioning_compute_steps_schedule)
+from .state import (GradientTransformation, GraftingType, MaskedNode,
+                    ParameterStats, PreconditionerType, QuantizedValue,
+                    ShampooState, TrainingMetrics)
+
+
+def __getattr__(name):
+  # HIP-backed helpers (import lazily so that bookkeeping works without torch.cuda)
+  if name in ("matrix_inverse_pth_root", "matrix_inverse_pth_root_batched",
+              "power_iteration", "mat_power", "gram_weighted_update"):
+    from . import kernels
+    return getattr(kernels, name)
+  raise AttributeError(name)

@@ -76,8 +76,8 @@ _SIGNATURES = {
     "ps_profile_enable": (C.c_int, [C.c_int]),
     "ps_profile_reset": (C.c_int, []),
     "ps_profile_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ps_gemm_nn_f32":
-        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+    "ps_gemm_f32":
+        (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                    C.c_int64, C.c_int64, C.c_int64]),
 }

@@ -1,0 +1,152 @@
+"""Partition of independent statistics blocks over the GPUs of a node, and the
+all-gather of the resulting preconditioners (RCCL over xGMI via
+torch.distributed; backend "nccl" is RCCL on ROCm).
+
+Replaces the reference's pmap sharding in _pmap_compute_preconditioners
+(DS:2841-2879): there, every statistic is padded to max_size, the list is padded
+to a multiple of the device count with identity / exponent 1 / padding_start 0
+entries, ``batch()`` gives rank r the contiguous chunk [r*b, (r+1)*b), each
+replica roots its chunk and ``jax.lax.all_gather`` returns everything in list
+order.  Here the ownership rule is the same (so results land in the same list
+order), but nothing is padded: each rank roots its own statistics at their true
+sizes into one flat send buffer, and ONE all-gather of equal-sized flat buffers
+(+ one of the [b, 8] metrics table) leaves every rank holding every root.  The
+per-statistic results are views into the gathered buffer (no unpack copies).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+METRICS_STRIDE = 8
+
+
+def resolve_group(batch_axis_name):
+  """None -> single device.  A ProcessGroup -> that group.  Any other truthy
+  value (the reference passes the pmap axis name) -> the default group."""
+  if not batch_axis_name:
+    return None
+  import torch.distributed as dist
+  if isinstance(batch_axis_name, dist.ProcessGroup):
+    return batch_axis_name
+  if not dist.is_initialized():
+    raise RuntimeError(
+        "batch_axis_name is set but torch.distributed is not initialised; start "
+        "one process per GPU (torchrun) and call init_process_group('nccl')")
+  return dist.group.WORLD
+
+
+def world_and_rank(group) -> Tuple[int, int]:
+  if group is None:
+    return 1, 0
+  import torch.distributed as dist
+  return dist.get_world_size(group), dist.get_rank(group)
+
+
+def reference_ownership(num_statistics: int, world: int) -> List[int]:
+  """owner[i] under the reference's batch(): pad the count to a multiple of
+  `world`, rank r owns the contiguous chunk [r*b, (r+1)*b) (DS:2844, 2862, 1827)."""
+  padded = num_statistics + (-num_statistics % world)
+  b = padded // world
+  return [i // b for i in range(num_statistics)]
+
+
+def cost_balanced_ownership(sizes: Sequence[int], exponents: Sequence[int],
+                            world: int) -> List[int]:
+  """Longest-processing-time assignment on cost c(p) * n^3 (perf mode; the
+  gathered result order is unchanged because results are addressed by index)."""
+
+  def c_of_p(p):
+    return int(np.floor(np.log2(p))) + bin(int(p)).count("1") - 1 + 2 if p > 0 else 1
+
+  order = sorted(range(len(sizes)),
+                 key=lambda i: -(c_of_p(exponents[i]) * float(sizes[i]) ** 3))
+  load = [0.0] * world
+  owner = [0] * len(sizes)
+  for i in order:
+    r = int(np.argmin(load))
+    owner[i] = r
+    load[r] += c_of_p(exponents[i]) * float(sizes[i]) ** 3
+  return owner
+
+
+def sharded_inverse_pth_roots(
+    statistics: Sequence[torch.Tensor],
+    exponents: Sequence[int],
+    group=None,
+    ridge_epsilon: float = 1e-6,
+    relative_matrix_epsilon: bool = True,
+    eigh: bool = False,
+    ownership: str = "reference",
+    root_fn: Optional[Callable] = None,
+) -> Tuple[List[torch.Tensor], torch.Tensor]:
+  """Roots every statistic on its owner rank and all-gathers the results.
+
+  Returns (roots in list order, metrics [num_statistics, 8]) on every rank.
+  `root_fn(matrices, ps, padding_starts, out=..., **kw) -> (roots, metrics)`
+  defaults to the HIP batched root; tests inject a CPU function to exercise the
+  sharding over gloo.
+  """
+  n_stats = len(statistics)
+  world, rank = world_and_rank(group)
+  sizes = [int(s.shape[0]) for s in statistics]
+  if ownership == "reference":
+    owner = reference_ownership(n_stats, world)
+  elif ownership == "lpt":
+    owner = cost_balanced_ownership(sizes, exponents, world)
+  else:
+    raise ValueError(f"unknown ownership {ownership!r}")
+  if root_fn is None:
+    from . import kernels
+    root_fn = kernels.matrix_inverse_pth_root_batched
+
+  # Offsets of every statistic inside its owner's flat buffer; all ranks derive
+  # the same table from shapes alone (no communication).
+  offsets, fill = [0] * n_stats, [0] * world
+  slot, count = [0] * n_stats, [0] * world
+  for i in range(n_stats):
+    r = owner[i]
+    offsets[i] = fill[r]
+    fill[r] += sizes[i] * sizes[i]
+    slot[i] = count[r]
+    count[r] += 1
+  buf_elems = max(max(fill), 1)
+  max_count = max(max(count), 1)
+
+  dev = statistics[0].device
+  send = torch.empty((buf_elems,), dtype=torch.float32, device=dev)
+  mine = [i for i in range(n_stats) if owner[i] == rank]
+  send_metrics = torch.zeros((max_count, METRICS_STRIDE), dtype=torch.float32, device=dev)
+  if mine:
+    outs = [send[offsets[i]:offsets[i] + sizes[i] * sizes[i]].view(sizes[i], sizes[i])
+            for i in mine]
+    _, m = root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
+                   [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
+                   relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
+                   out=outs)
+    send_metrics[:len(mine)] = m
+
+  if world == 1:
+    gathered = send.unsqueeze(0)
+    gathered_metrics = send_metrics.unsqueeze(0)
+  else:
+    import torch.distributed as dist
+    # flat outputs (concatenation form) are accepted by both RCCL and gloo
+    gathered = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
+    gathered_metrics = torch.empty((world * max_count * METRICS_STRIDE,),
+                                   dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(gathered, send, group=group)
+    dist.all_gather_into_tensor(gathered_metrics, send_metrics.reshape(-1), group=group)
+    gathered = gathered.view(world, buf_elems)
+    gathered_metrics = gathered_metrics.view(world, max_count, METRICS_STRIDE)
+
+  roots = [
+      gathered[owner[i], offsets[i]:offsets[i] + sizes[i] * sizes[i]].view(
+          sizes[i], sizes[i]) for i in range(n_stats)
+  ]
+  index = torch.tensor([owner[i] * max_count + slot[i] for i in range(n_stats)],
+                       dtype=torch.long, device=dev)
+  metrics = gathered_metrics.reshape(world * max_count, METRICS_STRIDE)[index]
+  return roots, metrics

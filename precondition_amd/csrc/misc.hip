@@ -60,8 +60,9 @@ namespace psk {
 
 constexpr int GBK = 16;
 
-// C[b] = A[b] * B[b], row-major, any sizes / alignment (guarded loads).
-__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(
+// C[b] = op(A[b]) * op(B[b]), row-major, any sizes / alignment (guarded loads).
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(
     const float* a, const float* b, float* c, int M, int N, int K, int lda, int ldb,
     int ldc, int64_t sa, int64_t sb, int64_t sc, int tiles_m, int tiles_n, int veca,
     int vecb) {
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(
   Operand A{a + bi * sa, lda, tm * TILE, M, K, veca != 0};
   Operand B{b + bi * sb, ldb, tn * TILE, N, K, vecb != 0};
   f32x16 acc[2][2];
-  gemm_tile<KC, MC, GBK, true>(A, B, K, smem, acc);
+  gemm_tile<LA, LB, GBK, true>(A, B, K, smem, acc);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   float* C = c + bi * sc;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(
       for (int r = 0; r < 16; ++r) {
         const int row = tm * TILE + acc_row(wm, i, r, lane);
         const int col = tn * TILE + acc_col(wn, j, lane);
-        if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[i][j][r];
+        if (row < M && col < N) gstore1(C + (int64_t)row * ldc + col, acc[i][j][r]);
       }
 }
 
@@ -94,21 +95,37 @@ static bool vec_ok(const float* p, int ld, int64_t stride) {
   return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0) && (stride % 4 == 0);
 }
 
-extern "C" int ps_gemm_nn_f32(void* stream, const float* a, const float* b, float* c,
-                              int m, int n, int k, int lda, int ldb, int ldc, int batch,
-                              int64_t stride_a, int64_t stride_b, int64_t stride_c) {
-  if (!a || !b || !c || m < 1 || n < 1 || k < 1 || batch < 1 || lda < k || ldb < n ||
-      ldc < n)
+extern "C" int ps_gemm_f32(void* stream, int transa, int transb, const float* a,
+                           const float* b, float* c, int m, int n, int k, int lda,
+                           int ldb, int ldc, int batch, int64_t stride_a,
+                           int64_t stride_b, int64_t stride_c) {
+  if (!a || !b || !c || m < 1 || n < 1 || k < 1 || batch < 1 || ldc < n ||
+      lda < (transa ? m : k) || ldb < (transb ? k : n))
     return PS_EINVAL;
   const int tm = (m + TILE - 1) / TILE, tn = (n + TILE - 1) / TILE;
   const int64_t grid = (int64_t)tm * tn * batch;
   if (grid > 0x7fffffff) return PS_EUNSUPPORTED;
-  hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)grid), dim3(256), 0,
-                     (hipStream_t)stream, a, b, c, m, n, k, lda, ldb, ldc, stride_a,
-                     stride_b, stride_c, tm, tn, vec_ok(a, lda, stride_a) ? 1 : 0,
-                     vec_ok(b, ldb, stride_b) ? 1 : 0);
+  const int va = vec_ok(a, lda, stride_a) ? 1 : 0, vb = vec_ok(b, ldb, stride_b) ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g((unsigned)grid), blk(256);
+  // A: rows are mn. transa=0 -> k-contiguous (KC); transa=1 -> mn-contiguous (MC).
+  // B: cols are mn. transb=0 -> mn-contiguous (MC); transb=1 -> k-contiguous (KC).
+#define PS_GEMM_LAUNCH(LA, LB)                                                        \
+  hipLaunchKernelGGL((gemm_kernel<LA, LB>), g, blk, 0, st, a, b, c, m, n, k, lda, ldb, \
+                     ldc, stride_a, stride_b, stride_c, tm, tn, va, vb)
+  if (!transa && !transb) PS_GEMM_LAUNCH(KC, MC);
+  else if (!transa && transb) PS_GEMM_LAUNCH(KC, KC);
+  else if (transa && !transb) PS_GEMM_LAUNCH(MC, MC);
+  else PS_GEMM_LAUNCH(MC, KC);
+#undef PS_GEMM_LAUNCH
   PS_LAUNCH_CHECK();
   return PS_OK;
+}
+
+static int ps_gemm_nn_f32(void* stream, const float* a, const float* b, float* c, int m,
+                          int n, int k, int lda, int ldb, int ldc, int batch,
+                          int64_t sa, int64_t sb, int64_t sc) {
+  return ps_gemm_f32(stream, 0, 0, a, b, c, m, n, k, lda, ldb, ldc, batch, sa, sb, sc);
 }
 
 // mat_power: the reference's loop (DS:663-677) with the exact "@ I" skipped.

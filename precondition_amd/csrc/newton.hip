@@ -311,12 +311,10 @@ __global__ __launch_bounds__(256) void newton_final_kernel(NewtonBlock* blocks,
   const int n = nb->n, nf = nb->n_full;
   const int tid = blockIdx.y * 256 + threadIdx.x, nth = gridDim.y * 256;
   float* out = nb->out;
-  if (n <= 1) {
-    float v = 0.f;
-    if (n == 1) v = powf(__fadd_rn(nb->a[0], nb->ridge), nb->alpha);  // DS:851-852
+  if (n == 0) {
     for (int64_t e = tid; e < (int64_t)nf * nf; e += nth) {
       const int row = e / nf, col = e % nf;
-      out[(int64_t)row * nb->ldo + col] = (row == 0 && col == 0) ? v : 0.f;
+      out[(int64_t)row * nb->ldo + col] = 0.f;
     }
   } else {
     const float* H = nb->H[nb->result_sel];
@@ -331,9 +329,6 @@ __global__ __launch_bounds__(256) void newton_final_kernel(NewtonBlock* blocks,
     if (n == 0) {  // all padding: DS:930-937 (error forced to 0)
       m[PS_M_ERROR] = 0.f; m[PS_M_ITERS] = 0.f; m[PS_M_ERROR_RATIO] = 1.f;
       m[PS_M_RETRIES] = 1.f; m[PS_M_TOTAL_ITERS] = 0.f;
-    } else if (n == 1) {
-      m[PS_M_ERROR] = 0.f; m[PS_M_ITERS] = 0.f; m[PS_M_ERROR_RATIO] = 0.f;
-      m[PS_M_RETRIES] = 0.f; m[PS_M_TOTAL_ITERS] = 0.f;
     } else {
       m[PS_M_ERROR] = nb->err; m[PS_M_ITERS] = (float)nb->it;
       m[PS_M_ERROR_RATIO] = nb->ratio; m[PS_M_RETRIES] = (float)nb->tries;
@@ -409,9 +404,9 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
     int ne = n[b];
     if (padding_start) ne = std::max(0, std::min(ne, (int)padding_start[b]));
     pl.n_eff[b] = ne;
-    pl.npad[b] = ne >= 2 ? psh::round_up(ne, TILE) : 0;
+    pl.npad[b] = ne >= 1 ? psh::round_up(ne, TILE) : 0;
     pl.max_n = std::max(pl.max_n, ne);
-    if (ne >= 2) {
+    if (ne >= 1) {
       std::vector<Product> ch;
       int power_id;
       if (p[b] < 1 || !build_chain(p[b], ch, power_id)) { pl.ok = false; return; }
@@ -645,7 +640,7 @@ extern "C" int ps_newton_root_batched_f32(
     nb.alpha = (float)(-1.0 / p[b]);        // DS:774 (float32 of the exact quotient)
     nb.one_minus_alpha = 1.0f - nb.alpha;   // DS:844, float32 subtraction
     nb.inv_p = (float)(1.0 / p[b]);
-    nb.phase = pl.n_eff[b] >= 2 ? PH_INIT : PH_DONE;
+    nb.phase = pl.n_eff[b] >= 1 ? PH_INIT : PH_DONE;
     nb.ratio = 1.f;
   }
   std::vector<PiBlock> hp;

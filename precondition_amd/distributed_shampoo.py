@@ -1,0 +1,367 @@
+"""Distributed Shampoo optimizer surface on the MI355X preconditioner kernels.
+
+Same factory signature, state types, step semantics and construction-time
+errors as the reference's ``distributed_shampoo`` (precondition/
+distributed_shampoo.py, DS:1849-2040 factory, DS:2585-2625 init_fn, DS:2631-2675
+_compute_stats, DS:2816-3010 _pmap_compute_preconditioners, DS:3442-3494
+_compute_preconditioners, DS:3496-3625 _transform_grad, DS:3627-3659 update_fn),
+re-hosted on torch tensors:
+
+  * statistics accumulation of a whole parameter tree = one grouped launch of the
+    HIP Gram kernel (kernels.stats_update_grouped);
+  * the preconditioner recompute = one batched call of the HIP Newton / eigh root
+    over the statistics this rank owns, then one RCCL all-gather of the roots and
+    one of the metrics table (comm.py) instead of jax.lax.all_gather;
+  * grafting / momentum (_transform_grad) are elementwise torch ops (row f2 of
+    SURVEY.md §8, "next").
+
+``batch_axis_name`` keeps its role as the switch for data-parallel sharding of
+the statistics blocks: pass a ``torch.distributed`` process group (or any truthy
+value for the default group).  There is no CPU fallback: the statistics and root
+steps raise without libprecondition_amd.so and an MI355X.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import comm
+from . import pytree
+from .blocking import Preconditioner, _precond_dim
+from .state import (GradientTransformation, GraftingType, MaskedNode,
+                    ParameterStats, PreconditionerType, QuantizedValue,
+                    ShampooState, TrainingMetrics, init_training_metrics)
+
+_EPSILON = 1e-25  # DS:41
+
+
+def preconditioning_compute_steps_schedule(lr_fn, start_preconditioning_compute_steps,
+                                           end_preconditioning_compute_steps, step):
+  """DS:44-76: recompute interval following the learning-rate decay, rounded
+  down to a multiple of 10, at least 1."""
+  decay_factor = float(lr_fn(step)) / float(lr_fn(0))
+  t = (start_preconditioning_compute_steps +
+       (1 - decay_factor) * end_preconditioning_compute_steps)
+  return max((t // 10) * 10, 1)
+
+
+def distributed_shampoo(
+    learning_rate,
+    block_size,
+    beta1=0.9,
+    beta2=0.999,
+    diagonal_epsilon=1e-10,
+    matrix_epsilon=1e-6,
+    weight_decay=0.0,
+    start_preconditioning_step=5,
+    preconditioning_compute_steps=1,
+    decay_preconditioning_compute_steps: bool = False,
+    end_preconditioning_compute_steps: Optional[int] = None,
+    statistics_compute_steps=1,
+    best_effort_shape_interpretation=True,
+    graft_type=GraftingType.SGD,
+    nesterov=True,
+    exponent_override=0,
+    batch_axis_name=None,
+    statistics_partition_spec=None,
+    preconditioner_partition_spec=None,
+    num_devices_for_pjit=None,
+    shard_optimizer_states=False,
+    best_effort_memory_usage_reduction=False,
+    inverse_failure_threshold=0.1,
+    moving_average_for_momentum=False,
+    skip_preconditioning_dim_size_gt=4096,
+    clip_by_scaled_gradient_norm=None,
+    precision=None,
+    tensordot_precision=None,
+    relative_matrix_epsilon=True,
+    merge_small_dims_block_size=4096,
+    lobpcg_topk_precondition: int = 0,
+    lobpcg_max_iter: int = 0,
+    precondtioner_type=PreconditionerType.ALL,  # (sic) the reference's spelling
+    generate_fd_metrics: bool = False,
+    compression_rank: int = 0,
+    frequent_directions: bool = False,
+    reset_preconditioner: bool = False,
+    average_grad: bool = False,
+    skip_preconditioning_rank_lt=1,
+    decoupled_learning_rate=True,
+    decoupled_weight_decay=False,
+    generate_training_metrics=True,
+    reuse_preconditioner=False,
+    eigh=False,
+    # build-specific (not in the reference): ownership of statistics across
+    # ranks ("reference" = batch() order of DS:1827, "lpt" = cost balanced), and
+    # a test seam (tests/ inject a CPU stand-in to exercise the host logic and
+    # the gloo sharding without a GPU; None = the HIP kernels, which fail loudly
+    # when the library or the GPU is missing).
+    block_ownership: str = "reference",
+    _backend_for_testing: Any = None,
+):
+  """Returns GradientTransformation(init_fn, update_fn); see module docstring."""
+  del precision, tensordot_precision  # always exact-f32 MFMA
+  del statistics_partition_spec, preconditioner_partition_spec, num_devices_for_pjit
+  del lobpcg_max_iter
+
+  # ---- construction-time validation: same conditions and messages as DS:2019-2040
+  if reset_preconditioner and not frequent_directions:
+    raise ValueError("reset_preconditioner=True requries frequent_directions")
+  generate_fd_metrics = generate_fd_metrics and frequent_directions
+  if frequent_directions and compression_rank <= 0:
+    raise ValueError("frequent_directions=True requires compression_rank > 0,"
+                     f" found {compression_rank}")
+  if average_grad and not frequent_directions:
+    raise ValueError("average_grad requested but frequent_directions is False")
+  if frequent_directions and (statistics_compute_steps !=
+                              preconditioning_compute_steps):
+    raise ValueError("frequent_directions=True requires "
+                     f"statistics_compute_steps ({statistics_compute_steps}) "
+                     "to equal != preconditioning_compute_steps "
+                     f"({preconditioning_compute_steps})")
+  # ---- scope of this build
+  if shard_optimizer_states:
+    raise NotImplementedError("shard_optimizer_states (pjit mode) is out of scope")
+  if best_effort_memory_usage_reduction:
+    raise NotImplementedError("quantized optimizer state is out of scope (f3)")
+  if lobpcg_topk_precondition:
+    raise NotImplementedError("LOBPCG deflation is out of scope")
+  if compression_rank != 0 or frequent_directions:
+    raise NotImplementedError("Sketchy / low-rank branch (config 5) is not built yet")
+
+  group = comm.resolve_group(batch_axis_name)
+  if _backend_for_testing is not None:
+    backend = _backend_for_testing
+  else:
+    from . import kernels as backend  # HIP path
+
+  def _graft_type_has_diagonal_statistics():
+    return graft_type not in (GraftingType.SGD, GraftingType.SQRT_N, GraftingType.NONE)
+
+  def _quantize(x):
+    return QuantizedValue.from_float_value(x, torch.float32)
+
+  def preconditioner_from_params(param):
+    return Preconditioner(param, block_size, merge_small_dims_block_size,
+                          best_effort_shape_interpretation, precondtioner_type,
+                          compression_rank)
+
+  def _skip_preconditioning(param):
+    return len(param.shape) < skip_preconditioning_rank_lt or any(
+        s > skip_preconditioning_dim_size_gt for s in param.shape)
+
+  # ---------------------------------------------------------------------------
+  def init_fn(params):
+    """DS:2585-2625: statistics = matrix_epsilon * I, preconditioners = I."""
+
+    def _init(param):
+      dev = param.device
+      statistics, preconditioners = [], []
+      if not _skip_preconditioning(param):
+        shapes = preconditioner_from_params(param).shapes_for_preconditioners()
+        statistics = [
+            matrix_epsilon * torch.eye(s[0], dtype=torch.float32, device=dev)
+            for s in shapes
+        ]
+        preconditioners = [
+            torch.eye(s[0], s[1], dtype=torch.float32, device=dev) * float(s[0] == s[1])
+            for s in shapes
+        ]
+      diagonal_statistics = []
+      if _graft_type_has_diagonal_statistics():
+        diagonal_statistics = torch.zeros_like(param)
+      return ParameterStats(
+          _quantize(diagonal_statistics), statistics, preconditioners,
+          _quantize(torch.zeros_like(param)), _quantize(torch.zeros_like(param)),
+          MaskedNode(),
+          init_training_metrics(len(statistics), generate_training_metrics,
+                                generate_fd_metrics, device=dev))
+
+    return ShampooState(count=torch.zeros([], dtype=torch.int32),
+                        stats=pytree.tree_map(_init, params))
+
+  # ---------------------------------------------------------------------------
+  def _compute_stats_all(grads_flat, stats_flat, params_flat, step):
+    """DS:2631-2675 for every parameter, as ONE grouped Gram launch."""
+    w1 = beta2
+    w2 = beta2 if beta2 == 1.0 else 1.0 - beta2  # DS:2635-2636
+    perform = statistics_compute_steps <= 1 or step % statistics_compute_steps == 0
+    new_lists, items = [], []
+    for grad, state, param in zip(grads_flat, stats_flat, params_flat):
+      if _skip_preconditioning(param) or not perform:
+        new_lists.append(state.statistics if not _skip_preconditioning(param)
+                         else [[]] * len(state.statistics))
+        continue
+      pc = preconditioner_from_params(param)
+      olds = [s.contiguous() for s in state.statistics]
+      news = [torch.empty_like(s) for s in olds]
+      items.extend(pc.statistics_update_items(olds, grad, news))
+      new_lists.append(news)
+    if items:
+      backend.stats_update_grouped(items, w1, w2)
+    return [
+        ParameterStats(s.diagonal_statistics, ns, s.preconditioners,
+                       s.diagonal_momentum, s.momentum, MaskedNode(),
+                       s.training_metrics)
+        for s, ns in zip(stats_flat, new_lists)
+    ]
+
+  # ---------------------------------------------------------------------------
+  def _compute_preconditioners(states, params, step):
+    """DS:3442-3494 + DS:2816-3010: shard the statistics over the ranks of
+    `group`, root them, all-gather, select against the previous value."""
+    statistics, exponents, prev, counts = [], [], [], []
+    for state, param in zip(states, params):
+      num = len(state.statistics)
+      counts.append(num)
+      if num > 0:
+        pc = preconditioner_from_params(param)
+        e = pc.exponent_for_preconditioner() if exponent_override == 0 else exponent_override
+        exponents.extend([e] * num)
+        statistics.extend(state.statistics)
+        prev.extend(state.preconditioners)
+    if not statistics:
+      return states
+
+    steps_t = preconditioning_compute_steps
+    if (decay_preconditioning_compute_steps and end_preconditioning_compute_steps
+        and callable(learning_rate)):
+      steps_t = preconditioning_compute_steps_schedule(
+          learning_rate, preconditioning_compute_steps,
+          end_preconditioning_compute_steps, step)
+    perform_step = step % steps_t == 0
+    if not perform_step:
+      # DS:2911-2926: "error = threshold" sentinels make the select keep every
+      # previous preconditioner; metrics keep their old values (DS:2983-2986).
+      return states
+
+    roots, metrics = comm.sharded_inverse_pth_roots(
+        statistics, exponents, group=group, ridge_epsilon=matrix_epsilon,
+        relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
+        ownership=block_ownership,
+        root_fn=backend.matrix_inverse_pth_root_batched)
+    errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
+    new_p = []
+    for i, (root, old) in enumerate(zip(roots, prev)):
+      err = errors[i]
+      bad = np.isnan(err) or err >= inverse_failure_threshold  # DS:2936-2943
+      new_p.append(old if bad else root)
+
+    out, idx = [], 0
+    for state, num in zip(states, counts):
+      if num == 0:
+        out.append(ParameterStats(
+            state.diagonal_statistics, state.statistics, [], state.diagonal_momentum,
+            state.momentum, state.avg_grad,
+            init_training_metrics(0, generate_training_metrics,
+                                  device=metrics.device)))
+        continue
+      tm = MaskedNode()
+      if generate_training_metrics:
+        m = metrics[idx:idx + num]
+        tm = state.training_metrics.replace(
+            inverse_pth_root_errors=m[:, 0].clone(),
+            inverse_pth_root_iters=m[:, 1].clone(),
+            final_error_ratio=m[:, 2].clone(),
+            max_eigen_value=m[:, 3].clone(),
+            total_retries=m[:, 4].clone())
+      out.append(ParameterStats(state.diagonal_statistics, state.statistics,
+                                new_p[idx:idx + num], state.diagonal_momentum,
+                                state.momentum, state.avg_grad, tm))
+      idx += num
+    return out
+
+  # ---------------------------------------------------------------------------
+  def _transform_grad(grad, state, param, step):
+    """DS:3496-3625: grafting, preconditioning, momentum."""
+    pc = preconditioner_from_params(param)
+    sgd_update = grad
+    new_diag = state.diagonal_statistics.to_float()
+    norm = torch.linalg.vector_norm
+    if graft_type in (GraftingType.ADAGRAD, GraftingType.ADAGRAD_NORMALIZED):
+      scaled = grad
+      if graft_type == GraftingType.ADAGRAD_NORMALIZED:
+        scaled = grad / (norm(grad) + _EPSILON)
+      new_diag = state.diagonal_statistics.to_float() + torch.square(scaled)
+      grafting_update = scaled / (torch.sqrt(new_diag) + diagonal_epsilon)
+    elif graft_type in (GraftingType.RMSPROP, GraftingType.RMSPROP_NORMALIZED):
+      scaled = grad
+      if graft_type == GraftingType.RMSPROP_NORMALIZED:
+        scaled = grad / (norm(grad) + _EPSILON)
+      w1 = beta2
+      w2 = beta2 if beta2 == 1.0 else 1.0 - beta2
+      new_diag = w1 * state.diagonal_statistics.to_float() + w2 * torch.square(scaled)
+      rms = scaled / (torch.sqrt(new_diag) + diagonal_epsilon)
+      if clip_by_scaled_gradient_norm:
+        scaled_norm = norm(rms) / float(np.sqrt(float(rms.numel())))
+        rms = rms / torch.clamp(scaled_norm / clip_by_scaled_gradient_norm, min=1.0)
+      grafting_update = rms
+    elif graft_type in (GraftingType.SGD, GraftingType.NONE):
+      grafting_update = sgd_update
+    else:  # SQRT_N
+      grafting_update = torch.ones_like(sgd_update) * torch.sign(sgd_update)
+
+    lr = learning_rate(step) if callable(learning_rate) else learning_rate
+    grafting_update = grafting_update * (lr if not decoupled_learning_rate else 1.0)
+
+    if not _skip_preconditioning(param):
+      precond_grad = pc.preconditioned_grad(grad, state.preconditioners,
+                                            tensordot_fn=backend.tensordot_axis0)
+    else:
+      if graft_type == GraftingType.NONE:
+        logging.error("skipping preconditioning without grafting for param %s", param)
+      precond_grad = grafting_update
+
+    if graft_type is not GraftingType.NONE:
+      multiplier = norm(grafting_update) / (norm(precond_grad) + _EPSILON)
+    else:
+      multiplier = 1.0
+    shampoo_update = precond_grad * multiplier
+
+    shampoo_wd, grafting_wd = shampoo_update, grafting_update
+    if weight_decay != 0 and not decoupled_weight_decay:
+      shampoo_wd = shampoo_update + weight_decay * param
+      grafting_wd = grafting_update + weight_decay * param
+
+    w = (1.0 - beta1) if moving_average_for_momentum else 1.0
+    shampoo_mom = state.momentum.to_float() * beta1 + w * shampoo_wd
+    grafting_mom = state.diagonal_momentum.to_float() * beta1 + w * grafting_wd
+
+    run_shampoo = 1.0 if step >= start_preconditioning_step else 0.0
+    momentum_update = run_shampoo * shampoo_mom + (1.0 - run_shampoo) * grafting_mom
+    wd_update = run_shampoo * shampoo_wd + (1.0 - run_shampoo) * grafting_wd
+
+    nesterov_update = momentum_update
+    if nesterov:
+      nesterov_update = w * wd_update + beta1 * momentum_update
+    if weight_decay != 0 and decoupled_weight_decay:
+      wd_lr = 1.0 if decoupled_learning_rate else lr
+      nesterov_update = nesterov_update + wd_lr * weight_decay * param
+
+    transformed = -1.0 * (lr if decoupled_learning_rate else 1.0) * nesterov_update
+    new_state = ParameterStats(_quantize(new_diag), state.statistics,
+                               state.preconditioners, _quantize(grafting_mom),
+                               _quantize(shampoo_mom), state.avg_grad,
+                               state.training_metrics)
+    return transformed, new_state
+
+  # ---------------------------------------------------------------------------
+  def update_fn(grads, state, params):
+    """DS:3627-3659."""
+    params_flat, treedef = pytree.tree_flatten(params)
+    stats_flat = treedef.flatten_up_to(state.stats)
+    grads_flat = treedef.flatten_up_to(grads)
+    step = int(state.count)
+
+    new_stats = _compute_stats_all(grads_flat, stats_flat, params_flat, step)
+    new_stats = _compute_preconditioners(new_stats, params_flat, step)
+    outs = [_transform_grad(g, s, p, step)
+            for g, s, p in zip(grads_flat, new_stats, params_flat)]
+    updates_flat = [o[0] for o in outs]
+    new_stats = [o[1] for o in outs]
+    return (treedef.unflatten(updates_flat),
+            ShampooState(count=state.count + 1, stats=treedef.unflatten(new_stats)))
+
+  return GradientTransformation(init_fn, update_fn)

@@ -119,6 +119,30 @@ def matrix_inverse_pth_root_batched(
   return list(out), metrics
 
 
+def matrix_inverse_pth_root(matrix: torch.Tensor, p: int, num_iters: int = 100,
+                            ridge_epsilon: float = 1e-6,
+                            error_tolerance: float = 1e-6, precision=None,
+                            relative_matrix_epsilon: bool = True,
+                            lobpcg_topk_precondition: int = 0,
+                            lobpcg_max_iter: int = 0,
+                            padding_start: Optional[int] = None, prev=None,
+                            eigh: bool = False):
+  """Single-matrix form with the reference's signature (DS:702-715).  Returns
+  (root, TrainingMetrics)."""
+  from .state import TrainingMetrics
+  del precision, prev, lobpcg_max_iter
+  if lobpcg_topk_precondition:
+    raise NotImplementedError("LOBPCG deflation is out of scope")
+  roots, m = matrix_inverse_pth_root_batched(
+      [matrix], [p], None if padding_start is None else [padding_start],
+      num_iters=num_iters, ridge_epsilon=ridge_epsilon,
+      error_tolerance=error_tolerance,
+      relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh)
+  return roots[0], TrainingMetrics(
+      inverse_pth_root_errors=m[0, 0], inverse_pth_root_iters=m[0, 1],
+      final_error_ratio=m[0, 2], max_eigen_value=m[0, 3], total_retries=m[0, 4])
+
+
 def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
                     error_tolerance: float = 1e-6,
                     padding_start: Optional[int] = None):
@@ -182,23 +206,38 @@ def mat_power(mat_m: torch.Tensor, p: int) -> torch.Tensor:
   return out
 
 
-def matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-  """Plain float32 product on the MFMA core ([m,k] @ [k,n] or batched 3-D)."""
+def matmul(a: torch.Tensor, b: torch.Tensor, transa: bool = False,
+           transb: bool = False) -> torch.Tensor:
+  """op(a) @ op(b) in float32 on the MFMA core (2-D, or 3-D batched)."""
   _require_gpu(a, "matmul")
   _require_gpu(b, "matmul")
-  if a.dim() == 2:
-    a3, b3 = a.unsqueeze(0), b.unsqueeze(0)
-  else:
-    a3, b3 = a, b
-  a3, b3 = a3.contiguous(), b3.contiguous()
-  bt, m, k = a3.shape
-  n = b3.shape[2]
+  squeeze = a.dim() == 2
+  a3 = (a.unsqueeze(0) if squeeze else a).contiguous()
+  b3 = (b.unsqueeze(0) if squeeze else b).contiguous()
+  bt = a3.shape[0]
+  m, k = (a3.shape[2], a3.shape[1]) if transa else (a3.shape[1], a3.shape[2])
+  n = b3.shape[1] if transb else b3.shape[2]
+  kb = b3.shape[2] if transb else b3.shape[1]
+  if kb != k or b3.shape[0] != bt:
+    raise ValueError(f"matmul shape mismatch: {tuple(a.shape)} x {tuple(b.shape)}")
   c = torch.empty((bt, m, n), dtype=torch.float32, device=a.device)
-  rc = lib().ps_gemm_nn_f32(_stream(), a3.data_ptr(), b3.data_ptr(),
-                            c.data_ptr(), m, n, k, k, n, n, bt, m * k, k * n,
-                            m * n)
-  check(rc, "ps_gemm_nn_f32")
-  return c[0] if a.dim() == 2 else c
+  rc = lib().ps_gemm_f32(_stream(), int(transa), int(transb), a3.data_ptr(),
+                         b3.data_ptr(), c.data_ptr(), m, n, k, a3.shape[2],
+                         b3.shape[2], n, bt, a3.shape[1] * a3.shape[2],
+                         b3.shape[1] * b3.shape[2], m * n)
+  check(rc, "ps_gemm_f32")
+  return c[0] if squeeze else c
+
+
+def tensordot_axis0(g: torch.Tensor, pc: torch.Tensor) -> torch.Tensor:
+  """tensordot(g, pc, axes=[[0],[0]]) (DS:1707): contracts g's leading axis
+  with pc's rows; result shape = g.shape[1:] + (pc.shape[1],)."""
+  _require_gpu(g, "preconditioned_grad")
+  lead = g.shape[0]
+  rest = tuple(g.shape[1:])
+  g2 = g.reshape(lead, -1)  # copies only if the block view is not mergeable
+  out = matmul(g2, pc, transa=True)  # [prod(rest), pc.shape[1]]
+  return out.reshape(rest + (pc.shape[1],))
 
 
 # ---------------------------------------------------------------------------

@@ -1,0 +1,166 @@
+"""State containers and enums of the optimizer surface, with the reference's
+names and field order (precondition/distributed_shampoo.py: TrainingMetrics
+DS:338-363, ParameterStats DS:367-375, ShampooState DS:488-490, GraftingType
+DS:499-506, PreconditionerType DS:509-517; optax.GradientTransformation /
+optax.MaskedNode; quantization_utils.QuantizedValue :26-113 in its float32
+pass-through mode)."""
+from __future__ import annotations
+
+import dataclasses
+import enum
+from typing import Any, Callable, List, NamedTuple, Optional, Union
+
+import torch
+
+from . import pytree
+
+
+class GradientTransformation(NamedTuple):
+  """Same shape as optax.GradientTransformation: (init, update)."""
+  init: Callable[..., Any]
+  update: Callable[..., Any]
+
+
+class MaskedNode(NamedTuple):
+  """Empty pytree node (optax.MaskedNode)."""
+
+
+class GraftingType(enum.IntEnum):
+  NONE = 0
+  SGD = 1
+  ADAGRAD = 2
+  RMSPROP = 3
+  RMSPROP_NORMALIZED = 4
+  SQRT_N = 5
+  ADAGRAD_NORMALIZED = 6
+
+
+class PreconditionerType(enum.IntEnum):
+  ALL = 1     # a factor for every dim
+  INPUT = 2   # every dim but the last
+  OUTPUT = 3  # only the last dim
+
+
+def _zero():
+  return torch.zeros((), dtype=torch.float32)
+
+
+@dataclasses.dataclass(frozen=True)
+class LOBPCGDiagnostics:
+  """Present for state-layout parity only; LOBPCG is out of scope (DS:149-194)."""
+  lobpcg_iters: Any = dataclasses.field(default_factory=_zero)
+  max_consistency_error: Any = dataclasses.field(default_factory=_zero)
+  avg_consistency_error: Any = dataclasses.field(default_factory=_zero)
+  avg_orthogonality_error: Any = dataclasses.field(default_factory=_zero)
+  max_eigenvalue: Any = dataclasses.field(default_factory=_zero)
+  min_eigenvalue: Any = dataclasses.field(default_factory=_zero)
+  num_topk_eigenvectors: Any = dataclasses.field(default_factory=_zero)
+
+  def replace(self, **kw):
+    return dataclasses.replace(self, **kw)
+
+
+@dataclasses.dataclass(frozen=True)
+class InversePthRootDiagnostics:
+  """Layout parity only (DS:109-146); populated by the reference only with LOBPCG."""
+  max_diag_error: Any = dataclasses.field(default_factory=_zero)
+  avg_diag_error: Any = dataclasses.field(default_factory=_zero)
+  max_off_diag_error: Any = dataclasses.field(default_factory=_zero)
+  avg_off_diag_error: Any = dataclasses.field(default_factory=_zero)
+  p: Any = dataclasses.field(default_factory=_zero)
+
+  def replace(self, **kw):
+    return dataclasses.replace(self, **kw)
+
+
+@dataclasses.dataclass(frozen=True)
+class TrainingMetrics:
+  """Per-statistic diagnostics kept inside the optimizer state (DS:338-363)."""
+  inverse_pth_root_errors: Any = dataclasses.field(default_factory=_zero)
+  inverse_pth_root_iters: Any = dataclasses.field(default_factory=_zero)
+  final_error_ratio: Any = dataclasses.field(default_factory=_zero)
+  max_eigen_value: Any = dataclasses.field(default_factory=_zero)
+  total_retries: Any = dataclasses.field(default_factory=_zero)
+  lobpcg_diagnostics: LOBPCGDiagnostics = dataclasses.field(
+      default_factory=LOBPCGDiagnostics)
+  inverse_pth_root_diagnostics: InversePthRootDiagnostics = dataclasses.field(
+      default_factory=InversePthRootDiagnostics)
+  conditioned_inverse_pth_root_diagnostics: InversePthRootDiagnostics = (
+      dataclasses.field(default_factory=InversePthRootDiagnostics))
+  fd: Any = dataclasses.field(default_factory=MaskedNode)
+
+  def replace(self, **kw):
+    return dataclasses.replace(self, **kw)
+
+
+pytree.register_dataclass(LOBPCGDiagnostics,
+                          [f.name for f in dataclasses.fields(LOBPCGDiagnostics)])
+pytree.register_dataclass(
+    InversePthRootDiagnostics,
+    [f.name for f in dataclasses.fields(InversePthRootDiagnostics)])
+pytree.register_dataclass(TrainingMetrics,
+                          [f.name for f in dataclasses.fields(TrainingMetrics)])
+
+
+@dataclasses.dataclass(frozen=True)
+class QuantizedValue:
+  """quantization_utils.QuantizedValue restricted to float32 pass-through
+  (quantized modes are the out-of-scope `best_effort_memory_usage_reduction`)."""
+  quantized: Any
+  diagonal: Any
+  bucket_size: Any
+  quantized_dtype: Any
+  extract_diagonal: bool
+  shape: Any
+
+  @classmethod
+  def from_float_value(cls, fvalue, quantized_dtype, extract_diagonal=False):
+    if isinstance(fvalue, list) and not fvalue:
+      return cls([], [], [], quantized_dtype, extract_diagonal, [])
+    if quantized_dtype != torch.float32:
+      raise NotImplementedError(
+          "only float32 pass-through QuantizedValue is implemented "
+          "(best_effort_memory_usage_reduction is out of scope)")
+    return cls(fvalue, [], [], quantized_dtype, extract_diagonal,
+               list(fvalue.shape))
+
+  def to_float(self):
+    return self.quantized
+
+  def replace(self, **kw):
+    return dataclasses.replace(self, **kw)
+
+
+pytree.register_dataclass(QuantizedValue, ["quantized", "diagonal", "bucket_size"],
+                          ["quantized_dtype", "extract_diagonal", "shape"])
+
+
+class ParameterStats(NamedTuple):
+  """State associated to each parameter (DS:367-375, same field order)."""
+  diagonal_statistics: QuantizedValue
+  statistics: Optional[List[Any]]
+  preconditioners: List[Any]
+  diagonal_momentum: QuantizedValue
+  momentum: QuantizedValue
+  avg_grad: Union[Any, MaskedNode]
+  training_metrics: Union[TrainingMetrics, MaskedNode]
+
+
+class ShampooState(NamedTuple):
+  count: Any
+  stats: Any
+
+
+def default_training_metrics(generate_fd_metrics: bool = False) -> TrainingMetrics:
+  del generate_fd_metrics  # FD diagnostics: config 5, not built yet
+  return TrainingMetrics()
+
+
+def init_training_metrics(num_statistics: int, generate_training_metrics: bool,
+                          generate_fd_metrics: bool = False, device=None):
+  """DS:439-451: every leaf repeated `num_statistics` times, or MaskedNode."""
+  if not generate_training_metrics:
+    return MaskedNode()
+  return pytree.tree_map(
+      lambda x: torch.zeros((num_statistics,), dtype=torch.float32, device=device),
+      default_training_metrics(generate_fd_metrics))

@@ -1,0 +1,104 @@
+"""N > 1 path on CPU: two processes over gloo shard the statistics, root their
+own chunk (CPU stand-in for the HIP root) and all-gather; every rank must end
+with the single-process result in list order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _make_stats():
+  rng = np.random.default_rng(11)
+  sizes = [8, 12, 8, 5, 16, 8, 12]  # 7 statistics: odd count => a padding slot on 2 ranks
+  exps = [4, 2, 4, 4, 2, 4, 2]
+  stats = []
+  for n in sizes:
+    g = rng.standard_normal((n, 4 * n)).astype(np.float32)
+    stats.append(torch.from_numpy((g @ g.T).astype(np.float32)))
+  return stats, exps
+
+
+def _worker(rank, world, port, ownership, ret):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    from precondition_amd import comm
+    from tests import cpu_backend
+    stats, exps = _make_stats()
+    calls = []
+
+    def root_fn(mats, ps, pads, **kw):
+      calls.append(len(mats))
+      return cpu_backend.matrix_inverse_pth_root_batched(mats, ps, pads, **kw)
+
+    roots, metrics = comm.sharded_inverse_pth_roots(
+        stats, exps, group=dist.group.WORLD, ownership=ownership, root_fn=root_fn)
+    ret[rank] = ([r.clone().numpy() for r in roots], metrics.numpy().copy(), calls)
+
+    # the optimizer surface over the same group: every rank must produce the
+    # same update as a single process.
+    import precondition_amd as pa
+    params = (torch.ones(20, 12), torch.ones(7, 9))
+    g = np.random.default_rng(3)
+    grads = tuple(torch.from_numpy(g.standard_normal(p.shape).astype(np.float32)) for p in params)
+    opt = pa.distributed_shampoo(0.1, 8, batch_axis_name=dist.group.WORLD,
+                                 start_preconditioning_step=1, block_ownership=ownership,
+                                 _backend_for_testing=cpu_backend)
+    st = opt.init(params)
+    for _ in range(3):
+      upd, st = opt.update(grads, st, params)
+    ret[rank + 100] = [u.numpy().copy() for u in upd]
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ownership", ["reference", "lpt"])
+def test_two_rank_sharding_matches_single_process(ownership):
+  from precondition_amd import comm
+  from tests import cpu_backend
+  import precondition_amd as pa
+  world = 2
+  mgr = mp.Manager()
+  ret = mgr.dict()
+  mp.spawn(_worker, args=(world, _free_port(), ownership, ret), nprocs=world, join=True)
+  stats, exps = _make_stats()
+  base_roots, base_metrics = comm.sharded_inverse_pth_roots(
+      stats, exps, group=None, root_fn=cpu_backend.matrix_inverse_pth_root_batched)
+  for rank in range(world):
+    roots, metrics, calls = ret[rank]
+    assert len(roots) == len(stats)
+    for a, b in zip(roots, base_roots):
+      assert np.array_equal(a, b.numpy())  # same CPU arithmetic => identical
+    assert np.array_equal(metrics, base_metrics.numpy())
+    assert sum(calls) in (3, 4)  # 7 statistics over 2 ranks
+  if ownership == "reference":
+    assert ret[0][2] == [4] and ret[1][2] == [3]  # chunks [0,4) and [4,7) + 1 padding slot
+  # optimizer surface
+  params = (torch.ones(20, 12), torch.ones(7, 9))
+  g = np.random.default_rng(3)
+  grads = tuple(torch.from_numpy(g.standard_normal(p.shape).astype(np.float32)) for p in params)
+  opt = pa.distributed_shampoo(0.1, 8, batch_axis_name=None, start_preconditioning_step=1,
+                               _backend_for_testing=cpu_backend)
+  st = opt.init(params)
+  for _ in range(3):
+    upd, st = opt.update(grads, st, params)
+  for rank in range(world):
+    for a, b in zip(ret[rank + 100], upd):
+      assert np.array_equal(a, b.numpy())

@@ -1,0 +1,235 @@
+"""Parity of the HIP path (through the C-ABI) with the reference: golden vectors
+produced by the reference's own source, the CPU oracle on fresh seeded inputs,
+and size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (float32, stated per test): well-conditioned inputs <= 5e-5 rel-Fro
+(north_star bar: 1e-4); ill-conditioned goldens scale with conditioning exactly as
+test_oracle_golden.root_tolerance does for the oracle itself.  Iteration and
+retry counts are compared exactly.  Integer bookkeeping is bit-exact
+(tests/test_bookkeeping.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shampoo_oracle as orc
+from tests.test_oracle_golden import check_root_case, newton_cases
+from tests.test_optimizer_host_logic import _index as e2e_index, run_e2e_case
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def K():
+  from precondition_amd import kernels
+  return kernels
+
+
+def hip_root(device):
+  def fn(a, p, ridge_epsilon=1e-6, relative_matrix_epsilon=True, padding_start=None):
+    roots, m = K().matrix_inverse_pth_root_batched(
+        [torch.tensor(a, device=device)], [p],
+        None if padding_start is None else [padding_start],
+        ridge_epsilon=ridge_epsilon, relative_matrix_epsilon=relative_matrix_epsilon)
+    m = m[0].cpu().numpy()
+    return roots[0].cpu().numpy(), dict(
+        inverse_pth_root_errors=float(m[0]), inverse_pth_root_iters=float(m[1]),
+        final_error_ratio=float(m[2]), max_eigen_value=float(m[3]),
+        total_retries=float(m[4]))
+  return fn
+
+
+def wishart(n, k, seed):
+  g = np.random.default_rng(seed).standard_normal((n, k)).astype(np.float32)
+  return (g @ g.T).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", newton_cases(GOLD), ids=lambda c: c["name"])
+def test_newton_root_hip_vs_reference_golden(case, device):
+  z = np.load(os.path.join(GOLD, "newton_root.npz"))
+  check_root_case(case, z, hip_root(device))
+
+
+def test_newton_root_hip_vs_oracle_fresh_inputs(device):
+  """Mixed batch (sizes, exponents, padding) in ONE call vs the oracle per block."""
+  sizes = [16, 130, 64, 257, 96, 512, 33, 200, 1, 48]
+  ps = [4, 2, 4, 4, 8, 4, 6, 2, 4, 3]
+  mats = [wishart(n, 4 * n, 100 + i) for i, n in enumerate(sizes)]
+  pads = [n for n in sizes]
+  # pad two of them inside a bigger buffer
+  mats[2] = orc.pad_square_matrix(mats[2], 80); pads[2] = 64
+  mats[6] = orc.pad_square_matrix(mats[6], 40); pads[6] = 33
+  roots, metrics = K().matrix_inverse_pth_root_batched(
+      [torch.tensor(m, device=device) for m in mats], ps, pads)
+  metrics = metrics.cpu().numpy()
+  for i, (a, p) in enumerate(zip(mats, ps)):
+    h_ref, m_ref = orc.matrix_inverse_pth_root(a, p, padding_start=pads[i])
+    h = roots[i].cpu().numpy()
+    rel = np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref)
+    assert rel < 5e-5, (i, sizes[i], p, rel)
+    assert metrics[i, 1] == m_ref["inverse_pth_root_iters"], (i, metrics[i], m_ref)
+    assert metrics[i, 4] == m_ref["total_retries"]
+    assert np.isclose(metrics[i, 3], m_ref["max_eigen_value"], rtol=2e-5)
+    if pads[i] < a.shape[0]:
+      assert not h[pads[i]:, :].any() and not h[:, pads[i]:].any()
+
+
+def test_failure_and_retry_path(device):
+  """A block whose first tries fail (error > 0.05) walks the ridge*10^i ladder
+  exactly as the oracle does (DS:858-885)."""
+  rng = np.random.default_rng(7)
+  q, _ = np.linalg.qr(rng.standard_normal((24, 24)))
+  e = np.logspace(0, -12, 24)
+  a = ((q * e) @ q.T).astype(np.float32)
+  a = ((a + a.T) / 2).astype(np.float32)
+  for ridge in (1e-12, 1e-9):
+    h_ref, m_ref = orc.matrix_inverse_pth_root(a, 4, ridge_epsilon=ridge)
+    roots, m = K().matrix_inverse_pth_root_batched([torch.tensor(a, device=device)], [4],
+                                                   ridge_epsilon=ridge)
+    m = m[0].cpu().numpy()
+    assert m[4] == m_ref["total_retries"], (m, m_ref)
+    assert abs(m[1] - m_ref["inverse_pth_root_iters"]) <= 1, (m, m_ref)
+    assert np.isnan(m[0]) == np.isnan(m_ref["inverse_pth_root_errors"])
+
+
+def test_batch_invariance_and_determinism(device):
+  """A block's result does not depend on what else is in the batch, and two runs
+  are bit-identical (no float atomics on the path)."""
+  mats = [torch.tensor(wishart(n, 4 * n, 7 + n), device=device) for n in (96, 256, 160)]
+  ps = [4, 2, 4]
+  r1, m1 = K().matrix_inverse_pth_root_batched(mats, ps)
+  r2, m2 = K().matrix_inverse_pth_root_batched(mats, ps)
+  for a, b in zip(r1, r2):
+    assert torch.equal(a, b)
+  assert torch.equal(m1, m2)
+  for i in range(3):
+    ri, mi = K().matrix_inverse_pth_root_batched([mats[i]], [ps[i]])
+    assert torch.equal(ri[0], r1[i])
+    assert torch.equal(mi[0, :5], m1[i, :5])
+
+
+def test_power_iteration_and_mat_power_vs_golden(device):
+  z = np.load(os.path.join(GOLD, "power_iter_matpower.npz"))
+  for nm in ("wishart128", "spec16_1e4", "wishart200", "diag_sep_n8"):
+    a = torch.tensor(z[f"pi_{nm}__a"], device=device)
+    v, s = K().power_iteration(a)
+    assert np.isclose(float(s), float(z[f"pi_{nm}__s"]), rtol=1e-5), nm
+    v = v.cpu().numpy()
+    assert min(np.linalg.norm(v - z[f"pi_{nm}__v"]), np.linalg.norm(v + z[f"pi_{nm}__v"])) < 2e-3
+  a = torch.tensor(z["pi_padded40in64__a"], device=device)
+  v, s = K().power_iteration(a, padding_start=40)
+  assert np.isclose(float(s), float(z["pi_padded40in64__s"]), rtol=1e-5)
+  assert not v[40:].any()
+  lam, its = K().power_iteration_batched(
+      [torch.tensor(z[f"pi_{nm}__a"], device=device) for nm in ("diag_sep_n8", "spec16_1e4")])
+  assert abs(int(its[0]) - int(z["pi_diag_sep_n8__iters"])) <= 1
+  for p in range(1, 9):
+    r = K().mat_power(torch.tensor(z[f"mp_p{p}__m"], device=device), p).cpu().numpy()
+    assert np.allclose(r, z[f"mp_p{p}__r"], rtol=1e-5, atol=1e-7), p
+
+
+def test_gram_update_vs_golden(device):
+  z = np.load(os.path.join(GOLD, "gram_update.npz"))
+  keys = [k for k in z.files if k.endswith("__new")]
+  for k in keys:
+    base = k[:-len("__new")]
+    nm, ax, w = base.split("__")
+    axis, w1 = int(ax[2:]), float(w[1:])
+    w2 = 1.0 if w1 == 1.0 else {0.999: 0.001, 0.9: 0.1}[w1]
+    got = K().gram_weighted_update(torch.tensor(z[base + "__old"], device=device),
+                                   torch.tensor(z[nm + "__g"], device=device), axis, w1, w2)
+    assert np.allclose(got.cpu().numpy(), z[k], rtol=2e-6, atol=1e-5), k
+
+
+def test_gram_update_strided_blocks_and_symmetry(device):
+  """Blocks of a partitioned tensor are read in place (strided views)."""
+  from precondition_amd.blocking import BlockPartitioner
+  rng = np.random.default_rng(2)
+  for shape, bs in (((300, 200), 128), ((6, 70, 40), 32), ((260,), 128)):
+    x = rng.standard_normal(shape).astype(np.float32)
+    t = torch.tensor(x, device=device)
+    parts = BlockPartitioner(t, bs).partition(t)
+    parts_np = BlockPartitioner(torch.from_numpy(x), bs).partition(torch.from_numpy(x))
+    items, refs = [], []
+    for blk, blk_np in zip(parts, parts_np):
+      for axis in range(blk.dim()):
+        d = blk.shape[axis]
+        old = torch.tensor(wishart(d, d + 3, axis), device=device)
+        new = torch.empty_like(old)
+        items.append((blk, axis, old, new))
+        refs.append(orc.gram_weighted_update(old.cpu().numpy(), blk_np.numpy(), axis, 0.9, 0.1))
+    K().stats_update_grouped(items, 0.9, 0.1)
+    for (_, _, _, new), ref in zip(items, refs):
+      got = new.cpu().numpy()
+      assert np.allclose(got, ref, rtol=1e-5, atol=1e-4)
+      assert np.array_equal(got, got.T) or np.allclose(got, got.T, rtol=0, atol=1e-6)
+
+
+def test_matmul_layouts_vs_fp64(device):
+  rng = np.random.default_rng(0)
+  for (m, n, k) in [(128, 128, 128), (200, 130, 77), (513, 65, 300)]:
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    for ta in (False, True):
+      for tb in (False, True):
+        aa = torch.tensor(a.T.copy() if ta else a, device=device)
+        bb = torch.tensor(b.T.copy() if tb else b, device=device)
+        c = K().matmul(aa, bb, transa=ta, transb=tb).cpu().numpy()
+        assert np.abs(c - ref).max() / np.abs(ref).max() < 2e-6, (m, n, k, ta, tb)
+  # A = I with an asymmetric B catches a transposed C write
+  b = np.arange(96 * 160, dtype=np.float32).reshape(96, 160)
+  c = K().matmul(torch.eye(96, device=device), torch.tensor(b, device=device)).cpu().numpy()
+  assert np.array_equal(c, b)
+
+
+@pytest.mark.parametrize("case", [c for c in e2e_index(GOLD) if "eigh" not in c["name"]],
+                         ids=lambda c: c["name"])
+def test_e2e_optimizer_hip_vs_reference_golden(case, device):
+  z = np.load(os.path.join(GOLD, "e2e.npz"))
+  st, worst = run_e2e_case(case, z, device, None)  # None => the HIP kernels
+  assert worst < 1e-3, worst
+  name = case["name"]
+  for i in range(case["n_params"]):
+    for j, x in enumerate(st.stats[i].statistics):
+      assert np.allclose(x.cpu().numpy(), z[f"{name}__stat{i}_{j}"], rtol=1e-5, atol=1e-6)
+    key = f"{name}__metrics{i}"
+    if key in z.files:
+      tm = st.stats[i].training_metrics
+      assert np.abs(tm.inverse_pth_root_iters.cpu().numpy() - z[key][:, 1]).max() <= 1
+      assert np.array_equal(tm.total_retries.cpu().numpy(), z[key][:, 4])
+
+
+# ---------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs 2 and the 1024 headline)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("nb,n,p", [(256, 512, 4), (64, 1024, 4), (8, 768, 2)])
+def test_full_size_inverse_root_properties(nb, n, p, device):
+  """H = A^{-1/p}: H^p (A + eps I) = I to fp32 accuracy, H symmetric, 8 Newton
+  steps per block as the reference takes on this input family, all blocks
+  converge, and a sampled block matches the oracle."""
+  gen = torch.Generator(device=device).manual_seed(1234)
+  g = torch.randn((nb, n, 4 * n), generator=gen, device=device, dtype=torch.float32)
+  stats = torch.zeros((nb, n, n), device=device)
+  K().stats_update_grouped([(g[i], 0, stats[i], stats[i]) for i in range(nb)], 0.0, 1.0)
+  del g
+  roots, metrics = K().matrix_inverse_pth_root_batched(list(stats.unbind(0)), [p] * nb,
+                                                       [n] * nb)
+  m = metrics.cpu().numpy()
+  assert (m[:, 4] == 1).all() and (m[:, 0] < 1e-6).all()
+  assert (m[:, 1] == (8 if p == 4 else m[0, 1])).all()
+  for i in (0, nb // 2, nb - 1):
+    h = roots[i]
+    assert (h - h.T).abs().max() <= 2e-6 * h.abs().max()
+    d = stats[i] + 1e-6 * m[i, 3] * torch.eye(n, device=device)
+    hp = K().mat_power(h, p)
+    resid = K().matmul(hp, d) - torch.eye(n, device=device)
+    assert resid.abs().max() < 5e-4, float(resid.abs().max())
+  i = nb // 3
+  h_ref, m_ref = orc.matrix_inverse_pth_root(stats[i].cpu().numpy(), p, padding_start=n)
+  h = roots[i].cpu().numpy()
+  assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 1e-4  # north_star bar
+  assert m[i, 1] == m_ref["inverse_pth_root_iters"]

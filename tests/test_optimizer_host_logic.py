@@ -1,0 +1,131 @@
+"""Host logic of the optimizer surface (tree handling, step gating, grafting,
+momentum, failure select) against end-to-end goldens produced by the reference.
+The numerical kernels are replaced by tests/cpu_backend.py here; the same goldens
+are checked through the HIP kernels in tests/test_gpu_parity.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import precondition_amd as pa
+from precondition_amd import pytree
+from tests import cpu_backend
+
+
+def _index(golden_dir):
+  with open(os.path.join(golden_dir, "e2e_index.json")) as f:
+    return json.load(f)
+
+
+def run_e2e_case(c, z, device, backend):
+  name, n = c["name"], c["n_params"]
+  kw = dict(c["kwargs"])
+  if "graft_type" in kw:
+    kw["graft_type"] = pa.GraftingType(kw["graft_type"])
+  if "precondtioner_type" in kw:
+    kw["precondtioner_type"] = pa.PreconditionerType(kw["precondtioner_type"])
+  block_size = kw.pop("block_size")
+  opt = pa.distributed_shampoo(c["lr"], block_size, batch_axis_name=None,
+                               _backend_for_testing=backend, **kw)
+  params = tuple(torch.tensor(z[f"{name}__param{i}"], device=device) for i in range(n))
+  st = opt.init(params)
+  worst = 0.0
+  for t in range(c["steps"]):
+    grads = tuple(torch.tensor(z[f"{name}__grad{i}_t{t}"], device=device) for i in range(n))
+    upd, st = opt.update(grads, st, params)
+    for i in range(n):
+      ref = z[f"{name}__upd{i}_t{t}"]
+      got = upd[i].cpu().numpy()
+      assert got.dtype == np.float32 and got.shape == ref.shape
+      err = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+      worst = max(worst, err)
+  assert int(st.count) == c["count"]
+  return st, worst
+
+
+@pytest.mark.parametrize("case", _index(os.path.join(os.path.dirname(__file__), "golden")),
+                         ids=lambda c: c["name"])
+def test_e2e_host_logic_vs_reference_golden(case, golden_dir):
+  z = np.load(os.path.join(golden_dir, "e2e.npz"))
+  st, worst = run_e2e_case(case, z, torch.device("cpu"), cpu_backend)
+  # statistics here are sums of a few rank-1 terms + 1e-6 I (cond ~1e5): roots
+  # move by ~1e-4 with the rounding order of the Gram update
+  assert worst < 1e-3, worst
+  name = case["name"]
+  for i in range(case["n_params"]):
+    s = st.stats[i]
+    for j, x in enumerate(s.statistics):
+      assert np.allclose(x.numpy(), z[f"{name}__stat{i}_{j}"], rtol=1e-5, atol=1e-7)
+    for j, x in enumerate(s.preconditioners):
+      ref = z[f"{name}__precond{i}_{j}"]
+      assert np.linalg.norm(x.numpy() - ref) <= 2e-3 * np.linalg.norm(ref)
+    mom, ref = s.momentum.to_float().numpy(), z[f"{name}__momentum{i}"]
+    assert np.linalg.norm(mom - ref) <= 2e-4 * max(np.linalg.norm(ref), 1e-30)
+
+
+def test_step0_known_answer_from_reference_test():
+  """DST:121-209/253-258: first update of the default config ends in -0.57."""
+  opt = pa.distributed_shampoo(0.1, 32, batch_axis_name=None,
+                               preconditioning_compute_steps=2,
+                               _backend_for_testing=cpu_backend)
+  params = (torch.tensor([[1., 3.], [2., 4.]]), torch.tensor([[3., 4.], [3., 4.]]))
+  grads = (torch.tensor([[3., 4.], [5., 6.]]), torch.tensor([[1., 3.], [2., 1.]]))
+  st = opt.init(params)
+  upd, st = opt.update(grads, st, params)
+  assert abs(float(upd[0][0, 0]) - (-0.57)) < 1e-4  # -0.1 * (3 + 0.9 * 3)
+  assert all(torch.isfinite(u).all() for u in upd)
+
+
+def test_constructor_validation_matches_reference():
+  with pytest.raises(ValueError, match="reset_preconditioner=True requries frequent_directions"):
+    pa.distributed_shampoo(0.1, 32, reset_preconditioner=True)
+  with pytest.raises(ValueError, match="frequent_directions=True requires compression_rank > 0"):
+    pa.distributed_shampoo(0.1, 32, frequent_directions=True)
+  with pytest.raises(ValueError, match="average_grad requested but frequent_directions is False"):
+    pa.distributed_shampoo(0.1, 32, average_grad=True)
+  with pytest.raises(ValueError, match="to equal != preconditioning_compute_steps"):
+    pa.distributed_shampoo(0.1, 32, frequent_directions=True, compression_rank=2,
+                           statistics_compute_steps=2, preconditioning_compute_steps=3)
+
+
+def test_state_layout():
+  opt = pa.distributed_shampoo(0.1, 32)
+  params = {"w": torch.zeros(100, 70), "b": torch.zeros(24), "big": torch.zeros(5000, 3)}
+  st = opt.init(params)
+  assert pa.ShampooState._fields == ("count", "stats")
+  assert pa.ParameterStats._fields == ("diagonal_statistics", "statistics", "preconditioners",
+                                       "diagonal_momentum", "momentum", "avg_grad",
+                                       "training_metrics")
+  assert st.count.dtype == torch.int32 and st.count.ndim == 0
+  w = st.stats["w"]
+  # [100, 70] does not merge (7000 > 4096); blocks [32,32,32,4] x [32,32,6]
+  shapes = [tuple(s.shape) for s in w.statistics]
+  assert len(shapes) == 24 and shapes[:6] == [(32, 32), (32, 32), (32, 32), (32, 32),
+                                               (32, 32), (6, 6)]
+  assert shapes[-2:] == [(4, 4), (6, 6)]
+  assert torch.equal(w.statistics[0], 1e-6 * torch.eye(32))
+  assert torch.equal(w.preconditioners[5], torch.eye(6))
+  assert [tuple(s.shape) for s in st.stats["b"].statistics] == [(24, 24)]
+  assert st.stats["big"].statistics == []  # dim 5000 > skip_preconditioning_dim_size_gt
+  assert tuple(w.training_metrics.inverse_pth_root_errors.shape) == (24,)
+  # the state is a plain pytree of tensors => torch.save-able
+  leaves = pytree.tree_leaves(st)
+  assert all(isinstance(x, torch.Tensor) for x in leaves)
+
+
+def test_pytree_roundtrip():
+  tree = {"a": [torch.ones(1), (torch.zeros(2), None)], "b": pa.MaskedNode()}
+  leaves, td = pytree.tree_flatten(tree)
+  assert len(leaves) == 2
+  back = pytree.tree_unflatten(td, leaves)
+  assert back["a"][1][1] is None and isinstance(back["b"], pa.MaskedNode)
+  doubled = pytree.tree_map(lambda x: x * 2, tree)
+  assert float(doubled["a"][0]) == 2.0
+
+
+def test_schedule():
+  lr = lambda t: 0.1 * (0.5 ** (t / 100))
+  assert pa.preconditioning_compute_steps_schedule(lr, 10, 100, 0) == 10
+  assert pa.preconditioning_compute_steps_schedule(lr, 10, 100, 100) == 60
