@@ -50,7 +50,7 @@ __device__ inline float fixed_order_sum_wave0(const float* x, int cnt, int tid,
   return *bcast;
 }
 
-__global__ __launch_bounds__(256) void pi_step_kernel(PiBlock* blocks,
+static __global__ __launch_bounds__(256) void pi_step_kernel(PiBlock* blocks,
                                                       const PiChunk* chunks,
                                                       int iter, float tol) {
   extern __shared__ __align__(16) float pi_smem[];  // [n] normalised v, then scratch
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void pi_step_kernel(PiBlock* blocks,
 
 // One workgroup per block: closes the loop (DS:649-652) and optionally writes
 // the normalised vector.
-__global__ __launch_bounds__(256) void pi_final_kernel(PiBlock* blocks, int num_iters,
+static __global__ __launch_bounds__(256) void pi_final_kernel(PiBlock* blocks, int num_iters,
                                                        float* out_lambda,
                                                        int* out_iters, float* out_v,
                                                        int ldv) {

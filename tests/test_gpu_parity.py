@@ -216,8 +216,7 @@ def test_matmul_layouts_vs_fp64(device):
   assert np.array_equal(c, b)
 
 
-@pytest.mark.parametrize("case", [c for c in e2e_index(GOLD) if "eigh" not in c["name"]],
-                         ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", e2e_index(GOLD), ids=lambda c: c["name"])
 def test_e2e_optimizer_hip_vs_reference_golden(case, device):
   z = np.load(os.path.join(GOLD, "e2e.npz"))
   st, worst = run_e2e_case(case, z, device, None)  # None => the HIP kernels
@@ -231,6 +230,88 @@ def test_e2e_optimizer_hip_vs_reference_golden(case, device):
       tm = st.stats[i].training_metrics
       assert np.abs(tm.inverse_pth_root_iters.cpu().numpy() - z[key][:, 1]).max() <= 1
       assert np.array_equal(tm.total_retries.cpu().numpy(), z[key][:, 4])
+
+
+# ---------------------------------------------------------------------------
+# eigh path (DS:943-1030): blocked Jacobi on the GPU vs LAPACK ssyevd in the goldens.
+# Eigenvectors are not unique => parity on the root `val` only.
+def test_eigh_root_hip_vs_reference_golden(device):
+  z = np.load(os.path.join(GOLD, "eigh_root.npz"))
+  with open(os.path.join(GOLD, "eigh_root_index.json")) as f:
+    idx = json.load(f)
+  mats = [torch.tensor(z[c["name"] + "__a"], device=device) for c in idx]
+  pads = [c["padding_start"] if c["padding_start"] is not None else m.shape[0]
+          for c, m in zip(idx, mats)]
+  roots, met = K().matrix_inverse_pth_root_batched(mats, [c["p"] for c in idx], pads,
+                                                   eigh=True)
+  met = met.cpu().numpy()
+  for i, c in enumerate(idx):
+    ref = z[c["name"] + "__root"]
+    h = roots[i].cpu().numpy()
+    nrm = np.linalg.norm(ref)
+    if nrm == 0:
+      assert not h.any() and met[i, 0] == 0.0, c["name"]
+      continue
+    assert np.linalg.norm(h - ref) / nrm < 5e-5, (c["name"], np.linalg.norm(h - ref) / nrm)
+    # error metric = max|u^T D u - diag(e)|: same order as LAPACK's (it measures the
+    # solver's own residual, so only the magnitude is comparable)
+    assert met[i, 0] <= max(4 * float(z[c["name"] + "__err"]), 1e-6 * float(np.abs(z[c["name"] + "__a"]).max()) * 64), \
+        (c["name"], met[i, 0], float(z[c["name"] + "__err"]))
+    assert (met[i, 1:5] == 0).all()  # DS:1022: only the error field is populated
+    ps = c["padding_start"]
+    if ps is not None and ps < h.shape[0]:
+      assert not h[ps:, :].any() and not h[:, ps:].any()
+
+
+def test_eigh_root_hip_vs_oracle_and_fp64(device):
+  sizes = [40, 128, 200, 384, 96]
+  ps = [2, 4, 2, 2, 8]
+  mats = [wishart(n, 4 * n, 300 + i) for i, n in enumerate(sizes)]
+  rng = np.random.default_rng(5)
+  q, _ = np.linalg.qr(rng.standard_normal((96, 96)))
+  mats[4] = (((q * np.logspace(0, -4, 96)) @ q.T + ((q * np.logspace(0, -4, 96)) @ q.T).T) / 2
+             ).astype(np.float32)
+  roots, met = K().matrix_inverse_pth_root_batched(
+      [torch.tensor(m, device=device) for m in mats], ps, eigh=True)
+  for i, (a, p) in enumerate(zip(mats, ps)):
+    h = roots[i].cpu().numpy()
+    h_ref, m_ref = orc.matrix_inverse_pth_root_eigh(a, p)
+    w, v = np.linalg.eigh(a.astype(np.float64))
+    _, lam, _ = orc.power_iteration(a, 100, 1e-6)
+    eps = 1e-6 * max(float(lam), 1e-6)
+    ref64 = (v * np.maximum(w + eps, eps) ** (-1.0 / p)) @ v.T
+    e_hip = np.linalg.norm(h - ref64) / np.linalg.norm(ref64)
+    e_lapack = np.linalg.norm(h_ref - ref64) / np.linalg.norm(ref64)
+    # Blocked Jacobi applies its rotations as float32 products, so eigenvalues
+    # carry an ABSOLUTE error of a few eps*lambda_max: the root is good to about
+    # eps*cond.  (LAPACK does better than that on graded spectra; on the Wishart
+    # family both sit at the float32 floor.)
+    cond = float(w.max() + eps) / float(max(w.min(), 0.0) + eps)
+    tol = max(5 * e_lapack, 2e-6, 1e-7 * cond)
+    assert e_hip < tol, (i, e_hip, e_lapack, cond)
+    assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < tol + 2 * e_lapack
+    assert np.abs(h - h.T).max() <= 1e-6 * np.abs(h).max()
+
+
+@pytest.mark.parametrize("nb,n", [(4, 2048), (16, 512)])
+def test_eigh_full_size_properties(nb, n, device):
+  """BASELINE config 3 geometry (2048^2, p=2): val^2 (A + eps I) = I, sampled oracle."""
+  gen = torch.Generator(device=device).manual_seed(2048)
+  g = torch.randn((nb, n, 2 * n), generator=gen, device=device, dtype=torch.float32)
+  stats = torch.zeros((nb, n, n), device=device)
+  K().stats_update_grouped([(g[i], 0, stats[i], stats[i]) for i in range(nb)], 0.0, 1.0)
+  del g
+  roots, met = K().matrix_inverse_pth_root_batched(list(stats.unbind(0)), [2] * nb,
+                                                   [n] * nb, eigh=True)
+  lam, _ = K().power_iteration_batched(list(stats.unbind(0)))
+  for i in (0, nb - 1):
+    h = roots[i]
+    d = stats[i] + 1e-6 * lam[i] * torch.eye(n, device=device)
+    resid = K().matmul(K().matmul(h, h), d) - torch.eye(n, device=device)
+    assert resid.abs().max() < 1e-3, float(resid.abs().max())
+  h_ref, _ = orc.matrix_inverse_pth_root_eigh(stats[1].cpu().numpy(), 2, padding_start=n)
+  h = roots[1].cpu().numpy()
+  assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 1e-4
 
 
 # ---------------------------------------------------------------------------
