@@ -128,15 +128,16 @@ __global__ void eigh_setup_kernel(EighBlock* blocks, const PiBlock* pis, int nbl
 }
 
 // ---- one cyclic Jacobi sweep on the 128x128 pivot, in LDS --------------------------
-__global__ __launch_bounds__(256) void jacobi_pair_kernel(EighBlock* blocks,
-                                                          const ETile* tiles, int round,
-                                                          int sweep_slot) {
+constexpr int JT = 1024;  // threads of the pivot kernel: 16 wavefronts hide LDS latency
+__global__ __launch_bounds__(JT) void jacobi_pair_kernel(EighBlock* blocks,
+                                                         const ETile* tiles, int round,
+                                                         int sweep_slot) {
   extern __shared__ __align__(16) float jsm[];
   float* S = jsm;                 // [128][129]
   float* Q = jsm + JP * JLD;      // [128][129]
   float* cs = Q + JP * JLD;       // [64][2]
   int* pq = reinterpret_cast<int*>(cs + 2 * JB);  // [64][2]
-  __shared__ float red[4];
+  __shared__ float red[JT / 64];
   const ETile te = tiles[blockIdx.x];
   EighBlock* eb = &blocks[te.block];
   if (!eb->active || round >= eb->nb - 1) return;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void jacobi_pair_kernel(EighBlock* blocks,
   rr_pair(eb->nb, round, te.k, I, J);
   const int ld = eb->npad, tid = threadIdx.x;
   const float* A = eb->A;
-  for (int e = tid; e < JP * JP; e += 256) {
+  for (int e = tid; e < JP * JP; e += JT) {
     const int r = e >> 7, c = e & 127;
     const int gr = r < JB ? I * JB + r : J * JB + (r - JB);
     const int gc = c < JB ? I * JB + c : J * JB + (c - JB);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void jacobi_pair_kernel(EighBlock* blocks,
   __syncthreads();
   // symmetrise (A is symmetric only to rounding) and measure the pivot off-norm
   float off = 0.f;
-  for (int e = tid; e < JP * JP; e += 256) {
+  for (int e = tid; e < JP * JP; e += JT) {
     const int r = e >> 7, c = e & 127;
     if (r < c) {
       const float v = 0.5f * (S[r * JLD + c] + S[c * JLD + r]);
@@ -169,11 +170,14 @@ __global__ __launch_bounds__(256) void jacobi_pair_kernel(EighBlock* blocks,
   off = wave_sum_f32(off);
   if ((tid & 63) == 0) red[tid >> 6] = off;
   __syncthreads();
-  if (tid == 0)
-    eb->offpart[round * eb->npairs + te.k] =
-        ((red[0] + red[1]) + red[2]) + red[3];
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < JT / 64; ++w) t += red[w];
+    eb->offpart[round * eb->npairs + te.k] = t;
+  }
 
   const int lane_i = tid & 127, half = tid >> 7;
+  constexpr int KSTEP = JT / 128;
   for (int rr = 0; rr < JP - 1; ++rr) {
     if (tid < JB) {
       int p, q;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256) void jacobi_pair_kernel(EighBlock* blocks,
     }
     __syncthreads();
     // rows p,q of S
-    for (int k = half; k < JB; k += 2) {
+    for (int k = half; k < JB; k += KSTEP) {
       const int p = pq[2 * k], q = pq[2 * k + 1];
       const float c = cs[2 * k], s = cs[2 * k + 1];
       const float x = S[p * JLD + lane_i], y = S[q * JLD + lane_i];
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void jacobi_pair_kernel(EighBlock* blocks,
     }
     __syncthreads();
     // columns p,q of S and of Q
-    for (int k = half; k < JB; k += 2) {
+    for (int k = half; k < JB; k += KSTEP) {
       const int p = pq[2 * k], q = pq[2 * k + 1];
       const float c = cs[2 * k], s = cs[2 * k + 1];
       float x = S[lane_i * JLD + p], y = S[lane_i * JLD + q];
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void jacobi_pair_kernel(EighBlock* blocks,
     __syncthreads();
   }
   float* Qg = eb->Q + (int64_t)te.k * JP * JP;
-  for (int e = tid; e < JP * JP; e += 256) {
+  for (int e = tid; e < JP * JP; e += JT) {
     const int r = e >> 7, c = e & 127;
     gstore1(Qg + e, Q[r * JLD + c]);
   }
@@ -659,7 +663,7 @@ extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
 
     auto sweep = [&]() {
       for (int r = 0; r < pl.max_nb - 1; ++r) {
-        hipLaunchKernelGGL(jacobi_pair_kernel, dim3(npair), blk, pair_lds, st, lo.blocks,
+        hipLaunchKernelGGL(jacobi_pair_kernel, dim3(npair), dim3(JT), pair_lds, st, lo.blocks,
                            lo.pair, r, 0);
         hipLaunchKernelGGL(jacobi_row_kernel, dim3(nrow), blk, 0, st, lo.blocks, lo.row, nrow, r);
         hipLaunchKernelGGL(jacobi_col_kernel, dim3(ncol), blk, 0, st, lo.blocks, lo.col, ncol, r);
