@@ -31,6 +31,7 @@ WORKLOADS = {
     # name: (blocks per GPU, n, k of the Wishart factor, p, seed)
     "cfg2_256x512_p4": (256, 512, 2048, 4, 1234),
     "headline_64x1024_p4": (64, 1024, 4096, 4, 1024),
+    "eigh_cfg3_64x2048_p2": (64, 2048, 4096, 2, 2048),
 }
 
 
@@ -45,7 +46,7 @@ def make_blocks(name, rank, dev):
   nb, n, k, p, seed = WORKLOADS[name]
   rng = np.random.default_rng(seed + 1000003 * rank)
   stats = torch.zeros((nb, n, n), dtype=torch.float32, device=dev)
-  chunk = 16
+  chunk = 8 if n >= 2048 else 16
   for b0 in range(0, nb, chunk):
     g = rng.standard_normal((min(chunk, nb - b0), n, k), dtype=np.float32)
     g_d = torch.from_numpy(g).to(dev)
@@ -72,7 +73,8 @@ class Workload:
     from precondition_amd import kernels as K
     _, self.metrics = K.matrix_inverse_pth_root_batched(
         list(self.stats.unbind(0)), [self.p] * self.nb,
-        padding_starts=[self.n] * self.nb, out=list(self.roots.unbind(0)))
+        padding_starts=[self.n] * self.nb, out=list(self.roots.unbind(0)),
+        eigh=self.name.startswith("eigh"))
     if self.world > 1:
       import torch.distributed as dist
       dist.all_gather_into_tensor(self.gathered.view(-1), self.roots.view(-1))
@@ -81,6 +83,65 @@ class Workload:
     """Algorithmic FLOPs of the last step on this rank."""
     it = self.metrics[:, 5].double().sum().item()  # PS_M_TOTAL_ITERS
     return it * c_of_p(self.p) * 2.0 * float(self.n) ** 3
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs[3]: ViT-B/16 parameter tree, block_size 1024, one full
+# recompute step = statistics update of every block + 395 roots (+ all-gather).
+# Strong scaling: the 395 statistics are partitioned over the ranks (LPT).
+VIT_B_SHAPES = (
+    [[16, 16, 3, 768], [768], [1, 1, 768], [1, 197, 768]] +
+    12 * [[768], [768], [768, 12, 64], [12, 64], [768, 12, 64], [12, 64],
+          [768, 12, 64], [12, 64], [12, 64, 768], [768], [768], [768],
+          [768, 3072], [3072], [3072, 768], [768]] +
+    [[768], [768], [768, 1000], [1000]])
+
+
+class VitBWorkload:
+
+  def __init__(self, rank, world, dev, group):
+    from precondition_amd.blocking import Preconditioner
+    self.group, self.world = group, world
+    self.pcs, self.grads, self.stats, self.exps = [], [], [], []
+    rng = np.random.default_rng(7)
+    for shape in VIT_B_SHAPES:
+      g = torch.from_numpy((rng.standard_normal(shape) * 0.02).astype(np.float32)).to(dev)
+      pc = Preconditioner(g, 1024, 4096, True)
+      st = [1e-6 * torch.eye(s[0], dtype=torch.float32, device=dev)
+            for s in pc.shapes_for_preconditioners()]
+      self.pcs.append(pc); self.grads.append(g); self.stats.append(st)
+      self.exps.extend([pc.exponent_for_preconditioner()] * len(st))
+    self.n_stats = sum(len(s) for s in self.stats)
+    self.metrics = None
+    self.stats_flops = 0.0
+    for pc, g in zip(self.pcs, self.grads):
+      for blk in pc.partitioned_blocks(g):
+        for d in blk.shape:
+          self.stats_flops += 2.0 * d * blk.numel()
+    for _ in range(4):  # warm statistics (beta2 = 0.999)
+      self.stats_step()
+
+  def stats_step(self):
+    from precondition_amd import kernels as K
+    items = []
+    for pc, g, st in zip(self.pcs, self.grads, self.stats):
+      items.extend(pc.statistics_update_items(st, g, st))  # in place
+    K.stats_update_grouped(items, 0.999, 1.0 - 0.999)
+
+  def step(self):
+    from precondition_amd import comm
+    self.stats_step()
+    flat = [s for st in self.stats for s in st]
+    _, self.metrics = comm.sharded_inverse_pth_roots(
+        flat, self.exps, group=self.group, ownership="lpt")
+
+  def flops(self):
+    m = self.metrics.cpu().numpy()
+    flat = [s for st in self.stats for s in st]
+    f = 0.0
+    for i, s in enumerate(flat):
+      f += m[i, 5] * c_of_p(self.exps[i]) * 2.0 * float(s.shape[0]) ** 3
+    return f  # roots of ALL ranks (metrics are gathered), statistics not included
 
 
 def timed(work, steps, warmup, world):
@@ -166,6 +227,8 @@ def main():
   ap.add_argument("--workload", default="cfg2_256x512_p4", choices=sorted(WORKLOADS))
   ap.add_argument("--no-headline", action="store_true")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-extras", action="store_true",
+                  help="skip the ViT-B (cfg4) and eigh (cfg3) side measurements")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,10 +322,69 @@ def main():
     line["headline_1024"] = head
     del hw
 
+  if not args.no_extras:
+    torch.cuda.empty_cache()
+    group = None
+    if world > 1:
+      import torch.distributed as dist
+      group = dist.group.WORLD
+    vw = VitBWorkload(rank, world, dev, group)
+    vsteps = 2
+    for _ in range(1):
+      vw.step()
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(vsteps):
+      vw.step()
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    vdt = (time.perf_counter() - t0) / vsteps
+    if world > 1:
+      t = torch.tensor([vdt], dtype=torch.float64, device="cuda")
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      vdt = t.item()
+    vm = vw.metrics.cpu().numpy()
+    vfl = vw.flops()
+    line["vit_b_cfg4"] = {
+        "workload": "ViT-B/16 tree (200 leaves, 395 statistics, block_size 1024): statistics "
+                    "update + all roots" + (" + all-gather" if world > 1 else "") +
+                    ", strong scaling (LPT ownership)",
+        "ms_per_step": round(vdt * 1e3, 3),
+        "roots_algorithmic_gflops": round(vfl / vdt / 1e9, 1),
+        "stats_gflop_per_step": round(vw.stats_flops / 1e9, 1),
+        "newton_iters": {"min": float(vm[:, 1].min()), "max": float(vm[:, 1].max()),
+                         "mean": round(float(vm[:, 1].mean()), 2)},
+        "retries_max": float(vm[:, 4].max()),
+        "failed_blocks": int((~(vm[:, 0] < 0.1)).sum()),
+    }
+    del vw
+    if world == 1 and rank == 0:
+      torch.cuda.empty_cache()
+      ew = Workload("eigh_cfg3_64x2048_p2", rank, 1, dev)
+      ew.step(); torch.cuda.synchronize()
+      t0 = time.perf_counter(); ew.step(); torch.cuda.synchronize()
+      edt = time.perf_counter() - t0
+      conv = (6 + 2.0 / 3 + 4) * 2048.0 ** 3 * 64
+      line["eigh_cfg3"] = {
+          "workload": "64 blocks of 2048x2048 fp32, p=2, eigh path (blocked Jacobi)",
+          "ms_per_step": round(edt * 1e3, 1),
+          "jacobi_sweeps": float(ew.metrics[:, 5].max()),
+          "conventional_gflops": round(conv / edt / 1e9, 1),
+          "note": "FLOP convention of SURVEY.md 8d: (6 2/3 + 4) n^3 per block incl. the error metric",
+      }
+      del ew
+
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     line["cpu_baseline"] = cpu_baseline(args.workload)
   if rank == 0:
-    print(json.dumps(line), flush=True)
+    def _plain(o):
+      if isinstance(o, (np.floating, np.integer)):
+        return o.item()
+      raise TypeError(type(o))
+    print(json.dumps(line, default=_plain), flush=True)
   if world > 1:
     import torch.distributed as dist
     dist.barrier()
