@@ -188,6 +188,23 @@ def profile_stage_kernel(work):
   return stage_ms.value, launches.value, pi_ms.value, other_ms.value
 
 
+def pmc_traffic(workload, kernel):
+  """HBM bytes per launch of `kernel` from the committed PMC summary (collected
+  with rocprofv3 --pmc in separate passes; cannot be measured live here)."""
+  path = os.path.join(ROOT, "profiles", "r01_pmc_cfg2_summary.json")
+  try:
+    with open(path) as f:
+      summ = json.load(f)
+    if summ.get("workload") != workload:
+      return None
+    for k in summ["kernels"]:
+      if k["kernel"] == kernel:
+        return k["hbm_bytes_per_launch_corrected"]
+  except (OSError, ValueError, KeyError):
+    pass
+  return None
+
+
 def cpu_baseline(name, budget_s=12.0):
   """The oracle executing the reference's op sequence (its 6 products per step
   at p=4) on the host cores, on a bounded sample of the same workload."""
@@ -286,7 +303,9 @@ def main():
         "kernel": "newton_stage_kernel",
         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-        "traffic": None,
+        "traffic": pmc_traffic(args.workload, "psk::newton_stage_kernel"),
+        "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate "
+                        "rocprofv3 --pmc passes (profiles/r01_pmc_cfg2_summary.json)",
         "launches": int(launches),
         "avg_launch_ms": round(stage_ms / max(launches, 1), 4),
         "algorithmic_gflop_per_launch": round(fl1 / max(launches, 1) / 1e9, 3),
