@@ -341,3 +341,158 @@ def newton_root_reference_opcount(matrix, p, ridge_epsilon=1e-6,
                                    padding_start=padding_start)
   finally:
     mat_power = saved
+
+
+# ---------------------------------------------------------------------------
+# Low-rank / Frequent-Directions branch (BASELINE config 5)
+# DS:520-537 _precond_dim/_should_compress ; DS:555-592 pack/unpack ;
+# DS:1033-1120 _low_rank_root ; DS:1123-1290 _fd_update_root ; DS:1473-1505
+# ---------------------------------------------------------------------------
+def precond_dim(compression_rank, dim):
+  if not compression_rank:
+    return dim
+  c = abs(compression_rank) + 2
+  return dim if c >= dim else c
+
+
+def fd_low_rank_unpack(pc, rank):
+  r = abs(rank)
+  pc = np.asarray(pc, F32)
+  return (pc[:, :r], pc[-r:, -1], pc[:r, -2], pc[0, -1], pc[1, -1], bool(pc[-1, -2]))
+
+
+def fd_low_rank_pack(eigvecs, deflated, inverted, const, tail, has_zeros, rank):
+  r = abs(rank)
+  d = eigvecs.shape[0]
+  pc = np.zeros((d, r + 2), F32)
+  pc[:, :r] = eigvecs
+  pc[:r, -2] = inverted
+  pc[0, -1] = const
+  pc[1, -1] = tail
+  pc[-r:, -1] = deflated
+  pc[-1, -2] = F32(1.0 if has_zeros else 0.0)
+  return pc
+
+
+def low_rank_root(matrix, p, compression_rank, ridge_epsilon=1e-6, error_tolerance=1e-6,
+                  relative_matrix_epsilon=True, padding_start=None):
+  """DS:1033-1120, statement by statement (LAPACK ssyevd for jnp.linalg.eigh)."""
+  matrix = np.array(matrix, F32)
+  d = matrix.shape[0]
+  alpha = F32(-1.0 / int(p))
+  identity = np.eye(d, dtype=F32)
+  ix = None
+  if padding_start is not None:
+    ix = (np.arange(d, dtype=np.int32) < padding_start).astype(F32)
+    matrix = matrix * ix[np.newaxis, :]
+    matrix = matrix * ix[:, np.newaxis]
+    identity = identity * ix
+  if relative_matrix_epsilon:
+    _, max_ev, _ = power_iteration(matrix, 100, error_tolerance, padding_start)
+  else:
+    max_ev = F32(1.0)
+  ridge = F32(F32(ridge_epsilon) * np.maximum(F32(max_ev), F32(error_tolerance)))
+  reg = matrix + ridge * identity
+  if np.all(np.isfinite(reg)):
+    e, u = np.linalg.eigh(reg)
+  else:
+    e, u = np.full(d, np.nan, F32), np.full((d, d), np.nan, F32)
+  e, u = e.astype(F32), u.astype(F32)
+  if ix is not None:
+    e = e * ix[::-1]
+  recovered = np.matmul(np.array(u.T), np.matmul(reg, u))
+  eig_error = recovered - np.diag(e)
+  if ix is not None:
+    eig_error = eig_error * ix[::-1]
+  error = F32(np.max(np.abs(eig_error)))
+  with np.errstate(all="ignore"):
+    inv_e = np.where(e == 0.0, F32(0.0), np.power(np.maximum(e, ridge), alpha)).astype(F32)
+  ps = d if padding_start is None else padding_start
+  if compression_rank < 0:
+    inv_e = np.roll(inv_e, -(d - ps))
+    u = np.roll(u, -(d - ps), axis=1)
+  else:
+    inv_e = inv_e[::-1]
+    u = u[:, ::-1]
+  r = abs(compression_rank)
+  keep_e, to_avg = inv_e[:r], inv_e[r:]
+  num = ps - r
+  const = F32(np.sum(to_avg) / (num if num > 0 else 1.0))
+  val = fd_low_rank_pack(u[:, :r], np.zeros(r, F32), keep_e, const, 0.0, False, r)
+  if padding_start is not None and padding_start == 0:
+    val = np.zeros_like(val)
+    error = F32(0.0)
+  return val, float(error)
+
+
+def frequent_directions_update(g, axis):
+  """DS:1497-1505: zero-padded R^T from qr(x^T, mode='r'); R R^T = x x^T."""
+  g = np.asarray(g, F32)
+  x = np.reshape(np.moveaxis(g, axis, 0), (g.shape[axis], -1))
+  r = np.linalg.qr(x.T, mode="r").T
+  return np.pad(r, ((0, 0), (0, x.shape[0] - r.shape[1]))).astype(F32)
+
+
+def fd_update_root(new_grad, p, rank, ridge_epsilon=1e-6, error_tolerance=1e-6,
+                   relative_matrix_epsilon=True, decay=1.0, padding_start=None, prev=None):
+  """DS:1123-1290 (without FDDiagnostics), SVD by LAPACK sgesdd as in the reference."""
+  new_grad = np.array(new_grad, F32)
+  max_size = new_grad.shape[0]
+  ps = max_size if padding_start is None else padding_start
+  sketch, fwd, _, _, tail, _ = fd_low_rank_unpack(prev, rank)
+  max_ev = fwd[0] if relative_matrix_epsilon else F32(1.0)
+  ridge = F32(F32(ridge_epsilon) * np.maximum(F32(max_ev), F32(error_tolerance)))
+  act_d = ps > np.arange(max_size)
+  act_r = ps > np.arange(rank)
+  sketch = sketch * act_d[:, None] * act_r
+  fwd = (fwd + ridge) * act_r
+  weighted = (sketch * np.sqrt(fwd)).astype(F32)
+  padded = new_grad * act_d * act_d[:, None]
+  updated = np.concatenate([F32(np.sqrt(decay)) * weighted, padded], axis=1).astype(F32)
+  u, s, _ = np.linalg.svd(updated, full_matrices=False)
+  cutoff = s[rank]
+  rho = cutoff ** 2
+  top = s[:rank]
+  deflated = (top - cutoff) * (top + cutoff)
+  eigvecs = u[:, :rank].copy()
+  tail = F32(tail * F32(decay))
+  new_tail = F32(tail + rho)
+  alpha = F32(-1.0 / int(p))
+  with np.errstate(all="ignore"):
+    new_const = F32(0.0) if new_tail <= 0 else F32(new_tail ** alpha)
+  new_tail = F32(0.0) if new_tail <= 0 else new_tail
+  deflated = np.where(deflated <= 0, F32(0.0), deflated).astype(F32)
+  eigvecs = eigvecs * (deflated > 0)
+  norms = np.linalg.norm(eigvecs, axis=0)
+  safe = (0.99 <= norms) & (norms <= 1.01)
+  eigvecs = eigvecs * safe
+  deflated = deflated * safe
+  eigvecs = eigvecs / np.where(safe, norms, 1.0)
+  pad_ix = np.arange(max_size) >= ps
+  mass = np.linalg.norm(eigvecs * pad_ix[:, None], axis=0, ord=1)
+  has_pad = mass > 0.01
+  eigvecs = eigvecs * (1 - has_pad)
+  deflated = deflated * (1 - has_pad)
+  up = (np.square(top) + tail) * (deflated > 0.0)
+  up = np.where(up <= 0, F32(0.0), up)
+  with np.errstate(all="ignore"):
+    inverted = np.where(up <= 0, F32(0.0), up ** alpha).astype(F32)
+  has_zeros = bool(np.any(deflated <= 0)) or bool(new_tail <= 0)
+  val = fd_low_rank_pack(eigvecs.astype(F32), deflated.astype(F32), inverted, new_const,
+                         new_tail, has_zeros, rank)
+  if padding_start is not None and padding_start == 0:
+    val = np.zeros_like(val)
+  return val
+
+
+def precondition_block_low_rank(g, pc, rank):
+  """DS:1690-1705 for one axis: low-rank + constant application, result rolled."""
+  eigvecs, _, eigvals, const, _, skip = fd_low_rank_unpack(pc, rank)
+  nd = g.ndim
+  basis = np.tensordot(g, eigvecs, axes=[[0], [0]])
+  comp = np.tensordot(basis, eigvecs, axes=[[nd - 1], [1]])
+  gr = np.transpose(g, tuple(range(1, nd)) + (0,))
+  complement = gr - comp
+  scaled = np.tensordot(basis * eigvals, eigvecs, axes=[[nd - 1], [1]])
+  new_g = const * complement + scaled
+  return (gr if skip else new_g).astype(F32)

@@ -73,6 +73,9 @@ _SIGNATURES = {
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ps_eigh_batched_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ps_profile_enable": (C.c_int, [C.c_int]),
     "ps_profile_reset": (C.c_int, []),
     "ps_profile_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

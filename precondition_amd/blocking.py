@@ -260,12 +260,17 @@ class Preconditioner:
     assert len(sel) == rank
     return sel
 
-  def preconditioned_grad(self, grad, preconditioners, tensordot_fn=None):
+  def preconditioned_grad(self, grad, preconditioners, tensordot_fn=None,
+                          matmul_fn=None):
     """Per block: contract every preconditioned axis with its factor, keeping
     the axes in their original cyclic order."""
     if tensordot_fn is None:
       from . import kernels
       tensordot_fn = kernels.tensordot_axis0
+    if matmul_fn is None:
+      from . import kernels
+      matmul_fn = kernels.matmul
+    self._matmul_fn = matmul_fn
     should = self.should_precondition_dims()
     num = sum(should)
     out_blocks = []
@@ -286,7 +291,21 @@ class Preconditioner:
       pc = preconditioners[j]
       dim, application_dim = pc.shape
       if application_dim != dim:
-        raise NotImplementedError("rank-compressed preconditioners (config 5)")
+        # low rank + constant (DS:1689-1705): g' = const * (g - B E^T) + (B * eigs) E^T
+        # with B = tensordot(g, E, [[0],[0]]); result has the contracted axis last.
+        r = abs(self._compression_rank)
+        eigvecs = pc[:, :r].contiguous()
+        eigvals, const, skip = pc[:r, -2], pc[0, -1], pc[-1, -2].bool()
+        basis = tensordot_fn(g, eigvecs)                      # [..., r]
+        b2 = basis.reshape(-1, r)
+        lowrank = self._matmul_fn(b2, eigvecs, transb=True).reshape(
+            tuple(basis.shape[:-1]) + (dim,))
+        g = g.permute(*range(1, rank), 0)
+        scaled = self._matmul_fn((b2 * eigvals).contiguous(), eigvecs, transb=True
+                                 ).reshape(lowrank.shape)
+        new_g = const * (g - lowrank) + scaled
+        g = torch.where(skip, g, new_g)
+        continue
       # tensordot(g, P, axes=[[0],[0]]): leading axis contracted, result last.
       g = tensordot_fn(g, pc)
     return g

@@ -81,13 +81,18 @@ def sharded_inverse_pth_roots(
     eigh: bool = False,
     ownership: str = "reference",
     root_fn: Optional[Callable] = None,
+    out_cols: Optional[Sequence[int]] = None,
+    compute_fn: Optional[Callable] = None,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
 
   Returns (roots in list order, metrics [num_statistics, 8]) on every rank.
   `root_fn(matrices, ps, padding_starts, out=..., **kw) -> (roots, metrics)`
   defaults to the HIP batched root; tests inject a CPU function to exercise the
-  sharding over gloo.
+  sharding over gloo.  `out_cols[i]` (default n_i) is the stored width of result i
+  (rank-compressed preconditioners are [n, rank+2], DS:520-532); `compute_fn(
+  indices, outs) -> metrics[len(indices), 8]` replaces the plain batched root when
+  statistics need per-index treatment (low-rank / Frequent-Directions branch).
   """
   n_stats = len(statistics)
   world, rank = world_and_rank(group)
@@ -102,6 +107,7 @@ def sharded_inverse_pth_roots(
     from . import kernels
     root_fn = kernels.matrix_inverse_pth_root_batched
 
+  cols = [int(c) for c in out_cols] if out_cols is not None else list(sizes)
   # Offsets of every statistic inside its owner's flat buffer; all ranks derive
   # the same table from shapes alone (no communication).
   offsets, fill = [0] * n_stats, [0] * world
@@ -109,7 +115,7 @@ def sharded_inverse_pth_roots(
   for i in range(n_stats):
     r = owner[i]
     offsets[i] = fill[r]
-    fill[r] += sizes[i] * sizes[i]
+    fill[r] += sizes[i] * cols[i]
     slot[i] = count[r]
     count[r] += 1
   buf_elems = max(max(fill), 1)
@@ -120,12 +126,15 @@ def sharded_inverse_pth_roots(
   mine = [i for i in range(n_stats) if owner[i] == rank]
   send_metrics = torch.zeros((max_count, METRICS_STRIDE), dtype=torch.float32, device=dev)
   if mine:
-    outs = [send[offsets[i]:offsets[i] + sizes[i] * sizes[i]].view(sizes[i], sizes[i])
+    outs = [send[offsets[i]:offsets[i] + sizes[i] * cols[i]].view(sizes[i], cols[i])
             for i in mine]
-    _, m = root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
-                   [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
-                   relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
-                   out=outs)
+    if compute_fn is not None:
+      m = compute_fn(mine, outs)
+    else:
+      _, m = root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
+                     [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
+                     relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
+                     out=outs)
     send_metrics[:len(mine)] = m
 
   if world == 1:
@@ -143,8 +152,8 @@ def sharded_inverse_pth_roots(
     gathered_metrics = gathered_metrics.view(world, max_count, METRICS_STRIDE)
 
   roots = [
-      gathered[owner[i], offsets[i]:offsets[i] + sizes[i] * sizes[i]].view(
-          sizes[i], sizes[i]) for i in range(n_stats)
+      gathered[owner[i], offsets[i]:offsets[i] + sizes[i] * cols[i]].view(
+          sizes[i], cols[i]) for i in range(n_stats)
   ]
   index = torch.tensor([owner[i] * max_count + slot[i] for i in range(n_stats)],
                        dtype=torch.long, device=dev)

@@ -53,6 +53,7 @@ struct EighBlock {
   float* offpart;  // [npairs * rounds] pivot off-norm^2 partials of the current sweep
   float* sumsq_partial;
   float* evals;
+  float* evals_out;  // mode 1 only
   int n, n_full, lda, ldo, npad, nb, npairs, p;
   float alpha, ridge, max_ev, normD;
   int active, sweeps;
@@ -438,6 +439,21 @@ __global__ __launch_bounds__(256) void eigh_scale_kernel(EighBlock* blocks,
   }
 }
 
+// mode 1: eigenvalues = diag(A), eigenvectors = V[:, :n] (cropped to n x n).
+__global__ __launch_bounds__(256) void eigh_copy_pairs_kernel(EighBlock* blocks,
+                                                              const ETile* tiles) {
+  const ETile te = tiles[blockIdx.x];
+  EighBlock* eb = &blocks[te.block];
+  const int ld = eb->npad, n = eb->n, tid = threadIdx.x;
+  for (int e = tid; e < TILE * TILE; e += 256) {
+    const int row = te.k * TILE + e / TILE, col = te.t * TILE + e % TILE;
+    if (row < n && col < n) {
+      eb->out[(int64_t)row * eb->ldo + col] = eb->V[(int64_t)row * ld + col];
+      if (row == col) eb->evals_out[col] = eb->A[(int64_t)col * ld + col];
+    }
+  }
+}
+
 __global__ void eigh_metrics_kernel(EighBlock* blocks, int nblocks, float* metrics) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblocks) return;
@@ -563,19 +579,22 @@ extern "C" size_t ps_eigh_root_workspace_bytes(int batch, const int32_t* n) {
   return ecarve(pl, ar, nullptr) + 256;
 }
 
-extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
-                                        const int32_t* n, const int32_t* lda,
-                                        const int32_t* p, const int32_t* padding_start,
-                                        int batch, float ridge_epsilon,
-                                        float error_tolerance, int relative_matrix_epsilon,
-                                        float* const* out, const int32_t* ldo,
-                                        float* metrics, void* workspace,
-                                        size_t workspace_bytes) {
-  if (batch <= 0 || !a || !n || !lda || !p || !out || !ldo || !metrics || !workspace)
-    return PS_EINVAL;
+// mode 0: inverse p-th root (out = val, metrics).  mode 1: plain eigenpairs
+// (out = eigenvectors [n, n] in columns, evals_out = eigenvalues, Jacobi order).
+static int eigh_driver(int mode, void* stream, const float* const* a, const int32_t* n,
+                       const int32_t* lda, const int32_t* p, const int32_t* padding_start,
+                       int batch, float ridge_epsilon, float error_tolerance,
+                       int relative_matrix_epsilon, float* const* out, const int32_t* ldo,
+                       float* const* evals_out, float* metrics, void* workspace,
+                       size_t workspace_bytes) {
+  if (batch <= 0 || !a || !n || !lda || !out || !ldo || !workspace) return PS_EINVAL;
+  if (mode == 0 && (!p || !metrics)) return PS_EINVAL;
+  if (mode == 1 && !evals_out) return PS_EINVAL;
   for (int b = 0; b < batch; ++b)
-    if (n[b] < 1 || lda[b] < n[b] || ldo[b] < n[b] || !a[b] || !out[b] || p[b] < 1)
+    if (n[b] < 1 || lda[b] < n[b] || ldo[b] < n[b] || !a[b] || !out[b] ||
+        (mode == 0 && p[b] < 1) || (mode == 1 && !evals_out[b]))
       return PS_EINVAL;
+  if (mode == 1) relative_matrix_epsilon = 0;
   hipStream_t st = (hipStream_t)stream;
   EPlan pl;
   make_eplan(pl, batch, n, padding_start);
@@ -604,8 +623,10 @@ extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
     eb.X = lo.mat[4][b]; eb.Q = lo.Q[b]; eb.offpart = lo.offp[b];
     eb.sumsq_partial = lo.ssq[b]; eb.evals = lo.evals[b];
     eb.n = pl.n_eff[b]; eb.n_full = n[b]; eb.lda = lda[b]; eb.ldo = ldo[b];
-    eb.npad = pl.npad[b]; eb.nb = pl.npad[b] / JB; eb.npairs = eb.nb / 2; eb.p = p[b];
-    eb.alpha = (float)(-1.0 / p[b]);
+    eb.npad = pl.npad[b]; eb.nb = pl.npad[b] / JB; eb.npairs = eb.nb / 2;
+    eb.p = mode == 0 ? p[b] : 1;
+    eb.alpha = (float)(-1.0 / eb.p);
+    eb.evals_out = mode == 1 ? evals_out[b] : nullptr;
     eb.active = eb.n > 0 ? 1 : 0;
     eb.off_rel = 1.f;
     PiBlock& pb = hp[b];
@@ -652,7 +673,8 @@ extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
     hipLaunchKernelGGL(pi_final_kernel, dim3(batch), blk, 0, st, lo.pis, 100, (float*)nullptr,
                        (int*)nullptr, (float*)nullptr, 0);
   hipLaunchKernelGGL(eigh_setup_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
-                     lo.pis, batch, ridge_epsilon, error_tolerance, relative_matrix_epsilon);
+                     lo.pis, batch, mode == 0 ? ridge_epsilon : 0.f, error_tolerance,
+                     relative_matrix_epsilon);
   PS_LAUNCH_CHECK();
 
   if (nsq > 0) {
@@ -704,6 +726,11 @@ extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
     // phase 2: finish (quadratic): stop once a sweep STARTED below 1e-4
     if ((rc = run_phase(1e-4f, 4))) return rc;
 
+    if (mode == 1) {
+      hipLaunchKernelGGL(eigh_copy_pairs_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      PS_LAUNCH_CHECK();
+      return PS_OK;
+    }
     // root and error metric
     hipLaunchKernelGGL(eigh_scale_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
     hipLaunchKernelGGL((eigh_gemm_kernel<KC, KC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
@@ -713,9 +740,31 @@ extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
     hipLaunchKernelGGL((eigh_gemm_kernel<MC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
                        (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_ERR);
   }
+  if (mode == 1) return PS_OK;
   hipLaunchKernelGGL(eigh_zero_out_kernel, dim3(batch, 16), blk, 0, st, lo.blocks);
   hipLaunchKernelGGL(eigh_metrics_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
                      batch, metrics);
   PS_LAUNCH_CHECK();
   return PS_OK;
+}
+
+extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
+                                        const int32_t* n, const int32_t* lda,
+                                        const int32_t* p, const int32_t* padding_start,
+                                        int batch, float ridge_epsilon,
+                                        float error_tolerance, int relative_matrix_epsilon,
+                                        float* const* out, const int32_t* ldo,
+                                        float* metrics, void* workspace,
+                                        size_t workspace_bytes) {
+  return eigh_driver(0, stream, a, n, lda, p, padding_start, batch, ridge_epsilon,
+                     error_tolerance, relative_matrix_epsilon, out, ldo, nullptr, metrics,
+                     workspace, workspace_bytes);
+}
+
+extern "C" int ps_eigh_batched_f32(void* stream, const float* const* a, const int32_t* n,
+                                   const int32_t* lda, int batch, float* const* evals,
+                                   float* const* evecs, const int32_t* ldv, void* workspace,
+                                   size_t workspace_bytes) {
+  return eigh_driver(1, stream, a, n, lda, nullptr, nullptr, batch, 0.f, 0.f, 0, evecs, ldv,
+                     evals, nullptr, workspace, workspace_bytes);
 }

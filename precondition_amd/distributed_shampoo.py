@@ -30,7 +30,7 @@ import torch
 
 from . import comm
 from . import pytree
-from .blocking import Preconditioner, _precond_dim
+from .blocking import Preconditioner, _precond_dim, _should_compress
 from .state import (GradientTransformation, GraftingType, MaskedNode,
                     ParameterStats, PreconditionerType, QuantizedValue,
                     ShampooState, TrainingMetrics, init_training_metrics)
@@ -128,8 +128,12 @@ def distributed_shampoo(
     raise NotImplementedError("quantized optimizer state is out of scope (f3)")
   if lobpcg_topk_precondition:
     raise NotImplementedError("LOBPCG deflation is out of scope")
-  if compression_rank != 0 or frequent_directions:
-    raise NotImplementedError("Sketchy / low-rank branch (config 5) is not built yet")
+  if generate_fd_metrics:
+    raise NotImplementedError("FDDiagnostics (generate_fd_metrics) are not built")
+  reset_frequency = None
+  if reset_preconditioner:  # DS:2022-2024
+    reset_frequency = int(np.round(1 / (1 - beta2))) if beta2 != 1 else None
+    beta2 = 1.0
 
   group = comm.resolve_group(batch_axis_name)
   if _backend_for_testing is not None:
@@ -175,7 +179,7 @@ def distributed_shampoo(
       return ParameterStats(
           _quantize(diagonal_statistics), statistics, preconditioners,
           _quantize(torch.zeros_like(param)), _quantize(torch.zeros_like(param)),
-          MaskedNode(),
+          torch.zeros_like(param) if (frequent_directions and average_grad) else MaskedNode(),
           init_training_metrics(len(statistics), generate_training_metrics,
                                 generate_fd_metrics, device=dev))
 
@@ -188,24 +192,44 @@ def distributed_shampoo(
     w1 = beta2
     w2 = beta2 if beta2 == 1.0 else 1.0 - beta2  # DS:2635-2636
     perform = statistics_compute_steps <= 1 or step % statistics_compute_steps == 0
-    new_lists, items = [], []
+    new_lists, items, fd_items, new_avg = [], [], [], []
     for grad, state, param in zip(grads_flat, stats_flat, params_flat):
-      if _skip_preconditioning(param) or not perform:
-        new_lists.append(state.statistics if not _skip_preconditioning(param)
-                         else [[]] * len(state.statistics))
+      avg = MaskedNode()
+      if _skip_preconditioning(param):
+        new_lists.append([[]] * len(state.statistics))
+        new_avg.append(avg)
+        continue
+      if frequent_directions and average_grad:  # DS:2640-2645
+        if statistics_compute_steps == 1 or step % statistics_compute_steps == 1:
+          avg = grad
+        else:
+          avg = state.avg_grad + grad
+        grad = avg / statistics_compute_steps
+      new_avg.append(avg)
+      if not perform:
+        new_lists.append(state.statistics)
         continue
       pc = preconditioner_from_params(param)
       olds = [s.contiguous() for s in state.statistics]
       news = [torch.empty_like(s) for s in olds]
-      items.extend(pc.statistics_update_items(olds, grad, news))
+      for it in pc.statistics_update_items(olds, grad, news):
+        g_blk, axis = it[0], it[1]
+        if frequent_directions and _should_compress(compression_rank, g_blk.shape[axis]):
+          # FD (DS:1585-1588): the slot holds the Gram matrix of the (averaged)
+          # gradient block itself (w1/w2 ignored, DS:1496).  The reference stores a
+          # triangular factor R of it; only R R^T is ever consumed (DS:1179-1193).
+          fd_items.append(it)
+        else:
+          items.append(it)
       new_lists.append(news)
     if items:
       backend.stats_update_grouped(items, w1, w2)
+    if fd_items:
+      backend.stats_update_grouped(fd_items, 0.0, 1.0)
     return [
         ParameterStats(s.diagonal_statistics, ns, s.preconditioners,
-                       s.diagonal_momentum, s.momentum, MaskedNode(),
-                       s.training_metrics)
-        for s, ns in zip(stats_flat, new_lists)
+                       s.diagonal_momentum, s.momentum, av, s.training_metrics)
+        for s, ns, av in zip(stats_flat, new_lists, new_avg)
     ]
 
   # ---------------------------------------------------------------------------
@@ -237,11 +261,73 @@ def distributed_shampoo(
       # previous preconditioner; metrics keep their old values (DS:2983-2986).
       return states
 
+    sizes = [int(s.shape[0]) for s in statistics]
+    compute_fn, out_cols = None, None
+    if compression_rank != 0:
+      max_size = max(sizes)
+      assert _precond_dim(compression_rank, max_size) < max_size, (
+          "all layers are too small for compression_rank")  # DS:2127-2133
+      out_cols = [_precond_dim(compression_rank, n) for n in sizes]
+      if frequent_directions:
+        assert reuse_preconditioner, "frequent_directions needs the previous sketch (DS:1137)"
+
+      def prev_for(i):  # DS:2140-2154 (reset) ; true-size, so no padding needed
+        pp = prev[i]
+        if reset_frequency is not None and step % reset_frequency == 0:
+          pp = torch.zeros_like(pp)
+        return pp
+
+      def compute_fn(indices, outs):  # new_mi_pth_root dispatch, DS:2706-2738
+        rows = torch.zeros((len(indices), comm.METRICS_STRIDE), dtype=torch.float32,
+                           device=statistics[0].device)
+        dense = [k for k, i in enumerate(indices)
+                 if not _should_compress(compression_rank, sizes[i])]
+        if dense:
+          _, m = backend.matrix_inverse_pth_root_batched(
+              [statistics[indices[k]] for k in dense], [exponents[indices[k]] for k in dense],
+              [sizes[indices[k]] for k in dense], ridge_epsilon=matrix_epsilon,
+              relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
+              out=[outs[k] for k in dense])
+          rows[dense] = m
+        for k, i in enumerate(indices):
+          if k in dense:
+            continue
+          if frequent_directions:
+            # The reference packs the sketch at the PADDED size (every statistic is
+            # padded to max_size, DS:2841-2843) and then crops to the block's own
+            # rows (DS:2950): for blocks smaller than max_size the deflated
+            # eigenvalues / has_zeros entries, which live in the last rows
+            # (DS:587-591), fall outside the crop.  Reproduced here so that the
+            # optimizer trajectory is identical.
+            n_i, stat_i, prev_i = sizes[i], statistics[i], prev_for(i)
+            if n_i < max_size:
+              gp = torch.zeros((max_size, max_size), dtype=torch.float32, device=stat_i.device)
+              gp[:n_i, :n_i] = stat_i
+              pp = torch.zeros((max_size, prev_i.shape[1]), dtype=torch.float32,
+                               device=stat_i.device)
+              pp[:n_i] = prev_i
+              stat_i, prev_i = gp, pp
+            val, tm = backend.fd_update_root(
+                stat_i, exponents[i], rank=compression_rank,
+                ridge_epsilon=matrix_epsilon,
+                relative_matrix_epsilon=relative_matrix_epsilon, decay=beta2,
+                padding_start=n_i, prev=prev_i, new_grad_is_gram=True)
+            val = val[:n_i]
+          else:
+            val, tm = backend.low_rank_root(
+                statistics[i], exponents[i], compression_rank=compression_rank,
+                ridge_epsilon=matrix_epsilon,
+                relative_matrix_epsilon=relative_matrix_epsilon, padding_start=sizes[i])
+          outs[k].copy_(val)
+          rows[k, 0] = tm.inverse_pth_root_errors
+        return rows
+
     roots, metrics = comm.sharded_inverse_pth_roots(
         statistics, exponents, group=group, ridge_epsilon=matrix_epsilon,
         relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
         ownership=block_ownership,
-        root_fn=backend.matrix_inverse_pth_root_batched)
+        root_fn=backend.matrix_inverse_pth_root_batched, out_cols=out_cols,
+        compute_fn=compute_fn)
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
     new_p = []
     for i, (root, old) in enumerate(zip(roots, prev)):
@@ -308,7 +394,8 @@ def distributed_shampoo(
 
     if not _skip_preconditioning(param):
       precond_grad = pc.preconditioned_grad(grad, state.preconditioners,
-                                            tensordot_fn=backend.tensordot_axis0)
+                                            tensordot_fn=backend.tensordot_axis0,
+                                            matmul_fn=backend.matmul)
     else:
       if graft_type == GraftingType.NONE:
         logging.error("skipping preconditioning without grafting for param %s", param)

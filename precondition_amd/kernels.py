@@ -143,6 +143,37 @@ def matrix_inverse_pth_root(matrix: torch.Tensor, p: int, num_iters: int = 100,
       final_error_ratio=m[0, 2], max_eigen_value=m[0, 3], total_retries=m[0, 4])
 
 
+def eigh_batched(matrices: Sequence[torch.Tensor]):
+  """jnp.linalg.eigh for a batch of symmetric matrices (blocked Jacobi on the
+  GPU).  Returns (eigenvalues ascending [n], eigenvectors [n, n] in columns) per
+  matrix, LAPACK order; signs of eigenvectors are arbitrary."""
+  batch = len(matrices)
+  dev = matrices[0].device
+  for m in matrices:
+    _require_gpu(m, "eigh")
+  mats = [m.contiguous() for m in matrices]
+  n = _i32([m.shape[0] for m in mats])
+  lda = _i32([_as_2d_ld(m) for m in mats])
+  evals = [torch.empty((int(k),), dtype=torch.float32, device=dev) for k in n]
+  evecs = [torch.empty((int(k), int(k)), dtype=torch.float32, device=dev) for k in n]
+  ldv = _i32([max(int(k), 1) for k in n])
+  L = lib()
+  ws = _workspace(L.ps_eigh_root_workspace_bytes(batch, n.ctypes.data), dev)
+  a_ptrs, e_ptrs, v_ptrs = _ptrs(mats), _ptrs(evals), _ptrs(evecs)
+  rc = L.ps_eigh_batched_f32(_stream(), a_ptrs.ctypes.data, n.ctypes.data,
+                             lda.ctypes.data, batch, e_ptrs.ctypes.data,
+                             v_ptrs.ctypes.data, ldv.ctypes.data, ws.data_ptr(),
+                             ws.numel())
+  check(rc, "ps_eigh_batched_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  out_e, out_v = [], []
+  for e, v in zip(evals, evecs):
+    order = torch.argsort(e)  # pure permutation (data movement, no arithmetic)
+    out_e.append(e[order])
+    out_v.append(v[:, order])
+  return out_e, out_v
+
+
 def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
                     error_tolerance: float = 1e-6,
                     padding_start: Optional[int] = None):
@@ -337,3 +368,16 @@ def gram_weighted_update(old_stats: torch.Tensor, g: torch.Tensor, axis: int,
   out = torch.empty_like(old)
   stats_update_grouped([(g, axis, old, out)], w1, w2)
   return out
+
+
+# ---------------------------------------------------------------------------
+# low-rank / Frequent-Directions branch (backend interface of distributed_shampoo)
+# ---------------------------------------------------------------------------
+def low_rank_root(*args, **kwargs):
+  from . import low_rank
+  return low_rank._low_rank_root(*args, **kwargs)
+
+
+def fd_update_root(*args, **kwargs):
+  from . import low_rank
+  return low_rank._fd_update_root(*args, **kwargs)

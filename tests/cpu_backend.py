@@ -42,3 +42,38 @@ def matrix_inverse_pth_root_batched(matrices, ps, padding_starts=None, num_iters
 def tensordot_axis0(g, pc):
   return torch.from_numpy(
       np.tensordot(g.cpu().numpy(), pc.cpu().numpy(), axes=[[0], [0]]).astype(np.float32))
+
+
+def matmul(a, b, transa=False, transb=False):
+  x = a.cpu().numpy().T if transa else a.cpu().numpy()
+  y = b.cpu().numpy().T if transb else b.cpu().numpy()
+  return torch.from_numpy((x @ y).astype(np.float32))
+
+
+class _TM:
+
+  def __init__(self, err):
+    self.inverse_pth_root_errors = torch.tensor(err, dtype=torch.float32)
+
+
+def low_rank_root(matrix, p, compression_rank=0, ridge_epsilon=1e-6, error_tolerance=1e-6,
+                  relative_matrix_epsilon=True, padding_start=None, prev=None):
+  val, err = orc.low_rank_root(matrix.cpu().numpy(), p, compression_rank, ridge_epsilon,
+                               error_tolerance, relative_matrix_epsilon, padding_start)
+  return torch.from_numpy(val), _TM(err)
+
+
+def fd_update_root(new_grad, p, rank=0, ridge_epsilon=1e-6, error_tolerance=1e-6,
+                   relative_matrix_epsilon=True, decay=1.0, padding_start=None, prev=None,
+                   new_grad_is_gram=False, **_):
+  g = new_grad.cpu().numpy()
+  if new_grad_is_gram:  # any factor with R R^T = Gram serves (DS:1179-1193)
+    w, v = np.linalg.eigh(g.astype(np.float64))
+    w = np.where(w <= g.shape[0] * 1.2e-7 * max(w.max(), 0.0), 0.0, w)  # keep exact rank deficiency
+    # (the reference's QR factor of a thin matrix has exact zero columns)
+    # nonzero columns first, like the triangular factor (the reference masks the
+    # factor's COLUMNS >= padding_start, DS:1173-1174)
+    g = (v[:, ::-1] * np.sqrt(w[::-1])).astype(np.float32)
+  val = orc.fd_update_root(g, p, rank, ridge_epsilon, error_tolerance,
+                           relative_matrix_epsilon, decay, padding_start, prev.cpu().numpy())
+  return torch.from_numpy(val), _TM(0.0)

@@ -113,3 +113,24 @@ def test_reference_ownership_with_padding():
   assert [owner.count(r) for r in range(8)] == [50] * 7 + [45]
   lpt = comm.cost_balanced_ownership([768] * 6 + [1024] * 2, [4] * 8, 2)
   assert sorted(set(lpt)) == [0, 1]
+
+
+def test_fd_pack_unpack_roundtrip_bit_exact():
+  """DST:753-768: pack(unpack(x)) == x, bit for bit, and the exact cell layout of
+  DS:555-592."""
+  from precondition_amd import low_rank
+  rng = np.random.default_rng(0)
+  for d, r in ((12, 4), (40, 3), (9, 1)):
+    vecs = torch.from_numpy(rng.standard_normal((d, r)).astype(np.float32))
+    defl = torch.from_numpy(rng.random(r).astype(np.float32))
+    inv = torch.from_numpy(rng.random(r).astype(np.float32))
+    packed = low_rank._fd_low_rank_pack(vecs, defl, inv, 0.25, 0.75, True, r)
+    assert tuple(packed.shape) == (d, r + 2)
+    assert torch.equal(packed[:, :r], vecs) and torch.equal(packed[:r, -2], inv)
+    assert float(packed[0, -1]) == 0.25 and float(packed[1, -1]) == 0.75
+    assert torch.equal(packed[-r:, -1], defl) and float(packed[-1, -2]) == 1.0
+    un = low_rank._fd_low_rank_unpack(packed, r)
+    again = low_rank._fd_low_rank_pack(un[0], un[1], un[2], un[3], un[4], un[5], r)
+    assert torch.equal(again, packed)
+    ev, inv2, const, hz = low_rank._low_rank_unpack(packed, -r)
+    assert torch.equal(inv2, inv) and float(const) == 0.25 and bool(hz)

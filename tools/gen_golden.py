@@ -386,6 +386,25 @@ def gen_e2e():
           precondtioner_type=ds.PreconditionerType.INPUT,
           graft_type=ds.GraftingType.SQRT_N, exponent_override=3), 4, "fresh"),
   ]
+  shapes_c = ([40, 24], [70, 33], [6, 10, 8], [12])
+  configs += [
+      # DST:116-261 'pos/neg_compression_rank(+nomerge)' analogues on a larger tree
+      ("tree_c_lowrank_pos3", tree(shapes_c, 6), None, dict(
+          block_size=32, preconditioning_compute_steps=2, start_preconditioning_step=2,
+          compression_rank=3, merge_small_dims_block_size=1), 6, "fresh"),
+      ("tree_c_lowrank_neg2", tree(shapes_c, 7), None, dict(
+          block_size=32, preconditioning_compute_steps=1, start_preconditioning_step=1,
+          compression_rank=-2), 4, "fresh"),
+      ("tree_c_fd_r4", tree(shapes_c, 8), None, dict(
+          block_size=32, preconditioning_compute_steps=1, statistics_compute_steps=1,
+          start_preconditioning_step=1, compression_rank=4, frequent_directions=True,
+          reuse_preconditioner=True, merge_small_dims_block_size=1), 5, "fresh"),
+      ("tree_c_fd_r3_avg_reset", tree(shapes_c, 9), None, dict(
+          block_size=32, preconditioning_compute_steps=2, statistics_compute_steps=2,
+          start_preconditioning_step=2, compression_rank=3, frequent_directions=True,
+          reuse_preconditioner=True, average_grad=True, reset_preconditioner=True,
+          beta2=0.8, merge_small_dims_block_size=1), 8, "fresh"),
+  ]
   for name, params, _, kw, steps, gmode in configs:
     lr = 0.1
     opt = ds.distributed_shampoo(lr, batch_axis_name=None, **kw)
@@ -439,8 +458,67 @@ def gen_e2e():
     json.dump(index, f, indent=1)
 
 
+def gen_lowrank():
+  """_low_rank_root / _fd_update_root / pack-unpack goldens (config 5 branch)."""
+  out, index = {}, []
+  rng = np.random.default_rng(1234)
+
+  def lr_case(name, a, p, rank, ridge, rel, ps):
+    with np.errstate(all="ignore"):
+      r, m = ds._low_rank_root(jnp.array(a), p, compression_rank=rank, ridge_epsilon=ridge,
+                               relative_matrix_epsilon=rel, padding_start=ps)
+    out[f"lr_{name}__a"] = a.astype(F32)
+    out[f"lr_{name}__packed"] = npy(r)
+    out[f"lr_{name}__err"] = np.array(float(np.asarray(m.inverse_pth_root_errors)), F32)
+    index.append(dict(kind="low_rank_root", name=name, p=p, rank=rank, ridge=ridge,
+                      rel=rel, padding_start=ps))
+    print("low_rank_root", name, "err", float(np.asarray(m.inverse_pth_root_errors)))
+
+  for p in (2, 4, 8):  # DST:482-500
+    a = np.zeros([4, 4], F32); a[0, 0] = 2 ** p
+    lr_case(f"dyn_p{p}", a, p, 1, 0.0, False, None)
+  b = rng.standard_normal(size=[5, 5]); b = (b.T @ b).astype(F32)
+  for padded, rank in ((5, 2), (8, 2), (5, -2), (8, -2)):  # DST:502-558
+    pa = np.zeros([padded, padded], F32); pa[:5, :5] = b
+    lr_case(f"basic_{padded}_r{rank}", pa, 2, rank, 0.1, False, 5)
+  lr_case("wishart40_r4_rel", wishart(40, 160, 77), 4, 4, 1e-6, True, None)
+  pa = np.zeros([32, 32], F32); pa[:24, :24] = wishart(24, 96, 78)
+  lr_case("padded24in32_rm3", pa, 2, -3, 1e-6, True, 24)
+
+  def fd_chain(name, d, rank, p, ps, decay, rel, ridge, steps, seed):
+    r = np.random.default_rng(seed)
+    prev = jnp.zeros((d, rank + 2), jnp.float32)
+    for t in range(steps):
+      g = r.standard_normal((ps, 3 * ps)).astype(F32) * (1.0 + 0.3 * t)
+      # directions with clear gaps so that the top-rank subspace is well defined
+      g[:rank + 2] *= np.linspace(6.0, 2.0, rank + 2)[:, None].astype(F32)
+      gfull = np.zeros((d, g.shape[1]), F32); gfull[:ps] = g
+      fac = ds.frequent_directions_update(None, jnp.array(gfull), 0, 0.0, 0.0)
+      out[f"fd_{name}__grad{t}"] = gfull
+      out[f"fd_{name}__factor{t}"] = npy(fac)
+      with np.errstate(all="ignore"):
+        new, _ = ds._fd_update_root(fac, p, rank=rank, ridge_epsilon=ridge,
+                                    relative_matrix_epsilon=rel, decay=decay,
+                                    padding_start=ps, prev=prev, error_tolerance=0.0)
+      out[f"fd_{name}__prev{t}"] = npy(prev)
+      out[f"fd_{name}__new{t}"] = npy(new)
+      prev = new
+    index.append(dict(kind="fd_chain", name=name, d=d, rank=rank, p=p, padding_start=ps,
+                      decay=decay, rel=rel, ridge=ridge, steps=steps))
+    ev = np.asarray(ds._fd_low_rank_unpack(prev, rank)[1])
+    print("fd_chain", name, "final deflated eigs", ev[:4], "tail", float(np.asarray(prev)[1, -1]))
+
+  fd_chain("d24_r4_p2", 24, 4, 2, 24, 1.0, False, 0.0, 3, 1)
+  fd_chain("d24_r4_p4_decay", 24, 4, 4, 24, 0.9, True, 1e-6, 3, 2)
+  fd_chain("d32_r5_pad26", 32, 5, 2, 26, 0.999, True, 1e-6, 3, 3)
+  fd_chain("d160_r8", 160, 8, 4, 160, 0.999, True, 1e-6, 2, 4)
+  np.savez_compressed(os.path.join(OUT, "low_rank.npz"), **out)
+  with open(os.path.join(OUT, "low_rank_index.json"), "w") as f:
+    json.dump(index, f, indent=1)
+
+
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e"]
+  which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e", "lowrank"]
   if "newton" in which:
     gen_newton()
   if "pi" in which:
@@ -453,4 +531,6 @@ if __name__ == "__main__":
     gen_bookkeeping()
   if "e2e" in which:
     gen_e2e()
+  if "lowrank" in which:
+    gen_lowrank()
   print("golden fixtures written to", OUT)
