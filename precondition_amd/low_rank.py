@@ -146,6 +146,9 @@ def frequent_directions_update(old_stats_factor, g: torch.Tensor, axis: int, w1,
   del old_stats_factor, w1, w2
   gram = gram_of_block(g, axis)
   (e,), (u,) = kernels.eigh_batched([gram])
+  # significant columns first (descending), like the triangular factor: the
+  # consumer masks factor COLUMNS >= padding_start (DS:1173-1174)
+  e, u = torch.flip(e, dims=[0]), torch.flip(u, dims=[1])
   return u * torch.sqrt(torch.clamp(e, min=0.0))
 
 

@@ -405,6 +405,21 @@ def gen_e2e():
           reuse_preconditioner=True, average_grad=True, reset_preconditioner=True,
           beta2=0.8, merge_small_dims_block_size=1), 8, "fresh"),
   ]
+  # tree_d: every block's Gram has rank > compression_rank + 1, so the FD cutoff
+  # singular value is a real quantity (on tree_c some blocks are rank 1 and the
+  # reference's tail/const there are SVD rounding noise).
+  shapes_d = ([40, 24], [64, 48], [8, 40])
+  configs += [
+      ("tree_d_fd_r4", tree(shapes_d, 10), None, dict(
+          block_size=32, preconditioning_compute_steps=1, statistics_compute_steps=1,
+          start_preconditioning_step=1, compression_rank=4, frequent_directions=True,
+          reuse_preconditioner=True, merge_small_dims_block_size=1), 5, "fresh"),
+      ("tree_d_fd_r3_avg_reset", tree(shapes_d, 11), None, dict(
+          block_size=32, preconditioning_compute_steps=2, statistics_compute_steps=2,
+          start_preconditioning_step=2, compression_rank=3, frequent_directions=True,
+          reuse_preconditioner=True, average_grad=True, reset_preconditioner=True,
+          beta2=0.8, merge_small_dims_block_size=1), 8, "fresh"),
+  ]
   for name, params, _, kw, steps, gmode in configs:
     lr = 0.1
     opt = ds.distributed_shampoo(lr, batch_axis_name=None, **kw)
