@@ -144,6 +144,36 @@ class VitBWorkload:
     return f  # roots of ALL ranks (metrics are gathered), statistics not included
 
 
+def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
+  """BASELINE.json configs[4]: Frequent-Directions sketch updates (rank 64) of
+  4096-dim factors: Gram of a [4096, 4096] gradient block + _fd_update_root, three
+  consecutive updates from a zero sketch.  float32 throughout (exact-f32 MFMA)."""
+  from precondition_amd import low_rank
+  gen = torch.Generator(device=dev).manual_seed(64)
+  prevs = [torch.zeros((d, rank + 2), dtype=torch.float32, device=dev) for _ in range(factors)]
+  times = []
+  for u in range(updates):
+    grads = [torch.randn((d, d), generator=gen, device=dev, dtype=torch.float32)
+             for _ in range(factors)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(factors):
+      gram = low_rank.gram_of_block(grads[f], 0)
+      prevs[f], _ = low_rank._fd_update_root(gram, 4, rank=rank, ridge_epsilon=1e-6,
+                                             decay=0.999, padding_start=d, prev=prevs[f],
+                                             new_grad_is_gram=True)
+    torch.cuda.synchronize()
+    times.append((time.perf_counter() - t0) / factors)
+    del grads
+  tails = [float(p[1, -1]) for p in prevs]
+  return {"workload": f"{factors} factors of dim {d}, rank {rank}, {updates} FD updates from a "
+                      "zero sketch, grad blocks ~N(0,1) [4096x4096], fp32",
+          "ms_per_factor_update": [round(t * 1e3, 1) for t in times],
+          "tail_after_updates": round(float(np.mean(tails)), 1),
+          "note": "Gram on the fp32 MFMA statistics kernel + full blocked-Jacobi eigh of the "
+                  "4096x4096 covariance update; a bf16 top-(r+1) subspace iteration is future work"}
+
+
 def timed(work, steps, warmup, world):
   import torch.distributed as dist
   for _ in range(warmup):
@@ -381,6 +411,8 @@ def main():
     }
     del vw
     if world == 1 and rank == 0:
+      torch.cuda.empty_cache()
+      line["fd_cfg5"] = fd_cfg5(dev)
       torch.cuda.empty_cache()
       ew = Workload("eigh_cfg3_64x2048_p2", rank, 1, dev)
       ew.step(); torch.cuda.synchronize()
