@@ -69,12 +69,16 @@ class Workload:
                      if world > 1 else None)
     self.metrics = None
 
-  def step(self):
+  def compute(self):
+    """This rank's roots only (no collective)."""
     from precondition_amd import kernels as K
     _, self.metrics = K.matrix_inverse_pth_root_batched(
         list(self.stats.unbind(0)), [self.p] * self.nb,
         padding_starts=[self.n] * self.nb, out=list(self.roots.unbind(0)),
         eigh=self.name.startswith("eigh"))
+
+  def step(self):
+    self.compute()
     if self.world > 1:
       import torch.distributed as dist
       dist.all_gather_into_tensor(self.gathered.view(-1), self.roots.view(-1))
@@ -207,7 +211,7 @@ def profile_stage_kernel(work):
   L.ps_profile_reset()
   L.ps_profile_enable(1)
   try:
-    work.step()
+    work.compute()  # rank-local: no collective, so only rank 0 needs to run it
     torch.cuda.synchronize()
   finally:
     L.ps_profile_enable(0)

@@ -21,6 +21,7 @@
 // Finished blocks cost nothing (their tiles exit at once).  The host only polls
 // "how many blocks are still running" one iteration behind the GPU.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -88,10 +89,11 @@ __device__ inline float* resolve(NewtonBlock* nb, int id) {
 }
 
 // ---- products -----------------------------------------------------------------
+template <int BK>
 __global__ __launch_bounds__(256, 2) void newton_stage_kernel(
     NewtonBlock* blocks, const NewtonTask* tasks, const TileEntry* tiles,
     int ntiles) {
-  __shared__ __align__(16) float smem[SmemCfg<NBK>::TOTAL];
+  extern __shared__ __align__(16) float smem[];  // SmemCfg<BK>::TOTAL floats
   const TileEntry te = tiles[xcd_remap(blockIdx.x, ntiles)];
   const NewtonTask tk = tasks[te.task];
   NewtonBlock* nb = &blocks[tk.block];
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void newton_stage_kernel(
   Operand B{resolve(nb, tk.b_id), ld, te.tn * TILE, ld, ld, true};
   float* C = resolve(nb, tk.c_id);
   f32x16 acc[2][2];
-  gemm_tile<KC, MC, NBK, false>(A, B, n, smem, acc);
+  gemm_tile<KC, MC, BK, false>(A, B, n, smem, acc);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -691,6 +693,17 @@ extern "C" int ps_newton_root_batched_f32(
   PS_LAUNCH_CHECK();
 
   // ---- Newton loop -------------------------------------------------------------
+  // K-tile depth of the product kernel: 32 (73.7 KB LDS => exactly 2 workgroups per
+  // CU, half the barriers) or 16 (40 KB, 3 per CU).  PS_NEWTON_BK overrides.
+  static int stage_bk = 0;
+  if (stage_bk == 0) {
+    const char* e = getenv("PS_NEWTON_BK");
+    stage_bk = (e && atoi(e) == 16) ? 16 : ((e && atoi(e) == 32) ? 32 : NBK);
+    if (hipFuncSetAttribute((const void*)newton_stage_kernel<32>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(SmemCfg<32>::TOTAL * sizeof(float))) != hipSuccess)
+      stage_bk = 16;
+  }
   const int ninit = (int)pl.init_tiles.size();
   int executed = 0;
   if (ninit > 0) {
@@ -716,8 +729,14 @@ extern "C" int ps_newton_root_batched_f32(
       for (int s = 0; s < pl.nstages; ++s) {
         const int nt = (int)pl.stage_tiles[s].size();
         prof.begin(0);
-        hipLaunchKernelGGL(newton_stage_kernel, dim3(nt), dim3(256), 0, st, lo.blocks,
-                           lo.tasks[s], lo.tiles[s], nt);
+        if (stage_bk == 32)
+          hipLaunchKernelGGL(newton_stage_kernel<32>, dim3(nt), dim3(256),
+                             SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.tasks[s],
+                             lo.tiles[s], nt);
+        else
+          hipLaunchKernelGGL(newton_stage_kernel<16>, dim3(nt), dim3(256),
+                             SmemCfg<16>::TOTAL * sizeof(float), st, lo.blocks, lo.tasks[s],
+                             lo.tiles[s], nt);
         prof.end();
       }
       hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.blocks,
