@@ -81,7 +81,12 @@ class Workload:
     self.compute()
     if self.world > 1:
       import torch.distributed as dist
-      dist.all_gather_into_tensor(self.gathered.view(-1), self.roots.view(-1))
+      if dist.get_backend() == "gloo":  # dev only (see main): stage through the host
+        out = torch.empty(self.gathered.numel(), dtype=torch.float32)
+        dist.all_gather_into_tensor(out, self.roots.view(-1).cpu())
+        self.gathered.view(-1).copy_(out)
+      else:
+        dist.all_gather_into_tensor(self.gathered.view(-1), self.roots.view(-1))
 
   def flops(self):
     """Algorithmic FLOPs of the last step on this rank."""
@@ -195,10 +200,11 @@ def timed(work, steps, warmup, world):
   dt = time.perf_counter() - t0
   fl = work.flops()
   if world > 1:
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    t = torch.tensor([dt], dtype=torch.float64, device=rdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
-    f = torch.tensor([fl], dtype=torch.float64, device="cuda")
+    f = torch.tensor([fl], dtype=torch.float64, device=rdev)
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     fl = f.item()
   return dt / steps, fl
@@ -285,6 +291,8 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
+  if os.environ.get("PS_BENCH_ONE_DEVICE"):  # dev only: several ranks on one GPU
+    local = 0
   if world != args.gpus and world > 1:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
   if not torch.cuda.is_available():
@@ -294,7 +302,11 @@ def main():
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="nccl", device_id=dev)
+    if os.environ.get("PS_BENCH_ONE_DEVICE"):
+      # dev only: RCCL refuses two ranks on one GPU; gloo exercises the same control flow
+      dist.init_process_group(backend="gloo")
+    else:
+      dist.init_process_group(backend="nccl", device_id=dev)
 
   work = Workload(args.workload, rank, world, dev)
   sec, flops = timed(work, args.steps, args.warmup, world)
@@ -396,7 +408,8 @@ def main():
       dist.barrier()
     vdt = (time.perf_counter() - t0) / vsteps
     if world > 1:
-      t = torch.tensor([vdt], dtype=torch.float64, device="cuda")
+      t = torch.tensor([vdt], dtype=torch.float64,
+                       device="cpu" if dist.get_backend() == "gloo" else "cuda")
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
       vdt = t.item()
     vm = vw.metrics.cpu().numpy()

@@ -146,8 +146,18 @@ def sharded_inverse_pth_roots(
     gathered = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
     gathered_metrics = torch.empty((world * max_count * METRICS_STRIDE,),
                                    dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(gathered, send, group=group)
-    dist.all_gather_into_tensor(gathered_metrics, send_metrics.reshape(-1), group=group)
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+      # gloo has no device all-gather: stage through the host (functional fallback
+      # for single-GPU debugging; the production backend is RCCL)
+      g_h = torch.empty(gathered.shape, dtype=torch.float32)
+      m_h = torch.empty(gathered_metrics.shape, dtype=torch.float32)
+      dist.all_gather_into_tensor(g_h, send.cpu(), group=group)
+      dist.all_gather_into_tensor(m_h, send_metrics.reshape(-1).cpu(), group=group)
+      gathered.copy_(g_h)
+      gathered_metrics.copy_(m_h)
+    else:
+      dist.all_gather_into_tensor(gathered, send, group=group)
+      dist.all_gather_into_tensor(gathered_metrics, send_metrics.reshape(-1), group=group)
     gathered = gathered.view(world, buf_elems)
     gathered_metrics = gathered_metrics.view(world, max_count, METRICS_STRIDE)
 
