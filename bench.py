@@ -228,6 +228,15 @@ def profile_stage_kernel(work):
   return stage_ms.value, launches.value, pi_ms.value, other_ms.value
 
 
+def executed_fraction(n):
+  """Share of a product's 2n^3 flops that newton_stage_kernel issues: the tiles with
+  tm <= tn of a T x T tile grid (symmetric mode, the default)."""
+  if os.environ.get("PS_NEWTON_SYMMETRIC", "1") == "0":
+    return 1.0
+  t = (n + 127) // 128
+  return (t + 1) / (2.0 * t)
+
+
 def pmc_traffic(workload, kernel):
   """HBM bytes per launch of `kernel` from the committed PMC summary (collected
   with rocprofv3 --pmc in separate passes; cannot be measured live here)."""
@@ -345,10 +354,17 @@ def main():
     stage_ms, launches, pi_ms, other_ms = profile_stage_kernel(work)
     fl1 = work.flops()
     ach = fl1 / (stage_ms * 1e-3) / 1e12 if stage_ms > 0 else 0.0
+    ex = executed_fraction(n)
     line["roofline"] = {
         "kernel": "newton_stage_kernel",
         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        # `achieved` prices the ALGORITHMIC 2n^3 per product.  The kernel
+        # computes only the upper tile triangle of each (symmetric) product and mirrors
+        # it, i.e. it executes (T+1)/(2T) of those flops on the MFMA pipe:
+        "executed_fraction_of_algorithmic_flops": round(ex, 4),
+        "executed_achieved": round(ach * ex, 2),
+        "executed_frac_of_peak": round(ach * ex / PEAK_F32_MFMA_TFLOPS, 4),
         "traffic": pmc_traffic(args.workload, "psk::newton_stage_kernel"),
         "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate "
                         "rocprofv3 --pmc passes (profiles/r01_pmc_cfg2_summary.json)",
@@ -378,6 +394,7 @@ def main():
       sm, ln, pm, om = profile_stage_kernel(hw)
       f1 = hw.flops()
       head["roofline_stage_kernel_tflops"] = round(f1 / (sm * 1e-3) / 1e12, 2) if sm > 0 else None
+      head["executed_fraction_of_algorithmic_flops"] = round(executed_fraction(1024), 4)
       head["step_breakdown_ms"] = {"product_stages": round(sm, 3),
                                    "power_iteration": round(pm, 3),
                                    "init_control_copyout": round(om, 3)}

@@ -252,6 +252,45 @@ __device__ inline int acc_col(int wn, int tn, int lane) {
   return wn * 64 + tn * 32 + (lane & 31);
 }
 
+// Mirror store for symmetric results: writes the TRANSPOSE of this workgroup's
+// 128x128 accumulator tile to dst (tile origin (row0, col0) of the transposed
+// position), and optionally alpha * value to dst2.  The tile is staged through LDS
+// in two 64-row halves (stride 129: conflict-free both ways) so that the global
+// stores are contiguous 256-byte runs.  smem must hold 64*129 floats and be free
+// (gemm_tile ends with a barrier).  All 256 threads must call.
+__device__ inline void store_tile_transposed(const f32x16 (&acc)[2][2], float* smem,
+                                             float* dst, float* dst2, float alpha, int ld,
+                                             int row0, int col0) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int TLD = 129;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wm == h) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // row in half
+            const int c = acc_col(wn, tn, lane);
+            smem[lr * TLD + c] = acc[tm][tn][r];
+          }
+    }
+    __syncthreads();
+    // transposed read: thread -> (output row = c, 64 consecutive output cols = lr)
+    for (int e = tid; e < 128 * 64; e += NTHREADS) {
+      const int c = e >> 6, lr = e & 63;
+      const float v = smem[lr * TLD + c];
+      const int64_t o = (int64_t)(row0 + c) * ld + col0 + h * 64 + lr;
+      gstore1(dst + o, v);
+      if (dst2 != nullptr) gstore1(dst2 + o, __fmul_rn(alpha, v));
+    }
+    __syncthreads();
+  }
+}
+
 // Bijective XCD-aware remap: consecutive logical tiles share an XCD (workgroups
 // are dealt round-robin over the 8 XCDs), so the tiles of one matrix block reuse
 // its operand panels out of one L2.  Speed only; any placement is correct.

@@ -58,6 +58,7 @@ struct NewtonBlock {
   float err, ratio, max_ev, ridge, ridge_try;
   unsigned err_bits;
   int power_iters;
+  int symmetric;  // products are computed on the upper tile triangle and mirrored
 };
 
 struct NewtonTask {
@@ -118,6 +119,8 @@ __global__ __launch_bounds__(256, 2) void newton_stage_kernel(
           const int col = te.tn * TILE + acc_col(wn, tn, lane);
           gstore1(C + (int64_t)row * ld + col, acc[tm][tn][r]);
         }
+    if (te.tm != te.tn && nb->symmetric)
+      store_tile_transposed(acc, smem, C, nullptr, 0.f, ld, te.tn * TILE, te.tm * TILE);
     return;
   }
   // EPI_NEWM: C = new M; Mi = (1-alpha) I + alpha M (DS:844, two roundings as
@@ -151,6 +154,11 @@ __global__ __launch_bounds__(256, 2) void newton_stage_kernel(
     m = red[2] > m ? red[2] : m;
     m = red[3] > m ? red[3] : m;
     atomicMax(&nb->err_bits, m);
+  }
+  if (te.tm != te.tn && nb->symmetric) {
+    __syncthreads();  // red[] lives in smem
+    // off-diagonal tile: identity is 0 there, so Mi = fl(alpha * M)
+    store_tile_transposed(acc, smem, C, Mi, alpha, ld, te.tn * TILE, te.tm * TILE);
   }
 }
 
@@ -396,6 +404,21 @@ struct Plan {
   bool ok = true;
 };
 
+// All iterates of the coupled Newton iteration are polynomials in the (symmetric)
+// input, hence symmetric and commuting: in symmetric mode only the tiles with
+// tm <= tn of every product are computed and the strict upper ones are mirrored,
+// which removes (T-1)/(2T) of the MFMA work (T = tiles per side).  The result
+// differs from the full products of DS:845-846 only by which of the two rounded
+// values x_ij / x_ji is kept.  PS_NEWTON_SYMMETRIC=0 restores the full products.
+bool symmetric_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("PS_NEWTON_SYMMETRIC");
+    mode = e ? (atoi(e) != 0) : 1;
+  }
+  return mode != 0;
+}
+
 void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
                const int32_t* padding_start) {
   pl.batch = batch;
@@ -450,7 +473,7 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
       const int tid = (int)pl.stage_tasks[s].size();
       pl.stage_tasks[s].push_back(tk);
       for (int tm = 0; tm < t; ++tm)
-        for (int tn = 0; tn < t; ++tn)
+        for (int tn = (symmetric_mode() ? tm : 0); tn < t; ++tn)
           pl.stage_tiles[s].push_back({tid, (short)tm, (short)tn});
     }
   }
@@ -644,6 +667,7 @@ extern "C" int ps_newton_root_batched_f32(
     nb.inv_p = (float)(1.0 / p[b]);
     nb.phase = pl.n_eff[b] >= 1 ? PH_INIT : PH_DONE;
     nb.ratio = 1.f;
+    nb.symmetric = symmetric_mode() ? 1 : 0;
   }
   std::vector<PiBlock> hp;
   fill_pi_blocks(pl, lo, a, lda, hp);
