@@ -247,7 +247,7 @@ def pmc_traffic(workload, kernel):
     if summ.get("workload") != workload:
       return None
     for k in summ["kernels"]:
-      if k["kernel"] == kernel:
+      if k["kernel"].startswith(kernel):
         return k["hbm_bytes_per_launch_corrected"]
   except (OSError, ValueError, KeyError):
     pass
