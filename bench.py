@@ -69,24 +69,46 @@ class Workload:
                      if world > 1 else None)
     self.metrics = None
 
+  def _roots(self, lo, hi):
+    from precondition_amd import kernels as K
+    _, m = K.matrix_inverse_pth_root_batched(
+        list(self.stats[lo:hi].unbind(0)), [self.p] * (hi - lo),
+        padding_starts=[self.n] * (hi - lo), out=list(self.roots[lo:hi].unbind(0)),
+        eigh=self.name.startswith("eigh"))
+    return m
+
   def compute(self):
     """This rank's roots only (no collective)."""
-    from precondition_amd import kernels as K
-    _, self.metrics = K.matrix_inverse_pth_root_batched(
-        list(self.stats.unbind(0)), [self.p] * self.nb,
-        padding_starts=[self.n] * self.nb, out=list(self.roots.unbind(0)),
-        eigh=self.name.startswith("eigh"))
+    self.metrics = self._roots(0, self.nb)
 
   def step(self):
-    self.compute()
-    if self.world > 1:
-      import torch.distributed as dist
+    if self.world == 1:
+      self.compute()
+      return
+    # N > 1: the batch is rooted in two halves so that the RCCL all-gather of the
+    # first half's roots (NCCL-side stream, async) runs under the second half's
+    # Newton iterations (measured cost of the split on one GPU: +3 % at 512^2,
+    # +7 % at 1024^2).  `gathered` is laid out [half][rank][block].
+    import torch.distributed as dist
+    h = self.nb // 2
+    per = self.n * self.n
+    g = self.gathered.view(-1)
+    handles = []
+    ms = []
+    for k, (lo, hi) in enumerate(((0, h), (h, self.nb))):
+      ms.append(self._roots(lo, hi))
+      off = k * self.world * h * per
+      out = g[off: off + self.world * (hi - lo) * per]
+      inp = self.roots[lo:hi].reshape(-1)
       if dist.get_backend() == "gloo":  # dev only (see main): stage through the host
-        out = torch.empty(self.gathered.numel(), dtype=torch.float32)
-        dist.all_gather_into_tensor(out, self.roots.view(-1).cpu())
-        self.gathered.view(-1).copy_(out)
+        tmp = torch.empty(out.numel(), dtype=torch.float32)
+        dist.all_gather_into_tensor(tmp, inp.cpu())
+        out.copy_(tmp)
       else:
-        dist.all_gather_into_tensor(self.gathered.view(-1), self.roots.view(-1))
+        handles.append(dist.all_gather_into_tensor(out, inp, async_op=True))
+    for w in handles:
+      w.wait()
+    self.metrics = torch.cat(ms, dim=0)
 
   def flops(self):
     """Algorithmic FLOPs of the last step on this rank."""

@@ -83,6 +83,8 @@ def sharded_inverse_pth_roots(
     root_fn: Optional[Callable] = None,
     out_cols: Optional[Sequence[int]] = None,
     compute_fn: Optional[Callable] = None,
+    overlap: bool = True,
+    overlap_min_bytes: int = 32 << 20,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
 
@@ -108,64 +110,88 @@ def sharded_inverse_pth_roots(
     root_fn = kernels.matrix_inverse_pth_root_batched
 
   cols = [int(c) for c in out_cols] if out_cols is not None else list(sizes)
-  # Offsets of every statistic inside its owner's flat buffer; all ranks derive
-  # the same table from shapes alone (no communication).
-  offsets, fill = [0] * n_stats, [0] * world
-  slot, count = [0] * n_stats, [0] * world
+  elems = [sizes[i] * cols[i] for i in range(n_stats)]
+  dev = statistics[0].device
+
+  # Phases: with several ranks and enough work, every rank roots its statistics in
+  # two halves so that the all-gather of the first half (RCCL's own stream,
+  # async) runs under the Newton iterations of the second.  Which half a statistic
+  # belongs to is derived from shapes alone, identically on every rank.
+  total = [0] * world
+  for i in range(n_stats):
+    total[owner[i]] += elems[i]
+  n_phases = 2 if (world > 1 and overlap and max(total) * 4 >= overlap_min_bytes) else 1
+  phase_of, seen = [0] * n_stats, [0] * world
   for i in range(n_stats):
     r = owner[i]
-    offsets[i] = fill[r]
-    fill[r] += sizes[i] * cols[i]
-    slot[i] = count[r]
-    count[r] += 1
-  buf_elems = max(max(fill), 1)
-  max_count = max(max(count), 1)
+    phase_of[i] = 1 if (n_phases == 2 and seen[r] * 2 >= total[r]) else 0
+    seen[r] += elems[i]
 
-  dev = statistics[0].device
-  send = torch.empty((buf_elems,), dtype=torch.float32, device=dev)
-  mine = [i for i in range(n_stats) if owner[i] == rank]
-  send_metrics = torch.zeros((max_count, METRICS_STRIDE), dtype=torch.float32, device=dev)
-  if mine:
-    outs = [send[offsets[i]:offsets[i] + sizes[i] * cols[i]].view(sizes[i], cols[i])
-            for i in mine]
-    if compute_fn is not None:
-      m = compute_fn(mine, outs)
-    else:
-      _, m = root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
-                     [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
-                     relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
-                     out=outs)
-    send_metrics[:len(mine)] = m
+  # Offsets of every statistic inside its owner's flat buffer of its phase; all
+  # ranks derive the same tables from shapes alone (no communication).
+  offsets = [0] * n_stats
+  slot = [0] * n_stats
+  fill = [[0] * world for _ in range(n_phases)]
+  count = [[0] * world for _ in range(n_phases)]
+  for i in range(n_stats):
+    r, ph = owner[i], phase_of[i]
+    offsets[i] = fill[ph][r]
+    fill[ph][r] += elems[i]
+    slot[i] = count[ph][r]
+    count[ph][r] += 1
 
-  if world == 1:
-    gathered = send.unsqueeze(0)
-    gathered_metrics = send_metrics.unsqueeze(0)
-  else:
+  gathered, gathered_metrics, handles = [], [], []
+  for ph in range(n_phases):
+    buf_elems = max(max(fill[ph]), 1)
+    max_count = max(max(count[ph]), 1)
+    send = torch.empty((buf_elems,), dtype=torch.float32, device=dev)
+    mine = [i for i in range(n_stats) if owner[i] == rank and phase_of[i] == ph]
+    send_metrics = torch.zeros((max_count, METRICS_STRIDE), dtype=torch.float32, device=dev)
+    if mine:
+      outs = [send[offsets[i]:offsets[i] + elems[i]].view(sizes[i], cols[i]) for i in mine]
+      if compute_fn is not None:
+        m = compute_fn(mine, outs)
+      else:
+        _, m = root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
+                       [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
+                       relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
+                       out=outs)
+      send_metrics[:len(mine)] = m
+    if world == 1:
+      gathered.append(send.unsqueeze(0))
+      gathered_metrics.append(send_metrics.unsqueeze(0))
+      continue
     import torch.distributed as dist
     # flat outputs (concatenation form) are accepted by both RCCL and gloo
-    gathered = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
-    gathered_metrics = torch.empty((world * max_count * METRICS_STRIDE,),
-                                   dtype=torch.float32, device=dev)
+    g = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
+    gm = torch.empty((world * max_count * METRICS_STRIDE,), dtype=torch.float32, device=dev)
     if dist.get_backend(group) == "gloo" and send.is_cuda:
       # gloo has no device all-gather: stage through the host (functional fallback
       # for single-GPU debugging; the production backend is RCCL)
-      g_h = torch.empty(gathered.shape, dtype=torch.float32)
-      m_h = torch.empty(gathered_metrics.shape, dtype=torch.float32)
+      g_h = torch.empty(g.shape, dtype=torch.float32)
+      m_h = torch.empty(gm.shape, dtype=torch.float32)
       dist.all_gather_into_tensor(g_h, send.cpu(), group=group)
       dist.all_gather_into_tensor(m_h, send_metrics.reshape(-1).cpu(), group=group)
-      gathered.copy_(g_h)
-      gathered_metrics.copy_(m_h)
+      g.copy_(g_h)
+      gm.copy_(m_h)
+    elif n_phases == 2 and send.is_cuda:
+      handles.append(dist.all_gather_into_tensor(g, send, group=group, async_op=True))
+      handles.append(dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group,
+                                                 async_op=True))
+      handles.append((send, send_metrics))  # keep the send buffers alive until wait()
     else:
-      dist.all_gather_into_tensor(gathered, send, group=group)
-      dist.all_gather_into_tensor(gathered_metrics, send_metrics.reshape(-1), group=group)
-    gathered = gathered.view(world, buf_elems)
-    gathered_metrics = gathered_metrics.view(world, max_count, METRICS_STRIDE)
+      dist.all_gather_into_tensor(g, send, group=group)
+      dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group)
+    gathered.append(g.view(world, buf_elems))
+    gathered_metrics.append(gm.view(world, max_count, METRICS_STRIDE))
+  for h in handles:
+    if hasattr(h, "wait"):
+      h.wait()
 
   roots = [
-      gathered[owner[i], offsets[i]:offsets[i] + sizes[i] * cols[i]].view(
-          sizes[i], cols[i]) for i in range(n_stats)
+      gathered[phase_of[i]][owner[i], offsets[i]:offsets[i] + elems[i]].view(sizes[i], cols[i])
+      for i in range(n_stats)
   ]
-  index = torch.tensor([owner[i] * max_count + slot[i] for i in range(n_stats)],
-                       dtype=torch.long, device=dev)
-  metrics = gathered_metrics.reshape(world * max_count, METRICS_STRIDE)[index]
+  rows = [gathered_metrics[phase_of[i]][owner[i], slot[i]] for i in range(n_stats)]
+  metrics = torch.stack(rows, dim=0)
   return roots, metrics

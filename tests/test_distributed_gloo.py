@@ -51,6 +51,17 @@ def _worker(rank, world, port, ownership, ret):
     roots, metrics = comm.sharded_inverse_pth_roots(
         stats, exps, group=dist.group.WORLD, ownership=ownership, root_fn=root_fn)
     ret[rank] = ([r.clone().numpy() for r in roots], metrics.numpy().copy(), calls)
+    # two-phase (compute/all-gather overlap) layout: same results, two root calls
+    calls2 = []
+
+    def root_fn2(mats, ps, pads, **kw):
+      calls2.append(len(mats))
+      return cpu_backend.matrix_inverse_pth_root_batched(mats, ps, pads, **kw)
+
+    roots2, metrics2 = comm.sharded_inverse_pth_roots(
+        stats, exps, group=dist.group.WORLD, ownership=ownership, root_fn=root_fn2,
+        overlap_min_bytes=0)
+    ret[rank + 200] = ([r.clone().numpy() for r in roots2], metrics2.numpy().copy(), calls2)
 
     # the optimizer surface over the same group: every rank must produce the
     # same update as a single process.
@@ -88,6 +99,11 @@ def test_two_rank_sharding_matches_single_process(ownership):
       assert np.array_equal(a, b.numpy())  # same CPU arithmetic => identical
     assert np.array_equal(metrics, base_metrics.numpy())
     assert sum(calls) in (3, 4)  # 7 statistics over 2 ranks
+    roots2, metrics2, calls2 = ret[rank + 200]
+    for a, b in zip(roots2, base_roots):
+      assert np.array_equal(a, b.numpy())
+    assert np.array_equal(metrics2, base_metrics.numpy())
+    assert len(calls2) == 2 and sum(calls2) == sum(calls)
   if ownership == "reference":
     assert ret[0][2] == [4] and ret[1][2] == [3]  # chunks [0,4) and [4,7) + 1 padding slot
   # optimizer surface
