@@ -474,11 +474,6 @@ __global__ __launch_bounds__(256) void eigh_zero_out_kernel(EighBlock* blocks) {
     eb->out[(e / nf) * eb->ldo + e % nf] = 0.f;
 }
 
-__global__ void eigh_fill_v0_kernel(PiBlock* pis, const float* v0) {
-  PiBlock* pb = &pis[blockIdx.x];
-  for (int j = threadIdx.x; j < pb->n; j += blockDim.x) pb->v[0][j] = v0[j];
-}
-
 }  // namespace psk
 
 // =============================================================================
@@ -494,8 +489,10 @@ struct EPlan {
   std::vector<ETile> pair_tiles;  // (block, k)
   std::vector<ETile> row_tiles;   // (block, k, coltile)
   std::vector<ETile> col_tiles;   // (block, k, rowtile, which)
-  std::vector<PiChunk> pi_chunks;
+  PiPlan pip;
 };
+
+void finish_eplan(EPlan& pl) { pl.pip.build(pl.batch, pl.n_eff); }
 
 void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_start) {
   pl.batch = batch;
@@ -519,29 +516,24 @@ void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_s
         pl.col_tiles.push_back({b, (short)k, (short)c, 1, 0});
       }
     }
-    for (int c = 0; c * PI_ROWS < ne; ++c) pl.pi_chunks.push_back({b, c});
   }
 }
 
 struct ELayout {
-  EighBlock* blocks; PiBlock* pis;
+  EighBlock* blocks;
   ETile *sq, *pair, *row, *col;
-  PiChunk* chunks; float* v0;
-  std::vector<float*> mat[5], Q, offp, ssq, evals, piv0, piv1, pip0, pip1;
+  std::vector<float*> mat[5], Q, offp, ssq, evals;
 };
 
-size_t ecarve(const EPlan& pl, Arena& ar, ELayout* lo) {
+size_t ecarve(EPlan& pl, Arena& ar, ELayout* lo) {
   const int B = pl.batch;
   EighBlock* blocks = ar.take<EighBlock>(B);
-  PiBlock* pis = ar.take<PiBlock>(B);
+  pl.pip.carve(ar, lo != nullptr);
   ETile* sq = ar.take<ETile>(pl.sq_tiles.size());
   ETile* pr = ar.take<ETile>(pl.pair_tiles.size());
   ETile* rw = ar.take<ETile>(pl.row_tiles.size());
   ETile* cl = ar.take<ETile>(pl.col_tiles.size());
-  PiChunk* ch = ar.take<PiChunk>(pl.pi_chunks.size());
-  float* v0 = ar.take<float>(std::max(pl.max_n, 1));
-  if (lo) { lo->blocks = blocks; lo->pis = pis; lo->sq = sq; lo->pair = pr; lo->row = rw;
-            lo->col = cl; lo->chunks = ch; lo->v0 = v0; }
+  if (lo) { lo->blocks = blocks; lo->sq = sq; lo->pair = pr; lo->row = rw; lo->col = cl; }
   for (int b = 0; b < B; ++b) {
     const size_t sq_e = (size_t)pl.npad[b] * pl.npad[b];
     for (int k = 0; k < 5; ++k) { float* m = ar.take<float>(sq_e); if (lo) lo->mat[k].push_back(m); }
@@ -550,14 +542,8 @@ size_t ecarve(const EPlan& pl, Arena& ar, ELayout* lo) {
     float* op = ar.take<float>((size_t)std::max(np * std::max(nb - 1, 1), 1));
     float* ss = ar.take<float>(std::max(t * t, 1));
     float* ev = ar.take<float>(std::max(pl.npad[b], 1));
-    const int ne = pl.n_eff[b], nch = (ne + PI_ROWS - 1) / PI_ROWS;
-    float* a0 = ar.take<float>(std::max(ne, 1));
-    float* a1 = ar.take<float>(std::max(ne, 1));
-    float* p0 = ar.take<float>(std::max(nch, 1));
-    float* p1 = ar.take<float>(std::max(nch, 1));
     if (lo) { lo->Q.push_back(q); lo->offp.push_back(op); lo->ssq.push_back(ss);
-              lo->evals.push_back(ev); lo->piv0.push_back(a0); lo->piv1.push_back(a1);
-              lo->pip0.push_back(p0); lo->pip1.push_back(p1); }
+              lo->evals.push_back(ev); }
   }
   return ar.off;
 }
@@ -575,6 +561,7 @@ extern "C" size_t ps_eigh_root_workspace_bytes(int batch, const int32_t* n) {
   if (batch <= 0 || !n) return 0;
   EPlan pl;
   make_eplan(pl, batch, n, nullptr);
+  finish_eplan(pl);
   Arena ar(nullptr, 0);
   return ecarve(pl, ar, nullptr) + 256;
 }
@@ -598,7 +585,8 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   hipStream_t st = (hipStream_t)stream;
   EPlan pl;
   make_eplan(pl, batch, n, padding_start);
-  if (pl.max_n * sizeof(float) > 60 * 1024) return PS_EUNSUPPORTED;
+  finish_eplan(pl);
+  if (pl.max_n > 16384) return PS_EUNSUPPORTED;
   Arena ar(workspace, workspace_bytes);
   ELayout lo;
   ecarve(pl, ar, &lo);
@@ -614,7 +602,6 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   }
 
   std::vector<EighBlock> hb(batch);
-  std::vector<PiBlock> hp(batch);
   for (int b = 0; b < batch; ++b) {
     EighBlock& eb = hb[b];
     memset(&eb, 0, sizeof(eb));
@@ -629,51 +616,29 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     eb.evals_out = mode == 1 ? evals_out[b] : nullptr;
     eb.active = eb.n > 0 ? 1 : 0;
     eb.off_rel = 1.f;
-    PiBlock& pb = hp[b];
-    memset(&pb, 0, sizeof(pb));
-    pb.a = a[b]; pb.lda = lda[b]; pb.n = pl.n_eff[b];
-    pb.vec_ok = (((uintptr_t)a[b] % 16 == 0) && (lda[b] % 4 == 0)) ? 1 : 0;
-    pb.v[0] = lo.piv0[b]; pb.v[1] = lo.piv1[b];
-    pb.partial[0] = lo.pip0[b]; pb.partial[1] = lo.pip1[b];
-    pb.nchunk = (pl.n_eff[b] + PI_ROWS - 1) / PI_ROWS;
-    pb.stop_iter = -1;
   }
-  std::vector<float> v0(std::max(pl.max_n, 1));
-  ps_power_iteration_v0(pl.max_n, v0.data());
   auto up = [&](void* d, const void* h, size_t bytes) -> int {
     if (bytes == 0) return 0;
     return (int)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
   };
   int rc;
   if ((rc = up(lo.blocks, hb.data(), sizeof(EighBlock) * batch))) return rc;
-  if ((rc = up(lo.pis, hp.data(), sizeof(PiBlock) * batch))) return rc;
-  if ((rc = up(lo.v0, v0.data(), sizeof(float) * v0.size()))) return rc;
   if ((rc = up(lo.sq, pl.sq_tiles.data(), sizeof(ETile) * pl.sq_tiles.size()))) return rc;
   if ((rc = up(lo.pair, pl.pair_tiles.data(), sizeof(ETile) * pl.pair_tiles.size()))) return rc;
   if ((rc = up(lo.row, pl.row_tiles.data(), sizeof(ETile) * pl.row_tiles.size()))) return rc;
   if ((rc = up(lo.col, pl.col_tiles.data(), sizeof(ETile) * pl.col_tiles.size()))) return rc;
-  if ((rc = up(lo.chunks, pl.pi_chunks.data(), sizeof(PiChunk) * pl.pi_chunks.size()))) return rc;
   PS_HIP(hipStreamSynchronize(st));
+  if (relative_matrix_epsilon && (rc = pl.pip.upload(st, a, lda))) return rc;
 
   const int nsq = (int)pl.sq_tiles.size();
   const int npair = (int)pl.pair_tiles.size();
   const int nrow = (int)pl.row_tiles.size(), ncol = (int)pl.col_tiles.size();
-  const int nch = (int)pl.pi_chunks.size();
   const dim3 blk(256);
 
   // power iteration with tol = error_tolerance (DS:996-1001)
-  if (relative_matrix_epsilon && nch > 0) {
-    hipLaunchKernelGGL(eigh_fill_v0_kernel, dim3(batch), blk, 0, st, lo.pis, lo.v0);
-    const size_t shm = (size_t)std::max(pl.max_n, 1) * sizeof(float);
-    for (int i = 0; i < 100; ++i)
-      hipLaunchKernelGGL(pi_step_kernel, dim3(nch), blk, shm, st, lo.pis, lo.chunks, i,
-                         error_tolerance);
-  }
-  if (relative_matrix_epsilon)
-    hipLaunchKernelGGL(pi_final_kernel, dim3(batch), blk, 0, st, lo.pis, 100, (float*)nullptr,
-                       (int*)nullptr, (float*)nullptr, 0);
+  if (relative_matrix_epsilon && (rc = pl.pip.enqueue(st, 100, error_tolerance))) return rc;
   hipLaunchKernelGGL(eigh_setup_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
-                     lo.pis, batch, mode == 0 ? ridge_epsilon : 0.f, error_tolerance,
+                     pl.pip.d_blocks, batch, mode == 0 ? ridge_epsilon : 0.f, error_tolerance,
                      relative_matrix_epsilon);
   PS_LAUNCH_CHECK();
 

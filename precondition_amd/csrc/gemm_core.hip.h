@@ -321,4 +321,18 @@ __device__ inline float wave_sum_f32(float v) {
   return v;
 }
 
+// sum of x[0..cnt) in a fixed order, computed by wavefront 0; result broadcast
+// through LDS slot `bcast`.
+__device__ inline float fixed_order_sum_wave0(const float* x, int cnt, int tid,
+                                              float* bcast) {
+  if (tid < 64) {
+    float s = 0.f;
+    for (int j = tid; j < cnt; j += 64) s += x[j];
+    s = wave_sum_f32(s);
+    if (tid == 0) *bcast = s;
+  }
+  __syncthreads();
+  return *bcast;
+}
+
 }  // namespace psk

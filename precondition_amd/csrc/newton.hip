@@ -350,11 +350,6 @@ __global__ __launch_bounds__(256) void newton_final_kernel(NewtonBlock* blocks,
   }
 }
 
-__global__ void fill_v0_kernel(PiBlock* pis, const float* v0, int nblocks) {
-  PiBlock* pb = &pis[blockIdx.x];
-  for (int j = threadIdx.x; j < pb->n; j += blockDim.x) pb->v[0][j] = v0[j];
-}
-
 }  // namespace psk
 
 // =============================================================================
@@ -399,7 +394,7 @@ struct Plan {
   std::vector<std::vector<NewtonTask>> stage_tasks;
   std::vector<std::vector<TileEntry>> stage_tiles;
   std::vector<TileEntry> init_tiles;  // one per (block, tile)
-  std::vector<PiChunk> pi_chunks;
+  PiPlan pip;
   int max_n = 0;
   bool ok = true;
 };
@@ -442,8 +437,8 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
       full.push_back({power_id, ID_MCUR, ID_MNEXT});
       pl.chains[b] = full;
     }
-    for (int c = 0; c * PI_ROWS < ne; ++c) pl.pi_chunks.push_back({b, c});
   }
+  pl.pip.build(batch, pl.n_eff);
   // Stage s runs product s+1 of every block (product 0, the H update, joins
   // stage 0); the M update of a block runs as soon as its chain is done.
   // (A block whose step is only {H update, M update} (p = 1) keeps them in
@@ -481,30 +476,25 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
 
 struct WsLayout {
   NewtonBlock* blocks;
-  PiBlock* pis;
   NewtonTask* tasks[MAX_PROD];
   TileEntry* tiles[MAX_PROD];
   TileEntry* init_tiles;
-  PiChunk* pi_chunks;
-  float* v0;
   std::vector<float*> mat[10];
-  std::vector<float*> sumsq, piv0, piv1, pip0, pip1;
+  std::vector<float*> sumsq;
 };
 
-size_t carve(const Plan& pl, Arena& ar, WsLayout* lo) {
+size_t carve(Plan& pl, Arena& ar, WsLayout* lo) {
   const int B = pl.batch;
   NewtonBlock* blocks = ar.take<NewtonBlock>(B);
-  PiBlock* pis = ar.take<PiBlock>(B);
-  if (lo) { lo->blocks = blocks; lo->pis = pis; }
+  pl.pip.carve(ar, lo != nullptr);
+  if (lo) { lo->blocks = blocks; }
   for (int s = 0; s < pl.nstages; ++s) {
     NewtonTask* t = ar.take<NewtonTask>(pl.stage_tasks[s].size());
     TileEntry* e = ar.take<TileEntry>(pl.stage_tiles[s].size());
     if (lo) { lo->tasks[s] = t; lo->tiles[s] = e; }
   }
   TileEntry* it = ar.take<TileEntry>(pl.init_tiles.size());
-  PiChunk* pc = ar.take<PiChunk>(pl.pi_chunks.size());
-  float* v0 = ar.take<float>(std::max(pl.max_n, 1));
-  if (lo) { lo->init_tiles = it; lo->pi_chunks = pc; lo->v0 = v0; }
+  if (lo) { lo->init_tiles = it; }
   for (int b = 0; b < B; ++b) {
     const size_t sq = (size_t)pl.npad[b] * pl.npad[b];
     for (int k = 0; k < 10; ++k) {
@@ -513,16 +503,7 @@ size_t carve(const Plan& pl, Arena& ar, WsLayout* lo) {
     }
     const int t = pl.npad[b] / TILE;
     float* ss = ar.take<float>(std::max(1, t * t));
-    const int ne = pl.n_eff[b];
-    const int nch = (ne + PI_ROWS - 1) / PI_ROWS;
-    float* a0 = ar.take<float>(std::max(ne, 1));
-    float* a1 = ar.take<float>(std::max(ne, 1));
-    float* p0 = ar.take<float>(std::max(nch, 1));
-    float* p1 = ar.take<float>(std::max(nch, 1));
-    if (lo) {
-      lo->sumsq.push_back(ss); lo->piv0.push_back(a0); lo->piv1.push_back(a1);
-      lo->pip0.push_back(p0); lo->pip1.push_back(p1);
-    }
+    if (lo) lo->sumsq.push_back(ss);
   }
   return ar.off;
 }
@@ -583,36 +564,6 @@ bool vec_ok(const float* p, int ld) {
   return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0);
 }
 
-int run_power_iteration(hipStream_t st, const Plan& pl, PiBlock* d_pis,
-                        const PiChunk* d_chunks, int num_iters, float tol) {
-  const int nch = (int)pl.pi_chunks.size();
-  if (nch == 0) return 0;
-  const size_t shm = (size_t)std::max(pl.max_n, 1) * sizeof(float);
-  for (int i = 0; i < num_iters; ++i) {
-    hipLaunchKernelGGL(pi_step_kernel, dim3(nch), dim3(256), shm, st, d_pis, d_chunks,
-                       i, tol);
-  }
-  PS_LAUNCH_CHECK();
-  return 0;
-}
-
-void fill_pi_blocks(const Plan& pl, const WsLayout& lo, const float* const* a,
-                    const int32_t* lda, std::vector<PiBlock>& h) {
-  h.resize(pl.batch);
-  for (int b = 0; b < pl.batch; ++b) {
-    PiBlock& pb = h[b];
-    memset(&pb, 0, sizeof(pb));
-    pb.a = a[b];
-    pb.lda = lda[b];
-    pb.n = pl.n_eff[b];
-    pb.vec_ok = vec_ok(a[b], lda[b]) ? 1 : 0;
-    pb.v[0] = lo.piv0[b]; pb.v[1] = lo.piv1[b];
-    pb.partial[0] = lo.pip0[b]; pb.partial[1] = lo.pip1[b];
-    pb.nchunk = (pl.n_eff[b] + PI_ROWS - 1) / PI_ROWS;
-    pb.stop_iter = -1;
-  }
-}
-
 }  // namespace
 
 extern "C" size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
@@ -641,7 +592,7 @@ extern "C" int ps_newton_root_batched_f32(
   Plan pl;
   make_plan(pl, batch, n, p, padding_start);
   if (!pl.ok) return PS_EUNSUPPORTED;
-  if (pl.max_n * sizeof(float) > 60 * 1024) return PS_EUNSUPPORTED;  // n <= 15360
+  if (pl.max_n > 16384) return PS_EUNSUPPORTED;
   Arena ar(workspace, workspace_bytes);
   WsLayout lo;
   carve(pl, ar, &lo);
@@ -669,16 +620,8 @@ extern "C" int ps_newton_root_batched_f32(
     nb.ratio = 1.f;
     nb.symmetric = symmetric_mode() ? 1 : 0;
   }
-  std::vector<PiBlock> hp;
-  fill_pi_blocks(pl, lo, a, lda, hp);
-  std::vector<float> v0(std::max(pl.max_n, 1));
-  ps_power_iteration_v0(pl.max_n, v0.data());
 
   PS_HIP(hipMemcpyAsync(lo.blocks, hb.data(), sizeof(NewtonBlock) * batch,
-                        hipMemcpyHostToDevice, st));
-  PS_HIP(hipMemcpyAsync(lo.pis, hp.data(), sizeof(PiBlock) * batch,
-                        hipMemcpyHostToDevice, st));
-  PS_HIP(hipMemcpyAsync(lo.v0, v0.data(), sizeof(float) * v0.size(),
                         hipMemcpyHostToDevice, st));
   for (int s = 0; s < pl.nstages; ++s) {
     PS_HIP(hipMemcpyAsync(lo.tasks[s], pl.stage_tasks[s].data(),
@@ -692,28 +635,25 @@ extern "C" int ps_newton_root_batched_f32(
     PS_HIP(hipMemcpyAsync(lo.init_tiles, pl.init_tiles.data(),
                           sizeof(TileEntry) * pl.init_tiles.size(),
                           hipMemcpyHostToDevice, st));
-  if (!pl.pi_chunks.empty())
-    PS_HIP(hipMemcpyAsync(lo.pi_chunks, pl.pi_chunks.data(),
-                          sizeof(PiChunk) * pl.pi_chunks.size(), hipMemcpyHostToDevice,
-                          st));
   // The host vectors above must outlive the async copies (pageable memory is
   // staged synchronously by the runtime, but do not rely on it).
   PS_HIP(hipStreamSynchronize(st));
+  {
+    int rc = pl.pip.upload(st, a, lda);
+    if (rc) return rc;
+  }
 
   ProfRun prof(st);
   // ---- power iteration -> ridge epsilon --------------------------------------
   prof.begin(1);
   if (relative_matrix_epsilon) {
-    hipLaunchKernelGGL(fill_v0_kernel, dim3(batch), dim3(256), 0, st, lo.pis, lo.v0,
-                       batch);
-    int rc = run_power_iteration(st, pl, lo.pis, lo.pi_chunks, 100, 1e-6f);  // DS:820-825
+    int rc = pl.pip.enqueue(st, 100, 1e-6f);  // DS:820-825
     if (rc) return rc;
-    hipLaunchKernelGGL(pi_final_kernel, dim3(batch), dim3(256), 0, st, lo.pis, 100,
-                       (float*)nullptr, (int*)nullptr, (float*)nullptr, 0);
   }
   prof.end();
   hipLaunchKernelGGL(newton_setup_kernel, dim3((batch + 255) / 256), dim3(256), 0, st,
-                     lo.blocks, lo.pis, batch, ridge_epsilon, relative_matrix_epsilon);
+                     lo.blocks, pl.pip.d_blocks, batch, ridge_epsilon,
+                     relative_matrix_epsilon);
   PS_LAUNCH_CHECK();
 
   // ---- Newton loop -------------------------------------------------------------
@@ -808,35 +748,24 @@ extern "C" int ps_profile_get(double* stage_ms, int64_t* stage_launches,
 
 // ---- standalone power iteration ---------------------------------------------------
 namespace {
-struct PiLayout {
-  PiBlock* pis; PiChunk* chunks; float* v0;
-  std::vector<float*> v0s, v1s, p0s, p1s;
-};
-size_t carve_pi(int batch, const std::vector<int>& ne, int nchunks, int max_n, Arena& ar,
-                PiLayout* lo) {
-  PiBlock* pis = ar.take<PiBlock>(batch);
-  PiChunk* ch = ar.take<PiChunk>(std::max(nchunks, 1));
-  float* v0 = ar.take<float>(std::max(max_n, 1));
-  if (lo) { lo->pis = pis; lo->chunks = ch; lo->v0 = v0; }
+void pi_plan_from_args(PiPlan& pp, int batch, const int32_t* n, const int32_t* padding_start) {
+  std::vector<int> ne(batch);
   for (int b = 0; b < batch; ++b) {
-    const int nch = (ne[b] + PI_ROWS - 1) / PI_ROWS;
-    float* a0 = ar.take<float>(std::max(ne[b], 1));
-    float* a1 = ar.take<float>(std::max(ne[b], 1));
-    float* p0 = ar.take<float>(std::max(nch, 1));
-    float* p1 = ar.take<float>(std::max(nch, 1));
-    if (lo) { lo->v0s.push_back(a0); lo->v1s.push_back(a1); lo->p0s.push_back(p0); lo->p1s.push_back(p1); }
+    int e = n[b];
+    if (padding_start) e = std::max(0, std::min(e, (int)padding_start[b]));
+    ne[b] = e;
   }
-  return ar.off;
+  pp.build(batch, ne);
 }
 }  // namespace
 
 extern "C" size_t ps_power_iteration_workspace_bytes(int batch, const int32_t* n) {
   if (batch <= 0 || !n) return 0;
-  std::vector<int> ne(n, n + batch);
-  int nch = 0, mx = 0;
-  for (int b = 0; b < batch; ++b) { nch += (ne[b] + PI_ROWS - 1) / PI_ROWS; mx = std::max(mx, ne[b]); }
+  PiPlan pp;
+  pi_plan_from_args(pp, batch, n, nullptr);
   Arena ar(nullptr, 0);
-  return carve_pi(batch, ne, nch, mx, ar, nullptr) + 256;
+  pp.carve(ar, false);
+  return ar.off + 256;
 }
 
 extern "C" int ps_power_iteration_batched_f32(
@@ -846,40 +775,21 @@ extern "C" int ps_power_iteration_batched_f32(
     size_t workspace_bytes) {
   if (batch <= 0 || !a || !n || !lda || !out_lambda || !workspace || num_iters < 1)
     return PS_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  Plan pl;
-  pl.batch = batch;
-  pl.n_eff.resize(batch);
-  for (int b = 0; b < batch; ++b) {
+  for (int b = 0; b < batch; ++b)
     if (n[b] < 1 || lda[b] < n[b] || !a[b]) return PS_EINVAL;
-    int ne = n[b];
-    if (padding_start) ne = std::max(0, std::min(ne, (int)padding_start[b]));
-    pl.n_eff[b] = ne;
-    pl.max_n = std::max(pl.max_n, ne);
-    for (int c = 0; c * PI_ROWS < ne; ++c) pl.pi_chunks.push_back({b, c});
-  }
-  if (pl.max_n * sizeof(float) > 60 * 1024) return PS_EUNSUPPORTED;
-  if (out_v && ldv < pl.max_n) return PS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  PiPlan pp;
+  pi_plan_from_args(pp, batch, n, padding_start);
+  if (pp.max_n > 16384) return PS_EUNSUPPORTED;
+  if (out_v && ldv < pp.max_n) return PS_EINVAL;
   Arena ar(workspace, workspace_bytes);
-  PiLayout pil;
-  carve_pi(batch, pl.n_eff, (int)pl.pi_chunks.size(), pl.max_n, ar, &pil);
+  pp.carve(ar, true);
   if (ar.overflow) return PS_EWORKSPACE;
-  WsLayout lo;
-  lo.piv0 = pil.v0s; lo.piv1 = pil.v1s; lo.pip0 = pil.p0s; lo.pip1 = pil.p1s;
-  std::vector<PiBlock> hp;
-  fill_pi_blocks(pl, lo, a, lda, hp);
-  std::vector<float> v0(std::max(pl.max_n, 1));
-  ps_power_iteration_v0(pl.max_n, v0.data());
-  PS_HIP(hipMemcpyAsync(pil.pis, hp.data(), sizeof(PiBlock) * batch, hipMemcpyHostToDevice, st));
-  PS_HIP(hipMemcpyAsync(pil.v0, v0.data(), sizeof(float) * v0.size(), hipMemcpyHostToDevice, st));
-  if (!pl.pi_chunks.empty())
-    PS_HIP(hipMemcpyAsync(pil.chunks, pl.pi_chunks.data(), sizeof(PiChunk) * pl.pi_chunks.size(),
-                          hipMemcpyHostToDevice, st));
-  PS_HIP(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(fill_v0_kernel, dim3(batch), dim3(256), 0, st, pil.pis, pil.v0, batch);
-  int rc = run_power_iteration(st, pl, pil.pis, pil.chunks, num_iters, error_tolerance);
+  int rc = pp.upload(st, a, lda);
   if (rc) return rc;
-  hipLaunchKernelGGL(pi_final_kernel, dim3(batch), dim3(256), 0, st, pil.pis, num_iters,
+  rc = pp.enqueue(st, num_iters, error_tolerance);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pi_output_kernel, dim3(batch), dim3(256), 0, st, pp.d_blocks, batch,
                      out_lambda, (int*)out_iters, out_v, (int)ldv);
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -1,176 +1,285 @@
 // power_iter.hip.h — batched power iteration (reference: power_iteration,
-// DS:595-652) as one launch per step over every (block, 32-row chunk).
+// DS:595-652): lambda_max estimate with the fixed seed vector, <= num_iters steps,
+// stop when |s_new - s| <= tol.
 //
-// HBM/L2-bound: one step reads each matrix once (n*n*4 bytes per block).  The
-// loop of DS:649 is data dependent (stop when |s_new - s| <= tol), so each
-// workgroup re-derives the block's stop decision from the previous step's
-// partial sums in a fixed order: every workgroup of a block takes the same
-// decision without any inter-workgroup communication inside a launch, and the
-// result is bit-reproducible (no float atomics).
+// HBM-bound: a step has to read every matrix.  The matrices are symmetric
+// (statistics and their regularised forms), so a step reads only the 128x128 tiles
+// (I, J >= I) of the upper block triangle — (T+1)/(2T) of the bytes — and uses each
+// off-diagonal tile twice out of LDS: u = A_IJ v_J goes to y_I and w = A_IJ^T v_I
+// to y_J.  Two launches per step over the whole batch:
+//   pi_mv_kernel  : one workgroup per tile, writes the partial products into a
+//                   per-block slab P[X][Y][128] ("contribution of v_Y to y_X");
+//   pi_red_kernel : one workgroup per block sums the slab in a fixed order,
+//                   forms s = v.(A v) and ||A v||, takes the stop decision of
+//                   DS:639 and writes the normalised iterate for the next step.
+// No float atomics, no inter-workgroup traffic inside a launch: results are
+// bit-reproducible.  (Only the upper block triangle of the input is read; for an
+// input that is symmetric only to rounding this differs from the reference's
+// full mat-vec by that rounding.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <string.h>
 
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
 #include "gemm_core.hip.h"
 
 namespace psk {
 
-constexpr int PI_ROWS = 32;  // rows per workgroup
+constexpr int PT = 128;        // tile side
+constexpr int PLD = PT + 1;    // LDS row stride (odd: column walks conflict-free)
 
 struct PiBlock {
   const float* a;
   int lda;
-  int n;            // effective size (rows/cols >= n are padding and ignored)
-  int vec_ok;       // float4 row loads are legal
-  float* v[2];      // ping-pong iterate, >= n floats each; v[0] starts as v0[:n]
-  float* partial[2];  // per-chunk partial sums of v.(A v), by step parity
-  int nchunk;
-  float s_val[2];   // s of steps (i-1), (i-2) by parity
-  int stop_iter;    // -1 while running, else the step after which the loop ended
-  float lambda;     // s_out
-  int iters;        // steps executed
+  int n;          // effective size (rows/cols >= n are padding and ignored)
+  int t;          // tiles per side = ceil(n / 128)
+  int vec_ok;     // float4 row loads are legal
+  float* vn;      // [t*128] normalised iterate (zero beyond n)
+  float* P;       // [t][t][128] partial products of the current step
+  float s_prev;   // s of the previous step (0 before the first)
+  int stop_iter;  // -1 while running, else the step after which the loop ended
+  float lambda;   // s_out
+  int iters;      // steps executed
 };
 
-struct PiChunk {
+struct PiTile {
   int block;
-  int chunk;  // index inside the block; rows [chunk*PI_ROWS, ...)
+  short I, J;  // J >= I
 };
 
-// sum of x[0..cnt) in a fixed order, computed by wavefront 0; result broadcast
-// through LDS slot `bcast`.
-__device__ inline float fixed_order_sum_wave0(const float* x, int cnt, int tid,
-                                              float* bcast) {
-  if (tid < 64) {
-    float s = 0.f;
-    for (int j = tid; j < cnt; j += 64) s += x[j];
-    s = wave_sum_f32(s);
-    if (tid == 0) *bcast = s;
-  }
-  __syncthreads();
-  return *bcast;
-}
-
-static __global__ __launch_bounds__(256) void pi_step_kernel(PiBlock* blocks,
-                                                      const PiChunk* chunks,
-                                                      int iter, float tol) {
-  extern __shared__ __align__(16) float pi_smem[];  // [n] normalised v, then scratch
-  __shared__ float red[8];
-  __shared__ int s_stop;
-  const PiChunk ch = chunks[blockIdx.x];
-  PiBlock* pb = &blocks[ch.block];
-  const int tid = threadIdx.x;
-  const int n = pb->n;
-  // Another workgroup of this block may be recording the stop right now: take
-  // the decision once per workgroup so that it is uniform.
-  if (tid == 0) s_stop = pb->stop_iter >= 0 ? 1 : 0;
-  __syncthreads();
-  if (s_stop) return;
-
-  if (iter >= 1) {
-    // s of the previous step, and the run_step predicate of DS:639.
-    const float s_cur =
-        fixed_order_sum_wave0(pb->partial[(iter - 1) & 1], pb->nchunk, tid, &red[7]);
-    if (tid == 0) {
-      const float s_prev = iter >= 2 ? pb->s_val[iter & 1] : 0.f;
-      const bool run = fabsf(s_cur - s_prev) > tol;
-      s_stop = run ? 0 : 1;
-      if (ch.chunk == 0) {
-        pb->s_val[(iter - 1) & 1] = s_cur;
-        if (!run) {
-          pb->lambda = s_cur;
-          pb->iters = iter;
-          pb->stop_iter = iter - 1;
-        }
-      }
-    }
-    __syncthreads();
-    if (s_stop) return;
-  }
-
-  const float* v = pb->v[iter & 1];
-  float* vnext = pb->v[(iter + 1) & 1];
-
-  // ||v||, same order in every workgroup of the block (DS:634).
+// ---- v0 -> normalised first iterate (DS:634 of step 0) --------------------------
+static __global__ __launch_bounds__(256) void pi_init_kernel(PiBlock* blocks,
+                                                            const float* v0) {
+  __shared__ float red[4];
+  PiBlock* pb = &blocks[blockIdx.x];
+  const int n = pb->n, tid = threadIdx.x;
   float ss = 0.f;
-  for (int j = tid; j < n; j += 256) ss += v[j] * v[j];
+  for (int j = tid; j < n; j += 256) ss += v0[j] * v0[j];
   ss = wave_sum_f32(ss);
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
   const float nrm = sqrtf(((red[0] + red[1]) + red[2]) + red[3]);
-  for (int j = tid; j < n; j += 256) pi_smem[j] = v[j] / nrm;
-  __syncthreads();
-
-  // rows of this chunk: A v (DS:636) and the partial of v.(A v) (DS:637).
-  const int wave = tid >> 6, lane = tid & 63;
-  float spart = 0.f;
-  const int row_end = min(n, (ch.chunk + 1) * PI_ROWS);
-  for (int r = ch.chunk * PI_ROWS + wave; r < row_end; r += 4) {
-    const float* arow = pb->a + (int64_t)r * pb->lda;
-    float acc = 0.f;
-    if (pb->vec_ok) {
-      const int n4 = n & ~3;
-      for (int j = lane * 4; j < n4; j += 256) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(arow + j);
-        const f32x4 y = *reinterpret_cast<const f32x4*>(pi_smem + j);
-        acc += x[0] * y[0];
-        acc += x[1] * y[1];
-        acc += x[2] * y[2];
-        acc += x[3] * y[3];
-      }
-      for (int j = n4 + lane; j < n; j += 64) acc += arow[j] * pi_smem[j];
-    } else {
-      for (int j = lane; j < n; j += 64) acc += arow[j] * pi_smem[j];
-    }
-    acc = wave_sum_f32(acc);
-    if (lane == 0) {
-      vnext[r] = acc;
-      spart += pi_smem[r] * acc;
-    }
-  }
-  __syncthreads();
-  if (lane == 0) red[wave] = spart;
-  __syncthreads();
-  if (tid == 0)
-    pb->partial[iter & 1][ch.chunk] = ((red[0] + red[1]) + red[2]) + red[3];
+  for (int j = tid; j < pb->t * PT; j += 256) pb->vn[j] = j < n ? v0[j] / nrm : 0.f;
 }
 
-// One workgroup per block: closes the loop (DS:649-652) and optionally writes
-// the normalised vector.
-static __global__ __launch_bounds__(256) void pi_final_kernel(PiBlock* blocks, int num_iters,
-                                                       float* out_lambda,
-                                                       int* out_iters, float* out_v,
-                                                       int ldv) {
+// ---- one tile of A v (and of A^T v for off-diagonal tiles) ------------------------
+// Register streaming, no LDS staging of the tile: lane = (row parity, float4 column
+// group); a wavefront walks 32 rows two at a time with all 16 loads in flight.
+// u[r] (row dot products) are reduced across the 32 lanes of a half-wave; w[c]
+// (column sums of A^T v_I) accumulate in 4 registers per lane over the rows the
+// lane visits and are combined across wavefronts through 2 KB of LDS.
+static __global__ __launch_bounds__(256) void pi_mv_kernel(PiBlock* blocks,
+                                                          const PiTile* tiles) {
+  __shared__ float vI[PT];
+  __shared__ float wpart[4][PT];
+  const PiTile te = tiles[blockIdx.x];
+  PiBlock* pb = &blocks[te.block];
+  if (pb->stop_iter >= 0) return;  // uniform: written only by earlier launches
+  const int n = pb->n, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int c4 = lane & 31, rh = lane >> 5;
+  const int r0 = te.I * PT, c0 = te.J * PT;
+  const float* a = pb->a;
+  const int lda = pb->lda;
+  const bool offdiag = te.I != te.J;
+  if (tid < PT) vI[tid] = pb->vn[r0 + tid];
+  const f32x4 vj = *reinterpret_cast<const f32x4*>(pb->vn + c0 + 4 * c4);
+  __syncthreads();
+  const bool fast = pb->vec_ok && c0 + PT <= n && r0 + PT <= n;
+  f32x4 x[16];
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int r = 32 * wave + 2 * it + rh;
+      x[it] = gload4(a + (int64_t)(r0 + r) * lda + c0 + 4 * c4);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int r = 32 * wave + 2 * it + rh;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + 4 * c4 + e < n) t[e] = gload1(a + (int64_t)(r0 + r) * lda + c0 + 4 * c4 + e);
+      }
+      x[it] = t;
+    }
+  }
+  float* P = pb->P;
+  const int t = pb->t;
+  f32x4 w = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int r = 32 * wave + 2 * it + rh;
+    float u = x[it][0] * vj[0];
+    u += x[it][1] * vj[1];
+    u += x[it][2] * vj[2];
+    u += x[it][3] * vj[3];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) u += __shfl_xor(u, off, 64);  // within the half
+    if (c4 == 0) P[((int64_t)te.I * t + te.J) * PT + r] = u;
+    const float vi = vI[r];
+    w[0] += x[it][0] * vi; w[1] += x[it][1] * vi; w[2] += x[it][2] * vi; w[3] += x[it][3] * vi;
+  }
+  if (offdiag) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] += __shfl_xor(w[e], 32, 64);  // the two row parities
+    if (rh == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wpart[wave][4 * c4 + e] = w[e];
+    }
+    __syncthreads();
+    if (tid < PT)
+      P[((int64_t)te.J * t + te.I) * PT + tid] =
+          ((wpart[0][tid] + wpart[1][tid]) + wpart[2][tid]) + wpart[3][tid];
+  }
+}
+
+// ---- per block: y = sum of partials, s, ||y||, stop decision, next iterate ---------
+static __global__ __launch_bounds__(256) void pi_red_kernel(PiBlock* blocks, int iter,
+                                                           int num_iters, float tol) {
   __shared__ float red[8];
   PiBlock* pb = &blocks[blockIdx.x];
-  const int tid = threadIdx.x;
-  const int n = pb->n;
-  if (pb->stop_iter < 0) {
-    float s;
-    if (n == 0) {
-      s = __uint_as_float(0x7fc00000u);  // v0 masked to zero: 0/0 (DS:634)
-      if (tid == 0) { pb->lambda = s; pb->iters = 1; pb->stop_iter = 0; }
-    } else {
-      s = fixed_order_sum_wave0(pb->partial[(num_iters - 1) & 1], pb->nchunk, tid,
-                                &red[7]);
-      if (tid == 0) { pb->lambda = s; pb->iters = num_iters; pb->stop_iter = num_iters - 1; }
+  if (pb->stop_iter >= 0) return;
+  const int n = pb->n, t = pb->t, tid = threadIdx.x;
+  if (n == 0) {  // all padding: v0 masked to zero, 0/0 (DS:634)
+    if (tid == 0) {
+      pb->lambda = __uint_as_float(0x7fc00000u);
+      pb->iters = 1;
+      pb->stop_iter = 0;
+    }
+    return;
+  }
+  float s = 0.f, ss = 0.f;
+  for (int j = tid; j < t * PT; j += 256) {
+    const int X = j >> 7, r = j & 127;
+    float y = 0.f;
+    for (int Y = 0; Y < t; ++Y) y += pb->P[((int64_t)X * t + Y) * PT + r];
+    s += pb->vn[j] * y;   // DS:637
+    ss += y * y;
+  }
+  s = wave_sum_f32(s);
+  ss = wave_sum_f32(ss);
+  if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = ss; }
+  __syncthreads();
+  const float s_new = ((red[0] + red[1]) + red[2]) + red[3];
+  const float nrm = sqrtf(((red[4] + red[5]) + red[6]) + red[7]);
+  const bool run = fabsf(s_new - pb->s_prev) > tol;  // DS:639
+  const bool last = iter + 1 >= num_iters;
+  // next iterate, normalised (DS:634 of the next step / DS:651 at the end)
+  for (int j = tid; j < t * PT; j += 256) {
+    const int X = j >> 7, r = j & 127;
+    float y = 0.f;  // same fixed order as above => same bits
+    for (int Y = 0; Y < t; ++Y) y += pb->P[((int64_t)X * t + Y) * PT + r];
+    pb->vn[j] = j < n ? y / nrm : 0.f;
+  }
+  __syncthreads();  // every thread has read s_prev before it is overwritten
+  if (tid == 0) {
+    pb->s_prev = s_new;
+    if (!run || last) {
+      pb->lambda = s_new;
+      pb->iters = iter + 1;
+      pb->stop_iter = iter;
     }
   }
-  __syncthreads();
-  if (tid == 0) {
-    if (out_lambda) out_lambda[blockIdx.x] = pb->lambda;
-    if (out_iters) out_iters[blockIdx.x] = pb->iters;
-  }
-  if (out_v != nullptr && n > 0) {
-    const float* v = pb->v[pb->iters & 1];
-    float ss = 0.f;
-    for (int j = tid; j < n; j += 256) ss += v[j] * v[j];
-    ss = wave_sum_f32(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
-    const float nrm = sqrtf(((red[0] + red[1]) + red[2]) + red[3]);
-    for (int j = tid; j < n; j += 256)
-      out_v[(int64_t)blockIdx.x * ldv + j] = v[j] / nrm;  // DS:651
-  }
 }
+
+static __global__ void pi_output_kernel(const PiBlock* blocks, int nblocks, float* out_lambda,
+                                        int* out_iters, float* out_v, int ldv) {
+  (void)nblocks;
+  const int b = blockIdx.x;
+  const PiBlock* pb = &blocks[b];
+  if (threadIdx.x == 0) {
+    if (out_lambda) out_lambda[b] = pb->lambda;
+    if (out_iters) out_iters[b] = pb->iters;
+  }
+  if (out_v)
+    for (int j = threadIdx.x; j < pb->n; j += blockDim.x) out_v[(int64_t)b * ldv + j] = pb->vn[j];
+}
+
+// ---- host side --------------------------------------------------------------------
+struct PiPlan {
+  int batch = 0, max_n = 0;
+  std::vector<int> n_eff;
+  std::vector<PiTile> tiles;
+  PiBlock* d_blocks = nullptr;
+  PiTile* d_tiles = nullptr;
+  float* d_v0 = nullptr;
+  std::vector<float*> d_vn, d_P;
+
+  void build(int b, const std::vector<int>& ne) {
+    batch = b;
+    n_eff = ne;
+    tiles.clear();
+    max_n = 0;
+    for (int i = 0; i < b; ++i) {
+      max_n = std::max(max_n, ne[i]);
+      const int t = (ne[i] + PT - 1) / PT;
+      for (int I = 0; I < t; ++I)
+        for (int J = I; J < t; ++J) tiles.push_back({i, (short)I, (short)J});
+    }
+  }
+
+  void carve(psh::Arena& ar, bool assign) {
+    PiBlock* blk = ar.take<PiBlock>(batch);
+    PiTile* tl = ar.take<PiTile>(std::max<size_t>(tiles.size(), 1));
+    float* v0 = ar.take<float>(std::max(max_n, 1));
+    if (assign) { d_blocks = blk; d_tiles = tl; d_v0 = v0; d_vn.clear(); d_P.clear(); }
+    for (int i = 0; i < batch; ++i) {
+      const int t = (n_eff[i] + PT - 1) / PT;
+      float* vn = ar.take<float>(std::max(t * PT, 1));
+      float* P = ar.take<float>(std::max(t * t * PT, 1));
+      if (assign) { d_vn.push_back(vn); d_P.push_back(P); }
+    }
+  }
+
+  // Uploads the descriptors (synchronises the stream: host vectors are temporary).
+  int upload(hipStream_t st, const float* const* a, const int32_t* lda) {
+    std::vector<PiBlock> h(batch);
+    for (int i = 0; i < batch; ++i) {
+      PiBlock& pb = h[i];
+      memset(&pb, 0, sizeof(pb));
+      pb.a = a[i];
+      pb.lda = lda[i];
+      pb.n = n_eff[i];
+      pb.t = (n_eff[i] + PT - 1) / PT;
+      pb.vec_ok = (((uintptr_t)a[i] % 16 == 0) && (lda[i] % 4 == 0)) ? 1 : 0;
+      pb.vn = d_vn[i];
+      pb.P = d_P[i];
+      pb.stop_iter = -1;
+    }
+    std::vector<float> v0(std::max(max_n, 1));
+    ps_power_iteration_v0(max_n, v0.data());
+    PS_HIP(hipMemcpyAsync(d_blocks, h.data(), sizeof(PiBlock) * batch, hipMemcpyHostToDevice, st));
+    PS_HIP(hipMemcpyAsync(d_v0, v0.data(), sizeof(float) * v0.size(), hipMemcpyHostToDevice, st));
+    if (!tiles.empty())
+      PS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(PiTile) * tiles.size(),
+                            hipMemcpyHostToDevice, st));
+    PS_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
+
+  // Enqueues the whole iteration: 2 launches per step, fixed count (data-dependent
+  // stops are taken on the device; stopped blocks' workgroups exit at once).
+  int enqueue(hipStream_t st, int num_iters, float tol) {
+    const size_t shm = 0;
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(pi_init_kernel, dim3(batch), dim3(256), 0, st, d_blocks, d_v0);
+    const int nt = (int)tiles.size();
+    for (int i = 0; i < num_iters; ++i) {
+      if (nt > 0)
+        hipLaunchKernelGGL(pi_mv_kernel, dim3(nt), dim3(256), shm, st, d_blocks, d_tiles);
+      hipLaunchKernelGGL(pi_red_kernel, dim3(batch), dim3(256), 0, st, d_blocks, i, num_iters,
+                         tol);
+    }
+    PS_LAUNCH_CHECK();
+    return 0;
+  }
+};
 
 }  // namespace psk
