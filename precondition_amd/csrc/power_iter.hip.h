@@ -141,9 +141,10 @@ static __global__ __launch_bounds__(256) void pi_mv_kernel(PiBlock* blocks,
 }
 
 // ---- per block: y = sum of partials, s, ||y||, stop decision, next iterate ---------
-static __global__ __launch_bounds__(256) void pi_red_kernel(PiBlock* blocks, int iter,
+static __global__ __launch_bounds__(512) void pi_red_kernel(PiBlock* blocks, int iter,
                                                            int num_iters, float tol) {
-  __shared__ float red[8];
+  extern __shared__ __align__(16) float ysm[];  // [t*128] y of this step
+  __shared__ float red[16];
   PiBlock* pb = &blocks[blockIdx.x];
   if (pb->stop_iter >= 0) return;
   const int n = pb->n, t = pb->t, tid = threadIdx.x;
@@ -156,28 +157,32 @@ static __global__ __launch_bounds__(256) void pi_red_kernel(PiBlock* blocks, int
     return;
   }
   float s = 0.f, ss = 0.f;
-  for (int j = tid; j < t * PT; j += 256) {
+  for (int j = tid; j < t * PT; j += 512) {
     const int X = j >> 7, r = j & 127;
+    const float* p = pb->P + (int64_t)X * t * PT + r;
     float y = 0.f;
-    for (int Y = 0; Y < t; ++Y) y += pb->P[((int64_t)X * t + Y) * PT + r];
+    int Y = 0;
+    for (; Y + 4 <= t; Y += 4) {  // independent loads, fixed summation order
+      const float p0 = p[(Y + 0) * PT], p1 = p[(Y + 1) * PT], p2 = p[(Y + 2) * PT],
+                  p3 = p[(Y + 3) * PT];
+      y = (((y + p0) + p1) + p2) + p3;
+    }
+    for (; Y < t; ++Y) y += p[Y * PT];
+    ysm[j] = y;
     s += pb->vn[j] * y;   // DS:637
     ss += y * y;
   }
   s = wave_sum_f32(s);
   ss = wave_sum_f32(ss);
-  if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = ss; }
+  if ((tid & 63) == 0) { red[tid >> 6] = s; red[8 + (tid >> 6)] = ss; }
   __syncthreads();
-  const float s_new = ((red[0] + red[1]) + red[2]) + red[3];
-  const float nrm = sqrtf(((red[4] + red[5]) + red[6]) + red[7]);
+  float s_new = 0.f, n2 = 0.f;
+  for (int w = 0; w < 8; ++w) { s_new += red[w]; n2 += red[8 + w]; }
+  const float nrm = sqrtf(n2);
   const bool run = fabsf(s_new - pb->s_prev) > tol;  // DS:639
   const bool last = iter + 1 >= num_iters;
   // next iterate, normalised (DS:634 of the next step / DS:651 at the end)
-  for (int j = tid; j < t * PT; j += 256) {
-    const int X = j >> 7, r = j & 127;
-    float y = 0.f;  // same fixed order as above => same bits
-    for (int Y = 0; Y < t; ++Y) y += pb->P[((int64_t)X * t + Y) * PT + r];
-    pb->vn[j] = j < n ? y / nrm : 0.f;
-  }
+  for (int j = tid; j < t * PT; j += 512) pb->vn[j] = j < n ? ysm[j] / nrm : 0.f;
   __syncthreads();  // every thread has read s_prev before it is overwritten
   if (tid == 0) {
     pb->s_prev = s_new;
@@ -268,14 +273,15 @@ struct PiPlan {
   // stops are taken on the device; stopped blocks' workgroups exit at once).
   int enqueue(hipStream_t st, int num_iters, float tol) {
     const size_t shm = 0;
+    const size_t red_shm = (size_t)((max_n + PT - 1) / PT) * PT * sizeof(float);  // <= 64 KB
     if (batch == 0) return 0;
     hipLaunchKernelGGL(pi_init_kernel, dim3(batch), dim3(256), 0, st, d_blocks, d_v0);
     const int nt = (int)tiles.size();
     for (int i = 0; i < num_iters; ++i) {
       if (nt > 0)
         hipLaunchKernelGGL(pi_mv_kernel, dim3(nt), dim3(256), shm, st, d_blocks, d_tiles);
-      hipLaunchKernelGGL(pi_red_kernel, dim3(batch), dim3(256), 0, st, d_blocks, i, num_iters,
-                         tol);
+      hipLaunchKernelGGL(pi_red_kernel, dim3(batch), dim3(512), red_shm, st, d_blocks, i,
+                         num_iters, tol);
     }
     PS_LAUNCH_CHECK();
     return 0;
