@@ -202,6 +202,25 @@ int ps_gemm_f32(void* stream, int transa, int transb, const float* a, const floa
                 float* c, int m, int n, int k, int lda, int ldb, int ldc, int batch,
                 int64_t stride_a, int64_t stride_b, int64_t stride_c);
 
+/* Grouped form: many independent products in one launch per operand-layout pair.
+ * Used by the every-step application of the preconditioners to all gradient
+ * blocks of a parameter tree (Preconditioner.preconditioned_grad, DS:1645-1708: per
+ * block tensordot(g, P, [[0],[0]]) per axis; the reference unrolls it in Python).
+ * c may be a strided view (ldc) so that results land directly in the merged
+ * gradient (no merge_partitions copy).  desc is a HOST array of device pointers. */
+typedef struct {
+  const float* a;
+  const float* b;
+  float* c;
+  int32_t m, n, k;
+  int32_t transa, transb; /* as in ps_gemm_f32 */
+  int64_t lda, ldb, ldc;
+} ps_gemm_desc;
+
+size_t ps_gemm_grouped_workspace_bytes(const ps_gemm_desc* desc, int count);
+int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count, void* workspace,
+                        size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

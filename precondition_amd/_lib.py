@@ -22,6 +22,16 @@ class PsError(RuntimeError):
   pass
 
 
+class GemmDesc(C.Structure):
+  """Mirror of ps_gemm_desc."""
+  _fields_ = [
+      ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p),
+      ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+      ("transa", C.c_int32), ("transb", C.c_int32),
+      ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+  ]
+
+
 class StatsDesc(C.Structure):
   """Mirror of ps_stats_desc."""
   _fields_ = [
@@ -73,6 +83,9 @@ _SIGNATURES = {
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ps_gemm_grouped_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc), C.c_int]),
+    "ps_gemm_grouped_f32":
+        (C.c_int, [C.c_void_p, C.POINTER(GemmDesc), C.c_int, C.c_void_p, C.c_size_t]),
     "ps_eigh_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

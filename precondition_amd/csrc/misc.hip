@@ -122,6 +122,103 @@ extern "C" int ps_gemm_f32(void* stream, int transa, int transb, const float* a,
   return PS_OK;
 }
 
+namespace psk {
+struct GTask {
+  const float* a; const float* b; float* c;
+  int m, n, k, lda, ldb, ldc, veca, vecb;
+};
+struct GTile { int task; short tm, tn; };
+
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GTask* tasks,
+                                                              const GTile* tiles, int ntiles) {
+  __shared__ __align__(16) float smem[SmemCfg<GBK>::TOTAL];
+  const GTile te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  const GTask tk = tasks[te.task];
+  Operand A{tk.a, tk.lda, te.tm * TILE, tk.m, tk.k, tk.veca != 0};
+  Operand B{tk.b, tk.ldb, te.tn * TILE, tk.n, tk.k, tk.vecb != 0};
+  f32x16 acc[2][2];
+  gemm_tile<LA, LB, GBK, true>(A, B, tk.k, smem, acc);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = te.tm * TILE + acc_row(wm, i, r, lane);
+        const int col = te.tn * TILE + acc_col(wn, j, lane);
+        if (row < tk.m && col < tk.n) gstore1(tk.c + (int64_t)row * tk.ldc + col, acc[i][j][r]);
+      }
+}
+}  // namespace psk
+
+static size_t grouped_gemm_bytes(const ps_gemm_desc* d, int count) {
+  size_t tiles = 0;
+  for (int i = 0; i < count; ++i)
+    tiles += (size_t)((d[i].m + TILE - 1) / TILE) * ((d[i].n + TILE - 1) / TILE);
+  return 4 * (psh::align_up(sizeof(GTask) * count, 256) + 256) +
+         4 * (psh::align_up(sizeof(GTile) * tiles, 256) + 256) + 1024;
+}
+
+extern "C" size_t ps_gemm_grouped_workspace_bytes(const ps_gemm_desc* desc, int count) {
+  if (!desc || count <= 0) return 0;
+  return grouped_gemm_bytes(desc, count);
+}
+
+extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count,
+                                   void* workspace, size_t workspace_bytes) {
+  if (!desc || count <= 0 || !workspace) return PS_EINVAL;
+  if (workspace_bytes < grouped_gemm_bytes(desc, count)) return PS_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<GTask> tasks[4];
+  std::vector<GTile> tiles[4];
+  for (int i = 0; i < count; ++i) {
+    const ps_gemm_desc& d = desc[i];
+    if (!d.a || !d.b || !d.c || d.m < 1 || d.n < 1 || d.k < 1 || d.ldc < d.n ||
+        d.lda < (d.transa ? d.m : d.k) || d.ldb < (d.transb ? d.k : d.n) ||
+        d.lda > 0x7fffffff || d.ldb > 0x7fffffff || d.ldc > 0x7fffffff)
+      return PS_EINVAL;
+    const int g = (d.transa ? 2 : 0) + (d.transb ? 1 : 0);
+    GTask t{d.a, d.b, d.c, d.m, d.n, d.k, (int)d.lda, (int)d.ldb, (int)d.ldc,
+            vec_ok(d.a, (int)d.lda, 0) ? 1 : 0, vec_ok(d.b, (int)d.ldb, 0) ? 1 : 0};
+    const int id = (int)tasks[g].size();
+    tasks[g].push_back(t);
+    const int tm = (d.m + TILE - 1) / TILE, tn = (d.n + TILE - 1) / TILE;
+    for (int a = 0; a < tm; ++a)
+      for (int b = 0; b < tn; ++b) tiles[g].push_back({id, (short)a, (short)b});
+  }
+  psh::Arena ar(workspace, workspace_bytes);
+  GTask* dt[4];
+  GTile* dl[4];
+  for (int g = 0; g < 4; ++g) {
+    dt[g] = ar.take<GTask>(std::max<size_t>(tasks[g].size(), 1));
+    dl[g] = ar.take<GTile>(std::max<size_t>(tiles[g].size(), 1));
+  }
+  if (ar.overflow) return PS_EWORKSPACE;
+  for (int g = 0; g < 4; ++g) {
+    if (tasks[g].empty()) continue;
+    PS_HIP(hipMemcpyAsync(dt[g], tasks[g].data(), sizeof(GTask) * tasks[g].size(),
+                          hipMemcpyHostToDevice, st));
+    PS_HIP(hipMemcpyAsync(dl[g], tiles[g].data(), sizeof(GTile) * tiles[g].size(),
+                          hipMemcpyHostToDevice, st));
+  }
+  PS_HIP(hipStreamSynchronize(st));
+  const dim3 blk(256);
+#define PS_GG(G, LA, LB)                                                                   \
+  if (!tasks[G].empty())                                                                   \
+    hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB>), dim3((unsigned)tiles[G].size()), blk, \
+                       0, st, dt[G], dl[G], (int)tiles[G].size())
+  PS_GG(0, KC, MC);
+  PS_GG(1, KC, KC);
+  PS_GG(2, MC, MC);
+  PS_GG(3, MC, KC);
+#undef PS_GG
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 static int ps_gemm_nn_f32(void* stream, const float* a, const float* b, float* c, int m,
                           int n, int k, int lda, int ldb, int ldc, int batch,
                           int64_t sa, int64_t sb, int64_t sc) {

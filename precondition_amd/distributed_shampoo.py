@@ -360,7 +360,49 @@ def distributed_shampoo(
     return out
 
   # ---------------------------------------------------------------------------
-  def _transform_grad(grad, state, param, step):
+  def _preconditioned_grads_all(grads_flat, states, params_flat):
+    """Preconditioner.preconditioned_grad (DS:1645-1708) for the whole tree.  Blocks
+    of parameters whose merged shape is 1-D or 2-D (the common case) are applied in
+    two grouped launches — X_b = g_b^T P_L for every block, then Y_b = X_b^T P_R
+    written straight into the merged gradient — instead of two products, a
+    transpose and a concatenation per block.  Everything else takes the per-block
+    path of blocking.Preconditioner."""
+    out = [None] * len(grads_flat)
+    stage_a, stage_b, keep = [], [], []
+    for idx, (grad, state, param) in enumerate(zip(grads_flat, states, params_flat)):
+      if _skip_preconditioning(param):
+        continue
+      pc = preconditioner_from_params(param)
+      tshape = pc._transformed_shape
+      should = pc.should_precondition_dims()
+      if compression_rank != 0 or not all(should) or len(tshape) not in (1, 2):
+        out[idx] = pc.preconditioned_grad(grad, state.preconditioners,
+                                          tensordot_fn=backend.tensordot_axis0,
+                                          matmul_fn=backend.matmul)
+        continue
+      g_t = grad.reshape(tshape)
+      res = torch.empty(tshape, dtype=torch.float32, device=grad.device)
+      nd = len(tshape)
+      for i, (gb, ob) in enumerate(zip(pc._partitioner.partition(g_t),
+                                       pc._partitioner.partition(res))):
+        pcs = state.preconditioners[i * nd:(i + 1) * nd]
+        if nd == 1:
+          d = gb.shape[0]
+          gb_c = gb.contiguous()
+          keep.append(gb_c)
+          stage_a.append((gb_c.view(d, 1), pcs[0], ob.view(1, d), True, False))
+        else:
+          m, n = gb.shape
+          x = torch.empty((n, m), dtype=torch.float32, device=grad.device)
+          stage_a.append((gb, pcs[0], x, True, False))   # [n, m] = g^T P_L
+          stage_b.append((x, pcs[1], ob, True, False))   # [m, n] = X^T P_R
+      out[idx] = res.reshape(tuple(param.shape))
+    backend.gemm_grouped(stage_a)
+    backend.gemm_grouped(stage_b)
+    del keep
+    return out
+
+  def _transform_grad(grad, state, param, step, precond_grad=None):
     """DS:3496-3625: grafting, preconditioning, momentum."""
     pc = preconditioner_from_params(param)
     sgd_update = grad
@@ -393,9 +435,10 @@ def distributed_shampoo(
     grafting_update = grafting_update * (lr if not decoupled_learning_rate else 1.0)
 
     if not _skip_preconditioning(param):
-      precond_grad = pc.preconditioned_grad(grad, state.preconditioners,
-                                            tensordot_fn=backend.tensordot_axis0,
-                                            matmul_fn=backend.matmul)
+      if precond_grad is None:
+        precond_grad = pc.preconditioned_grad(grad, state.preconditioners,
+                                              tensordot_fn=backend.tensordot_axis0,
+                                              matmul_fn=backend.matmul)
     else:
       if graft_type == GraftingType.NONE:
         logging.error("skipping preconditioning without grafting for param %s", param)
@@ -444,8 +487,9 @@ def distributed_shampoo(
 
     new_stats = _compute_stats_all(grads_flat, stats_flat, params_flat, step)
     new_stats = _compute_preconditioners(new_stats, params_flat, step)
-    outs = [_transform_grad(g, s, p, step)
-            for g, s, p in zip(grads_flat, new_stats, params_flat)]
+    pgs = _preconditioned_grads_all(grads_flat, new_stats, params_flat)
+    outs = [_transform_grad(g, s, p, step, pg)
+            for g, s, p, pg in zip(grads_flat, new_stats, params_flat, pgs)]
     updates_flat = [o[0] for o in outs]
     new_stats = [o[1] for o in outs]
     return (treedef.unflatten(updates_flat),

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import StatsDesc, check, lib
+from ._lib import GemmDesc, StatsDesc, check, lib
 
 
 def _require_gpu(t: torch.Tensor, what: str):
@@ -258,6 +258,32 @@ def matmul(a: torch.Tensor, b: torch.Tensor, transa: bool = False,
                          b3.shape[1] * b3.shape[2], m * n)
   check(rc, "ps_gemm_f32")
   return c[0] if squeeze else c
+
+
+def gemm_grouped(items):
+  """items: list of (a, b, c, transa, transb) with 2-D row-contiguous (possibly
+  strided) tensors; c = op(a) @ op(b) for all of them in one launch per layout pair."""
+  if not items:
+    return
+  dev = items[0][0].device
+  descs = (GemmDesc * len(items))()
+  for i, (a, b, c, ta, tb) in enumerate(items):
+    _require_gpu(a, "gemm_grouped")
+    _require_gpu(b, "gemm_grouped")
+    m, k = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    n = b.shape[0] if tb else b.shape[1]
+    kb = b.shape[1] if tb else b.shape[0]
+    if kb != k or tuple(c.shape) != (m, n):
+      raise ValueError(f"gemm_grouped shape mismatch in item {i}")
+    d = descs[i]
+    d.a, d.b, d.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    d.m, d.n, d.k, d.transa, d.transb = int(m), int(n), int(k), int(bool(ta)), int(bool(tb))
+    d.lda, d.ldb, d.ldc = _as_2d_ld(a), _as_2d_ld(b), _as_2d_ld(c)
+  L = lib()
+  ws = _workspace(L.ps_gemm_grouped_workspace_bytes(descs, len(items)), dev)
+  rc = L.ps_gemm_grouped_f32(_stream(), descs, len(items), ws.data_ptr(), ws.numel())
+  check(rc, "ps_gemm_grouped_f32")
+  ws.record_stream(torch.cuda.current_stream())
 
 
 def tensordot_axis0(g: torch.Tensor, pc: torch.Tensor) -> torch.Tensor:

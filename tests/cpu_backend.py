@@ -77,3 +77,8 @@ def fd_update_root(new_grad, p, rank=0, ridge_epsilon=1e-6, error_tolerance=1e-6
   val = orc.fd_update_root(g, p, rank, ridge_epsilon, error_tolerance,
                            relative_matrix_epsilon, decay, padding_start, prev.cpu().numpy())
   return torch.from_numpy(val), _TM(0.0)
+
+
+def gemm_grouped(items):
+  for a, b, c, ta, tb in items:
+    c.copy_(matmul(a, b, transa=ta, transb=tb))

@@ -217,6 +217,31 @@ def test_matmul_layouts_vs_fp64(device):
   assert np.array_equal(c, b)
 
 
+def test_gemm_grouped_strided_outputs(device):
+  """Grouped products write into strided block views of a bigger tensor."""
+  rng = np.random.default_rng(1)
+  big = torch.zeros((300, 200), device=device)
+  items, refs = [], []
+  for (r0, c0, m, n) in ((0, 0, 128, 128), (128, 0, 172, 128), (0, 128, 128, 72), (128, 128, 172, 72)):
+    k = 37 + m
+    a = rng.standard_normal((k, m)).astype(np.float32)  # stored [k, m] => transa
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    items.append((torch.tensor(a, device=device), torch.tensor(b, device=device),
+                  big[r0:r0 + m, c0:c0 + n], True, False))
+    refs.append((r0, c0, a.T.astype(np.float64) @ b.astype(np.float64)))
+  v = rng.standard_normal(64).astype(np.float32)
+  pm = rng.standard_normal((64, 64)).astype(np.float32)
+  vec_out = torch.zeros(64, device=device)
+  items.append((torch.tensor(v, device=device).view(64, 1), torch.tensor(pm, device=device),
+                vec_out.view(1, 64), True, False))
+  K().gemm_grouped(items)
+  got = big.cpu().numpy()
+  for r0, c0, ref in refs:
+    blk = got[r0:r0 + ref.shape[0], c0:c0 + ref.shape[1]]
+    assert np.abs(blk - ref).max() / np.abs(ref).max() < 2e-6
+  assert np.allclose(vec_out.cpu().numpy(), v @ pm, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("case", e2e_index(GOLD), ids=lambda c: c["name"])
 def test_e2e_optimizer_hip_vs_reference_golden(case, device):
   z = np.load(os.path.join(GOLD, "e2e.npz"))
