@@ -221,6 +221,50 @@ size_t ps_gemm_grouped_workspace_bytes(const ps_gemm_desc* desc, int count);
 int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count, void* workspace,
                         size_t workspace_bytes);
 
+/* ---- fused _transform_grad for a whole parameter tree (DS:3496-3625) -------------
+ * Grafting, norm matching of the preconditioned gradient, weight decay, momentum /
+ * Nesterov for every parameter in three launches.  All arrays of one parameter are
+ * contiguous with `numel` float32 elements.  pgrad == NULL marks a parameter whose
+ * preconditioning is skipped (precond_grad = grafting_update, DS:3557-3561).
+ * diag_in/diag_out are required for Adagrad/RMSProp grafting types only; param only
+ * when weight_decay != 0.  Outputs must not alias inputs of OTHER parameters;
+ * x_out may alias x_in of the same parameter (each element is read then written by
+ * one thread). */
+typedef struct {
+  const float* grad;
+  const float* pgrad;
+  const float* param;
+  const float* diag_in;
+  float* diag_out;
+  const float* mom_in;
+  float* mom_out;
+  const float* dmom_in;
+  float* dmom_out;
+  float* upd_out;
+  int64_t numel;
+} ps_transform_desc;
+
+typedef struct {
+  int32_t graft_type;  /* GraftingType values of DS:499-506 */
+  int32_t nesterov;
+  int32_t moving_average_for_momentum;
+  int32_t decoupled_learning_rate;
+  int32_t decoupled_weight_decay;
+  int32_t run_shampoo;  /* step >= start_preconditioning_step */
+  float beta1;
+  float beta2_w1;       /* beta2 */
+  float beta2_w2;       /* 1 - beta2, or 1 if beta2 == 1 (DS:3521-3522) */
+  float diagonal_epsilon;
+  float weight_decay;
+  float lr;             /* learning_rate(step) */
+  float clip_by_scaled_gradient_norm; /* <= 0: off */
+} ps_transform_config;
+
+size_t ps_transform_grads_workspace_bytes(const ps_transform_desc* desc, int count);
+int ps_transform_grads_f32(void* stream, const ps_transform_desc* desc, int count,
+                           const ps_transform_config* cfg, void* workspace,
+                           size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,23 @@ class GemmDesc(C.Structure):
   ]
 
 
+class TransformDesc(C.Structure):
+  """Mirror of ps_transform_desc."""
+  _fields_ = [(n, C.c_void_p) for n in ("grad", "pgrad", "param", "diag_in", "diag_out",
+                                         "mom_in", "mom_out", "dmom_in", "dmom_out",
+                                         "upd_out")] + [("numel", C.c_int64)]
+
+
+class TransformConfig(C.Structure):
+  """Mirror of ps_transform_config."""
+  _fields_ = [(n, C.c_int32) for n in ("graft_type", "nesterov",
+                                        "moving_average_for_momentum",
+                                        "decoupled_learning_rate",
+                                        "decoupled_weight_decay", "run_shampoo")] + \
+             [(n, C.c_float) for n in ("beta1", "beta2_w1", "beta2_w2", "diagonal_epsilon",
+                                       "weight_decay", "lr", "clip_by_scaled_gradient_norm")]
+
+
 class StatsDesc(C.Structure):
   """Mirror of ps_stats_desc."""
   _fields_ = [
@@ -86,6 +103,10 @@ _SIGNATURES = {
     "ps_gemm_grouped_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc), C.c_int]),
     "ps_gemm_grouped_f32":
         (C.c_int, [C.c_void_p, C.POINTER(GemmDesc), C.c_int, C.c_void_p, C.c_size_t]),
+    "ps_transform_grads_workspace_bytes": (C.c_size_t, [C.POINTER(TransformDesc), C.c_int]),
+    "ps_transform_grads_f32":
+        (C.c_int, [C.c_void_p, C.POINTER(TransformDesc), C.c_int, C.POINTER(TransformConfig),
+                   C.c_void_p, C.c_size_t]),
     "ps_eigh_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

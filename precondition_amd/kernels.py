@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, StatsDesc, check, lib
+from ._lib import GemmDesc, StatsDesc, TransformConfig, TransformDesc, check, lib
 
 
 def _require_gpu(t: torch.Tensor, what: str):
@@ -407,3 +407,50 @@ def low_rank_root(*args, **kwargs):
 def fd_update_root(*args, **kwargs):
   from . import low_rank
   return low_rank._fd_update_root(*args, **kwargs)
+
+
+# ---------------------------------------------------------------------------
+# fused _transform_grad for a whole tree (DS:3496-3625)
+# ---------------------------------------------------------------------------
+def transform_grads_fused(items, cfg: dict):
+  """items: list of dicts with contiguous float32 device tensors
+  {grad, pgrad|None, param|None, diag_in|None, mom_in, dmom_in}; returns per item
+  (update, new_diag|None, new_mom, new_dmom).  cfg: fields of ps_transform_config."""
+  if not items:
+    return []
+  dev = items[0]["grad"].device
+  descs = (TransformDesc * len(items))()
+  outs, keep = [], []
+  for i, it in enumerate(items):
+    g = it["grad"].contiguous()
+    _require_gpu(g, "_transform_grad")
+    upd = torch.empty_like(g)
+    mom = torch.empty_like(g)
+    dmom = torch.empty_like(g)
+    nd = torch.empty_like(g) if it.get("diag_in") is not None else None
+    d = descs[i]
+    d.grad = g.data_ptr()
+    keep.append(g)
+    for name in ("pgrad", "param", "diag_in", "mom_in", "dmom_in"):
+      t = it.get(name)
+      if t is not None:
+        t = t.contiguous()
+        keep.append(t)
+        setattr(d, name, t.data_ptr())
+      else:
+        setattr(d, name, None)
+    d.diag_out = nd.data_ptr() if nd is not None else None
+    d.mom_out, d.dmom_out, d.upd_out = mom.data_ptr(), dmom.data_ptr(), upd.data_ptr()
+    d.numel = g.numel()
+    outs.append((upd, nd, mom, dmom))
+  c = TransformConfig()
+  for k, v in cfg.items():
+    setattr(c, k, v)
+  L = lib()
+  ws = _workspace(L.ps_transform_grads_workspace_bytes(descs, len(items)), dev)
+  rc = L.ps_transform_grads_f32(_stream(), descs, len(items), C.byref(c), ws.data_ptr(),
+                                ws.numel())
+  check(rc, "ps_transform_grads_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  del keep
+  return outs

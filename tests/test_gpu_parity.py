@@ -217,6 +217,50 @@ def test_matmul_layouts_vs_fp64(device):
   assert np.array_equal(c, b)
 
 
+class _NoFusedBackend:
+  """The HIP kernels minus transform_grads_fused: forces the torch restatement of
+  _transform_grad (itself checked against the reference's goldens on CPU)."""
+
+  def __getattr__(self, name):
+    if name == "transform_grads_fused":
+      raise AttributeError(name)
+    return getattr(K(), name)
+
+
+@pytest.mark.parametrize("graft", [0, 1, 2, 3, 4, 5, 6])
+def test_fused_transform_grad_vs_elementwise_restatement(graft, device):
+  import precondition_amd as pa
+  rng = np.random.default_rng(graft)
+  shapes = [(70, 33), (24,), (6, 10, 8), (5000, 3), (9000,)]
+  params = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=device) for s in shapes]
+  for variant in range(3):
+    kw = dict(graft_type=pa.GraftingType(graft), start_preconditioning_step=2,
+              preconditioning_compute_steps=2)
+    if variant == 1:
+      kw.update(weight_decay=0.01, nesterov=False, moving_average_for_momentum=True,
+                beta2=0.9, clip_by_scaled_gradient_norm=0.3)
+    if variant == 2:
+      kw.update(weight_decay=0.02, decoupled_weight_decay=True, decoupled_learning_rate=False,
+                beta1=0.8)
+    fused = pa.distributed_shampoo(0.05, 32, **kw)
+    plain = pa.distributed_shampoo(0.05, 32, _backend_for_testing=_NoFusedBackend(), **kw)
+    sf, sp = fused.init(params), plain.init(params)
+    for t in range(4):
+      grads = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=device)
+               for s in shapes]
+      uf, sf = fused.update(grads, sf, params)
+      up, sp = plain.update(grads, sp, params)
+      for a, b in zip(uf, up):
+        assert torch.isfinite(a).all()
+        assert (a - b).norm() <= 2e-6 * b.norm() + 1e-12, (graft, variant, t)
+    for a, b in zip(sf.stats, sp.stats):
+      assert (a.momentum.to_float() - b.momentum.to_float()).norm() <= \
+          2e-6 * b.momentum.to_float().norm() + 1e-12
+      da, db = a.diagonal_statistics.to_float(), b.diagonal_statistics.to_float()
+      if isinstance(db, torch.Tensor):
+        assert (da - db).norm() <= 2e-6 * db.norm() + 1e-12
+
+
 def test_gemm_grouped_strided_outputs(device):
   """Grouped products write into strided block views of a bigger tensor."""
   rng = np.random.default_rng(1)

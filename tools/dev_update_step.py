@@ -1,0 +1,26 @@
+"""Every-step cost of update_fn on the ViT-B tree (dev only)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import precondition_amd as pa
+import bench
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+params = [torch.from_numpy((rng.standard_normal(s) * 0.02).astype(np.float32)).to(dev) for s in bench.VIT_B_SHAPES]
+grads = [torch.from_numpy((rng.standard_normal(s) * 0.02).astype(np.float32)).to(dev) for s in bench.VIT_B_SHAPES]
+opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=50, start_preconditioning_step=1, graft_type=pa.GraftingType.RMSPROP_NORMALIZED)
+st = opt.init(params)
+torch.cuda.synchronize()
+times = []
+for t in range(8):
+  t0 = time.perf_counter()
+  upd, st = opt.update(grads, st, params)
+  torch.cuda.synchronize()
+  times.append((time.perf_counter() - t0) * 1e3)
+print("update ms per step (step 0 includes the root recompute):", [round(x, 1) for x in times])
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for t in range(3):
+  upd, st = opt.update(grads, st, params)
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
