@@ -132,10 +132,13 @@ class BlockPartitioner:
         if self._split_sizes else 1
 
   def _ranges(self):
+    if getattr(self, "_ranges_cache", None) is not None:
+      return self._ranges_cache
     per_axis = []
     for sizes in self._split_sizes:
       offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
       per_axis.append([(int(o), int(s)) for o, s in zip(offs, sizes)])
+    self._ranges_cache = per_axis
     return per_axis
 
   def partition(self, tensor: torch.Tensor) -> List[torch.Tensor]:

@@ -147,10 +147,18 @@ def distributed_shampoo(
   def _quantize(x):
     return QuantizedValue.from_float_value(x, torch.float32)
 
+  _pc_cache = {}
+
   def preconditioner_from_params(param):
-    return Preconditioner(param, block_size, merge_small_dims_block_size,
+    """Bookkeeping depends on the shape only: one Preconditioner per distinct shape."""
+    key = tuple(param.shape)
+    pc = _pc_cache.get(key)
+    if pc is None:
+      pc = Preconditioner(param, block_size, merge_small_dims_block_size,
                           best_effort_shape_interpretation, precondtioner_type,
                           compression_rank)
+      _pc_cache[key] = pc
+    return pc
 
   def _skip_preconditioning(param):
     return len(param.shape) < skip_preconditioning_rank_lt or any(
