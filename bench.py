@@ -58,15 +58,16 @@ def make_blocks(name, rank, dev):
 
 class Workload:
 
-  def __init__(self, name, rank, world, dev):
+  def __init__(self, name, rank, world, dev, multi=None):
     self.name = name
     self.world = world
+    self.multi = (world > 1) if multi is None else multi
     self.stats, self.p = make_blocks(name, rank, dev)
     nb, n = self.stats.shape[0], self.stats.shape[1]
     self.nb, self.n = nb, n
     self.roots = torch.empty_like(self.stats)
     self.gathered = (torch.empty((world * nb, n, n), dtype=torch.float32, device=dev)
-                     if world > 1 else None)
+                     if self.multi else None)
     self.metrics = None
 
   def _roots(self, lo, hi):
@@ -82,7 +83,7 @@ class Workload:
     self.metrics = self._roots(0, self.nb)
 
   def step(self):
-    if self.world == 1:
+    if not self.multi:
       self.compute()
       return
     # N > 1: the batch is rooted in two halves so that the RCCL all-gather of the
@@ -205,23 +206,23 @@ def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
                   "4096x4096 covariance update; a bf16 top-(r+1) subspace iteration is future work"}
 
 
-def timed(work, steps, warmup, world):
+def timed(work, steps, warmup, multi):
   import torch.distributed as dist
   for _ in range(warmup):
     work.step()
   torch.cuda.synchronize()
-  if world > 1:
+  if multi:
     dist.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(steps):
     work.step()
   torch.cuda.synchronize()
-  if world > 1:
+  if multi:
     dist.barrier()
   dt = time.perf_counter() - t0
   fl = work.flops()
-  if world > 1:
+  if multi:
     rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
     t = torch.tensor([dt], dtype=torch.float64, device=rdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,6 +321,9 @@ def main():
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
+  # dev only: PS_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1` takes the
+  # N > 1 code path (RCCL init, async all-gathers, barriers) with a one-rank group
+  multi = world > 1 or bool(os.environ.get("PS_BENCH_FORCE_DIST"))
   rank = int(os.environ.get("RANK", "0"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
   if os.environ.get("PS_BENCH_ONE_DEVICE"):  # dev only: several ranks on one GPU
@@ -330,7 +334,7 @@ def main():
     raise SystemExit("bench.py needs an MI355X (no CPU path)")
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
-  if world > 1:
+  if multi:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if os.environ.get("PS_BENCH_ONE_DEVICE"):
@@ -339,8 +343,8 @@ def main():
     else:
       dist.init_process_group(backend="nccl", device_id=dev)
 
-  work = Workload(args.workload, rank, world, dev)
-  sec, flops = timed(work, args.steps, args.warmup, world)
+  work = Workload(args.workload, rank, world, dev, multi)
+  sec, flops = timed(work, args.steps, args.warmup, multi)
   nb, n, _, p, _ = WORKLOADS[args.workload]
   iters = work.metrics[:, 1].cpu().numpy()
   errs = work.metrics[:, 0].cpu().numpy()
@@ -365,7 +369,7 @@ def main():
                       "ridge 1e-6 relative, Newton",
           "blocks_per_gpu": nb, "n": n, "p": p,
           "parallelism": f"blocks partitioned over {world} GPU(s)" +
-                         (", RCCL all-gather of roots in the timed region" if world > 1 else ""),
+                         (", RCCL all-gather of roots in the timed region" if multi else ""),
           "newton_iters_per_block": {"min": float(iters.min()), "max": float(iters.max())},
           "max_newton_error": float(np.nanmax(errs)),
           "frac_of_f32_mfma_peak": round(flops / sec / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
@@ -397,17 +401,17 @@ def main():
                               "power_iteration": round(pi_ms, 3),
                               "init_control_copyout": round(other_ms, 3)},
     }
-  elif world > 1:
+  elif multi:
     pass
-  if world > 1:
+  if multi:
     import torch.distributed as dist
     dist.barrier()
 
   if not args.no_headline and args.workload != "headline_64x1024_p4":
     del work
     torch.cuda.empty_cache()
-    hw = Workload("headline_64x1024_p4", rank, world, dev)
-    hsec, hflops = timed(hw, max(2, args.steps // 2), 1, world)
+    hw = Workload("headline_64x1024_p4", rank, world, dev, multi)
+    hsec, hflops = timed(hw, max(2, args.steps // 2), 1, multi)
     head = {"workload": "64 blocks/GPU of 1024x1024 fp32, p=4",
             "value": round(hflops / hsec / 1e9, 1), "unit": "GFLOP/s",
             "ms_per_step": round(hsec * 1e3, 3),
@@ -420,7 +424,7 @@ def main():
       head["step_breakdown_ms"] = {"product_stages": round(sm, 3),
                                    "power_iteration": round(pm, 3),
                                    "init_control_copyout": round(om, 3)}
-    if world > 1:
+    if multi:
       import torch.distributed as dist
       dist.barrier()
     line["headline_1024"] = head
@@ -429,7 +433,7 @@ def main():
   if not args.no_extras:
     torch.cuda.empty_cache()
     group = None
-    if world > 1:
+    if multi:
       import torch.distributed as dist
       group = dist.group.WORLD
     vw = VitBWorkload(rank, world, dev, group)
@@ -437,16 +441,16 @@ def main():
     for _ in range(1):
       vw.step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
       dist.barrier()
     t0 = time.perf_counter()
     for _ in range(vsteps):
       vw.step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
       dist.barrier()
     vdt = (time.perf_counter() - t0) / vsteps
-    if world > 1:
+    if multi:
       t = torch.tensor([vdt], dtype=torch.float64,
                        device="cpu" if dist.get_backend() == "gloo" else "cuda")
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -455,7 +459,7 @@ def main():
     vfl = vw.flops()
     line["vit_b_cfg4"] = {
         "workload": "ViT-B/16 tree (200 leaves, 395 statistics, block_size 1024): statistics "
-                    "update + all roots" + (" + all-gather" if world > 1 else "") +
+                    "update + all roots" + (" + all-gather" if multi else "") +
                     ", strong scaling (LPT ownership)",
         "ms_per_step": round(vdt * 1e3, 3),
         "roots_algorithmic_gflops": round(vfl / vdt / 1e9, 1),
@@ -492,7 +496,7 @@ def main():
         return o.item()
       raise TypeError(type(o))
     print(json.dumps(line, default=_plain), flush=True)
-  if world > 1:
+  if multi:
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()

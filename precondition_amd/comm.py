@@ -120,7 +120,7 @@ def sharded_inverse_pth_roots(
   total = [0] * world
   for i in range(n_stats):
     total[owner[i]] += elems[i]
-  n_phases = 2 if (world > 1 and overlap and max(total) * 4 >= overlap_min_bytes) else 1
+  n_phases = 2 if (group is not None and overlap and max(total) * 4 >= overlap_min_bytes) else 1
   phase_of, seen = [0] * n_stats, [0] * world
   for i in range(n_stats):
     r = owner[i]
@@ -157,7 +157,7 @@ def sharded_inverse_pth_roots(
                        relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
                        out=outs)
       send_metrics[:len(mine)] = m
-    if world == 1:
+    if group is None:
       gathered.append(send.unsqueeze(0))
       gathered_metrics.append(send_metrics.unsqueeze(0))
       continue
