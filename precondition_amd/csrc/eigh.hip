@@ -85,6 +85,13 @@ __device__ __host__ inline void rr_pair(int m, int r, int k, int& I, int& J) {
   J = a < b ? b : a;
 }
 
+// Same tournament without ordering the two players (the in-LDS pivot sweep walks
+// the first players (r+k) % (m-1) and the second players (r-k) % (m-1) with lanes).
+__device__ inline void rr_pair_raw(int m, int r, int k, int& a, int& b) {
+  if (k == 0) { a = m - 1; b = r % (m - 1); }
+  else { a = (r + k) % (m - 1); b = (r - k + (m - 1)) % (m - 1); }
+}
+
 // ---- init: D = A_in masked + ridge I, A = D, V = I; ||D||_F partials -------------
 __global__ __launch_bounds__(256) void eigh_init_kernel(EighBlock* blocks,
                                                         const ETile* tiles) {
@@ -137,7 +144,6 @@ __global__ __launch_bounds__(JT) void jacobi_pair_kernel(EighBlock* blocks,
   float* S = jsm;                 // [128][129]
   float* Q = jsm + JP * JLD;      // [128][129]
   float* cs = Q + JP * JLD;       // [64][2]
-  int* pq = reinterpret_cast<int*>(cs + 2 * JB);  // [64][2]
   __shared__ float red[JT / 64];
   const ETile te = tiles[blockIdx.x];
   EighBlock* eb = &blocks[te.block];
@@ -177,12 +183,19 @@ __global__ __launch_bounds__(JT) void jacobi_pair_kernel(EighBlock* blocks,
     eb->offpart[round * eb->npairs + te.k] = t;
   }
 
-  const int lane_i = tid & 127, half = tid >> 7;
-  constexpr int KSTEP = JT / 128;
+  // One round = 64 disjoint rotations (p_k, q_k).  Every 2x2 block {p_k,q_k} x {p_k',q_k'}
+  // of S belongs to exactly one thread, which applies rotation k from the left and k'
+  // from the right in registers (no barrier between the two sides).  Lanes run over
+  // k': the round-robin columns (r+k') % 127 and (r-k') % 127 are consecutive in a
+  // row, so the LDS walks are bank-conflict free.
+  float2* cs2 = reinterpret_cast<float2*>(cs);
+  // wave index as a scalar: the row pairs of this wave are then SALU work
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = JT / 64;
   for (int rr = 0; rr < JP - 1; ++rr) {
     if (tid < JB) {
       int p, q;
-      rr_pair(JP, rr, tid, p, q);
+      rr_pair_raw(JP, rr, tid, p, q);
       const float app = S[p * JLD + p], aqq = S[q * JLD + q], apq = S[p * JLD + q];
       float c = 1.f, s = 0.f;
       if (fabsf(apq) > 1e-30f) {
@@ -192,29 +205,48 @@ __global__ __launch_bounds__(JT) void jacobi_pair_kernel(EighBlock* blocks,
         s = t * c;
         if (!(c == c) || !(s == s)) { c = 1.f; s = 0.f; }
       }
-      cs[2 * tid] = c; cs[2 * tid + 1] = s;
-      pq[2 * tid] = p; pq[2 * tid + 1] = q;
+      cs2[tid] = make_float2(c, s);
     }
     __syncthreads();
-    // rows p,q of S
-    for (int k = half; k < JB; k += KSTEP) {
-      const int p = pq[2 * k], q = pq[2 * k + 1];
-      const float c = cs[2 * k], s = cs[2 * k + 1];
-      const float x = S[p * JLD + lane_i], y = S[q * JLD + lane_i];
-      S[p * JLD + lane_i] = c * x - s * y;
-      S[q * JLD + lane_i] = s * x + c * y;
+    int ca, cb;
+    rr_pair_raw(JP, rr, lane, ca, cb);
+    const float2 cc = cs2[lane];
+    // all loads first (the compiler cannot reorder LDS loads over possibly aliasing
+    // stores itself), then the arithmetic, then all stores
+    constexpr int NB = JB / NW, NQ = JP / NW;
+    float x00[NB], x01[NB], x10[NB], x11[NB], qx[NQ], qy[NQ];
+    float2 cr[NB];
+    int ra[NB], rb[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int k = wave + NW * i;
+      rr_pair_raw(JP, rr, k, ra[i], rb[i]);
+      cr[i] = cs2[k];
+      const float* s0 = S + ra[i] * JLD;
+      const float* s1 = S + rb[i] * JLD;
+      x00[i] = s0[ca]; x01[i] = s0[cb]; x10[i] = s1[ca]; x11[i] = s1[cb];
     }
-    __syncthreads();
-    // columns p,q of S and of Q
-    for (int k = half; k < JB; k += KSTEP) {
-      const int p = pq[2 * k], q = pq[2 * k + 1];
-      const float c = cs[2 * k], s = cs[2 * k + 1];
-      float x = S[lane_i * JLD + p], y = S[lane_i * JLD + q];
-      S[lane_i * JLD + p] = c * x - s * y;
-      S[lane_i * JLD + q] = s * x + c * y;
-      x = Q[lane_i * JLD + p]; y = Q[lane_i * JLD + q];
-      Q[lane_i * JLD + p] = c * x - s * y;
-      Q[lane_i * JLD + q] = s * x + c * y;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const float* q0 = Q + (wave + NW * i) * JLD;
+      qx[i] = q0[ca]; qy[i] = q0[cb];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const float y00 = cr[i].x * x00[i] - cr[i].y * x10[i], y10 = cr[i].y * x00[i] + cr[i].x * x10[i];
+      const float y01 = cr[i].x * x01[i] - cr[i].y * x11[i], y11 = cr[i].y * x01[i] + cr[i].x * x11[i];
+      float* s0 = S + ra[i] * JLD;
+      float* s1 = S + rb[i] * JLD;
+      s0[ca] = cc.x * y00 - cc.y * y01;
+      s0[cb] = cc.y * y00 + cc.x * y01;
+      s1[ca] = cc.x * y10 - cc.y * y11;
+      s1[cb] = cc.y * y10 + cc.x * y11;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      float* q0 = Q + (wave + NW * i) * JLD;
+      q0[ca] = cc.x * qx[i] - cc.y * qy[i];
+      q0[cb] = cc.y * qx[i] + cc.x * qy[i];
     }
     __syncthreads();
   }
