@@ -265,6 +265,38 @@ int ps_transform_grads_f32(void* stream, const ps_transform_desc* desc, int coun
                            const ps_transform_config* cfg, void* workspace,
                            size_t workspace_bytes);
 
+/* ---------------------------------------------------------------------------
+ * Quantized optimizer state.  Replaces QuantizedValue.quantize
+ * (precondition/quantization_utils.py:45-95) and QuantizedValue.to_float
+ * (quantization_utils.py:97-113) as used by distributed_shampoo.py for int16
+ * statistics / preconditioners with extract_diagonal=True (DS:2087-2106, 2746-2768,
+ * 3012-3281) and int8 momentum (DS:2047-2049, 2111-2114, 3617-3619).
+ *
+ * A tensor of shape [d0, d1, ...] is passed as rows = d0, cols = prod(d1...) (the
+ * reference reduces max|x| over axis 0; a 1-D tensor is rows = n, cols = 1).
+ *   bucket_size[c] = max_r |x[r,c]| / (127 | 32767)
+ *   codes[r,c]     = round_half_even(x[r,c] / (bucket_size[c] > 0 ? bucket_size[c] : 1))
+ *   extract_diagonal (rows == cols): diagonal[r] = x[r,r] and x[r,r] counts as 0.
+ * Codes, diagonal and bucket sizes are bit-exact with the reference for finite input.
+ * Every tensor of the tree goes in ONE call (two launches for quantize, one for
+ * dequantize).  `fvalue` is read by ps_quantize_f32 and written by ps_dequantize_f32. */
+typedef struct {
+  float* fvalue;        /* [rows, cols] float32, leading dimension ld */
+  void* codes;          /* int8_t or int16_t [rows, cols], leading dimension ldq */
+  float* diagonal;      /* [rows] when extract_diagonal, else may be NULL */
+  float* bucket_size;   /* [cols] */
+  int64_t rows, cols, ld, ldq;
+  int32_t bits;         /* 8 or 16 */
+  int32_t extract_diagonal;
+} ps_quant_desc;
+
+size_t ps_quantize_workspace_bytes(const ps_quant_desc* desc, int count);
+int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int count, void* workspace,
+                    size_t workspace_bytes);
+size_t ps_dequantize_workspace_bytes(const ps_quant_desc* desc, int count);
+int ps_dequantize_f32(void* stream, const ps_quant_desc* desc, int count, void* workspace,
+                      size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

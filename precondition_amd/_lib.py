@@ -49,6 +49,14 @@ class TransformConfig(C.Structure):
                                        "weight_decay", "lr", "clip_by_scaled_gradient_norm")]
 
 
+class QuantDesc(C.Structure):
+  """Mirror of ps_quant_desc."""
+  _fields_ = [("fvalue", C.c_void_p), ("codes", C.c_void_p), ("diagonal", C.c_void_p),
+              ("bucket_size", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64),
+              ("ld", C.c_int64), ("ldq", C.c_int64), ("bits", C.c_int32),
+              ("extract_diagonal", C.c_int32)]
+
+
 class StatsDesc(C.Structure):
   """Mirror of ps_stats_desc."""
   _fields_ = [
@@ -107,6 +115,12 @@ _SIGNATURES = {
     "ps_transform_grads_f32":
         (C.c_int, [C.c_void_p, C.POINTER(TransformDesc), C.c_int, C.POINTER(TransformConfig),
                    C.c_void_p, C.c_size_t]),
+    "ps_quantize_workspace_bytes": (C.c_size_t, [C.POINTER(QuantDesc), C.c_int]),
+    "ps_quantize_f32":
+        (C.c_int, [C.c_void_p, C.POINTER(QuantDesc), C.c_int, C.c_void_p, C.c_size_t]),
+    "ps_dequantize_workspace_bytes": (C.c_size_t, [C.POINTER(QuantDesc), C.c_int]),
+    "ps_dequantize_f32":
+        (C.c_int, [C.c_void_p, C.POINTER(QuantDesc), C.c_int, C.c_void_p, C.c_size_t]),
     "ps_eigh_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

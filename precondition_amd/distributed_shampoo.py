@@ -124,8 +124,6 @@ def distributed_shampoo(
   # ---- scope of this build
   if shard_optimizer_states:
     raise NotImplementedError("shard_optimizer_states (pjit mode) is out of scope")
-  if best_effort_memory_usage_reduction:
-    raise NotImplementedError("quantized optimizer state is out of scope (f3)")
   if lobpcg_topk_precondition:
     raise NotImplementedError("LOBPCG deflation is out of scope")
   if generate_fd_metrics:
@@ -146,6 +144,57 @@ def distributed_shampoo(
 
   def _quantize(x):
     return QuantizedValue.from_float_value(x, torch.float32)
+
+  # ---- quantized optimizer state (best_effort_memory_usage_reduction) -------------
+  # DS:2047-2070: momentum buffers of rank > 1 parameters are int8; statistics and
+  # preconditioners are int16 with the diagonal kept in float32, but only in the
+  # sharded (batch_axis_name) dense mode.
+  def quantized_dtype_for_momentum_buffers(var):
+    return torch.int8 if (best_effort_memory_usage_reduction and
+                          len(var.shape) > 1) else torch.float32
+
+  quantize_second_moment = bool(best_effort_memory_usage_reduction and
+                                not compression_rank and not frequent_directions and
+                                batch_axis_name)
+  qdt_second_moment = torch.int16 if quantize_second_moment else torch.float32
+
+  def _quantize_many(tensors, dtype, extract_diagonal):
+    """QuantizedValue.from_float_value for a list of tensors in one grouped launch."""
+    if dtype == torch.float32:
+      return [QuantizedValue.from_float_value(t, torch.float32, extract_diagonal)
+              for t in tensors]
+    triples = backend.quantize_grouped(tensors, dtype, extract_diagonal)
+    return [QuantizedValue(q, d, b, dtype, extract_diagonal, list(q.shape))
+            for q, d, b in triples]
+
+  def _to_float_many(values):
+    """_to_float (DS:2072-2076) for a list of QuantizedValue / tensors, grouped."""
+    out = list(values)
+    idx = [i for i, v in enumerate(values) if isinstance(v, QuantizedValue) and
+           v.quantized_dtype in (torch.int8, torch.int16)]
+    if idx:
+      fl = backend.dequantize_grouped([
+          (values[i].quantized, values[i].diagonal if values[i].extract_diagonal else [],
+           values[i].bucket_size) for i in idx])
+      for i, f in zip(idx, fl):
+        out[i] = f
+    for i, v in enumerate(out):
+      if isinstance(v, QuantizedValue):
+        out[i] = v.to_float()  # float32 / bfloat16 pass-through
+    return out
+
+  def _quantize_momentum_many(moms, params):
+    """_quantize_momentum (DS:2111-2114) for the whole tree."""
+    out = [None] * len(moms)
+    q_idx = [i for i, p in enumerate(params)
+             if quantized_dtype_for_momentum_buffers(p) == torch.int8]
+    if q_idx:
+      for i, qv in zip(q_idx, _quantize_many([moms[i] for i in q_idx], torch.int8, False)):
+        out[i] = qv
+    for i, m in enumerate(moms):
+      if out[i] is None:
+        out[i] = _quantize(m)
+    return out
 
   _pc_cache = {}
 
@@ -184,9 +233,14 @@ def distributed_shampoo(
       diagonal_statistics = []
       if _graft_type_has_diagonal_statistics():
         diagonal_statistics = torch.zeros_like(param)
+      if quantize_second_moment:  # DS:2613-2614
+        statistics = _quantize_many(statistics, qdt_second_moment, True)
+        preconditioners = _quantize_many(preconditioners, qdt_second_moment, True)
+      zeros_q = _quantize_momentum_many([torch.zeros_like(param), torch.zeros_like(param)],
+                                        [param, param])  # DS:2608-2609
       return ParameterStats(
           _quantize(diagonal_statistics), statistics, preconditioners,
-          _quantize(torch.zeros_like(param)), _quantize(torch.zeros_like(param)),
+          zeros_q[0], zeros_q[1],
           torch.zeros_like(param) if (frequent_directions and average_grad) else MaskedNode(),
           init_training_metrics(len(statistics), generate_training_metrics,
                                 generate_fd_metrics, device=dev))
@@ -201,7 +255,14 @@ def distributed_shampoo(
     w2 = beta2 if beta2 == 1.0 else 1.0 - beta2  # DS:2635-2636
     perform = statistics_compute_steps <= 1 or step % statistics_compute_steps == 0
     new_lists, items, fd_items, new_avg = [], [], [], []
-    for grad, state, param in zip(grads_flat, stats_flat, params_flat):
+    float_old = None
+    if quantize_second_moment and perform:  # to_float=_to_float, DS:2652
+      flat = _to_float_many([q for st in stats_flat for q in st.statistics])
+      float_old, k = [], 0
+      for st in stats_flat:
+        float_old.append(flat[k:k + len(st.statistics)])
+        k += len(st.statistics)
+    for pidx, (grad, state, param) in enumerate(zip(grads_flat, stats_flat, params_flat)):
       avg = MaskedNode()
       if _skip_preconditioning(param):
         new_lists.append([[]] * len(state.statistics))
@@ -218,8 +279,10 @@ def distributed_shampoo(
         new_lists.append(state.statistics)
         continue
       pc = preconditioner_from_params(param)
-      olds = [s.contiguous() for s in state.statistics]
-      news = [torch.empty_like(s) for s in olds]
+      olds = [s.contiguous() for s in (float_old[pidx] if float_old is not None
+                                       else state.statistics)]
+      # quantized mode: the dequantized copies are temporaries, update them in place
+      news = olds if float_old is not None else [torch.empty_like(s) for s in olds]
       for it in pc.statistics_update_items(olds, grad, news):
         g_blk, axis = it[0], it[1]
         if frequent_directions and _should_compress(compression_rank, g_blk.shape[axis]):
@@ -234,6 +297,14 @@ def distributed_shampoo(
       backend.stats_update_grouped(items, w1, w2)
     if fd_items:
       backend.stats_update_grouped(fd_items, 0.0, 1.0)
+    if float_old is not None:  # from_float=_maybe_quantize_statistics, DS:2654
+      upd = [i for i, (st, p) in enumerate(zip(stats_flat, params_flat))
+             if not _skip_preconditioning(p) and len(st.statistics)]
+      qs = _quantize_many([t for i in upd for t in new_lists[i]], qdt_second_moment, True)
+      k = 0
+      for i in upd:
+        new_lists[i] = qs[k:k + len(new_lists[i])]
+        k += len(new_lists[i])
     return [
         ParameterStats(s.diagonal_statistics, ns, s.preconditioners,
                        s.diagonal_momentum, s.momentum, av, s.training_metrics)
@@ -269,6 +340,10 @@ def distributed_shampoo(
       # previous preconditioner; metrics keep their old values (DS:2983-2986).
       return states
 
+    if quantize_second_moment:
+      # _quantized_matrix_inverse_pth_root_vmap (DS:2746-2773): the root is taken of the
+      # DEQUANTIZED statistics and quantized again before the failure select.
+      statistics = _to_float_many(statistics)
     sizes = [int(s.shape[0]) for s in statistics]
     compute_fn, out_cols = None, None
     if compression_rank != 0:
@@ -337,6 +412,8 @@ def distributed_shampoo(
         root_fn=backend.matrix_inverse_pth_root_batched, out_cols=out_cols,
         compute_fn=compute_fn)
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
+    if quantize_second_moment:
+      roots = _quantize_many([r.contiguous() for r in roots], qdt_second_moment, True)
     new_p = []
     for i, (root, old) in enumerate(zip(roots, prev)):
       err = errors[i]
@@ -377,6 +454,13 @@ def distributed_shampoo(
     path of blocking.Preconditioner."""
     out = [None] * len(grads_flat)
     stage_a, stage_b, keep = [], [], []
+    precs = [st.preconditioners for st in states]
+    if quantize_second_moment:  # _maybe_dequantize_preconditioners, DS:2097-2106
+      flat = _to_float_many([q for st in states for q in st.preconditioners])
+      precs, k = [], 0
+      for st in states:
+        precs.append(flat[k:k + len(st.preconditioners)])
+        k += len(st.preconditioners)
     for idx, (grad, state, param) in enumerate(zip(grads_flat, states, params_flat)):
       if _skip_preconditioning(param):
         continue
@@ -384,7 +468,7 @@ def distributed_shampoo(
       tshape = pc._transformed_shape
       should = pc.should_precondition_dims()
       if compression_rank != 0 or not all(should) or len(tshape) not in (1, 2):
-        out[idx] = pc.preconditioned_grad(grad, state.preconditioners,
+        out[idx] = pc.preconditioned_grad(grad, precs[idx],
                                           tensordot_fn=backend.tensordot_axis0,
                                           matmul_fn=backend.matmul)
         continue
@@ -393,7 +477,7 @@ def distributed_shampoo(
       nd = len(tshape)
       for i, (gb, ob) in enumerate(zip(pc._partitioner.partition(g_t),
                                        pc._partitioner.partition(res))):
-        pcs = state.preconditioners[i * nd:(i + 1) * nd]
+        pcs = precs[idx][i * nd:(i + 1) * nd]
         if nd == 1:
           d = gb.shape[0]
           gb_c = gb.contiguous()
@@ -530,6 +614,13 @@ def distributed_shampoo(
     new_stats = _compute_stats_all(grads_flat, stats_flat, params_flat, step)
     new_stats = _compute_preconditioners(new_stats, params_flat, step)
     pgs = _preconditioned_grads_all(grads_flat, new_stats, params_flat)
+    if best_effort_memory_usage_reduction:
+      # int8 momentum (DS:3581-3586 to_float): dequantize the whole tree in one launch
+      n = len(new_stats)
+      fl = _to_float_many([s.momentum for s in new_stats] +
+                          [s.diagonal_momentum for s in new_stats])
+      new_stats = [s._replace(momentum=_quantize(fl[i]), diagonal_momentum=_quantize(fl[n + i]))
+                   for i, s in enumerate(new_stats)]
     if hasattr(backend, "transform_grads_fused"):
       outs = _transform_grads_fused(grads_flat, new_stats, params_flat, pgs, step)
     else:  # host-logic test seam: the same arithmetic as torch elementwise ops
@@ -537,6 +628,12 @@ def distributed_shampoo(
               for g, s, p, pg in zip(grads_flat, new_stats, params_flat, pgs)]
     updates_flat = [o[0] for o in outs]
     new_stats = [o[1] for o in outs]
+    if best_effort_memory_usage_reduction:  # _quantize_momentum, DS:3617-3619
+      moms = _quantize_momentum_many([s.momentum.to_float() for s in new_stats], params_flat)
+      dmoms = _quantize_momentum_many([s.diagonal_momentum.to_float() for s in new_stats],
+                                      params_flat)
+      new_stats = [s._replace(momentum=m, diagonal_momentum=d)
+                   for s, m, d in zip(new_stats, moms, dmoms)]
     return (treedef.unflatten(updates_flat),
             ShampooState(count=state.count + 1, stats=treedef.unflatten(new_stats)))
 

@@ -454,3 +454,92 @@ def transform_grads_fused(items, cfg: dict):
   ws.record_stream(torch.cuda.current_stream())
   del keep
   return outs
+
+
+# ---------------------------------------------------------------------------
+# quantized optimizer state (quantization_utils.py:45-113; SURVEY.md 8(f3))
+# ---------------------------------------------------------------------------
+_QBITS = {torch.int8: 8, torch.int16: 16}
+
+
+def _as_rows_cols(shape):
+  """[d0, d1, ...] -> (rows, cols) with the reference's reduction axis 0 as rows."""
+  if len(shape) < 1:
+    raise ValueError("Input array must have a strictly positive number of dimensions.")
+  rows = int(shape[0])
+  cols = 1
+  for d in shape[1:]:
+    cols *= int(d)
+  return rows, cols
+
+
+def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False):
+  """QuantizedValue.quantize (QU:45-95) for a list of float32 device tensors in one
+  ps_quantize_f32 call.  Returns a list of (codes, diagonal | [], bucket_size)."""
+  if quantized_dtype not in _QBITS:
+    raise ValueError(f"Quantized dtype {quantized_dtype} not supported.")
+  if not fvalues:
+    return []
+  from ._lib import QuantDesc
+  dev = fvalues[0].device
+  descs = (QuantDesc * len(fvalues))()
+  outs, keep = [], []
+  for i, f in enumerate(fvalues):
+    _require_gpu(f, "QuantizedValue.quantize")
+    if extract_diagonal and f.dim() != 2:
+      raise ValueError("Input array must be 2D to work with extract_diagonal.")
+    f = f.contiguous()
+    rows, cols = _as_rows_cols(f.shape)
+    codes = torch.empty(f.shape, dtype=quantized_dtype, device=dev)
+    bucket = torch.empty(tuple(f.shape[1:]), dtype=torch.float32, device=dev)
+    diag = torch.empty((rows,), dtype=torch.float32, device=dev) if extract_diagonal else []
+    d = descs[i]
+    d.fvalue, d.codes, d.bucket_size = f.data_ptr(), codes.data_ptr(), bucket.data_ptr()
+    d.diagonal = diag.data_ptr() if extract_diagonal else None
+    d.rows, d.cols, d.ld, d.ldq = rows, cols, cols, cols
+    d.bits, d.extract_diagonal = _QBITS[quantized_dtype], int(bool(extract_diagonal))
+    keep.append(f)
+    outs.append((codes, diag, bucket))
+  L = lib()
+  ws = _workspace(L.ps_quantize_workspace_bytes(descs, len(fvalues)), dev)
+  check(L.ps_quantize_f32(_stream(), descs, len(fvalues), ws.data_ptr(), ws.numel()),
+        "ps_quantize_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  del keep
+  return outs
+
+
+def dequantize_grouped(items, out=None):
+  """QuantizedValue.to_float (QU:97-113) for a list of (codes, diagonal | [], bucket_size)
+  in one ps_dequantize_f32 call.  Returns float32 tensors of the codes' shapes."""
+  if not items:
+    return []
+  from ._lib import QuantDesc
+  dev = items[0][0].device
+  descs = (QuantDesc * len(items))()
+  outs, keep = [], []
+  for i, (codes, diag, bucket) in enumerate(items):
+    if not codes.is_cuda or codes.dtype not in _QBITS:
+      raise _lib.PsError("QuantizedValue.to_float: expected int8/int16 codes on an MI355X "
+                         f"device, got {codes.dtype} on {codes.device}; no CPU path.")
+    codes = codes.contiguous()
+    bucket = bucket.contiguous()
+    rows, cols = _as_rows_cols(codes.shape)
+    extract = not (isinstance(diag, list) and not diag)
+    f = out[i] if out is not None else torch.empty(codes.shape, dtype=torch.float32, device=dev)
+    if not f.is_contiguous():
+      raise ValueError("dequantize_grouped: out tensors must be contiguous")
+    d = descs[i]
+    d.fvalue, d.codes, d.bucket_size = f.data_ptr(), codes.data_ptr(), bucket.data_ptr()
+    d.diagonal = diag.contiguous().data_ptr() if extract else None
+    d.rows, d.cols, d.ld, d.ldq = rows, cols, cols, cols
+    d.bits, d.extract_diagonal = _QBITS[codes.dtype], int(extract)
+    keep.append((codes, bucket, diag))
+    outs.append(f)
+  L = lib()
+  ws = _workspace(L.ps_dequantize_workspace_bytes(descs, len(items)), dev)
+  check(L.ps_dequantize_f32(_stream(), descs, len(items), ws.data_ptr(), ws.numel()),
+        "ps_dequantize_f32")
+  ws.record_stream(torch.cuda.current_stream())
+  del keep
+  return outs

@@ -104,8 +104,10 @@ pytree.register_dataclass(TrainingMetrics,
 
 @dataclasses.dataclass(frozen=True)
 class QuantizedValue:
-  """quantization_utils.QuantizedValue restricted to float32 pass-through
-  (quantized modes are the out-of-scope `best_effort_memory_usage_reduction`)."""
+  """quantization_utils.QuantizedValue (QU:26-113): float32 / bfloat16 pass-through, or
+  int8 / int16 codes with one float32 bucket size per column (max over axis 0) and,
+  with extract_diagonal, the float32 diagonal of a square matrix kept aside.  The
+  integer modes run on the HIP kernels (ps_quantize_f32 / ps_dequantize_f32)."""
   quantized: Any
   diagonal: Any
   bucket_size: Any
@@ -117,15 +119,33 @@ class QuantizedValue:
   def from_float_value(cls, fvalue, quantized_dtype, extract_diagonal=False):
     if isinstance(fvalue, list) and not fvalue:
       return cls([], [], [], quantized_dtype, extract_diagonal, [])
-    if quantized_dtype != torch.float32:
-      raise NotImplementedError(
-          "only float32 pass-through QuantizedValue is implemented "
-          "(best_effort_memory_usage_reduction is out of scope)")
-    return cls(fvalue, [], [], quantized_dtype, extract_diagonal,
-               list(fvalue.shape))
+    quantized, diagonal, bucket_size = cls.quantize(fvalue, quantized_dtype, extract_diagonal)
+    return cls(quantized, diagonal, bucket_size, quantized_dtype, extract_diagonal,
+               list(quantized.shape))
+
+  @classmethod
+  def quantize(cls, fvalue, quantized_dtype, extract_diagonal=False):
+    """Returns (quantized, diagonal, bucket_size) (QU:45-95)."""
+    if quantized_dtype == torch.float32:
+      return fvalue, [], []
+    if quantized_dtype == torch.bfloat16:
+      return fvalue.to(torch.bfloat16), [], []
+    if quantized_dtype not in (torch.int8, torch.int16):
+      raise ValueError(f"Quantized dtype {quantized_dtype} not supported.")
+    from . import kernels
+    return kernels.quantize_grouped([fvalue], quantized_dtype, extract_diagonal)[0]
 
   def to_float(self):
-    return self.quantized
+    """QU:97-113."""
+    if isinstance(self.quantized, list) and not self.quantized:
+      return self.quantized
+    if self.quantized_dtype == torch.float32:
+      return self.quantized
+    if self.quantized_dtype == torch.bfloat16:
+      return self.quantized.to(torch.float32)
+    from . import kernels
+    diag = self.diagonal if self.extract_diagonal else []
+    return kernels.dequantize_grouped([(self.quantized, diag, self.bucket_size)])[0]
 
   def replace(self, **kw):
     return dataclasses.replace(self, **kw)

@@ -24,3 +24,19 @@ def device():
   if not torch.cuda.is_available():
     pytest.skip("no GPU")
   return torch.device("cuda:0")
+
+
+_GROUP = {}
+
+
+def single_rank_group(backend):
+  """A world-size-1 process group (the reference's int16 second-moment mode needs a
+  batch axis, DS:2051-2054).  gloo on CPU; on the GPU box "nccl" is RCCL."""
+  import tempfile
+  import torch.distributed as dist
+  if "g" not in _GROUP:
+    if not dist.is_initialized():
+      store = dist.FileStore(os.path.join(tempfile.mkdtemp(), "store"), 1)
+      dist.init_process_group(backend, store=store, rank=0, world_size=1)
+    _GROUP["g"] = dist.group.WORLD
+  return _GROUP["g"]

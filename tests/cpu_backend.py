@@ -82,3 +82,31 @@ def fd_update_root(new_grad, p, rank=0, ridge_epsilon=1e-6, error_tolerance=1e-6
 def gemm_grouped(items):
   for a, b, c, ta, tb in items:
     c.copy_(matmul(a, b, transa=ta, transb=tb))
+
+
+_NP_Q = {torch.int8: np.int8, torch.int16: np.int16}
+
+
+def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False):
+  from oracle import quantization_oracle as qorc
+  out = []
+  for f in fvalues:
+    q, d, b = qorc.quantize(f.cpu().numpy(), _NP_Q[quantized_dtype], extract_diagonal)
+    out.append((torch.from_numpy(q), torch.from_numpy(d) if extract_diagonal else [],
+                torch.from_numpy(np.asarray(b, dtype=np.float32))))
+  return out
+
+
+def dequantize_grouped(items, out=None):
+  from oracle import quantization_oracle as qorc
+  res = []
+  for i, (q, d, b) in enumerate(items):
+    extract = not (isinstance(d, list) and not d)
+    f = qorc.to_float(q.cpu().numpy(), d.cpu().numpy() if extract else [], b.cpu().numpy(),
+                      q.cpu().numpy().dtype, extract)
+    t = torch.from_numpy(np.asarray(f, dtype=np.float32))
+    if out is not None:
+      out[i].copy_(t)
+      t = out[i]
+    res.append(t)
+  return res

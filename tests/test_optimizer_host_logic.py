@@ -14,12 +14,26 @@ from precondition_amd import pytree
 from tests import cpu_backend
 
 
-def _index(golden_dir):
-  with open(os.path.join(golden_dir, "e2e_index.json")) as f:
+def _index(golden_dir, name="e2e_index.json"):
+  with open(os.path.join(golden_dir, name)) as f:
     return json.load(f)
 
 
-def run_e2e_case(c, z, device, backend, skip_params=()):
+def np_float(x):
+  """Tensor or QuantizedValue -> float32 ndarray (int codes through the oracle's to_float,
+  so that the CPU tests never touch the HIP library)."""
+  from precondition_amd.state import QuantizedValue
+  if isinstance(x, QuantizedValue):
+    if x.quantized_dtype in (torch.int8, torch.int16):
+      from oracle import quantization_oracle as qorc
+      codes = x.quantized.cpu().numpy()
+      return qorc.to_float(codes, x.diagonal.cpu().numpy() if x.extract_diagonal else [],
+                           x.bucket_size.cpu().numpy(), codes.dtype, x.extract_diagonal)
+    return x.quantized.float().cpu().numpy()
+  return x.cpu().numpy()
+
+
+def run_e2e_case(c, z, device, backend, skip_params=(), group=None):
   name, n = c["name"], c["n_params"]
   kw = dict(c["kwargs"])
   if "graft_type" in kw:
@@ -27,7 +41,10 @@ def run_e2e_case(c, z, device, backend, skip_params=()):
   if "precondtioner_type" in kw:
     kw["precondtioner_type"] = pa.PreconditionerType(kw["precondtioner_type"])
   block_size = kw.pop("block_size")
-  opt = pa.distributed_shampoo(c["lr"], block_size, batch_axis_name=None,
+  if c.get("batch_axis"):
+    assert group is not None
+  opt = pa.distributed_shampoo(c["lr"], block_size,
+                               batch_axis_name=group if c.get("batch_axis") else None,
                                _backend_for_testing=backend, **kw)
   params = tuple(torch.tensor(z[f"{name}__param{i}"], device=device) for i in range(n))
   st = opt.init(params)
@@ -59,11 +76,14 @@ def test_e2e_host_logic_vs_reference_golden(case, golden_dir):
   check_final_state(case, z, st)
 
 
-def stat_matches(mine, ref):
+def stat_matches(mine, ref, quantized=False):
   """Dense mode: equal.  FD mode: the reference keeps a triangular factor R of the
-  Gram matrix in the slot (DS:1497-1505), this build keeps the Gram itself."""
+  Gram matrix in the slot (DS:1497-1505), this build keeps the Gram itself.
+  int16 mode: equal up to a couple of code steps (max|column| / 32767)."""
   if np.allclose(mine, ref, rtol=1e-5, atol=1e-6):
     return True
+  if quantized:
+    return bool(np.abs(mine - ref).max() <= 1e-4 * np.abs(ref).max())
   return np.allclose(mine, ref @ ref.T, rtol=1e-4, atol=1e-5 * max(np.abs(mine).max(), 1e-30))
 
 
@@ -97,11 +117,14 @@ def check_final_state(case, z, st, skip_params=()):
     if i in skip_params:
       continue
     s = st.stats[i]
+    quantized = f"{name}__stat{i}_0_codes" in z.files
     for j, x in enumerate(s.statistics):
-      assert stat_matches(x.cpu().numpy(), z[f"{name}__stat{i}_{j}"]), (name, i, j)
+      if quantized:
+        assert x.quantized.dtype == torch.int16 and x.extract_diagonal
+      assert stat_matches(np_float(x), z[f"{name}__stat{i}_{j}"], quantized), (name, i, j)
     for j, x in enumerate(s.preconditioners):
       ref = z[f"{name}__precond{i}_{j}"]
-      got = x.cpu().numpy()
+      got = np_float(x)
       assert got.shape == ref.shape, (name, i, j, got.shape, ref.shape)
       if ref.shape[0] != ref.shape[1]:
         assert packed_matches(got, ref, rank), (name, i, j)
@@ -110,13 +133,43 @@ def check_final_state(case, z, st, skip_params=()):
         assert np.linalg.norm(got - ref) <= 3e-2 * np.linalg.norm(ref), (name, i, j)
 
 
-def _unused():
-  for i in []:
-    for j in []:
-      pass
+def check_momentum(case, z, st, skip_params=()):
+  """Momentum buffers: int8 codes + per-column bucket sizes where the reference
+  quantizes (rank > 1 parameters, DS:2047-2049), float32 elsewhere."""
+  name = case["name"]
   for i in range(case["n_params"]):
-    mom, ref = st.stats[i].momentum.to_float().numpy(), z[f"{name}__momentum{i}"]
-    assert np.linalg.norm(mom - ref) <= 1e-3 * max(np.linalg.norm(ref), 1e-30)
+    if i in skip_params:
+      continue
+    m = st.stats[i].momentum
+    ref = z[f"{name}__momentum{i}"]
+    got = np_float(m)
+    if f"{name}__momentum{i}_codes" in z.files:
+      assert m.quantized.dtype == torch.int8 and not m.extract_diagonal
+      assert tuple(m.bucket_size.shape) == z[f"{name}__momentum{i}_bucket"].shape
+      # within a few code steps of the reference's dequantized momentum: a rounding-level
+      # difference in an update flips a code now and then, and a flipped code is carried
+      # into the next step's momentum (x beta1), where it can flip again
+      step = z[f"{name}__momentum{i}_bucket"][None, ...]
+      assert np.all(np.abs(got - ref) <= 4.0 * step + 1e-3 * np.abs(ref)), (name, i)
+      assert np.mean(np.abs(got - ref) > 0.75 * step) < 0.25, (name, i)
+    else:
+      assert m.quantized.dtype == torch.float32
+      assert np.linalg.norm(got - ref) <= 2e-3 * max(np.linalg.norm(ref), 1e-30), (name, i)
+
+
+@pytest.mark.parametrize(
+    "case", _index(os.path.join(os.path.dirname(__file__), "golden"), "e2e_quant_index.json"),
+    ids=lambda c: c["name"])
+def test_e2e_quantized_state_host_logic_vs_reference_golden(case, golden_dir):
+  """best_effort_memory_usage_reduction: int8 momentum; int16 statistics
+  and preconditioners with a batch axis.  Kernels replaced by the oracle here."""
+  from tests.conftest import single_rank_group
+  z = np.load(os.path.join(golden_dir, "e2e_quant.npz"))
+  group = single_rank_group("gloo") if case.get("batch_axis") else None
+  st, worst = run_e2e_case(case, z, torch.device("cpu"), cpu_backend, group=group)
+  assert worst < 2e-3, worst
+  check_final_state(case, z, st)
+  check_momentum(case, z, st)
 
 
 def test_step0_known_answer_from_reference_test():

@@ -168,3 +168,41 @@ def test_multi_replica_emulation_is_order_preserving():
     assert owners == sorted(owners)
     for m in metrics[len(stats):]:
       assert m["inverse_pth_root_errors"] == 0.0
+
+
+def test_quantization_oracle_vs_reference_golden(golden_dir):
+  """quantization_utils.py:45-113 — elementwise IEEE arithmetic, so bit-exact anywhere."""
+  import json
+  from oracle import quantization_oracle as qorc
+  z = np.load(os.path.join(golden_dir, "quantization.npz"))
+  with open(os.path.join(golden_dir, "quantization_index.json")) as f:
+    index = json.load(f)
+  assert len(index) >= 15
+  for c in index:
+    name = c["name"]
+    assert c["oracle_bitexact_at_gen"]
+    dt = np.int8 if c["bits"] == 8 else np.int16
+    x = z[f"{name}__x"]
+    q, d, b = qorc.quantize(x, dt, c["extract"])
+    assert q.dtype == dt and np.array_equal(q, z[f"{name}__codes"]), name
+    assert np.array_equal(np.asarray(b, np.float32).view(np.uint32),
+                          z[f"{name}__bucket"].view(np.uint32)), name
+    if c["extract"]:
+      assert np.array_equal(d.view(np.uint32), z[f"{name}__diag"].view(np.uint32)), name
+    if f"{name}__float" in z.files:
+      f32 = qorc.to_float(q, d, b, dt, c["extract"])
+      assert np.array_equal(f32.view(np.uint32), z[f"{name}__float"].view(np.uint32)), name
+  # the most negative code is never produced (QU:56-63)
+  assert int(z["half_ties_i8__codes"].min()) >= -127
+  # round half to even
+  t = z["half_ties_i8__x"][1:, 0]
+  assert np.array_equal(z["half_ties_i8__codes"][1:, 0], np.round(t).astype(np.int8))
+
+
+def test_quantization_oracle_errors():
+  from oracle import quantization_oracle as qorc
+  import pytest
+  with pytest.raises(ValueError):
+    qorc.quantize(np.zeros((3, 4, 5), np.float32), np.int16, True)   # QU:67-69
+  with pytest.raises(ValueError):
+    qorc.quantize(np.zeros((3, 3), np.float32), np.int32, False)     # QU:64

@@ -420,9 +420,17 @@ def gen_e2e():
           reuse_preconditioner=True, average_grad=True, reset_preconditioner=True,
           beta2=0.8, merge_small_dims_block_size=1), 8, "fresh"),
   ]
+  _run_e2e_configs(configs, grads_small, "e2e.npz", "e2e_index.json")
+
+
+def _run_e2e_configs(configs, grads_small, npz_name, index_name):
+  out = {}
+  index = []
   for name, params, _, kw, steps, gmode in configs:
     lr = 0.1
-    opt = ds.distributed_shampoo(lr, batch_axis_name=None, **kw)
+    kw = dict(kw)
+    axis = kw.pop("batch_axis_name", None)
+    opt = ds.distributed_shampoo(lr, batch_axis_name=axis, **kw)
     p_j = tuple(jnp.array(p) for p in params)
     st = opt.init(p_j)
     grs = []
@@ -446,10 +454,15 @@ def gen_e2e():
         out[f"{name}__grad{i}_t{t}"] = grs[t][i]
         out[f"{name}__upd{i}_t{t}"] = ups[t][i]
       s = st.stats[i]
-      for j, x in enumerate(s.statistics):
-        out[f"{name}__stat{i}_{j}"] = npy(x)
-      for j, x in enumerate(s.preconditioners):
-        out[f"{name}__precond{i}_{j}"] = npy(x)
+      for kind, lst in (("stat", s.statistics), ("precond", s.preconditioners)):
+        for j, x in enumerate(lst):
+          if hasattr(x, "quantized"):  # QuantizedValue (int16 second moment)
+            out[f"{name}__{kind}{i}_{j}"] = npy(x.to_float())
+            out[f"{name}__{kind}{i}_{j}_codes"] = npy(x.quantized)
+            out[f"{name}__{kind}{i}_{j}_diag"] = npy(x.diagonal)
+            out[f"{name}__{kind}{i}_{j}_bucket"] = npy(x.bucket_size)
+          else:
+            out[f"{name}__{kind}{i}_{j}"] = npy(x)
       if len(s.statistics):
         tm = s.training_metrics
         out[f"{name}__metrics{i}"] = np.stack([
@@ -458,6 +471,9 @@ def gen_e2e():
             npy(tm.total_retries)], axis=1)
       out[f"{name}__momentum{i}"] = npy(s.momentum.to_float())
       out[f"{name}__diag_momentum{i}"] = npy(s.diagonal_momentum.to_float())
+      if np.asarray(s.momentum.quantized).dtype == np.int8:
+        out[f"{name}__momentum{i}_codes"] = npy(s.momentum.quantized)
+        out[f"{name}__momentum{i}_bucket"] = npy(s.momentum.bucket_size)
       dsf = s.diagonal_statistics.to_float()
       if not (isinstance(dsf, list) and not dsf):
         out[f"{name}__diag_stats{i}"] = npy(dsf)
@@ -465,11 +481,102 @@ def gen_e2e():
                                             ds.PreconditionerType)) else v)
                for k, v in kw.items()}
     index.append(dict(name=name, n_params=len(params), steps=steps, lr=lr,
-                      kwargs=kw_json, count=int(np.asarray(st.count))))
+                      kwargs=kw_json, count=int(np.asarray(st.count)),
+                      batch_axis=bool(axis)))
     print(f"e2e {name}: {steps} steps, last upd[0][:3]="
           f"{ups[-1][0].ravel()[:3]}")
-  np.savez_compressed(os.path.join(OUT, "e2e.npz"), **out)
-  with open(os.path.join(OUT, "e2e_index.json"), "w") as f:
+  np.savez_compressed(os.path.join(OUT, npz_name), **out)
+  with open(os.path.join(OUT, index_name), "w") as f:
+    json.dump(index, f, indent=1)
+
+
+def gen_e2e_quant():
+  """best_effort_memory_usage_reduction (DST:116-261 'quantized' combos): int8 momentum,
+  and int16 statistics / preconditioners in the sharded (batch axis) mode."""
+
+  def tree(shapes, seed):
+    r = np.random.default_rng(seed)
+    return tuple(r.standard_normal(s).astype(F32) for s in shapes)
+
+  shapes_a = ([40, 24], [24], [6, 10, 8], [70, 33])
+  configs = [
+      ("tree_a_q_momentum_only", tree(shapes_a, 21), None, dict(
+          block_size=32, preconditioning_compute_steps=2, start_preconditioning_step=2,
+          best_effort_memory_usage_reduction=True), 6, "fresh"),
+      ("tree_a_q_second_moment", tree(shapes_a, 22), None, dict(
+          block_size=32, preconditioning_compute_steps=2, start_preconditioning_step=2,
+          matrix_epsilon=1e-3,  # see the note on the next config
+          best_effort_memory_usage_reduction=True, batch_axis_name="batch"), 7, "fresh"),
+      ("tree_a_q_rmsprop_stats2", tree(shapes_a, 23), None, dict(
+          block_size=16, beta2=0.9, graft_type=ds.GraftingType.RMSPROP,
+          statistics_compute_steps=2, preconditioning_compute_steps=2,
+          start_preconditioning_step=3, weight_decay=0.01, moving_average_for_momentum=True,
+          # few-step statistics of vector blocks are rank deficient; with the default
+          # relative ridge 1e-6 the int16 rounding (3e-5 of the column max) leaves them
+          # INDEFINITE and the reference's own root is then rounding noise.  A ridge
+          # above the quantization step keeps every block well posed.
+          matrix_epsilon=1e-3,
+          best_effort_memory_usage_reduction=True, batch_axis_name="batch"), 7, "fresh"),
+  ]
+  _run_e2e_configs(configs, None, "e2e_quant.npz", "e2e_quant_index.json")
+
+
+def gen_quant():
+  """QuantizedValue.quantize / to_float goldens (quantization_utils.py:45-113)."""
+  from precondition.quantization_utils import QuantizedValue
+  from oracle import quantization_oracle as qorc
+  rng = np.random.default_rng(99)
+  cases = []
+
+  def psd(n, k, seed):
+    return wishart(n, k, seed)
+
+  cases.append(("psd40_i16", psd(40, 160, 1), np.int16, True))
+  cases.append(("psd33_i16", psd(33, 100, 2), np.int16, True))
+  cases.append(("psd8_i8_extract", psd(8, 32, 3), np.int8, True))
+  cases.append(("eps_eye_i16", (1e-6 * np.eye(24)).astype(F32), np.int16, True))
+  cases.append(("eye_i16", np.eye(24, dtype=F32), np.int16, True))
+  cases.append(("mom_6x10x8_i8", rng.standard_normal((6, 10, 8)).astype(F32), np.int8, False))
+  cases.append(("mom_70x33_i8", rng.standard_normal((70, 33)).astype(F32), np.int8, False))
+  cases.append(("mom_40x24_i8", (rng.standard_normal((40, 24)) * 1e-3).astype(F32), np.int8, False))
+  cases.append(("zeros_i8", np.zeros((12, 20), F32), np.int8, False))
+  z = rng.standard_normal((16, 12)).astype(F32); z[:, 3] = 0.0; z[:, 7] = 0.0
+  cases.append(("zero_columns_i8", z, np.int8, False))
+  cases.append(("vector24_i8", rng.standard_normal((24,)).astype(F32), np.int8, False))
+  # exact .5 ties: bucket = 127/127 = 1 in every column, so x = k + 0.5 must go to even
+  t = np.zeros((9, 4), F32); t[0] = 127.0
+  t[1:] = (np.arange(8, dtype=F32)[:, None] - 3.5) * np.array([1, -1, 3, 5], F32)
+  cases.append(("half_ties_i8", t, np.int8, False))
+  # more than one 64-row x 256-column chunk in both directions (the HIP kernels' tiling)
+  cases.append(("multi_chunk_130x516_i8", rng.standard_normal((130, 516)).astype(F32), np.int8, False))
+  cases.append(("multi_chunk_130x516_i16", (rng.standard_normal((130, 516)) * 40).astype(F32), np.int16, False))
+  cases.append(("ragged_67x257_i16", rng.standard_normal((67, 257)).astype(F32), np.int16, False))
+  cases.append(("psd264_i16", psd(264, 300, 4), np.int16, True))
+  out, index = {}, []
+  jdt = {np.int8: jnp.int8, np.int16: jnp.int16}
+  for name, x, dt, extract in cases:
+    qv = QuantizedValue.from_float_value(jnp.array(x), jdt[dt], extract)
+    q, d, b = npy(qv.quantized), (npy(qv.diagonal) if extract else None), npy(qv.bucket_size)
+    f = npy(qv.to_float())
+    assert q.dtype == dt and b.dtype == F32 and f.dtype == F32
+    oq, od, ob = qorc.quantize(x, dt, extract)
+    of = qorc.to_float(oq, od, ob, dt, extract)
+    exact = (np.array_equal(oq, q) and bitexact(np.asarray(ob, F32), b) and bitexact(of, f) and
+             (not extract or bitexact(od, d)))
+    assert exact, name
+    out[f"{name}__x"] = x
+    out[f"{name}__codes"] = q
+    out[f"{name}__bucket"] = b
+    if x.size <= 5000:  # to_float of the large cases is covered by the oracle, not stored
+      out[f"{name}__float"] = f
+    if extract:
+      out[f"{name}__diag"] = d
+    index.append(dict(name=name, bits=8 if dt == np.int8 else 16, extract=bool(extract),
+                      shape=list(x.shape), oracle_bitexact_at_gen=bool(exact)))
+    print("quant", name, "max code", int(np.abs(q.astype(np.int32)).max()),
+          "rel err", float(np.abs(f - x).max() / max(np.abs(x).max(), 1e-30)))
+  np.savez_compressed(os.path.join(OUT, "quantization.npz"), **out)
+  with open(os.path.join(OUT, "quantization_index.json"), "w") as f:
     json.dump(index, f, indent=1)
 
 
@@ -533,7 +640,8 @@ def gen_lowrank():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e", "lowrank"]
+  which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e", "lowrank", "quant",
+                           "e2e_quant"]
   if "newton" in which:
     gen_newton()
   if "pi" in which:
@@ -546,6 +654,10 @@ if __name__ == "__main__":
     gen_bookkeeping()
   if "e2e" in which:
     gen_e2e()
+  if "quant" in which:
+    gen_quant()
+  if "e2e_quant" in which:
+    gen_e2e_quant()
   if "lowrank" in which:
     gen_lowrank()
   print("golden fixtures written to", OUT)
