@@ -85,6 +85,7 @@ def sharded_inverse_pth_roots(
     compute_fn: Optional[Callable] = None,
     overlap: bool = True,
     overlap_min_bytes: int = 32 << 20,
+    payload_elems: Optional[Sequence[int]] = None,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
 
@@ -95,6 +96,9 @@ def sharded_inverse_pth_roots(
   (rank-compressed preconditioners are [n, rank+2], DS:520-532); `compute_fn(
   indices, outs) -> metrics[len(indices), 8]` replaces the plain batched root when
   statistics need per-index treatment (low-rank / Frequent-Directions branch).
+  `payload_elems[i]` (needs `compute_fn`): result i travels as an opaque payload of
+  that many float32 words (the int16-quantized preconditioner + its diagonal and
+  bucket sizes, DS:3102-3127); `outs` and the returned roots are then flat views.
   """
   n_stats = len(statistics)
   world, rank = world_and_rank(group)
@@ -111,6 +115,11 @@ def sharded_inverse_pth_roots(
 
   cols = [int(c) for c in out_cols] if out_cols is not None else list(sizes)
   elems = [sizes[i] * cols[i] for i in range(n_stats)]
+  raw = payload_elems is not None
+  if raw:
+    if compute_fn is None:
+      raise ValueError("payload_elems needs compute_fn")
+    elems = [int(e) for e in payload_elems]
   dev = statistics[0].device
 
   # Phases: with several ranks and enough work, every rank roots its statistics in
@@ -148,7 +157,9 @@ def sharded_inverse_pth_roots(
     mine = [i for i in range(n_stats) if owner[i] == rank and phase_of[i] == ph]
     send_metrics = torch.zeros((max_count, METRICS_STRIDE), dtype=torch.float32, device=dev)
     if mine:
-      outs = [send[offsets[i]:offsets[i] + elems[i]].view(sizes[i], cols[i]) for i in mine]
+      outs = [send[offsets[i]:offsets[i] + elems[i]] for i in mine]
+      if not raw:
+        outs = [o.view(sizes[i], cols[i]) for o, i in zip(outs, mine)]
       if compute_fn is not None:
         m = compute_fn(mine, outs)
       else:
@@ -189,9 +200,10 @@ def sharded_inverse_pth_roots(
       h.wait()
 
   roots = [
-      gathered[phase_of[i]][owner[i], offsets[i]:offsets[i] + elems[i]].view(sizes[i], cols[i])
-      for i in range(n_stats)
+      gathered[phase_of[i]][owner[i], offsets[i]:offsets[i] + elems[i]] for i in range(n_stats)
   ]
+  if not raw:
+    roots = [r.view(sizes[i], cols[i]) for i, r in enumerate(roots)]
   rows = [gathered_metrics[phase_of[i]][owner[i], slot[i]] for i in range(n_stats)]
   metrics = torch.stack(rows, dim=0)
   return roots, metrics

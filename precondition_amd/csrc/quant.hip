@@ -73,14 +73,24 @@ __global__ __launch_bounds__(256) void quant_colmax_kernel(const QTensor* ts, in
     const long long col = (long long)strip * QW + lane * 4;
     unsigned m[4] = {0u, 0u, 0u, 0u};
     if (col < cols) {
-      for (long long r = r0 + wave; r < r1; r += 4) {
-        const F4 v = ldg4(t->fin + r * ld + col);
-        float x[4] = {v.x, v.y, v.z, v.w};
+      // four rows in flight per lane (independent 16-byte loads) before the first use
+      for (long long rb = r0 + wave; rb < r1; rb += 16) {
+        F4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (t->extract && col + j == r) x[j] = 0.f;
-          const unsigned b = __float_as_uint(fabsf(x[j]));
-          m[j] = b > m[j] ? b : m[j];
+        for (int u = 0; u < 4; ++u) {
+          const long long r = rb + 4 * u;
+          v[u] = r < r1 ? ldg4(t->fin + r * ld + col) : F4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long r = rb + 4 * u;
+          float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (t->extract && col + j == r) x[j] = 0.f;
+            const unsigned b = __float_as_uint(fabsf(x[j]));
+            m[j] = b > m[j] ? b : m[j];
+          }
         }
       }
     }
@@ -133,24 +143,34 @@ __global__ __launch_bounds__(256) void quant_encode_kernel(const QTensor* ts, in
     }
     if (rc == 0 && wave == 0)
       *reinterpret_cast<float4*>(t->bucket + col) = make_float4(bs[0], bs[1], bs[2], bs[3]);
-    for (long long r = r0 + wave; r < r1; r += 4) {
-      const F4 v = ldg4(t->fin + r * ld + col);
-      float x[4] = {v.x, v.y, v.z, v.w};
-      int q[4];
+    for (long long rb = r0 + wave; rb < r1; rb += 16) {
+      F4 v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (t->extract && col + j == r) { t->diag[r] = x[j]; x[j] = __fsub_rn(x[j], x[j]); }
-        q[j] = encode1(x[j], bnz[j]);
+      for (int u = 0; u < 4; ++u) {
+        const long long r = rb + 4 * u;
+        v[u] = r < r1 ? ldg4(t->fin + r * ld + col) : F4{0.f, 0.f, 0.f, 0.f};
       }
-      if (t->bits == 16) {
-        uint2 pk;
-        pk.x = ((unsigned)q[0] & 0xffffu) | ((unsigned)q[1] << 16);
-        pk.y = ((unsigned)q[2] & 0xffffu) | ((unsigned)q[3] << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<short*>(t->codes) + r * ldq + col) = pk;
-      } else {
-        const unsigned pk = ((unsigned)q[0] & 0xffu) | (((unsigned)q[1] & 0xffu) << 8) |
-                            (((unsigned)q[2] & 0xffu) << 16) | ((unsigned)q[3] << 24);
-        *reinterpret_cast<unsigned*>(reinterpret_cast<signed char*>(t->codes) + r * ldq + col) = pk;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long r = rb + 4 * u;
+        if (r >= r1) break;
+        float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        int q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (t->extract && col + j == r) { t->diag[r] = x[j]; x[j] = __fsub_rn(x[j], x[j]); }
+          q[j] = encode1(x[j], bnz[j]);
+        }
+        if (t->bits == 16) {
+          uint2 pk;
+          pk.x = ((unsigned)q[0] & 0xffffu) | ((unsigned)q[1] << 16);
+          pk.y = ((unsigned)q[2] & 0xffffu) | ((unsigned)q[3] << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<short*>(t->codes) + r * ldq + col) = pk;
+        } else {
+          const unsigned pk = ((unsigned)q[0] & 0xffu) | (((unsigned)q[1] & 0xffu) << 8) |
+                              (((unsigned)q[2] & 0xffu) << 16) | ((unsigned)q[3] << 24);
+          *reinterpret_cast<unsigned*>(reinterpret_cast<signed char*>(t->codes) + r * ldq + col) = pk;
+        }
       }
     }
   } else {

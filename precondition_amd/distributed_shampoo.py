@@ -172,11 +172,14 @@ def distributed_shampoo(
     out = list(values)
     idx = [i for i, v in enumerate(values) if isinstance(v, QuantizedValue) and
            v.quantized_dtype in (torch.int8, torch.int16)]
-    if idx:
+    for extract in (False, True):  # one grouped launch per kind
+      sel = [i for i in idx if bool(values[i].extract_diagonal) == extract]
+      if not sel:
+        continue
       fl = backend.dequantize_grouped([
-          (values[i].quantized, values[i].diagonal if values[i].extract_diagonal else [],
-           values[i].bucket_size) for i in idx])
-      for i, f in zip(idx, fl):
+          (values[i].quantized, values[i].diagonal if extract else [], values[i].bucket_size)
+          for i in sel])
+      for i, f in zip(sel, fl):
         out[i] = f
     for i, v in enumerate(out):
       if isinstance(v, QuantizedValue):
@@ -405,15 +408,43 @@ def distributed_shampoo(
           rows[k, 0] = tm.inverse_pth_root_errors
         return rows
 
+    payload_elems = None
+    if quantize_second_moment:
+      # DS:3102-3127: the owner quantizes its roots and the all-gather carries int16 codes
+      # + float32 diagonal + float32 bucket sizes (half the bytes of float32 roots).
+      # Payload of statistic i, in float32 words, every part 16-byte aligned:
+      #   [codes: n*n int16 | diagonal: n | bucket_size: n]
+      def _parts(n):
+        return (n * n + 1) // 2 + (-((n * n + 1) // 2) % 4), n + (-n % 4)
+
+      payload_elems = [_parts(n)[0] + 2 * _parts(n)[1] for n in sizes]
+
+      def _unpack(flat, n):
+        c, v = _parts(n)
+        codes = flat[:c].view(torch.int16)[:n * n].view(n, n)
+        return codes, flat[c:c + n], flat[c + v:c + v + n]
+
+      def compute_fn(indices, outs):  # _quantized_matrix_inverse_pth_root_vmap, DS:2746-2773
+        tmp = [torch.empty((sizes[i], sizes[i]), dtype=torch.float32,
+                           device=statistics[0].device) for i in indices]
+        _, m = backend.matrix_inverse_pth_root_batched(
+            [statistics[i] for i in indices], [exponents[i] for i in indices],
+            [sizes[i] for i in indices], ridge_epsilon=matrix_epsilon,
+            relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh, out=tmp)
+        backend.quantize_grouped(tmp, qdt_second_moment, True,
+                                 out=[_unpack(o, sizes[i]) for o, i in zip(outs, indices)])
+        return m
+
     roots, metrics = comm.sharded_inverse_pth_roots(
         statistics, exponents, group=group, ridge_epsilon=matrix_epsilon,
         relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
         ownership=block_ownership,
         root_fn=backend.matrix_inverse_pth_root_batched, out_cols=out_cols,
-        compute_fn=compute_fn)
+        compute_fn=compute_fn, payload_elems=payload_elems)
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
     if quantize_second_moment:
-      roots = _quantize_many([r.contiguous() for r in roots], qdt_second_moment, True)
+      roots = [QuantizedValue(*_unpack(r, n), qdt_second_moment, True, [n, n])
+               for r, n in zip(roots, sizes)]
     new_p = []
     for i, (root, old) in enumerate(zip(roots, prev)):
       err = errors[i]

@@ -473,39 +473,116 @@ def _as_rows_cols(shape):
   return rows, cols
 
 
-def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False):
+_QDESC_DT = np.dtype([("fvalue", "u8"), ("codes", "u8"), ("diagonal", "u8"),
+                      ("bucket_size", "u8"), ("rows", "i8"), ("cols", "i8"), ("ld", "i8"),
+                      ("ldq", "i8"), ("bits", "i4"), ("extract_diagonal", "i4")])
+
+
+def _contig_strides(shape):
+  st, acc = [], 1
+  for d in reversed(shape):
+    st.append(acc)
+    acc *= int(d)
+  return tuple(reversed(st))
+
+
+def _flat_views(shapes, dtype, device, align):
+  """One allocation holding a contiguous tensor per shape (segments `align`-element
+  aligned, tensors of equal shape adjacent); returns (views, flat, element offsets).
+  One allocator call and one unbind per DISTINCT shape instead of an allocation per
+  tensor: a parameter tree has hundreds of tensors but a handful of shapes."""
+  n = len(shapes)
+  groups = {}
+  for i, sh in enumerate(shapes):
+    groups.setdefault(tuple(sh), []).append(i)
+  plan, total = [], 0
+  for sh, idxs in groups.items():
+    ne = 1
+    for d in sh:
+      ne *= int(d)
+    pad = (ne + align - 1) // align * align
+    plan.append((sh, idxs, ne, pad, total))
+    total += pad * len(idxs)
+  flat = torch.empty(total, dtype=dtype, device=device)
+  views, offs = [None] * n, np.zeros(n, np.int64)
+  for sh, idxs, ne, pad, base in plan:
+    k = len(idxs)
+    offs[idxs] = base + np.arange(k, dtype=np.int64) * pad
+    if ne == 0:
+      for i in idxs:
+        views[i] = flat.new_empty(sh)
+      continue
+    seg = flat[base:base + k * pad].view(k, pad)
+    if pad != ne:
+      seg = seg[:, :ne]
+    for i, v in zip(idxs, seg.view((k,) + sh).unbind(0)):
+      views[i] = v
+  return views, flat, offs
+
+
+def _quant_desc_table(n):
+  from ._lib import QuantDesc
+  assert _QDESC_DT.itemsize == C.sizeof(QuantDesc)
+  tbl = np.zeros(n, _QDESC_DT)
+  return tbl, C.cast(tbl.ctypes.data, C.POINTER(QuantDesc))
+
+
+def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False, out=None):
   """QuantizedValue.quantize (QU:45-95) for a list of float32 device tensors in one
-  ps_quantize_f32 call.  Returns a list of (codes, diagonal | [], bucket_size)."""
+  ps_quantize_f32 call.  Returns a list of (codes, diagonal | [], bucket_size);
+  `out` = list of such triples of preallocated contiguous tensors to fill (e.g. views
+  of an all-gather send buffer)."""
   if quantized_dtype not in _QBITS:
     raise ValueError(f"Quantized dtype {quantized_dtype} not supported.")
   if not fvalues:
     return []
-  from ._lib import QuantDesc
+  n = len(fvalues)
   dev = fvalues[0].device
-  descs = (QuantDesc * len(fvalues))()
-  outs, keep = [], []
-  for i, f in enumerate(fvalues):
+  fv = []
+  for f in fvalues:
     _require_gpu(f, "QuantizedValue.quantize")
+    if f.dim() < 1:
+      raise ValueError("Input array must have a strictly positive number of dimensions.")
     if extract_diagonal and f.dim() != 2:
       raise ValueError("Input array must be 2D to work with extract_diagonal.")
-    f = f.contiguous()
-    rows, cols = _as_rows_cols(f.shape)
-    codes = torch.empty(f.shape, dtype=quantized_dtype, device=dev)
-    bucket = torch.empty(tuple(f.shape[1:]), dtype=torch.float32, device=dev)
-    diag = torch.empty((rows,), dtype=torch.float32, device=dev) if extract_diagonal else []
-    d = descs[i]
-    d.fvalue, d.codes, d.bucket_size = f.data_ptr(), codes.data_ptr(), bucket.data_ptr()
-    d.diagonal = diag.data_ptr() if extract_diagonal else None
-    d.rows, d.cols, d.ld, d.ldq = rows, cols, cols, cols
-    d.bits, d.extract_diagonal = _QBITS[quantized_dtype], int(bool(extract_diagonal))
-    keep.append(f)
-    outs.append((codes, diag, bucket))
+    fv.append(f if f.is_contiguous() else f.contiguous())
+  shapes = [tuple(f.shape) for f in fv]
+  rows = np.array([s[0] for s in shapes], np.int64)
+  numel = np.array([f.numel() for f in fv], np.int64)
+  cols = numel // np.maximum(rows, 1)
+  tbl, descs = _quant_desc_table(n)
+  tbl["fvalue"] = [f.data_ptr() for f in fv]
+  if out is not None:
+    for i, (codes, diag, bucket) in enumerate(out):
+      if (codes.dtype != quantized_dtype or not codes.is_contiguous() or
+          codes.numel() != numel[i] or bucket.numel() != cols[i] or not bucket.is_contiguous()
+          or (extract_diagonal and (diag.numel() != rows[i] or not diag.is_contiguous()))):
+        raise ValueError("quantize_grouped: out[i] does not match fvalues[i]")
+    tbl["codes"] = [o[0].data_ptr() for o in out]
+    tbl["bucket_size"] = [o[2].data_ptr() for o in out]
+    if extract_diagonal:
+      tbl["diagonal"] = [o[1].data_ptr() for o in out]
+    outs = list(out)
+  else:
+    esz = 2 if quantized_dtype == torch.int16 else 1
+    cviews, cflat, coff = _flat_views(shapes, quantized_dtype, dev, 16 // esz)
+    bviews, bflat, boff = _flat_views([s[1:] for s in shapes], torch.float32, dev, 4)
+    tbl["codes"] = cflat.data_ptr() + coff * esz
+    tbl["bucket_size"] = bflat.data_ptr() + boff * 4
+    if extract_diagonal:
+      dviews, dflat, doff = _flat_views([(s[0],) for s in shapes], torch.float32, dev, 4)
+      tbl["diagonal"] = dflat.data_ptr() + doff * 4
+    else:
+      dviews = [[]] * n
+    outs = list(zip(cviews, dviews, bviews))
+  tbl["rows"], tbl["cols"], tbl["ld"], tbl["ldq"] = rows, cols, cols, cols
+  tbl["bits"] = _QBITS[quantized_dtype]
+  tbl["extract_diagonal"] = int(bool(extract_diagonal))
   L = lib()
-  ws = _workspace(L.ps_quantize_workspace_bytes(descs, len(fvalues)), dev)
-  check(L.ps_quantize_f32(_stream(), descs, len(fvalues), ws.data_ptr(), ws.numel()),
-        "ps_quantize_f32")
+  ws = _workspace(L.ps_quantize_workspace_bytes(descs, n), dev)
+  check(L.ps_quantize_f32(_stream(), descs, n, ws.data_ptr(), ws.numel()), "ps_quantize_f32")
   ws.record_stream(torch.cuda.current_stream())
-  del keep
+  del fv
   return outs
 
 
@@ -514,32 +591,45 @@ def dequantize_grouped(items, out=None):
   in one ps_dequantize_f32 call.  Returns float32 tensors of the codes' shapes."""
   if not items:
     return []
-  from ._lib import QuantDesc
+  n = len(items)
   dev = items[0][0].device
-  descs = (QuantDesc * len(items))()
-  outs, keep = [], []
-  for i, (codes, diag, bucket) in enumerate(items):
-    if not codes.is_cuda or codes.dtype not in _QBITS:
+  codes, diags, buckets = [], [], []
+  extract = not (isinstance(items[0][1], list) and not items[0][1])
+  for c, d, b in items:
+    if not c.is_cuda or c.dtype not in _QBITS:
       raise _lib.PsError("QuantizedValue.to_float: expected int8/int16 codes on an MI355X "
-                         f"device, got {codes.dtype} on {codes.device}; no CPU path.")
-    codes = codes.contiguous()
-    bucket = bucket.contiguous()
-    rows, cols = _as_rows_cols(codes.shape)
-    extract = not (isinstance(diag, list) and not diag)
-    f = out[i] if out is not None else torch.empty(codes.shape, dtype=torch.float32, device=dev)
-    if not f.is_contiguous():
-      raise ValueError("dequantize_grouped: out tensors must be contiguous")
-    d = descs[i]
-    d.fvalue, d.codes, d.bucket_size = f.data_ptr(), codes.data_ptr(), bucket.data_ptr()
-    d.diagonal = diag.contiguous().data_ptr() if extract else None
-    d.rows, d.cols, d.ld, d.ldq = rows, cols, cols, cols
-    d.bits, d.extract_diagonal = _QBITS[codes.dtype], int(extract)
-    keep.append((codes, bucket, diag))
-    outs.append(f)
+                         f"device, got {c.dtype} on {c.device}; no CPU path.")
+    if (not (isinstance(d, list) and not d)) != extract:
+      raise ValueError("dequantize_grouped: mixed extract_diagonal in one call")
+    codes.append(c if c.is_contiguous() else c.contiguous())
+    buckets.append(b if b.is_contiguous() else b.contiguous())
+    if extract:
+      diags.append(d if d.is_contiguous() else d.contiguous())
+  shapes = [tuple(c.shape) for c in codes]
+  rows = np.array([s[0] for s in shapes], np.int64)
+  numel = np.array([c.numel() for c in codes], np.int64)
+  cols = numel // np.maximum(rows, 1)
+  tbl, descs = _quant_desc_table(n)
+  if out is not None:
+    for f in out:
+      if not f.is_contiguous():
+        raise ValueError("dequantize_grouped: out tensors must be contiguous")
+    outs = list(out)
+    tbl["fvalue"] = [f.data_ptr() for f in outs]
+  else:
+    outs, fflat, foff = _flat_views(shapes, torch.float32, dev, 4)
+    tbl["fvalue"] = fflat.data_ptr() + foff * 4
+  tbl["codes"] = [c.data_ptr() for c in codes]
+  tbl["bucket_size"] = [b.data_ptr() for b in buckets]
+  if extract:
+    tbl["diagonal"] = [d.data_ptr() for d in diags]
+  tbl["rows"], tbl["cols"], tbl["ld"], tbl["ldq"] = rows, cols, cols, cols
+  tbl["bits"] = [_QBITS[c.dtype] for c in codes]
+  tbl["extract_diagonal"] = int(extract)
   L = lib()
-  ws = _workspace(L.ps_dequantize_workspace_bytes(descs, len(items)), dev)
-  check(L.ps_dequantize_f32(_stream(), descs, len(items), ws.data_ptr(), ws.numel()),
+  ws = _workspace(L.ps_dequantize_workspace_bytes(descs, n), dev)
+  check(L.ps_dequantize_f32(_stream(), descs, n, ws.data_ptr(), ws.numel()),
         "ps_dequantize_f32")
   ws.record_stream(torch.cuda.current_stream())
-  del keep
+  del codes, diags, buckets
   return outs

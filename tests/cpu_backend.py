@@ -87,14 +87,21 @@ def gemm_grouped(items):
 _NP_Q = {torch.int8: np.int8, torch.int16: np.int16}
 
 
-def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False):
+def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False, out=None):
   from oracle import quantization_oracle as qorc
-  out = []
-  for f in fvalues:
+  res = []
+  for i, f in enumerate(fvalues):
     q, d, b = qorc.quantize(f.cpu().numpy(), _NP_Q[quantized_dtype], extract_diagonal)
-    out.append((torch.from_numpy(q), torch.from_numpy(d) if extract_diagonal else [],
-                torch.from_numpy(np.asarray(b, dtype=np.float32))))
-  return out
+    t = (torch.from_numpy(q), torch.from_numpy(d) if extract_diagonal else [],
+         torch.from_numpy(np.asarray(b, dtype=np.float32)))
+    if out is not None:
+      out[i][0].copy_(t[0].view(out[i][0].shape))
+      if extract_diagonal:
+        out[i][1].copy_(t[1])
+      out[i][2].copy_(t[2].view(out[i][2].shape))
+      t = out[i]
+    res.append(t)
+  return res
 
 
 def dequantize_grouped(items, out=None):

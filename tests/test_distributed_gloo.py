@@ -118,3 +118,58 @@ def test_two_rank_sharding_matches_single_process(ownership):
   for rank in range(world):
     for a, b in zip(ret[rank + 100], upd):
       assert np.array_equal(a, b.numpy())
+
+
+def _quant_problem():
+  params = (torch.ones(20, 12), torch.ones(7, 9), torch.ones(3, 4, 5))
+  g = np.random.default_rng(31)
+  grads = [tuple(torch.from_numpy(g.standard_normal(p.shape).astype(np.float32)) for p in params)
+           for _ in range(4)]
+  kw = dict(start_preconditioning_step=1, preconditioning_compute_steps=2, matrix_epsilon=1e-3,
+            best_effort_memory_usage_reduction=True)
+  return params, grads, kw
+
+
+def _run_quant(group):
+  import precondition_amd as pa
+  from tests import cpu_backend
+  params, grads, kw = _quant_problem()
+  opt = pa.distributed_shampoo(0.1, 8, batch_axis_name=group, _backend_for_testing=cpu_backend,
+                               **kw)
+  st = opt.init(params)
+  for g in grads:
+    upd, st = opt.update(g, st, params)
+  s0 = st.stats[0]
+  assert s0.statistics[0].quantized.dtype == torch.int16
+  assert s0.preconditioners[0].quantized.dtype == torch.int16
+  assert s0.momentum.quantized.dtype == torch.int8
+  return ([u.numpy().copy() for u in upd],
+          [p.quantized.numpy().copy() for s in st.stats for p in s.preconditioners],
+          [p.bucket_size.numpy().copy() for s in st.stats for p in s.preconditioners])
+
+
+def _quant_worker(rank, world, port, ret):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    ret[rank] = _run_quant(dist.group.WORLD)
+  finally:
+    dist.destroy_process_group()
+
+
+def test_two_rank_quantized_second_moment_matches_one_rank():
+  """int16 preconditioners travel through the all-gather as codes + diagonal + bucket
+  sizes (DS:3102-3127); two ranks must end bit-identical to a one-rank group."""
+  from tests.conftest import single_rank_group
+  world = 2
+  mgr = mp.Manager()
+  ret = mgr.dict()
+  mp.spawn(_quant_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+  base = _run_quant(single_rank_group("gloo"))
+  for rank in range(world):
+    for got, ref in zip(ret[rank], base):
+      assert len(got) == len(ref)
+      for a, b in zip(got, ref):
+        assert a.dtype == b.dtype and np.array_equal(a, b)

@@ -8,7 +8,14 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 params = [torch.from_numpy((rng.standard_normal(s) * 0.02).astype(np.float32)).to(dev) for s in bench.VIT_B_SHAPES]
 grads = [torch.from_numpy((rng.standard_normal(s) * 0.02).astype(np.float32)).to(dev) for s in bench.VIT_B_SHAPES]
-opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=50, start_preconditioning_step=1, graft_type=pa.GraftingType.RMSPROP_NORMALIZED)
+kw = {}
+if "--quant" in sys.argv:  # int8 momentum + int16 statistics / preconditioners (needs a batch axis)
+  import tempfile
+  import torch.distributed as dist
+  dist.init_process_group("nccl", store=dist.FileStore(os.path.join(tempfile.mkdtemp(), "s"), 1),
+                          rank=0, world_size=1)
+  kw = dict(best_effort_memory_usage_reduction=True, batch_axis_name=dist.group.WORLD)
+opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=50, start_preconditioning_step=1, graft_type=pa.GraftingType.RMSPROP_NORMALIZED, **kw)
 st = opt.init(params)
 torch.cuda.synchronize()
 times = []
@@ -24,3 +31,7 @@ for t in range(3):
   upd, st = opt.update(grads, st, params)
 torch.cuda.synchronize(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+nbytes = sum(x.numel() * x.element_size() for x in pa.pytree.tree_leaves(st) if isinstance(x, torch.Tensor))
+print(f"optimizer state: {nbytes / 2**20:.1f} MiB")
+if "--quant" in sys.argv:
+  dist.destroy_process_group()
