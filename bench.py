@@ -206,6 +206,46 @@ def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
                   "4096x4096 covariance update; a bf16 top-(r+1) subspace iteration is future work"}
 
 
+def quant_f3(dev):
+  """int16 quantize / dequantize of the ViT-B statistics (395 matrices,
+  282.8 M elements, diagonal extracted) and int8 of its rank > 1 momentum buffers; HBM
+  roofline (algorithmic bytes: 4 B read + 2 or 1 B written per element, and the reverse)."""
+  from precondition_amd import kernels as K
+  from precondition_amd.blocking import Preconditioner
+  gen = torch.Generator(device=dev).manual_seed(3)
+  stats, moms = [], []
+  for shape in VIT_B_SHAPES:
+    p = torch.empty(shape, device=dev)
+    if len(shape) > 1:
+      moms.append(torch.randn(shape, generator=gen, device=dev))
+    for s in Preconditioner(p, 1024, 4096, True).shapes_for_preconditioners():
+      g = torch.randn((s[0], 64), generator=gen, device=dev)
+      stats.append(g @ g.T)
+
+  def t(fn, reps=5):
+    out = fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, out
+
+  ne = sum(x.numel() for x in stats)
+  nm = sum(x.numel() for x in moms)
+  tq, tr = t(lambda: K.quantize_grouped(stats, torch.int16, True))
+  td, _ = t(lambda: K.dequantize_grouped(tr))
+  mq, mr = t(lambda: K.quantize_grouped(moms, torch.int8, False))
+  md, _ = t(lambda: K.dequantize_grouped(mr))
+  return {"workload": f"ViT-B state: {len(stats)} statistics ({ne / 1e6:.1f} M elements) as int16 + "
+                      f"diagonal, {len(moms)} momentum buffers ({nm / 1e6:.1f} M elements) as int8; "
+                      "wall clock of the grouped calls incl. host descriptor building",
+          "bound": "hbm", "peak_GBps": 8000,
+          "int16_quantize_ms": round(tq * 1e3, 3), "int16_quantize_GBps": round(ne * 6 / tq / 1e9, 1),
+          "int16_dequantize_ms": round(td * 1e3, 3), "int16_dequantize_GBps": round(ne * 6 / td / 1e9, 1),
+          "int8_quantize_ms": round(mq * 1e3, 3), "int8_quantize_GBps": round(nm * 5 / mq / 1e9, 1),
+          "int8_dequantize_ms": round(md * 1e3, 3), "int8_dequantize_GBps": round(nm * 5 / md / 1e9, 1)}
+
+
 def timed(work, steps, warmup, multi):
   import torch.distributed as dist
   for _ in range(warmup):
@@ -473,6 +513,8 @@ def main():
     if world == 1 and rank == 0:
       torch.cuda.empty_cache()
       line["fd_cfg5"] = fd_cfg5(dev)
+      torch.cuda.empty_cache()
+      line["quant_f3"] = quant_f3(dev)
       torch.cuda.empty_cache()
       ew = Workload("eigh_cfg3_64x2048_p2", rank, 1, dev)
       ew.step(); torch.cuda.synchronize()
