@@ -8,6 +8,11 @@
 // operands, "d-contiguous" columns through the MC image for both (gemm_core).
 // MFMA-bound: arithmetic intensity ~ d/4 flop per byte of g for one axis.
 // Epilogue: out = fl(fl(w1*old) + fl(w2*gram)), the rounding sequence of DS:1470.
+// X X^T is symmetric and tile (j,i) of it is the bitwise transpose of tile (i,j) (same
+// products, same k order), so only the tiles with tm <= tn are computed; the strictly
+// upper ones are mirrored through an LDS transpose, with `old` read at the mirrored
+// position (a caller-supplied asymmetric `old` therefore stays asymmetric exactly as in
+// the reference).  This removes (T-1)/(2T) of the MFMA work, T = tiles per side.
 #include <string.h>
 
 #include <vector>
@@ -31,6 +36,43 @@ struct StatsTile {
   int task;
   short tm, tn;
 };
+
+// out[tn-tile rows, tm-tile cols] = w1*old + w2*acc^T, in two 64-row halves through LDS
+// (stride 129: conflict-free both ways) so that the global accesses are 256-byte runs.
+__device__ inline void stats_store_mirror(const f32x16 (&acc)[2][2], float* smem,
+                                          const StatsTask& tk, int tm, int tn, float w1,
+                                          float w2) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int TLD = 129;
+  const int row0 = tn * TILE, col0 = tm * TILE;
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wm == h) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            smem[lr * TLD + acc_col(wn, j, lane)] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    for (int e = tid; e < 128 * 64; e += NTHREADS) {
+      const int c = e >> 6, lr = e & 63;
+      const int row = row0 + c, col = col0 + h * 64 + lr;
+      if (row < tk.d && col < tk.d) {
+        const int64_t o = (int64_t)row * tk.lds + col;
+        gstore1(tk.sout + o, __fadd_rn(__fmul_rn(w1, gload1(tk.sin + o)),
+                                       __fmul_rn(w2, smem[lr * TLD + c])));
+      }
+    }
+    __syncthreads();
+  }
+}
 
 template <int LAYOUT>
 __device__ inline void stats_tile(const StatsTask& tk, int tm, int tn, float w1, float w2,
@@ -59,6 +101,7 @@ __device__ inline void stats_tile(const StatsTask& tk, int tm, int tn, float w1,
                                          __fmul_rn(w2, acc[i][j][r])));
         }
       }
+  if (tm != tn) stats_store_mirror(acc, smem, tk, tm, tn, w1, w2);
 }
 
 template <int LAYOUT>
@@ -77,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void stats_single_kernel(StatsTask tk, int 
                                                               float w1, float w2) {
   __shared__ __align__(16) float smem[SmemCfg<SBK>::TOTAL];
   const int t = xcd_remap(blockIdx.x, gridDim.x);
+  if (t / tiles_n > t % tiles_n) return;  // lower tiles are written by their mirrors
   stats_tile<LAYOUT>(tk, t / tiles_n, t % tiles_n, w1, w2, smem);
 }
 
@@ -134,7 +178,7 @@ extern "C" int ps_stats_update_grouped_f32(void* stream, const ps_stats_desc* de
     tasks[L].push_back(t);
     const int nt = (t.d + TILE - 1) / TILE;
     for (int tm = 0; tm < nt; ++tm)
-      for (int tn = 0; tn < nt; ++tn) tiles[L].push_back({id, (short)tm, (short)tn});
+      for (int tn = tm; tn < nt; ++tn) tiles[L].push_back({id, (short)tm, (short)tn});
   }
   psh::Arena ar(workspace, workspace_bytes);
   StatsTask* d_tasks[2];

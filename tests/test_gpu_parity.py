@@ -199,6 +199,29 @@ def test_gram_update_strided_blocks_and_symmetry(device):
       assert np.array_equal(got, got.T) or np.allclose(got, got.T, rtol=0, atol=1e-6)
 
 
+def test_gram_update_mirrored_tiles_exact_and_asymmetric_old(device):
+  """Only the upper tile triangle of g g^T is computed and mirrored: the Gram part must
+  be EXACTLY symmetric, `old` is read at the mirrored position (an asymmetric `old`
+  stays asymmetric, as in w1*old + w2*gram of DS:1470), in place and out of place,
+  for sizes with ragged last tiles and both operand layouts."""
+  rng = np.random.default_rng(8)
+  for d, k, axis in ((300, 520, 0), (257, 96, 1), (128, 64, 0), (1000, 130, 1), (129, 129, 0)):
+    shape = (d, k) if axis == 0 else (k, d)
+    g = torch.tensor(rng.standard_normal(shape).astype(np.float32), device=device)
+    zero = torch.zeros((d, d), device=device)
+    gram = K().gram_weighted_update(zero, g, axis, 0.0, 1.0)
+    assert torch.equal(gram, gram.T)
+    ref = orc.gram_weighted_update(np.zeros((d, d), np.float32), g.cpu().numpy(), axis, 0.0, 1.0)
+    assert np.allclose(gram.cpu().numpy(), ref, rtol=1e-5, atol=1e-4)
+    old = torch.tensor(rng.standard_normal((d, d)).astype(np.float32), device=device)  # asymmetric
+    want = (np.float32(0.75) * old.cpu().numpy()) + (np.float32(0.25) * gram.cpu().numpy())
+    out = K().gram_weighted_update(old, g, axis, 0.75, 0.25)
+    assert np.array_equal(out.cpu().numpy(), want)  # same rounding sequence, bit for bit
+    inplace = old.clone()
+    K().stats_update_grouped([(g, axis, inplace, inplace)], 0.75, 0.25)
+    assert torch.equal(inplace, out)
+
+
 def test_matmul_layouts_vs_fp64(device):
   rng = np.random.default_rng(0)
   for (m, n, k) in [(128, 128, 128), (200, 130, 77), (513, 65, 300)]:
