@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
+
+#include <mutex>
 
 #include "../../include/ps_api.h"
 
@@ -10,6 +13,12 @@
   do {                                        \
     hipError_t e__ = (expr);                  \
     if (e__ != hipSuccess) return (int)e__;   \
+  } while (0)
+
+#define PS_RC(expr)                           \
+  do {                                        \
+    int rc__ = (expr);                        \
+    if (rc__ != 0) return rc__;               \
   } while (0)
 
 #define PS_LAUNCH_CHECK()                     \
@@ -40,5 +49,34 @@ struct Arena {
     return r;
   }
 };
+
+// Host -> device upload of a small descriptor table without a stream synchronisation: the
+// bytes are copied into a slot of a process-wide ring of pinned staging buffers and
+// the H2D copy is enqueued from there, so the caller's host vectors may go out of scope
+// at once and the host keeps running ahead of the GPU.  A slot is reused only after the
+// event recorded behind its last copy has completed (32 slots: practically never waits).
+inline int upload_async(hipStream_t st, void* dst, const void* src, size_t bytes) {
+  struct Slot { void* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+  static std::mutex mu;
+  static Slot slots[32];
+  static unsigned next = 0;
+  if (bytes == 0) return 0;
+  std::lock_guard<std::mutex> lk(mu);
+  Slot& s = slots[next++ % 32];
+  if (s.used) PS_HIP(hipEventSynchronize(s.ev));
+  if (s.cap < bytes) {
+    if (s.host) (void)hipHostFree(s.host);
+    s.host = nullptr; s.cap = 0;
+    const size_t cap = align_up(bytes + bytes / 2, 1 << 16);
+    PS_HIP(hipHostMalloc(&s.host, cap, hipHostMallocDefault));
+    s.cap = cap;
+  }
+  if (!s.ev) PS_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  memcpy(s.host, src, bytes);
+  PS_HIP(hipMemcpyAsync(dst, s.host, bytes, hipMemcpyHostToDevice, st));
+  PS_HIP(hipEventRecord(s.ev, st));
+  s.used = true;
+  return 0;
+}
 
 }  // namespace psh

@@ -199,12 +199,9 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
   if (ar.overflow) return PS_EWORKSPACE;
   for (int g = 0; g < 4; ++g) {
     if (tasks[g].empty()) continue;
-    PS_HIP(hipMemcpyAsync(dt[g], tasks[g].data(), sizeof(GTask) * tasks[g].size(),
-                          hipMemcpyHostToDevice, st));
-    PS_HIP(hipMemcpyAsync(dl[g], tiles[g].data(), sizeof(GTile) * tiles[g].size(),
-                          hipMemcpyHostToDevice, st));
+    PS_RC(psh::upload_async(st, dt[g], tasks[g].data(), sizeof(GTask) * tasks[g].size()));
+    PS_RC(psh::upload_async(st, dl[g], tiles[g].data(), sizeof(GTile) * tiles[g].size()));
   }
-  PS_HIP(hipStreamSynchronize(st));
   const dim3 blk(256);
 #define PS_GG(G, LA, LB)                                                                   \
   if (!tasks[G].empty())                                                                   \

@@ -307,8 +307,7 @@ extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int coun
     off += psh::align_up((size_t)ht[i].cols, 4);
   }
   PS_HIP(hipMemsetAsync(colmax, 0, sizeof(unsigned) * total_cols, st));
-  PS_HIP(hipMemcpyAsync(dt, ht.data(), sizeof(QTensor) * count, hipMemcpyHostToDevice, st));
-  PS_HIP(hipStreamSynchronize(st));
+  PS_RC(psh::upload_async(st, dt, ht.data(), sizeof(QTensor) * count));
   const dim3 grid((unsigned)chunks), blk(256);
   hipLaunchKernelGGL(quant_colmax_kernel, grid, blk, 0, st, dt, count);
   hipLaunchKernelGGL(quant_encode_kernel, grid, blk, 0, st, dt, count);
@@ -334,8 +333,7 @@ extern "C" int ps_dequantize_f32(void* stream, const ps_quant_desc* desc, int co
   psh::Arena ar(workspace, workspace_bytes);
   QTensor* dt = ar.take<QTensor>(count);
   if (ar.overflow) return PS_EWORKSPACE;
-  PS_HIP(hipMemcpyAsync(dt, ht.data(), sizeof(QTensor) * count, hipMemcpyHostToDevice, st));
-  PS_HIP(hipStreamSynchronize(st));
+  PS_RC(psh::upload_async(st, dt, ht.data(), sizeof(QTensor) * count));
   hipLaunchKernelGGL(quant_decode_kernel, dim3((unsigned)chunks), dim3(256), 0, st, dt, count);
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -190,12 +190,9 @@ extern "C" int ps_stats_update_grouped_f32(void* stream, const ps_stats_desc* de
   if (ar.overflow) return PS_EWORKSPACE;
   for (int L = 0; L < 2; ++L) {
     if (tasks[L].empty()) continue;
-    PS_HIP(hipMemcpyAsync(d_tasks[L], tasks[L].data(), sizeof(StatsTask) * tasks[L].size(),
-                          hipMemcpyHostToDevice, st));
-    PS_HIP(hipMemcpyAsync(d_tiles[L], tiles[L].data(), sizeof(StatsTile) * tiles[L].size(),
-                          hipMemcpyHostToDevice, st));
+    PS_RC(psh::upload_async(st, d_tasks[L], tasks[L].data(), sizeof(StatsTask) * tasks[L].size()));
+    PS_RC(psh::upload_async(st, d_tiles[L], tiles[L].data(), sizeof(StatsTile) * tiles[L].size()));
   }
-  PS_HIP(hipStreamSynchronize(st));  // host vectors go out of scope below
   if (!tasks[0].empty()) {
     const int nt = (int)tiles[0].size();
     hipLaunchKernelGGL(stats_grouped_kernel<KC>, dim3(nt), dim3(256), 0, st, d_tasks[0],

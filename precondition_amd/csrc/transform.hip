@@ -228,9 +228,8 @@ extern "C" int ps_transform_grads_f32(void* stream, const ps_transform_desc* des
   TChunk* dc = ar.take<TChunk>(hc.size());
   float* slab = ar.take<float>(4 * hc.size());
   if (ar.overflow) return PS_EWORKSPACE;
-  PS_HIP(hipMemcpyAsync(dp, hp.data(), sizeof(TParam) * count, hipMemcpyHostToDevice, st));
-  PS_HIP(hipMemcpyAsync(dc, hc.data(), sizeof(TChunk) * hc.size(), hipMemcpyHostToDevice, st));
-  PS_HIP(hipStreamSynchronize(st));
+  PS_RC(psh::upload_async(st, dp, hp.data(), sizeof(TParam) * count));
+  PS_RC(psh::upload_async(st, dc, hc.data(), sizeof(TChunk) * hc.size()));
   const dim3 grid((unsigned)hc.size()), blk(256);
   hipLaunchKernelGGL(transform_pass_a, grid, blk, 0, st, dp, dc, slab, *cfg);
   if (diag) hipLaunchKernelGGL(transform_pass_b, grid, blk, 0, st, dp, dc, slab, *cfg);

@@ -31,6 +31,7 @@ for t in range(3):
   upd, st = opt.update(grads, st, params)
 torch.cuda.synchronize(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 nbytes = sum(x.numel() * x.element_size() for x in pa.pytree.tree_leaves(st) if isinstance(x, torch.Tensor))
 print(f"optimizer state: {nbytes / 2**20:.1f} MiB")
 if "--quant" in sys.argv:
