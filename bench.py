@@ -144,8 +144,13 @@ class VitBWorkload:
       self.pcs.append(pc); self.grads.append(g); self.stats.append(st)
       self.exps.extend([pc.exponent_for_preconditioner()] * len(st))
     self.n_stats = sum(len(s) for s in self.stats)
+    # owner-only statistics: a rank updates just the statistics it roots
+    from precondition_amd import comm
+    sizes = [int(s.shape[0]) for st in self.stats for s in st]
+    owner = comm.ownership_table(sizes, self.exps, world, "lpt")
+    self.mine = [o == rank for o in owner]
     self.metrics = None
-    self.stats_flops = 0.0
+    self.stats_flops = 0.0  # whole tree (all ranks together)
     for pc, g in zip(self.pcs, self.grads):
       for blk in pc.partitioned_blocks(g):
         for d in blk.shape:
@@ -158,6 +163,8 @@ class VitBWorkload:
     items = []
     for pc, g, st in zip(self.pcs, self.grads, self.stats):
       items.extend(pc.statistics_update_items(st, g, st))  # in place
+    if self.world > 1:
+      items = [it for it, m in zip(items, self.mine) if m]
     K.stats_update_grouped(items, 0.999, 1.0 - 0.999)
 
   def step(self):

@@ -72,6 +72,16 @@ def cost_balanced_ownership(sizes: Sequence[int], exponents: Sequence[int],
   return owner
 
 
+def ownership_table(sizes: Sequence[int], exponents: Sequence[int], world: int,
+                    ownership: str = "reference") -> List[int]:
+  """owner[i] of every statistic; a pure function of shapes, identical on every rank."""
+  if ownership == "reference":
+    return reference_ownership(len(sizes), world)
+  if ownership == "lpt":
+    return cost_balanced_ownership(sizes, exponents, world)
+  raise ValueError(f"unknown ownership {ownership!r}")
+
+
 def sharded_inverse_pth_roots(
     statistics: Sequence[torch.Tensor],
     exponents: Sequence[int],
@@ -86,6 +96,7 @@ def sharded_inverse_pth_roots(
     overlap: bool = True,
     overlap_min_bytes: int = 32 << 20,
     payload_elems: Optional[Sequence[int]] = None,
+    sizes: Optional[Sequence[int]] = None,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
 
@@ -99,16 +110,13 @@ def sharded_inverse_pth_roots(
   `payload_elems[i]` (needs `compute_fn`): result i travels as an opaque payload of
   that many float32 words (the int16-quantized preconditioner + its diagonal and
   bucket sizes, DS:3102-3127); `outs` and the returned roots are then flat views.
+  `sizes[i]` (default statistics[i].shape[0]): with owner-only statistics
+  (`shard_statistics`) the entries this rank does not own are placeholders.
   """
   n_stats = len(statistics)
   world, rank = world_and_rank(group)
-  sizes = [int(s.shape[0]) for s in statistics]
-  if ownership == "reference":
-    owner = reference_ownership(n_stats, world)
-  elif ownership == "lpt":
-    owner = cost_balanced_ownership(sizes, exponents, world)
-  else:
-    raise ValueError(f"unknown ownership {ownership!r}")
+  sizes = [int(s) for s in sizes] if sizes is not None else [int(s.shape[0]) for s in statistics]
+  owner = ownership_table(sizes, exponents, world, ownership)
   if root_fn is None:
     from . import kernels
     root_fn = kernels.matrix_inverse_pth_root_batched
@@ -120,7 +128,7 @@ def sharded_inverse_pth_roots(
     if compute_fn is None:
       raise ValueError("payload_elems needs compute_fn")
     elems = [int(e) for e in payload_elems]
-  dev = statistics[0].device
+  dev = next((s.device for s in statistics if hasattr(s, 'device')), None)
 
   # Phases: with several ranks and enough work, every rank roots its statistics in
   # two halves so that the all-gather of the first half (RCCL's own stream,

@@ -580,8 +580,10 @@ size_t ecarve(EPlan& pl, Arena& ar, ELayout* lo) {
   return ar.off;
 }
 
+// One mapped status ring per host thread: a thread runs one call at a time, so calls
+// on distinct (stream, workspace) pairs from different threads never share slots.
 EStatus* epinned() {
-  static EStatus* st = nullptr;
+  static thread_local EStatus* st = nullptr;
   if (!st && hipHostMalloc((void**)&st, 64 * sizeof(EStatus), hipHostMallocMapped) != hipSuccess)
     st = nullptr;
   return st;

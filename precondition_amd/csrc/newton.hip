@@ -550,8 +550,10 @@ struct ProfRun {
   }
 };
 
+// One mapped status ring per host thread: a thread runs one call at a time, so calls
+// on distinct (stream, workspace) pairs from different threads never share slots.
 HostStatus* pinned_status() {
-  static HostStatus* st = nullptr;
+  static thread_local HostStatus* st = nullptr;
   if (!st) {
     if (hipHostMalloc((void**)&st, 64 * sizeof(HostStatus), hipHostMallocMapped) !=
         hipSuccess)
@@ -673,7 +675,10 @@ extern "C" int ps_newton_root_batched_f32(
   if (ninit > 0) {
     hipEvent_t ev[2];
     PS_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    PS_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    {
+      const hipError_t e1 = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+      if (e1 != hipSuccess) { (void)hipEventDestroy(ev[0]); return (int)e1; }
+    }
     const int cap = 6 * (num_iters + 2) + 4;
     bool need_init = true;
     int rc = 0;

@@ -99,6 +99,12 @@ def distributed_shampoo(
     # the gloo sharding without a GPU; None = the HIP kernels, which fail loudly
     # when the library or the GPU is missing).
     block_ownership: str = "reference",
+    # Owner-only statistics: with a process group, a rank keeps and updates
+    # only the statistics it roots; the others are empty placeholders in its state.
+    # Memory and Gram FLOPs of the statistics drop by the group size; preconditioners
+    # stay replicated (every rank applies them to its full gradient).  The optimizer
+    # state is then rank-local: checkpoint every rank (or gather) to save it.
+    shard_statistics: bool = False,
     _backend_for_testing: Any = None,
 ):
   """Returns GradientTransformation(init_fn, update_fn); see module docstring."""
@@ -134,6 +140,29 @@ def distributed_shampoo(
     beta2 = 1.0
 
   group = comm.resolve_group(batch_axis_name)
+  shard_stats = bool(shard_statistics and group is not None)
+  if shard_stats and (frequent_directions or compression_rank != 0):
+    raise NotImplementedError("shard_statistics supports the dense preconditioner mode")
+
+  def _owned_mask(params_flat):
+    """mask[p][j]: does this rank own statistic j of parameter p (list order = the
+    order _compute_preconditioners flattens them in)?  Pure function of shapes."""
+    sizes, exps, counts = [], [], []
+    for param in params_flat:
+      n = 0
+      if not _skip_preconditioning(param):
+        pc = preconditioner_from_params(param)
+        e = pc.exponent_for_preconditioner() if exponent_override == 0 else exponent_override
+        for sh in pc.shapes_for_preconditioners():
+          sizes.append(int(sh[0])); exps.append(e); n += 1
+      counts.append(n)
+    world, rank = comm.world_and_rank(group)
+    owner = comm.ownership_table(sizes, exps, world, block_ownership)
+    mask, k = [], 0
+    for n in counts:
+      mask.append([owner[k + j] == rank for j in range(n)])
+      k += n
+    return mask
   if _backend_for_testing is not None:
     backend = _backend_for_testing
   else:
@@ -163,15 +192,28 @@ def distributed_shampoo(
     if dtype == torch.float32:
       return [QuantizedValue.from_float_value(t, torch.float32, extract_diagonal)
               for t in tensors]
-    triples = backend.quantize_grouped(tensors, dtype, extract_diagonal)
-    return [QuantizedValue(q, d, b, dtype, extract_diagonal, list(q.shape))
-            for q, d, b in triples]
+    full = [i for i, t in enumerate(tensors) if t.numel() > 0]
+    triples = backend.quantize_grouped([tensors[i] for i in full], dtype, extract_diagonal)
+    out = [None] * len(tensors)
+    for i, (q, d, b) in zip(full, triples):
+      out[i] = QuantizedValue(q, d, b, dtype, extract_diagonal, list(q.shape))
+    for i, t in enumerate(tensors):
+      if out[i] is None:  # empty placeholder (a statistic another rank owns)
+        zf = torch.empty((0,), dtype=torch.float32, device=t.device)
+        out[i] = QuantizedValue(torch.empty(t.shape, dtype=dtype, device=t.device), zf, zf,
+                                dtype, extract_diagonal, list(t.shape))
+    return out
 
   def _to_float_many(values):
     """_to_float (DS:2072-2076) for a list of QuantizedValue / tensors, grouped."""
     out = list(values)
     idx = [i for i, v in enumerate(values) if isinstance(v, QuantizedValue) and
            v.quantized_dtype in (torch.int8, torch.int16)]
+    for i in idx:
+      if values[i].quantized.numel() == 0:  # empty placeholder
+        out[i] = torch.empty(tuple(values[i].quantized.shape), dtype=torch.float32,
+                             device=values[i].quantized.device)
+    idx = [i for i in idx if values[i].quantized.numel() > 0]
     for extract in (False, True):  # one grouped launch per kind
       sel = [i for i in idx if bool(values[i].extract_diagonal) == extract]
       if not sel:
@@ -216,6 +258,14 @@ def distributed_shampoo(
     return len(param.shape) < skip_preconditioning_rank_lt or any(
         s > skip_preconditioning_dim_size_gt for s in param.shape)
 
+  def _placeholder_like(x):
+    """A statistic this rank does not own: no storage."""
+    if isinstance(x, QuantizedValue):
+      z = torch.empty((0, 0), dtype=x.quantized.dtype, device=x.quantized.device)
+      zf = torch.empty((0,), dtype=torch.float32, device=x.quantized.device)
+      return QuantizedValue(z, zf, zf, x.quantized_dtype, x.extract_diagonal, [0, 0])
+    return torch.empty((0, 0), dtype=x.dtype, device=x.device)
+
   # ---------------------------------------------------------------------------
   def init_fn(params):
     """DS:2585-2625: statistics = matrix_epsilon * I, preconditioners = I."""
@@ -248,8 +298,17 @@ def distributed_shampoo(
           init_training_metrics(len(statistics), generate_training_metrics,
                                 generate_fd_metrics, device=dev))
 
-    return ShampooState(count=torch.zeros([], dtype=torch.int32),
-                        stats=pytree.tree_map(_init, params))
+    stats = pytree.tree_map(_init, params)
+    if shard_stats:
+      params_flat, treedef = pytree.tree_flatten(params)
+      st_flat = treedef.flatten_up_to(stats)
+      mask = _owned_mask(params_flat)
+      st_flat = [
+          st._replace(statistics=[x if own else _placeholder_like(x)
+                                  for x, own in zip(st.statistics, m)])
+          for st, m in zip(st_flat, mask)]
+      stats = treedef.unflatten(st_flat)
+    return ShampooState(count=torch.zeros([], dtype=torch.int32), stats=stats)
 
   # ---------------------------------------------------------------------------
   def _compute_stats_all(grads_flat, stats_flat, params_flat, step):
@@ -258,6 +317,7 @@ def distributed_shampoo(
     w2 = beta2 if beta2 == 1.0 else 1.0 - beta2  # DS:2635-2636
     perform = statistics_compute_steps <= 1 or step % statistics_compute_steps == 0
     new_lists, items, fd_items, new_avg = [], [], [], []
+    owned = _owned_mask(params_flat) if shard_stats else None
     float_old = None
     if quantize_second_moment and perform:  # to_float=_to_float, DS:2652
       flat = _to_float_many([q for st in stats_flat for q in st.statistics])
@@ -286,7 +346,10 @@ def distributed_shampoo(
                                        else state.statistics)]
       # quantized mode: the dequantized copies are temporaries, update them in place
       news = olds if float_old is not None else [torch.empty_like(s) for s in olds]
-      for it in pc.statistics_update_items(olds, grad, news):
+      for j, it in enumerate(pc.statistics_update_items(olds, grad, news)):
+        if owned is not None and not owned[pidx][j]:
+          news[j] = olds[j]  # not ours: stays an empty placeholder
+          continue
         g_blk, axis = it[0], it[1]
         if frequent_directions and _should_compress(compression_rank, g_blk.shape[axis]):
           # FD (DS:1585-1588): the slot holds the Gram matrix of the (averaged)
@@ -347,7 +410,9 @@ def distributed_shampoo(
       # _quantized_matrix_inverse_pth_root_vmap (DS:2746-2773): the root is taken of the
       # DEQUANTIZED statistics and quantized again before the failure select.
       statistics = _to_float_many(statistics)
-    sizes = [int(s.shape[0]) for s in statistics]
+    # sizes from the (replicated) preconditioners: with shard_statistics the statistics
+    # this rank does not own are empty placeholders
+    sizes = [int(p.shape[0]) for p in prev]
     compute_fn, out_cols = None, None
     if compression_rank != 0:
       max_size = max(sizes)
@@ -440,7 +505,7 @@ def distributed_shampoo(
         relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
         ownership=block_ownership,
         root_fn=backend.matrix_inverse_pth_root_batched, out_cols=out_cols,
-        compute_fn=compute_fn, payload_elems=payload_elems)
+        compute_fn=compute_fn, payload_elems=payload_elems, sizes=sizes)
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
     if quantize_second_moment:
       roots = [QuantizedValue(*_unpack(r, n), qdt_second_moment, True, [n, n])

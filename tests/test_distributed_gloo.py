@@ -173,3 +173,63 @@ def test_two_rank_quantized_second_moment_matches_one_rank():
       assert len(got) == len(ref)
       for a, b in zip(got, ref):
         assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
+def _run_sharded_stats(group, shard, quant, ownership):
+  import precondition_amd as pa
+  from tests import cpu_backend
+  params, grads, kw = _quant_problem()
+  kw = dict(kw)
+  kw["best_effort_memory_usage_reduction"] = quant
+  opt = pa.distributed_shampoo(0.1, 8, batch_axis_name=group, _backend_for_testing=cpu_backend,
+                               shard_statistics=shard, block_ownership=ownership, **kw)
+  st = opt.init(params)
+  for g in grads:
+    upd, st = opt.update(g, st, params)
+  stats = []
+  for s in st.stats:
+    for x in s.statistics:
+      q = x.quantized if hasattr(x, "quantized") else x
+      stats.append(q.numpy().copy())
+  precs = [(p.quantized if hasattr(p, "quantized") else p).numpy().copy()
+           for s in st.stats for p in s.preconditioners]
+  return [u.numpy().copy() for u in upd], stats, precs
+
+
+def _sharded_worker(rank, world, port, quant, ownership, ret):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    ret[rank] = _run_sharded_stats(dist.group.WORLD, True, quant, ownership)
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("quant,ownership", [(False, "reference"), (True, "lpt")])
+def test_owner_only_statistics_two_ranks(quant, ownership):
+  """shard_statistics: a rank keeps and updates only the statistics it
+  roots.  Updates and (replicated) preconditioners must equal the replicated mode
+  bit for bit; every statistic lives on exactly one rank and equals the replicated one."""
+  from tests.conftest import single_rank_group
+  world = 2
+  mgr = mp.Manager()
+  ret = mgr.dict()
+  mp.spawn(_sharded_worker, args=(world, _free_port(), quant, ownership, ret), nprocs=world,
+           join=True)
+  base_upd, base_stats, base_precs = _run_sharded_stats(single_rank_group("gloo"), False, quant,
+                                                        ownership)
+  for rank in range(world):
+    upd, stats, precs = ret[rank]
+    for a, b in zip(upd, base_upd):
+      assert np.array_equal(a, b)
+    for a, b in zip(precs, base_precs):
+      assert np.array_equal(a, b)
+  n_owned = [0, 0]
+  for j, ref in enumerate(base_stats):
+    holders = [r for r in range(world) if ret[r][1][j].size > 0]
+    assert len(holders) == 1, (j, holders)       # exactly one owner
+    assert np.array_equal(ret[holders[0]][1][j], ref)
+    n_owned[holders[0]] += 1
+  assert min(n_owned) > 0
