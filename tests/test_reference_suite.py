@@ -1,0 +1,180 @@
+"""The reference's own optimizer-level tests (precondition/distributed_shampoo_test.py,
+"DST"), restated against this build with the same names, inputs and constants:
+DST:116-261 (17 option combos over a batch axis: six finite steps, step-0 known answers
+-0.57 / -0.17019942), DST:263-287 (no batch axis), DST:289-339 (scheduled recompute
+interval).  Each runs twice: host logic over the CPU stand-in (not gpu), and through the
+HIP kernels with a one-rank RCCL group as the batch axis (gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import precondition_amd as pa
+from precondition_amd import pytree
+
+DST_CASES = [
+    dict(testcase_name="default", best_effort_memory_usage_reduction=True, expected_value=-0.57),
+    dict(testcase_name="default_nomerge", best_effort_memory_usage_reduction=True,
+         merge_small_dims_block_size=1, expected_value=-0.57),
+    dict(testcase_name="default_larger", best_effort_memory_usage_reduction=True,
+         slightly_larger=True, expected_value=-0.17019942),
+    dict(testcase_name="default_larger_nomerge", best_effort_memory_usage_reduction=True,
+         slightly_larger=True, merge_small_dims_block_size=1, expected_value=-0.17019942),
+    dict(testcase_name="materialize_statistics", best_effort_memory_usage_reduction=True),
+    dict(testcase_name="blocked_statistics", best_effort_memory_usage_reduction=True),
+    dict(testcase_name="default_quantized"),
+    dict(testcase_name="materialize_statistics_quantized"),
+    dict(testcase_name="blocked_statistics_quantized"),
+    dict(testcase_name="pos_compression_rank", compression_rank=1, slightly_larger=True,
+         expected_value=-0.17019942),
+    dict(testcase_name="pos_compression_rank_nomerge", compression_rank=1, slightly_larger=True,
+         merge_small_dims_block_size=1, expected_value=-0.17019942),
+    dict(testcase_name="neg_compression_rank", compression_rank=-1, slightly_larger=True,
+         expected_value=-0.17019942),
+    dict(testcase_name="neg_compression_rank_nomerge", compression_rank=-1, slightly_larger=True,
+         merge_small_dims_block_size=1, expected_value=-0.17019942),
+    dict(testcase_name="no_training_metrics", generate_training_metrics=False),
+    dict(testcase_name="larger_reuse", best_effort_memory_usage_reduction=True,
+         reuse_preconditioner=True, slightly_larger=True, expected_value=-0.17019942),
+    dict(testcase_name="larger_reuse_highmem", best_effort_memory_usage_reduction=False,
+         reuse_preconditioner=True, slightly_larger=True, expected_value=-0.17019942),
+    dict(testcase_name="larger_reuse_highmem_nomerge", best_effort_memory_usage_reduction=False,
+         merge_small_dims_block_size=1, reuse_preconditioner=True, slightly_larger=True,
+         expected_value=-0.17019942),
+]
+
+
+def _inputs(device):
+  """DST setUp (DST:90-114): the fixed 2x2 pair, and the rng(1234) [2,5] / [6,3] pair
+  whose updates have their first column scaled by 100."""
+  t = lambda a: torch.tensor(np.asarray(a, np.float32), device=device)
+  init = (t([[1., 3.], [2., 4.]]), t([[3., 4.], [3., 4.]]))
+  upd = (t([[500., 5.], [500., 5.]]), t([[300., 3.], [300., 3.]]))
+  rng = np.random.default_rng(1234)
+  shape = ([2, 5], [6, 3])
+
+  def make_shape(bigger_first_entry):
+    x = tuple(rng.standard_normal(size=s) for s in shape)
+    if bigger_first_entry:
+      for xx in x:
+        xx[..., 0] *= 100
+    return tuple(t(xx) for xx in x)
+
+  init_larger = make_shape(False)
+  upd_larger = make_shape(True)
+  return init, upd, init_larger, upd_larger
+
+
+def _all_finite(tree):
+  for leaf in pytree.tree_leaves(tree):
+    if isinstance(leaf, torch.Tensor) and leaf.is_floating_point():
+      assert torch.isfinite(leaf).all()
+
+
+def _env(kind):
+  from tests.conftest import single_rank_group
+  if kind == "cpu":
+    from tests import cpu_backend
+    return torch.device("cpu"), cpu_backend, single_rank_group("gloo")
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  return torch.device("cuda:0"), None, single_rank_group("nccl")
+
+
+def _run_dst_case(kind, best_effort_memory_usage_reduction=False, compression_rank=0,
+                  merge_small_dims_block_size=4096, generate_training_metrics=True,
+                  slightly_larger=False, expected_value=None, reuse_preconditioner=False,
+                  testcase_name=None):
+  device, backend, group = _env(kind)
+  init, upd, init_larger, upd_larger = _inputs(device)
+  params = init_larger if slightly_larger else init
+  updates = upd_larger if slightly_larger else upd
+  optim = pa.distributed_shampoo(
+      0.1, 32, batch_axis_name=group, preconditioning_compute_steps=2,
+      best_effort_memory_usage_reduction=best_effort_memory_usage_reduction,
+      relative_matrix_epsilon=True, compression_rank=compression_rank,
+      merge_small_dims_block_size=merge_small_dims_block_size,
+      generate_training_metrics=generate_training_metrics,
+      reuse_preconditioner=reuse_preconditioner, _backend_for_testing=backend)
+  state = optim.init(params)
+  _all_finite(state)
+  out, state = optim.update(updates, state, params)
+  _all_finite((out, state))
+  if expected_value is not None:
+    last_entry = float(out[1][-1, -1])
+    assert abs(last_entry - expected_value) < 1e-4, (last_entry, expected_value)
+  for _ in range(5):
+    out, state = optim.update(updates, state, params)
+    _all_finite((out, state))
+
+
+@pytest.mark.parametrize("case", DST_CASES, ids=lambda c: c["testcase_name"])
+def test_distributed_shampoo_host_logic(case):
+  _run_dst_case("cpu", **case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DST_CASES, ids=lambda c: c["testcase_name"])
+def test_distributed_shampoo(case):
+  _run_dst_case("gpu", **case)
+
+
+def _no_pmap(kind, generate_training_metrics):
+  device, backend, _ = _env(kind)
+  init, upd, _, _ = _inputs(device)
+  optim = pa.distributed_shampoo(0.1, 32, batch_axis_name=None, preconditioning_compute_steps=2,
+                                 generate_training_metrics=generate_training_metrics,
+                                 _backend_for_testing=backend)
+  state = optim.init(init)
+  _all_finite(state)
+  out, state = optim.update(upd, state, init)
+  _all_finite((out, state))
+
+
+@pytest.mark.parametrize("generate_training_metrics", [True, False],
+                         ids=["default", "no_training_metrics"])
+def test_distributed_shampoo_no_pmap_host_logic(generate_training_metrics):
+  _no_pmap("cpu", generate_training_metrics)   # DST:263-287
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generate_training_metrics", [True, False],
+                         ids=["default", "no_training_metrics"])
+def test_distributed_shampoo_no_pmap(generate_training_metrics):
+  _no_pmap("gpu", generate_training_metrics)
+
+
+def _schedule(kind, preconditioning_compute_steps, end_preconditioning_steps):
+  device, backend, group = _env(kind)
+  init, upd, _, _ = _inputs(device)
+  base_lr = 0.1
+
+  def lr_fn(t):
+    return base_lr * (t + 1) ** -0.5
+
+  optim = pa.distributed_shampoo(
+      lr_fn, 32, batch_axis_name=group,
+      preconditioning_compute_steps=preconditioning_compute_steps,
+      decay_preconditioning_compute_steps=True,
+      end_preconditioning_compute_steps=end_preconditioning_steps,
+      _backend_for_testing=backend)
+  state = optim.init(init)
+  _all_finite(state)
+  for _ in range(6):
+    out, state = optim.update(upd, state, init)
+    _all_finite((out, state))
+
+
+_SCHED = [(2, 100), (1, 1)]
+_SCHED_IDS = ["preconditioning_compute_steps_schedule",
+              "preconditioning_compute_steps_schedule_short_circuit"]
+
+
+@pytest.mark.parametrize("steps,end", _SCHED, ids=_SCHED_IDS)
+def test_preconditioning_compute_steps_schedule_host_logic(steps, end):
+  _schedule("cpu", steps, end)   # DST:289-339
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps,end", _SCHED, ids=_SCHED_IDS)
+def test_preconditioning_compute_steps_schedule(steps, end):
+  _schedule("gpu", steps, end)
