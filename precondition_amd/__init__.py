@@ -10,7 +10,7 @@ __version__ = "0.1.0"
 
 from .blocking import (BlockPartitioner, Preconditioner, batch, merge_small_dims,
                        pad_square_matrix, pad_vector, unbatch)
-from .distributed_shampoo import (distributed_shampoo,
+from .distributed_shampoo import (_pth_root_difference, distributed_shampoo,
                                   preconditioning_compute_steps_schedule)
 from .state import (GradientTransformation, GraftingType, MaskedNode,
                     ParameterStats, PreconditionerType, QuantizedValue,
@@ -23,4 +23,9 @@ def __getattr__(name):
               "power_iteration", "mat_power", "gram_weighted_update"):
     from . import kernels
     return getattr(kernels, name)
+  if name in ("frequent_directions_update", "_fd_update_root", "_low_rank_root",
+              "_fd_low_rank_pack", "_fd_low_rank_unpack", "_low_rank_pack",
+              "_low_rank_unpack"):  # config-5 branch, same names as the reference module
+    from . import low_rank
+    return getattr(low_rank, name)
   raise AttributeError(name)

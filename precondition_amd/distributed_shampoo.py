@@ -38,6 +38,24 @@ from .state import (GradientTransformation, GraftingType, MaskedNode,
 _EPSILON = 1e-25  # DS:41
 
 
+def _pth_root_difference(w, alpha, beta, p):
+  """(w+alpha)^(-1/p) - (w+beta)^(-1/p) without cancellation (DS:681-699); float32
+  scalars or tensors, evaluated where the arguments live (host math, O(rank) values:
+  the LOBPCG re-deflation weights)."""
+  w, alpha, beta = (torch.as_tensor(x, dtype=torch.float32) for x in (w, alpha, beta))
+  a = w + alpha
+  b = w + beta
+  a_minus_b = alpha - beta
+  exp = -1.0 / float(p)
+
+  def _stable_subtract(base, diff):
+    # (base)^exp * expm1(exp * log1p(diff / base)): the common factor pulled out
+    return torch.pow(base, exp) * torch.expm1(exp * torch.log1p(diff / base))
+
+  return torch.where(torch.abs(a_minus_b / b) < torch.abs(a_minus_b / a),
+                     -_stable_subtract(a, -a_minus_b), _stable_subtract(b, a_minus_b))
+
+
 def preconditioning_compute_steps_schedule(lr_fn, start_preconditioning_compute_steps,
                                            end_preconditioning_compute_steps, step):
   """DS:44-76: recompute interval following the learning-rate decay, rounded

@@ -178,3 +178,35 @@ def test_preconditioning_compute_steps_schedule_host_logic(steps, end):
 @pytest.mark.parametrize("steps,end", _SCHED, ids=_SCHED_IDS)
 def test_preconditioning_compute_steps_schedule(steps, end):
   _schedule("gpu", steps, end)
+
+
+def _pth_root_difference_cases():
+  """DST:75-86."""
+  import itertools
+  p_vals = [2, 4, 6, 8]
+  a_vals = b_vals = [1e-6, 1e-5, 0.0, 1.0]
+  w_vals = [1e-6, 1e-5, 1.0, 1e3]
+  return list(itertools.product(p_vals, a_vals, b_vals, w_vals))
+
+
+def test_pth_root_difference():
+  """DST:415-430: stable (w+a)^(-1/p) - (w+b)^(-1/p) against float64, delta 1e-2."""
+  for p, a, b, w in _pth_root_difference_cases():
+    actual = float(pa._pth_root_difference(w, a, b, p))
+    exp = -1.0 / p
+    expected = (w + a) ** exp - (w + b) ** exp
+    assert abs(actual - expected) <= 1e-2, (p, a, b, w, actual, expected)
+  # the relative accuracy the plain float32 formula loses to cancellation is kept
+  got = float(pa._pth_root_difference(1.0, 1e-6, 0.0, 4))
+  assert abs(got - (-2.5e-7)) < 1e-9
+
+
+def test_public_names_of_the_path():
+  """the module-level names the reference's tests reach for."""
+  for name in ("distributed_shampoo", "matrix_inverse_pth_root", "power_iteration", "mat_power",
+               "pad_square_matrix", "merge_small_dims", "BlockPartitioner", "Preconditioner",
+               "gram_weighted_update", "frequent_directions_update", "_fd_update_root",
+               "_low_rank_root", "_fd_low_rank_pack", "_fd_low_rank_unpack",
+               "_pth_root_difference", "GraftingType", "PreconditionerType", "QuantizedValue",
+               "ShampooState", "ParameterStats", "TrainingMetrics"):
+    assert getattr(pa, name) is not None, name
