@@ -23,6 +23,7 @@
 // : max(e, eps)^(-1/p); val = (u sqrt(inv_e))(u sqrt(inv_e))^T; error = max|u^T D u - diag(e)|.
 // Eigenvector order/sign is not unique, so parity is checked on val, never on u.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -703,6 +704,9 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
         e = hipStreamSynchronize(st);  // one sync per sweep (a sweep is tens of ms)
         if (e != hipSuccess) return (int)e;
         if (slot->gen != gen) return PS_EINTERNAL;
+        if (getenv("PS_EIGH_TRACE"))
+          fprintf(stderr, "eigh sweep %d: tol %.1e max off_rel (start of sweep) %.3e active %d\n",
+                  gen, tol, slot->max_off, slot->active);
         ++gen;
         if (slot->active == 0) break;
       }
