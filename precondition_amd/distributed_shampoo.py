@@ -458,6 +458,7 @@ def distributed_shampoo(
               relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
               out=[outs[k] for k in dense])
           rows[dense] = m
+        fd_calls, fd_slots = [], []
         for k, i in enumerate(indices):
           if k in dense:
             continue
@@ -476,19 +477,23 @@ def distributed_shampoo(
                                device=stat_i.device)
               pp[:n_i] = prev_i
               stat_i, prev_i = gp, pp
-            val, tm = backend.fd_update_root(
-                stat_i, exponents[i], rank=compression_rank,
+            fd_calls.append(dict(
+                new_grad=stat_i, p=exponents[i], rank=compression_rank,
                 ridge_epsilon=matrix_epsilon,
                 relative_matrix_epsilon=relative_matrix_epsilon, decay=beta2,
-                padding_start=n_i, prev=prev_i, new_grad_is_gram=True)
-            val = val[:n_i]
+                padding_start=n_i, prev=prev_i, new_grad_is_gram=True))
+            fd_slots.append((k, n_i))
           else:
             val, tm = backend.low_rank_root(
                 statistics[i], exponents[i], compression_rank=compression_rank,
                 ridge_epsilon=matrix_epsilon,
                 relative_matrix_epsilon=relative_matrix_epsilon, padding_start=sizes[i])
-          outs[k].copy_(val)
-          rows[k, 0] = tm.inverse_pth_root_errors
+            outs[k].copy_(val)
+            rows[k, 0] = tm.inverse_pth_root_errors
+        if fd_calls:  # the eigen-step of all sketch updates of this rank runs batched
+          for (k, n_i), (val, tm) in zip(fd_slots, backend.fd_update_root_batched(fd_calls)):
+            outs[k].copy_(val[:n_i])
+            rows[k, 0] = tm.inverse_pth_root_errors
         return rows
 
     payload_elems = None

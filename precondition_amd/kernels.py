@@ -409,6 +409,12 @@ def fd_update_root(*args, **kwargs):
   return low_rank._fd_update_root(*args, **kwargs)
 
 
+def fd_update_root_batched(calls):
+  """_fd_update_root for a list of keyword dicts with the eigen-step batched."""
+  from . import low_rank
+  return low_rank._fd_update_root_batched(calls)
+
+
 # ---------------------------------------------------------------------------
 # fused _transform_grad for a whole tree (DS:3496-3625)
 # ---------------------------------------------------------------------------

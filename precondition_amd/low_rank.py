@@ -5,8 +5,9 @@ DS:1473-1505; BASELINE config 5).
 
 Division of labour: everything O(d^2) or larger runs in the HIP library — the
 Gram matrix (stats kernel), the covariance update C = decay * W W^T + R R^T
-(gemm), its symmetric eigendecomposition (blocked Jacobi, ps_eigh_batched_f32)
-and the error metrics (gemm).  What is left on the host are O(rank) vector
+(gemm), its symmetric eigendecomposition (blocked Jacobi, ps_eigh_batched_f32; from
+size 1024 only the leading rank+1 eigenpairs, by the block method of subspace.py on
+the MFMA GEMM) and the error metrics (gemm).  What is left on the host are O(rank) vector
 selections, masks and the exact packing layout, kept as torch index ops.
 
 The reference takes an SVD of `updated = [sqrt(decay) * W | R]` (DS:1193); its
@@ -153,6 +154,11 @@ def frequent_directions_update(old_stats_factor, g: torch.Tensor, axis: int, w1,
 
 
 # ---- _fd_update_root (DS:1123-1290) -------------------------------------------------
+# Size from which the covariance update's leading eigenpairs come from the block method
+# of subspace.py instead of the full eigendecomposition, and the width it may use.
+SUBSPACE_MIN_N = 1024
+
+
 def _fd_update_root(new_grad: torch.Tensor, p: int, rank: int = 0,
                     ridge_epsilon: float = 1e-6, error_tolerance: float = 1e-6,
                     relative_matrix_epsilon: bool = True, decay: float = 1.0,
@@ -162,9 +168,60 @@ def _fd_update_root(new_grad: torch.Tensor, p: int, rank: int = 0,
                     ) -> Tuple[torch.Tensor, TrainingMetrics]:
   """One Frequent-Directions sketch update.  `new_grad` is a factor R with
   R R^T = Gram (reference semantics) or, with new_grad_is_gram, the Gram itself."""
-  del generate_training_metrics
-  if generate_fd_metrics:
-    raise NotImplementedError("FDDiagnostics are not built")
+  return _fd_update_root_batched([dict(
+      new_grad=new_grad, p=p, rank=rank, ridge_epsilon=ridge_epsilon,
+      error_tolerance=error_tolerance, relative_matrix_epsilon=relative_matrix_epsilon,
+      decay=decay, padding_start=padding_start, prev=prev,
+      generate_training_metrics=generate_training_metrics,
+      generate_fd_metrics=generate_fd_metrics, new_grad_is_gram=new_grad_is_gram)])[0]
+
+
+def _fd_update_root_batched(calls) -> list:
+  """_fd_update_root for a list of keyword dicts.  The eigen-step of all of them runs
+  batched: covariance updates of size >= SUBSPACE_MIN_N take their leading rank+1
+  eigenpairs from subspace.top_eigenpairs_batched (MFMA GEMMs), the others (and any
+  that does not converge) the full blocked-Jacobi eigendecomposition."""
+  n_calls = len(calls)
+  results = [None] * n_calls
+  preps = [None] * n_calls
+  for i, kw in enumerate(calls):
+    if kw.get("generate_fd_metrics"):
+      raise NotImplementedError("FDDiagnostics are not built")
+    preps[i] = _fd_prepare(**{k: v for k, v in kw.items()
+                              if k not in ("generate_training_metrics", "generate_fd_metrics")})
+    if preps[i]["ps"] == 0:  # DS:1284-1288
+      results[i] = (torch.zeros_like(kw["prev"]), _metrics(0.0))
+  todo = [i for i in range(n_calls) if results[i] is None]
+  # leading eigenpairs, batched by (size, rank)
+  eig = {}
+  groups = {}
+  for i in todo:
+    ps, rank = preps[i]["ps"], preps[i]["rank"]
+    if ps >= SUBSPACE_MIN_N and 4 * (rank + 33) <= ps:
+      groups.setdefault((ps, rank), []).append(i)
+  full = [i for i in todo if not any(i in g for g in groups.values())]
+  for (ps, rank), idxs in groups.items():
+    from . import subspace
+    e, v, conv, _ = subspace.top_eigenpairs_batched([preps[i]["c"] for i in idxs], rank + 1)
+    conv = conv.cpu().tolist()
+    for j, i in enumerate(idxs):
+      if conv[j]:
+        eig[i] = (e[j], v[j])
+      else:
+        full.append(i)
+  if full:
+    es, us = kernels.eigh_batched([preps[i]["c"] for i in full])  # ascending, like LAPACK
+    for i, e, u in zip(full, es, us):
+      eig[i] = (e.flip(0), u.flip(1))
+  for i in todo:
+    results[i] = _fd_finish(preps[i], *eig[i])
+  return results
+
+
+def _fd_prepare(new_grad, p, rank=0, ridge_epsilon=1e-6, error_tolerance=1e-6,
+                relative_matrix_epsilon=True, decay=1.0, padding_start=None, prev=None,
+                new_grad_is_gram=False):
+  """Everything before the eigendecomposition: the unpadded covariance update C."""
   assert prev is not None and rank > 0
   max_size = new_grad.shape[0]
   assert list(new_grad.shape) == [max_size, max_size]
@@ -172,9 +229,9 @@ def _fd_update_root(new_grad: torch.Tensor, p: int, rank: int = 0,
   assert list(prev.shape) == [max_size, pd] and rank + 2 == pd and rank + 2 < max_size
   dev = new_grad.device
   ps = max_size if padding_start is None else int(padding_start)
-  if ps == 0:  # DS:1284-1288
-    return torch.zeros_like(prev), _metrics(0.0)
-
+  st = dict(ps=ps, rank=rank, p=p, decay=decay, max_size=max_size, dev=dev)
+  if ps == 0:
+    return st
   sketch_dr, fwd_eigvals_r, _, _, tail, _ = _fd_low_rank_unpack(prev, rank)
   max_ev = float(fwd_eigvals_r[0]) if relative_matrix_epsilon else 1.0
   ridge = ridge_epsilon * max(max_ev, error_tolerance)
@@ -191,8 +248,17 @@ def _fd_update_root(new_grad: torch.Tensor, p: int, rank: int = 0,
     rr = new_grad[:ps, :ps].contiguous()
     gram = kernels.matmul(rr, rr, transb=True)
   c = decay * kernels.matmul(weighted, weighted, transb=True) + gram
-  c = 0.5 * (c + c.T)
-  (e,), (u,) = kernels.eigh_batched([c])
+  st["c"] = 0.5 * (c + c.T)
+  st["tail"] = tail
+  return st
+
+
+def _fd_finish(st, e, u):
+  """Everything after it.  `e`: eigenvalues of C DESCENDING (all ps of them, or at least
+  the leading rank+1), `u`: the matching eigenvectors in columns."""
+  ps, rank, p, decay, max_size, dev = (st[k] for k in ("ps", "rank", "p", "decay",
+                                                        "max_size", "dev"))
+  tail = st["tail"]
   # Rank-deficient updates (a vector parameter's Gram has rank 1) give the
   # reference EXACT zero singular values, because it takes the SVD of a thin factor
   # (DS:1179-1193); they steer has_zeros / the deflation masks.  A float32
@@ -200,18 +266,17 @@ def _fd_update_root(new_grad: torch.Tensor, p: int, rank: int = 0,
   # noise band are snapped to zero.
   noise = ps * 1.2e-7 * torch.clamp(e.max(), min=0.0)
   e = torch.where(e <= noise, torch.zeros_like(e), e)
-  order = torch.arange(ps - 1, -1, -1, device=dev)  # descending singular values
-  s = torch.sqrt(torch.clamp(e[order], min=0.0))
-  u = u[:, order]
+  s = torch.sqrt(torch.clamp(e, min=0.0))
   # the padded problem has max_size singular values: pad with zeros
-  s_full = torch.zeros((max_size,), dtype=torch.float32, device=dev)
-  s_full[:ps] = s
+  s_full = torch.zeros((max(max_size, rank + 1),), dtype=torch.float32, device=dev)
+  m = min(int(s.shape[0]), rank + 1)
+  s_full[:m] = s[:m]
   cutoff = s_full[rank]
   rho_t = cutoff ** 2
   top_eigs = s_full[:rank]
   deflated = (top_eigs - cutoff) * (top_eigs + cutoff)
   eigvecs = torch.zeros((max_size, rank), dtype=torch.float32, device=dev)
-  k = min(rank, ps)
+  k = min(rank, ps, int(u.shape[1]))
   eigvecs[:ps, :k] = u[:, :k]
   tail = tail * decay
   new_tail = tail + rho_t

@@ -1,0 +1,151 @@
+"""Leading eigenpairs of symmetric PSD matrices by Chebyshev-filtered subspace iteration.
+
+Used by the Frequent-Directions branch (config 5, DS:1123-1290), which needs only the
+top rank+1 singular values / rank singular vectors of the d x d covariance update but
+gets them in the reference from a full SVD of a d x (rank+d) factor (DS:1193).  Here the
+heavy work is d x d @ d x b products (b = k + oversampling columns) on the fp32 MFMA GEMM
+(`ps_gemm_grouped_f32`, all matrices of a call in one launch), the small b x b Gram /
+Rayleigh-Ritz problems go to the batched Jacobi eigensolver (`ps_eigh_batched_f32`), and
+the O(d b) recurrences are elementwise torch ops on stacked tensors.
+
+Algorithm (Zhou & Saad's scaled Chebyshev filter inside subspace iteration):
+  X <- orth(random d x b);  Rayleigh-Ritz -> theta_1 >= ... >= theta_b, X <- Ritz vectors
+  repeat: X <- p(C) X with p the degree-m Chebyshev polynomial that damps [0, theta_b]
+          and is scaled to 1 at theta_1;  X <- orth(X) (eigen-based Cholesky-free QR of the
+          Gram matrix + one Newton-Schulz polish);  Rayleigh-Ritz;  stop when the residuals
+          ||C x_i - theta_i x_i|| of the k wanted pairs are below tol * theta_1.
+The caller falls back to the full eigendecomposition if this does not converge.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+
+
+def _K():
+  from . import kernels
+  return kernels
+
+
+def _gemm(items):
+  _K().gemm_grouped(items)
+
+
+def _small_eigh_desc(mats: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+  """Batched eigh of [B, b, b] symmetric matrices, eigenvalues DESCENDING."""
+  sym = 0.5 * (mats + mats.transpose(1, 2))
+  es, us = _K().eigh_batched(list(sym.unbind(0)))
+  e = torch.stack(es, 0).flip(1)
+  u = torch.stack(us, 0).flip(2)
+  return e, u
+
+
+def _orthonormalize(x: torch.Tensor, tmp: torch.Tensor) -> torch.Tensor:
+  """Columns of every x[j] ([B, n, b]) made orthonormal: x <- x U L^{-1/2} from the
+  eigendecomposition of the Gram matrix, then one Newton-Schulz step
+  x <- x (1.5 I - 0.5 x^T x).  Directions below 1e-10 of the largest Gram eigenvalue
+  (a rank-deficient C) are dropped (zero columns, Ritz value 0)."""
+  bsz, n, b = x.shape
+  gram = torch.empty((bsz, b, b), dtype=torch.float32, device=x.device)
+  _gemm([(x[j], x[j], gram[j], True, False) for j in range(bsz)])
+  lam, u = _small_eigh_desc(gram)
+  keep = lam > 1e-10 * lam[:, :1].clamp_min(1e-30)
+  scale = torch.where(keep, lam.clamp_min(1e-30).rsqrt(), torch.zeros_like(lam))
+  m = u * scale[:, None, :]
+  _gemm([(x[j], m[j], tmp[j], False, False) for j in range(bsz)])
+  _gemm([(tmp[j], tmp[j], gram[j], True, False) for j in range(bsz)])
+  eye = torch.eye(b, dtype=torch.float32, device=x.device)
+  # dropped directions have a zero row/column in the Gram matrix: 1.5 I there is harmless
+  polish = 1.5 * eye - 0.5 * gram
+  _gemm([(tmp[j], polish[j], x[j], False, False) for j in range(bsz)])
+  return x
+
+
+def _rayleigh_ritz(c: Sequence[torch.Tensor], x: torch.Tensor, z: torch.Tensor,
+                   tmp: torch.Tensor):
+  """x orthonormal [B, n, b].  Returns (theta desc [B, b], residual norms [B, b]); x holds
+  the Ritz vectors and z = C x afterwards."""
+  bsz, n, b = x.shape
+  _gemm([(c[j], x[j], z[j], False, False) for j in range(bsz)])
+  t = torch.empty((bsz, b, b), dtype=torch.float32, device=x.device)
+  _gemm([(x[j], z[j], t[j], True, False) for j in range(bsz)])
+  theta, y = _small_eigh_desc(t)
+  _gemm([(x[j], y[j], tmp[j], False, False) for j in range(bsz)])
+  x.copy_(tmp)
+  _gemm([(z[j], y[j], tmp[j], False, False) for j in range(bsz)])
+  z.copy_(tmp)
+  res = torch.linalg.vector_norm(z - x * theta[:, None, :], dim=1)
+  return theta, res
+
+
+def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e-5,
+                           degree: int = 12, max_outer: int = 14, oversample: int = 31,
+                           seed: int = 1729):
+  """Leading k eigenpairs of each symmetric PSD matrix in `mats` (all n x n with the same
+  n, float32, on the GPU).  Returns (evals [B, k] descending, evecs [B, n, k], converged
+  [B] bool, info dict).  Deterministic (fixed-seed start block)."""
+  bsz = len(mats)
+  n = int(mats[0].shape[0])
+  dev = mats[0].device
+  b = min(n, ((k + oversample + 31) // 32) * 32)
+  c = [m if m.is_contiguous() else m.contiguous() for m in mats]
+  gen = torch.Generator(device=dev).manual_seed(seed)
+  x = torch.randn((bsz, n, b), generator=gen, device=dev, dtype=torch.float32)
+  z = torch.empty_like(x)
+  tmp = torch.empty_like(x)
+  x = _orthonormalize(x, tmp)
+  theta, res = _rayleigh_ritz(c, x, z, tmp)
+  gemms = 1
+  converged = torch.zeros((bsz,), dtype=torch.bool, device=dev)
+  outer = 0
+  for outer in range(1, max_outer + 1):
+    top = theta[:, :1].clamp_min(1e-30)
+    # pairs inside the float32 noise floor of the solver count as converged zeros
+    wanted = theta[:, :k] > n * 2.4e-7 * top
+    converged = ((res[:, :k] <= tol * top) | ~wanted).all(dim=1)
+    if bool(converged.all()):
+      break
+    # Chebyshev filter: damp [0, theta_b], scaled to 1 at theta_1
+    cut = theta[:, -1:].clamp_min(0.0)
+    e = (0.5 * cut).clamp_min(1e-30 * top)[:, :, None]
+    ctr = (0.5 * cut)[:, :, None]
+    a0 = (top * (1.0 + 1e-6))[:, :, None]
+    sigma1 = e / (a0 - ctr)
+    sigma = sigma1
+    # Per-matrix degree: the filter may amplify theta_1 over theta_k by at most ~1e2,
+    # else the block collapses onto the leading directions in float32 (its Gram matrix
+    # is then conditioned 1e4, which the eigen-QR + polish below still resolves).
+    # T_m(x) ~ exp(m acosh x) / 2 with x = (theta - ctr) / e.
+    def _acosh(v):
+      v = v.clamp(1.0, 1e30)  # log v + log(1 + sqrt(1 - v^-2)): no overflow for huge v
+      return torch.log(v) + torch.log1p(torch.sqrt((1.0 - 1.0 / (v * v)).clamp_min(0.0)))
+
+    xk = theta[:, k - 1:k].clamp_min(1e-30 * top)
+    spread = (_acosh((top - ctr[:, :, 0]) / e[:, :, 0]) -
+              _acosh((xk - ctr[:, :, 0]) / e[:, :, 0])).clamp_min(1e-6)
+    deg = torch.clamp(torch.floor(4.6 / spread), 1, degree)[:, :, None]   # [B, 1, 1]
+    max_deg = int(deg.max())
+    # z = C x is current from the Rayleigh-Ritz step
+    y_prev = x.clone()
+    y = (z - ctr * x) * (sigma1 / e)
+    for step in range(2, max_deg + 1):
+      _gemm([(c[j], y[j], z[j], False, False) for j in range(bsz)])
+      gemms += 1
+      sigma_new = 1.0 / (2.0 / sigma1 - sigma)
+      y_next = (z - ctr * y) * (2.0 * sigma_new / e) - (sigma * sigma_new) * y_prev
+      active = deg >= step
+      y_prev = torch.where(active, y, y_prev)
+      y = torch.where(active, y_next, y)
+      sigma = torch.where(active, sigma_new, sigma)
+    x.copy_(y)
+    x = _orthonormalize(x, tmp)
+    theta, res = _rayleigh_ritz(c, x, z, tmp)
+    gemms += 1
+  else:
+    top = theta[:, :1].clamp_min(1e-30)
+    wanted = theta[:, :k] > n * 2.4e-7 * top
+    converged = ((res[:, :k] <= tol * top) | ~wanted).all(dim=1)
+  info = {"outer_iterations": outer, "big_gemms": gemms, "block": b,
+          "max_residual_rel": float((res[:, :k] / theta[:, :1].clamp_min(1e-30)).max())}
+  return theta[:, :k].contiguous(), x[:, :, :k].contiguous(), converged, info

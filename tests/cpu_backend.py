@@ -79,6 +79,10 @@ def fd_update_root(new_grad, p, rank=0, ridge_epsilon=1e-6, error_tolerance=1e-6
   return torch.from_numpy(val), _TM(0.0)
 
 
+def fd_update_root_batched(calls):
+  return [fd_update_root(**kw) for kw in calls]
+
+
 def gemm_grouped(items):
   for a, b, c, ta, tb in items:
     c.copy_(matmul(a, b, transa=ta, transb=tb))

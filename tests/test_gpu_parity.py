@@ -648,3 +648,78 @@ def test_e2e_quantized_state_hip_vs_reference_golden(case, device):
   assert worst < 6e-3, worst
   check_final_state(case, z, st)
   check_momentum(case, z, st)
+
+
+# ---------------------------------------------------------------------------
+# leading eigenpairs by Chebyshev-filtered subspace iteration (config 5 at full size)
+# ---------------------------------------------------------------------------
+def _spectrum_matrix(n, vals, seed, device):
+  rng = np.random.default_rng(seed)
+  q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  return torch.tensor(((q * vals) @ q.T).astype(np.float32), device=device)
+
+
+def test_top_eigenpairs_subspace_vs_fp64(device):
+  """Residuals, orthonormality and eigenvalues against numpy float64 for gapped,
+  geometrically decaying, flat (Wishart) and rank-deficient spectra; two sizes batched."""
+  from precondition_amd import subspace
+  n = 1024
+  cases = [
+      ("gapped", [_spectrum_matrix(n, np.concatenate([np.linspace(100, 20, 20),
+                                                       np.linspace(5, 0.1, n - 20)]), s, device)
+                  for s in (1, 2)], 17),
+      ("decay", [_spectrum_matrix(n, 1000.0 * 0.97 ** np.arange(n), 3, device)], 33),
+      ("wishart", [torch.tensor(wishart(n, 2 * n, 4), device=device)], 24),
+  ]
+  g = torch.tensor(np.random.default_rng(5).standard_normal((n, 30)).astype(np.float32), device=device)
+  cases.append(("rank30", [g @ g.T], 40))
+  for name, mats, k in cases:
+    e, v, conv, info = subspace.top_eigenpairs_batched(mats, k)
+    assert bool(conv.all()), (name, info)
+    for j, m in enumerate(mats):
+      a = m.double().cpu().numpy()
+      w = np.linalg.eigvalsh(a)[::-1][:k]
+      ee, vv = e[j].double().cpu().numpy(), v[j].double().cpu().numpy()
+      assert np.abs(ee - w).max() <= 2e-5 * w[0], (name, np.abs(ee - w).max() / w[0])
+      live = w > 1e-4 * w[0]
+      res = np.linalg.norm(a @ vv - vv * ee, axis=0) / w[0]
+      assert res[live].max() < 5e-5, (name, res.max())
+      gram = vv[:, live].T @ vv[:, live]
+      assert np.abs(gram - np.eye(live.sum())).max() < 1e-4, name
+
+
+def test_fd_update_root_subspace_path_matches_full_eigh(device, monkeypatch):
+  """At d >= 1024 _fd_update_root takes the leading rank+1 eigenpairs from the block
+  method; the packed sketch must agree with the full-eigendecomposition path over a
+  chain of updates (clear spectral gaps, so the top-rank subspace is well defined)."""
+  from precondition_amd import low_rank
+  d, rank, p = 1024, 8, 4
+  rng = np.random.default_rng(12)
+  grads = []
+  for t in range(3):
+    g = rng.standard_normal((d, 2 * d)).astype(np.float32) * (1.0 + 0.3 * t)
+    g[:rank + 2] *= np.linspace(9.0, 3.0, rank + 2)[:, None].astype(np.float32)
+    grads.append(torch.tensor(g, device=device))
+
+  def chain():
+    prev = torch.zeros((d, rank + 2), device=device)
+    outs = []
+    for g in grads:
+      gram = low_rank.gram_of_block(g, 0)
+      prev, _ = low_rank._fd_update_root(gram, p, rank=rank, ridge_epsilon=1e-6, decay=0.9,
+                                         padding_start=d, prev=prev, new_grad_is_gram=True)
+      outs.append(prev.cpu().numpy())
+    return outs
+
+  calls = []
+  from precondition_amd import subspace
+  real = subspace.top_eigenpairs_batched
+  monkeypatch.setattr(subspace, "top_eigenpairs_batched",
+                      lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+  fast = chain()
+  assert len(calls) == 3  # the block method ran
+  monkeypatch.setattr(low_rank, "SUBSPACE_MIN_N", 10 ** 9)
+  full = chain()
+  assert len(calls) == 3
+  for a, b in zip(fast, full):
+    assert packed_matches(a, b, rank, tol=1e-3)
