@@ -160,6 +160,19 @@ int ps_newton_root_batched_f32(void* stream, const float* const* a,
                                float* metrics, void* workspace,
                                size_t workspace_bytes, int32_t* iters_executed_host);
 
+/* Same with the largest eigenvalue GIVEN (device array max_ev[batch]) instead of the
+ * power iteration: the lobpcg_topk_precondition branch of matrix_inverse_pth_root already
+ * has it from the top-k eigenpairs (DS:813-817) and roots the DEFLATED matrix (DS:804-812).
+ * Always the relative-epsilon form: ridge = ridge_epsilon * max(max_ev[b], 1e-25). */
+int ps_newton_root_batched_maxev_f32(void* stream, const float* const* a,
+                                     const int32_t* n, const int32_t* lda,
+                                     const int32_t* p, const int32_t* padding_start,
+                                     int batch, int num_iters, float ridge_epsilon,
+                                     float error_tolerance, const float* max_ev,
+                                     float* const* out, const int32_t* ldo,
+                                     float* metrics, void* workspace,
+                                     size_t workspace_bytes, int32_t* iters_executed_host);
+
 /* ---- batched inverse p-th root by symmetric eigendecomposition (DS:943-1030) - */
 size_t ps_eigh_root_workspace_bytes(int batch, const int32_t* n);
 int ps_eigh_root_batched_f32(void* stream, const float* const* a, const int32_t* n,

@@ -103,6 +103,11 @@ _SIGNATURES = {
                    C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                    C.c_void_p]),
+    "ps_newton_root_batched_maxev_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                   C.c_void_p]),
     "ps_eigh_root_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p]),
     "ps_eigh_root_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

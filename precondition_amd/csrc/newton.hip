@@ -299,13 +299,17 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
 
 // After the power iteration: ridge = ridge_epsilon * max(max_ev, 1e-25) (DS:830).
 __global__ void newton_setup_kernel(NewtonBlock* blocks, const PiBlock* pis,
-                                    int nblocks, float ridge_epsilon, int relative) {
+                                    int nblocks, float ridge_epsilon, int relative,
+                                    const float* max_ev_given) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblocks) return;
   NewtonBlock* nb = &blocks[b];
   float max_ev = 1.f;
   int pit = 0;
-  if (relative) { max_ev = pis[b].lambda; pit = pis[b].iters; }
+  if (relative) {
+    if (max_ev_given) max_ev = max_ev_given[b];  // DS:815-817: lobpcg already has it
+    else { max_ev = pis[b].lambda; pit = pis[b].iters; }
+  }
   nb->max_ev = max_ev;
   nb->power_iters = pit;
   nb->ridge = __fmul_rn(ridge_epsilon, fmaxf(max_ev, 1e-25f));
@@ -579,12 +583,12 @@ extern "C" size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
   return carve(pl, ar, nullptr) + 256;
 }
 
-extern "C" int ps_newton_root_batched_f32(
+static int newton_driver(
     void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
     const int32_t* p, const int32_t* padding_start, int batch, int num_iters,
     float ridge_epsilon, float error_tolerance, int relative_matrix_epsilon,
-    float* const* out, const int32_t* ldo, float* metrics, void* workspace,
-    size_t workspace_bytes, int32_t* iters_executed_host) {
+    const float* max_ev_given, float* const* out, const int32_t* ldo, float* metrics,
+    void* workspace, size_t workspace_bytes, int32_t* iters_executed_host) {
   if (batch <= 0 || !a || !n || !lda || !p || !out || !ldo || !metrics || !workspace ||
       num_iters < 1)
     return PS_EINVAL;
@@ -648,14 +652,14 @@ extern "C" int ps_newton_root_batched_f32(
   ProfRun prof(st);
   // ---- power iteration -> ridge epsilon --------------------------------------
   prof.begin(1);
-  if (relative_matrix_epsilon) {
+  if (relative_matrix_epsilon && !max_ev_given) {
     int rc = pl.pip.enqueue(st, 100, 1e-6f);  // DS:820-825
     if (rc) return rc;
   }
   prof.end();
   hipLaunchKernelGGL(newton_setup_kernel, dim3((batch + 255) / 256), dim3(256), 0, st,
                      lo.blocks, pl.pip.d_blocks, batch, ridge_epsilon,
-                     relative_matrix_epsilon);
+                     relative_matrix_epsilon, max_ev_given);
   PS_LAUNCH_CHECK();
 
   // ---- Newton loop -------------------------------------------------------------
@@ -798,4 +802,27 @@ extern "C" int ps_power_iteration_batched_f32(
                      out_lambda, (int*)out_iters, out_v, (int)ldv);
   PS_LAUNCH_CHECK();
   return PS_OK;
+}
+
+extern "C" int ps_newton_root_batched_f32(
+    void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
+    const int32_t* p, const int32_t* padding_start, int batch, int num_iters,
+    float ridge_epsilon, float error_tolerance, int relative_matrix_epsilon,
+    float* const* out, const int32_t* ldo, float* metrics, void* workspace,
+    size_t workspace_bytes, int32_t* iters_executed_host) {
+  return newton_driver(stream, a, n, lda, p, padding_start, batch, num_iters, ridge_epsilon,
+                       error_tolerance, relative_matrix_epsilon, nullptr, out, ldo, metrics,
+                       workspace, workspace_bytes, iters_executed_host);
+}
+
+extern "C" int ps_newton_root_batched_maxev_f32(
+    void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
+    const int32_t* p, const int32_t* padding_start, int batch, int num_iters,
+    float ridge_epsilon, float error_tolerance, const float* max_ev, float* const* out,
+    const int32_t* ldo, float* metrics, void* workspace, size_t workspace_bytes,
+    int32_t* iters_executed_host) {
+  if (!max_ev) return PS_EINVAL;
+  return newton_driver(stream, a, n, lda, p, padding_start, batch, num_iters, ridge_epsilon,
+                       error_tolerance, 1, max_ev, out, ldo, metrics, workspace,
+                       workspace_bytes, iters_executed_host);
 }

@@ -128,7 +128,6 @@ def distributed_shampoo(
   """Returns GradientTransformation(init_fn, update_fn); see module docstring."""
   del precision, tensordot_precision  # always exact-f32 MFMA
   del statistics_partition_spec, preconditioner_partition_spec, num_devices_for_pjit
-  del lobpcg_max_iter
 
   # ---- construction-time validation: same conditions and messages as DS:2019-2040
   if reset_preconditioner and not frequent_directions:
@@ -148,8 +147,8 @@ def distributed_shampoo(
   # ---- scope of this build
   if shard_optimizer_states:
     raise NotImplementedError("shard_optimizer_states (pjit mode) is out of scope")
-  if lobpcg_topk_precondition:
-    raise NotImplementedError("LOBPCG deflation is out of scope")
+  if lobpcg_topk_precondition and (eigh or compression_rank != 0):
+    raise NotImplementedError("lobpcg_topk_precondition is built for the dense Newton branch")
   if generate_fd_metrics:
     raise NotImplementedError("FDDiagnostics (generate_fd_metrics) are not built")
   reset_frequency = None
@@ -496,6 +495,31 @@ def distributed_shampoo(
             rows[k, 0] = tm.inverse_pth_root_errors
         return rows
 
+    root_fn = backend.matrix_inverse_pth_root_batched
+    if lobpcg_topk_precondition:
+      # top-k deflated roots (DS:787-812, 889-928); blocks not larger than k (possible
+      # here because nothing is padded to max_size) take the plain iteration
+      def root_fn(mats, exps_, pads_, ridge_epsilon=1e-6, relative_matrix_epsilon=True,
+                  eigh=False, out=None, **_):
+        big = [j for j, n_ in enumerate(pads_) if n_ > lobpcg_topk_precondition + 1]
+        small = [j for j in range(len(mats)) if j not in big]
+        rows = torch.zeros((len(mats), comm.METRICS_STRIDE), dtype=torch.float32,
+                           device=mats[0].device)
+        if big:
+          _, m_big, _ = backend.matrix_inverse_pth_root_deflated_batched(
+              [mats[j] for j in big], [exps_[j] for j in big], [pads_[j] for j in big],
+              topk=lobpcg_topk_precondition, max_iter=lobpcg_max_iter,
+              ridge_epsilon=ridge_epsilon, relative_matrix_epsilon=relative_matrix_epsilon,
+              out=[out[j] for j in big])
+          rows[big] = m_big
+        if small:
+          _, m_small = backend.matrix_inverse_pth_root_batched(
+              [mats[j] for j in small], [exps_[j] for j in small], [pads_[j] for j in small],
+              ridge_epsilon=ridge_epsilon, relative_matrix_epsilon=relative_matrix_epsilon,
+              out=[out[j] for j in small])
+          rows[small] = m_small
+        return out, rows
+
     payload_elems = None
     if quantize_second_moment:
       # DS:3102-3127: the owner quantizes its roots and the all-gather carries int16 codes
@@ -515,7 +539,7 @@ def distributed_shampoo(
       def compute_fn(indices, outs):  # _quantized_matrix_inverse_pth_root_vmap, DS:2746-2773
         tmp = [torch.empty((sizes[i], sizes[i]), dtype=torch.float32,
                            device=statistics[0].device) for i in indices]
-        _, m = backend.matrix_inverse_pth_root_batched(
+        _, m = root_fn(
             [statistics[i] for i in indices], [exponents[i] for i in indices],
             [sizes[i] for i in indices], ridge_epsilon=matrix_epsilon,
             relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh, out=tmp)
@@ -526,8 +550,7 @@ def distributed_shampoo(
     roots, metrics = comm.sharded_inverse_pth_roots(
         statistics, exponents, group=group, ridge_epsilon=matrix_epsilon,
         relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
-        ownership=block_ownership,
-        root_fn=backend.matrix_inverse_pth_root_batched, out_cols=out_cols,
+        ownership=block_ownership, root_fn=root_fn, out_cols=out_cols,
         compute_fn=compute_fn, payload_elems=payload_elems, sizes=sizes)
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
     if quantize_second_moment:

@@ -65,11 +65,14 @@ def matrix_inverse_pth_root_batched(
     relative_matrix_epsilon: bool = True,
     eigh: bool = False,
     out: Optional[Sequence[torch.Tensor]] = None,
+    max_ev: Optional[torch.Tensor] = None,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """vmap(matrix_inverse_pth_root) over independent blocks (DS:2742-2744).
 
   Returns (roots, metrics[batch, 8]); metrics columns are the PS_M_* indices
   (0..4 = TrainingMetrics fields of DS:902-907).  Blocks may differ in size.
+  `max_ev` (float32 device tensor [batch]): the largest eigenvalue is given instead of
+  being found by the power iteration (the lobpcg branch, DS:813-817).
   """
   batch = len(matrices)
   if batch == 0:
@@ -108,13 +111,27 @@ def matrix_inverse_pth_root_batched(
       raise _lib.PsError("ps_newton_root_workspace_bytes: unsupported exponent")
     ws = _workspace(nbytes, dev)
     iters = C.c_int32(0)
-    rc = L.ps_newton_root_batched_f32(
-        _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
-        p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
-        error_tolerance, int(relative_matrix_epsilon), o_ptrs.ctypes.data,
-        ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
-        C.addressof(iters))
-    check(rc, "ps_newton_root_batched_f32")
+    if max_ev is not None:
+      if not relative_matrix_epsilon:
+        raise ValueError("max_ev only applies to the relative-epsilon form")
+      mev = max_ev.to(torch.float32).contiguous()
+      if not mev.is_cuda or mev.numel() != batch:
+        raise ValueError("max_ev must be a device tensor with one value per block")
+      rc = L.ps_newton_root_batched_maxev_f32(
+          _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
+          p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
+          error_tolerance, mev.data_ptr(), o_ptrs.ctypes.data,
+          ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
+          C.addressof(iters))
+      check(rc, "ps_newton_root_batched_maxev_f32")
+    else:
+      rc = L.ps_newton_root_batched_f32(
+          _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
+          p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
+          error_tolerance, int(relative_matrix_epsilon), o_ptrs.ctypes.data,
+          ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
+          C.addressof(iters))
+      check(rc, "ps_newton_root_batched_f32")
   ws.record_stream(torch.cuda.current_stream())
   return list(out), metrics
 
@@ -130,9 +147,20 @@ def matrix_inverse_pth_root(matrix: torch.Tensor, p: int, num_iters: int = 100,
   """Single-matrix form with the reference's signature (DS:702-715).  Returns
   (root, TrainingMetrics)."""
   from .state import TrainingMetrics
-  del precision, prev, lobpcg_max_iter
+  del precision, prev
   if lobpcg_topk_precondition:
-    raise NotImplementedError("LOBPCG deflation is out of scope")
+    if eigh:
+      raise ValueError("lobpcg_topk_precondition applies to the Newton branch")
+    from . import deflation
+    roots, m, diags = deflation.matrix_inverse_pth_root_deflated_batched(
+        [matrix], [p], None if padding_start is None else [padding_start],
+        topk=lobpcg_topk_precondition, max_iter=lobpcg_max_iter, num_iters=num_iters,
+        ridge_epsilon=ridge_epsilon, error_tolerance=error_tolerance,
+        relative_matrix_epsilon=relative_matrix_epsilon)
+    return roots[0], TrainingMetrics(
+        inverse_pth_root_errors=m[0, 0], inverse_pth_root_iters=m[0, 1],
+        final_error_ratio=m[0, 2], max_eigen_value=m[0, 3], total_retries=m[0, 4],
+        **diags[0])
   roots, m = matrix_inverse_pth_root_batched(
       [matrix], [p], None if padding_start is None else [padding_start],
       num_iters=num_iters, ridge_epsilon=ridge_epsilon,
@@ -141,6 +169,12 @@ def matrix_inverse_pth_root(matrix: torch.Tensor, p: int, num_iters: int = 100,
   return roots[0], TrainingMetrics(
       inverse_pth_root_errors=m[0, 0], inverse_pth_root_iters=m[0, 1],
       final_error_ratio=m[0, 2], max_eigen_value=m[0, 3], total_retries=m[0, 4])
+
+
+def matrix_inverse_pth_root_deflated_batched(*args, **kwargs):
+  """The lobpcg_topk_precondition branch (DS:787-812, 889-928), see deflation.py."""
+  from . import deflation
+  return deflation.matrix_inverse_pth_root_deflated_batched(*args, **kwargs)
 
 
 def eigh_batched(matrices: Sequence[torch.Tensor]):

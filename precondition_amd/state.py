@@ -47,7 +47,7 @@ def _zero():
 
 @dataclasses.dataclass(frozen=True)
 class LOBPCGDiagnostics:
-  """Present for state-layout parity only; LOBPCG is out of scope (DS:149-194)."""
+  """DS:149-194; filled by the top-k deflated root (deflation.py)."""
   lobpcg_iters: Any = dataclasses.field(default_factory=_zero)
   max_consistency_error: Any = dataclasses.field(default_factory=_zero)
   avg_consistency_error: Any = dataclasses.field(default_factory=_zero)
@@ -62,7 +62,7 @@ class LOBPCGDiagnostics:
 
 @dataclasses.dataclass(frozen=True)
 class InversePthRootDiagnostics:
-  """Layout parity only (DS:109-146); populated by the reference only with LOBPCG."""
+  """DS:109-146; the reference (and this build) fill it only in the deflated branch."""
   max_diag_error: Any = dataclasses.field(default_factory=_zero)
   avg_diag_error: Any = dataclasses.field(default_factory=_zero)
   max_off_diag_error: Any = dataclasses.field(default_factory=_zero)

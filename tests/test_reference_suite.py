@@ -210,3 +210,125 @@ def test_public_names_of_the_path():
                "_pth_root_difference", "GraftingType", "PreconditionerType", "QuantizedValue",
                "ShampooState", "ParameterStats", "TrainingMetrics"):
     assert getattr(pa, name) is not None, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [2, 4, 8])
+def test_lobpcg_preconditioning(p):
+  """DST:431-479: the root with top-k deflation is as valid as the plain one (median
+  spectrum error and mean entrywise error of inv(root)^p-recovered identity within 2x)."""
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  dev = torch.device("cuda:0")
+  rng = np.random.RandomState(seed=42)
+  n = 11
+  epsilon = 1e-4
+  a_asymm = rng.random((n, n)).astype(np.float32)
+  a_np = (a_asymm.T.astype(np.float64) @ a_asymm.astype(np.float64)).astype(np.float32)
+  a = torch.tensor(a_np, device=dev)
+  log2 = (p - 1).bit_length()
+  assert 2 ** log2 == p
+  methods = {
+      "default": lambda: pa.matrix_inverse_pth_root(a, p, ridge_epsilon=epsilon),
+      "precond": lambda: pa.matrix_inverse_pth_root(a, p, ridge_epsilon=epsilon,
+                                                    lobpcg_topk_precondition=2,
+                                                    lobpcg_max_iter=10),
+  }
+  spectrum_err, entry_err = {}, {}
+  for name, method in methods.items():
+    rt, tm = method()
+    inv = rt.cpu().numpy().astype(np.float64)
+    for _ in range(log2):
+      inv = inv.dot(inv)
+    approx_id = inv.dot(a_np.astype(np.float64))
+    spectrum = np.linalg.eigvalsh(approx_id)
+    spectrum_err[name] = np.abs(1 - spectrum)
+    entry_err[name] = np.mean(np.abs(approx_id - np.eye(n)))
+    if name == "precond":
+      lob = tm.lobpcg_diagnostics
+      assert float(lob.num_topk_eigenvectors) == 2.0
+      w = np.linalg.eigvalsh(a_np.astype(np.float64))
+      assert abs(float(lob.max_eigenvalue) - w[-1]) < 1e-4 * w[-1]
+      assert abs(float(lob.min_eigenvalue) - w[-2]) < 1e-4 * w[-1]
+      assert float(lob.max_consistency_error) < 1e-4
+      assert abs(float(tm.max_eigen_value) - w[-1]) < 1e-4 * w[-1]
+  assert np.median(spectrum_err["precond"]) <= 2 * np.median(spectrum_err["default"])
+  assert entry_err["precond"] <= entry_err["default"] * 2
+
+
+@pytest.mark.gpu
+def test_deflated_root_batched_vs_fp64():
+  """Blocks with a few dominant directions (the case deflation is for), two sizes and a
+  padded block in one call: roots against the float64 closed form, fewer Newton steps
+  than the plain path, metrics of the unconditioned problem."""
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  from precondition_amd import deflation, kernels as K
+  dev = torch.device("cuda:0")
+  rng = np.random.default_rng(3)
+
+  def mat(n, tops):
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    vals = np.concatenate([tops, np.linspace(1.0, 0.05, n - len(tops))])
+    return ((q * vals) @ q.T).astype(np.float32), vals
+
+  mats, p = [], 4
+  for n, tops in ((256, [900.0, 400.0, 150.0]), (256, [5000.0, 60.0, 30.0]), (384, [300.0, 200.0, 100.0])):
+    mats.append(mat(n, np.array(tops))[0])
+  padded = np.zeros((300, 300), np.float32)
+  padded[:256, :256] = mats[0]
+  inputs = [torch.tensor(m, device=dev) for m in mats] + [torch.tensor(padded, device=dev)]
+  pads = [256, 256, 384, 256]
+  roots, m, diags = deflation.matrix_inverse_pth_root_deflated_batched(
+      inputs, [p] * 4, pads, topk=3, ridge_epsilon=1e-6)
+  plain_roots, pm = K.matrix_inverse_pth_root_batched(inputs, [p] * 4, pads, ridge_epsilon=1e-6)
+  m, pm = m.cpu().numpy(), pm.cpu().numpy()
+  for b, a in enumerate(mats + [mats[0]]):
+    n = pads[b]
+    w, v = np.linalg.eigh(a.astype(np.float64))
+    ridge = 1e-6 * w.max()
+    want = (v * (w + ridge) ** (-1.0 / p)) @ v.T
+    got = roots[b].cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(got[:n, :n] - want) <= 2e-4 * np.linalg.norm(want), b
+    if got.shape[0] > n:
+      assert np.all(got[n:] == 0) and np.all(got[:, n:] == 0)
+    assert abs(m[b, 3] - w.max()) < 1e-4 * w.max()          # max_ev from the eigenpairs
+    # unconditioned error metric max|H^p (A + eps I) - I| (DS:909-922): float32 roundoff
+    # times the condition number (1e5 here), below the failure threshold 0.1
+    assert m[b, 0] < 0.1
+    assert m[b, 1] < pm[b, 1]                                  # deflation saves Newton steps
+    assert float(diags[b]["lobpcg_diagnostics"].num_topk_eigenvectors) == 3.0
+    assert float(diags[b]["inverse_pth_root_diagnostics"].p) == p
+
+
+@pytest.mark.gpu
+def test_optimizer_with_topk_deflation_tracks_plain_optimizer():
+  """lobpcg_topk_precondition in the optimizer (dense Newton branch): the deflated roots
+  are the same roots, so the trajectory stays with the plain optimizer's."""
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  dev = torch.device("cuda:0")
+  rng = np.random.default_rng(17)
+  params = tuple(torch.tensor(rng.standard_normal(s).astype(np.float32), device=dev)
+                 for s in ([96, 64], [40], [8, 12, 10]))
+  grads = [tuple(torch.tensor(rng.standard_normal(p.shape).astype(np.float32), device=dev)
+                 for p in params) for _ in range(5)]
+
+  def run(**kw):
+    opt = pa.distributed_shampoo(0.1, 64, preconditioning_compute_steps=2,
+                                 start_preconditioning_step=2, matrix_epsilon=1e-4, **kw)
+    st = opt.init(params)
+    outs = []
+    for g in grads:
+      upd, st = opt.update(g, st, params)
+      outs.append([u.cpu().numpy() for u in upd])
+    return outs, st
+
+  plain, _ = run()
+  defl, st = run(lobpcg_topk_precondition=3)
+  for a, b in zip(plain, defl):
+    for x, y in zip(a, b):
+      assert np.isfinite(y).all()
+      assert np.linalg.norm(x - y) <= 2e-2 * np.linalg.norm(x)
+  tm = st.stats[0].training_metrics
+  assert float(tm.inverse_pth_root_errors.max()) < 0.1
