@@ -448,8 +448,6 @@ def main():
                               "power_iteration": round(pi_ms, 3),
                               "init_control_copyout": round(other_ms, 3)},
     }
-  elif multi:
-    pass
   if multi:
     import torch.distributed as dist
     dist.barrier()
