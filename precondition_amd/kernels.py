@@ -41,6 +41,9 @@ def _ptrs(ts: Sequence[torch.Tensor]) -> np.ndarray:
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
+  """Scratch for one library call.  Allocated on the current stream, which is also the
+  stream the call is enqueued on (_stream()), so the caching allocator's stream-ordered
+  reuse is already safe once the tensor is dropped: no record_stream needed."""
   return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
@@ -132,7 +135,6 @@ def matrix_inverse_pth_root_batched(
           ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
           C.addressof(iters))
       check(rc, "ps_newton_root_batched_f32")
-  ws.record_stream(torch.cuda.current_stream())
   return list(out), metrics
 
 
@@ -199,7 +201,6 @@ def eigh_batched(matrices: Sequence[torch.Tensor]):
                              v_ptrs.ctypes.data, ldv.ctypes.data, ws.data_ptr(),
                              ws.numel())
   check(rc, "ps_eigh_batched_f32")
-  ws.record_stream(torch.cuda.current_stream())
   out_e, out_v = [], []
   for e, v in zip(evals, evecs):
     order = torch.argsort(e)  # pure permutation (data movement, no arithmetic)
@@ -228,7 +229,6 @@ def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
       None if pad is None else pad.ctypes.data, 1, num_iters, error_tolerance,
       lam.data_ptr(), its.data_ptr(), v.data_ptr(), n, ws.data_ptr(), ws.numel())
   check(rc, "ps_power_iteration_batched_f32")
-  ws.record_stream(torch.cuda.current_stream())
   return v[0], lam[0]
 
 
@@ -253,7 +253,6 @@ def power_iteration_batched(matrices: Sequence[torch.Tensor], num_iters=100,
       error_tolerance, lam.data_ptr(), its.data_ptr(), None, 0, ws.data_ptr(),
       ws.numel())
   check(rc, "ps_power_iteration_batched_f32")
-  ws.record_stream(torch.cuda.current_stream())
   return lam, its
 
 
@@ -267,7 +266,6 @@ def mat_power(mat_m: torch.Tensor, p: int) -> torch.Tensor:
   rc = L.ps_mat_power_f32(_stream(), mat_m.data_ptr(), n, _as_2d_ld(mat_m),
                           int(p), out.data_ptr(), n, ws.data_ptr(), ws.numel())
   check(rc, "ps_mat_power_f32")
-  ws.record_stream(torch.cuda.current_stream())
   return out
 
 
@@ -294,30 +292,60 @@ def matmul(a: torch.Tensor, b: torch.Tensor, transa: bool = False,
   return c[0] if squeeze else c
 
 
+_GDESC_DT = np.dtype([("a", "u8"), ("b", "u8"), ("c", "u8"), ("m", "i4"), ("n", "i4"),
+                      ("k", "i4"), ("transa", "i4"), ("transb", "i4"), ("lda", "i8"),
+                      ("ldb", "i8"), ("ldc", "i8")], align=True)
+
+
+def _ld_2d(shapes: np.ndarray, strides: np.ndarray) -> np.ndarray:
+  """_as_2d_ld for [n, 2] shape / stride arrays."""
+  if np.any((shapes[:, 1] > 1) & (strides[:, 1] != 1)):
+    raise ValueError("matrix rows must be contiguous")
+  return np.where(shapes[:, 0] > 1, strides[:, 0], np.maximum(shapes[:, 1], 1))
+
+
 def gemm_grouped(items):
   """items: list of (a, b, c, transa, transb) with 2-D row-contiguous (possibly
-  strided) tensors; c = op(a) @ op(b) for all of them in one launch per layout pair."""
+  strided) tensors; c = op(a) @ op(b) for all of them in one launch per layout pair.
+  The descriptor table is filled column-wise with NumPy (a parameter tree has hundreds
+  of blocks: per-item ctypes stores were the cost of a step)."""
   if not items:
     return
+  n_items = len(items)
   dev = items[0][0].device
-  descs = (GemmDesc * len(items))()
-  for i, (a, b, c, ta, tb) in enumerate(items):
-    _require_gpu(a, "gemm_grouped")
-    _require_gpu(b, "gemm_grouped")
-    m, k = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
-    n = b.shape[0] if tb else b.shape[1]
-    kb = b.shape[1] if tb else b.shape[0]
-    if kb != k or tuple(c.shape) != (m, n):
-      raise ValueError(f"gemm_grouped shape mismatch in item {i}")
-    d = descs[i]
-    d.a, d.b, d.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
-    d.m, d.n, d.k, d.transa, d.transb = int(m), int(n), int(k), int(bool(ta)), int(bool(tb))
-    d.lda, d.ldb, d.ldc = _as_2d_ld(a), _as_2d_ld(b), _as_2d_ld(c)
+  A = [it[0] for it in items]
+  B = [it[1] for it in items]
+  Cm = [it[2] for it in items]
+  for t in A + B + Cm:
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2:
+      _require_gpu(t, "gemm_grouped")
+      raise ValueError("gemm_grouped expects 2-D tensors")
+  sa = np.array([t.shape for t in A], np.int64)
+  sb = np.array([t.shape for t in B], np.int64)
+  sc = np.array([t.shape for t in Cm], np.int64)
+  ta = np.array([bool(it[3]) for it in items])
+  tb = np.array([bool(it[4]) for it in items])
+  m = np.where(ta, sa[:, 1], sa[:, 0])
+  k = np.where(ta, sa[:, 0], sa[:, 1])
+  n = np.where(tb, sb[:, 0], sb[:, 1])
+  kb = np.where(tb, sb[:, 1], sb[:, 0])
+  bad = (kb != k) | (sc[:, 0] != m) | (sc[:, 1] != n)
+  if bad.any():
+    raise ValueError(f"gemm_grouped shape mismatch in item {int(np.argmax(bad))}")
+  tbl = np.zeros(n_items, _GDESC_DT)
+  assert _GDESC_DT.itemsize == C.sizeof(GemmDesc)
+  tbl["a"] = [t.data_ptr() for t in A]
+  tbl["b"] = [t.data_ptr() for t in B]
+  tbl["c"] = [t.data_ptr() for t in Cm]
+  tbl["m"], tbl["n"], tbl["k"], tbl["transa"], tbl["transb"] = m, n, k, ta, tb
+  tbl["lda"] = _ld_2d(sa, np.array([t.stride() for t in A], np.int64))
+  tbl["ldb"] = _ld_2d(sb, np.array([t.stride() for t in B], np.int64))
+  tbl["ldc"] = _ld_2d(sc, np.array([t.stride() for t in Cm], np.int64))
+  descs = C.cast(tbl.ctypes.data, C.POINTER(GemmDesc))
   L = lib()
-  ws = _workspace(L.ps_gemm_grouped_workspace_bytes(descs, len(items)), dev)
-  rc = L.ps_gemm_grouped_f32(_stream(), descs, len(items), ws.data_ptr(), ws.numel())
+  ws = _workspace(L.ps_gemm_grouped_workspace_bytes(descs, n_items), dev)
+  rc = L.ps_gemm_grouped_f32(_stream(), descs, n_items, ws.data_ptr(), ws.numel())
   check(rc, "ps_gemm_grouped_f32")
-  ws.record_stream(torch.cuda.current_stream())
 
 
 def tensordot_axis0(g: torch.Tensor, pc: torch.Tensor) -> torch.Tensor:
@@ -397,25 +425,67 @@ def gram_desc(g: torch.Tensor, axis: int, stat_in: torch.Tensor,
   return d, keep
 
 
+_SDESC_DT = np.dtype([("g", "u8"), ("layout", "i4"), ("d", "i4"), ("k", "i4"), ("nseg", "i4"),
+                      ("ld", "i8"), ("seg_stride", "i8"), ("stat_in", "u8"),
+                      ("stat_out", "u8"), ("lds", "i8")], align=True)
+
+
 def stats_update_grouped(items, w1: float, w2: float):
-  """items: list of (g_block, axis, stat_in, stat_out). One launch per layout."""
+  """items: list of (g_block, axis, stat_in, stat_out). One launch per layout.  Row-
+  contiguous 2-D blocks (the common case) are described column-wise with NumPy; other
+  ranks / strides go through gram_desc one by one."""
   if not items:
     return
+  n_items = len(items)
   dev = items[0][0].device
-  descs = (StatsDesc * len(items))()
+  assert _SDESC_DT.itemsize == C.sizeof(StatsDesc)
+  tbl = np.zeros(n_items, _SDESC_DT)
   keep = []
+  fast = [i for i, it in enumerate(items)
+          if it[0].dim() == 2 and (it[0].stride(1) == 1 or it[0].shape[1] == 1)]
+  fast_set = set(fast)
   for i, (g, axis, sin, sout) in enumerate(items):
-    _require_gpu(g, "gram_weighted_update")
-    _require_gpu(sin, "gram_weighted_update")
-    d, k = gram_desc(g, axis, sin, sout)
-    descs[i] = d
-    keep.append(k)
+    if not g.is_cuda or g.dtype != torch.float32 or not sin.is_cuda:
+      _require_gpu(g, "gram_weighted_update")
+      _require_gpu(sin, "gram_weighted_update")
+    if i not in fast_set:
+      d, k = gram_desc(g, axis, sin, sout)
+      keep.append(k)
+      row = tbl[i]
+      for name in _SDESC_DT.names:
+        row[name] = getattr(d, name) or 0
+  if fast:
+    G = [items[i][0] for i in fast]
+    SI = [items[i][2] for i in fast]
+    SO = [items[i][3] for i in fast]
+    axis = np.array([items[i][1] for i in fast], np.int64)
+    if np.any((axis != 0) & (axis != 1)):
+      raise ValueError("axis out of range for a 2-D block")
+    sg = np.array([t.shape for t in G], np.int64)
+    ld = _ld_2d(sg, np.array([t.stride() for t in G], np.int64))
+    so = np.array([t.shape for t in SO], np.int64)
+    lds = _ld_2d(so, np.array([t.stride() for t in SO], np.int64))
+    lds_in = _ld_2d(np.array([t.shape for t in SI], np.int64),
+                    np.array([t.stride() for t in SI], np.int64))
+    if np.any((lds_in != lds) & (so[:, 0] != 1)):
+      raise ValueError("stat_in and stat_out must share their leading dimension")
+    sub = np.zeros(len(fast), _SDESC_DT)
+    sub["g"] = [t.data_ptr() for t in G]
+    sub["layout"] = axis
+    sub["d"] = np.where(axis == 0, sg[:, 0], sg[:, 1])
+    sub["k"] = np.where(axis == 0, sg[:, 1], sg[:, 0])
+    sub["nseg"] = 1
+    sub["ld"] = ld
+    sub["stat_in"] = [t.data_ptr() for t in SI]
+    sub["stat_out"] = [t.data_ptr() for t in SO]
+    sub["lds"] = lds
+    tbl[fast] = sub
+  descs = C.cast(tbl.ctypes.data, C.POINTER(StatsDesc))
   L = lib()
-  ws = _workspace(L.ps_stats_update_grouped_workspace_bytes(descs, len(items)), dev)
-  rc = L.ps_stats_update_grouped_f32(_stream(), descs, len(items), float(w1),
+  ws = _workspace(L.ps_stats_update_grouped_workspace_bytes(descs, n_items), dev)
+  rc = L.ps_stats_update_grouped_f32(_stream(), descs, n_items, float(w1),
                                      float(w2), ws.data_ptr(), ws.numel())
   check(rc, "ps_stats_update_grouped_f32")
-  ws.record_stream(torch.cuda.current_stream())
   del keep
 
 
@@ -491,7 +561,6 @@ def transform_grads_fused(items, cfg: dict):
   rc = L.ps_transform_grads_f32(_stream(), descs, len(items), C.byref(c), ws.data_ptr(),
                                 ws.numel())
   check(rc, "ps_transform_grads_f32")
-  ws.record_stream(torch.cuda.current_stream())
   del keep
   return outs
 
@@ -515,7 +584,7 @@ def _as_rows_cols(shape):
 
 _QDESC_DT = np.dtype([("fvalue", "u8"), ("codes", "u8"), ("diagonal", "u8"),
                       ("bucket_size", "u8"), ("rows", "i8"), ("cols", "i8"), ("ld", "i8"),
-                      ("ldq", "i8"), ("bits", "i4"), ("extract_diagonal", "i4")])
+                      ("ldq", "i8"), ("bits", "i4"), ("extract_diagonal", "i4")], align=True)
 
 
 def _contig_strides(shape):
@@ -621,7 +690,6 @@ def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False, out=None)
   L = lib()
   ws = _workspace(L.ps_quantize_workspace_bytes(descs, n), dev)
   check(L.ps_quantize_f32(_stream(), descs, n, ws.data_ptr(), ws.numel()), "ps_quantize_f32")
-  ws.record_stream(torch.cuda.current_stream())
   del fv
   return outs
 
@@ -670,6 +738,5 @@ def dequantize_grouped(items, out=None):
   ws = _workspace(L.ps_dequantize_workspace_bytes(descs, n), dev)
   check(L.ps_dequantize_f32(_stream(), descs, n, ws.data_ptr(), ws.numel()),
         "ps_dequantize_f32")
-  ws.record_stream(torch.cuda.current_stream())
   del codes, diags, buckets
   return outs

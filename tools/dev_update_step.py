@@ -25,6 +25,13 @@ for t in range(8):
   torch.cuda.synchronize()
   times.append((time.perf_counter() - t0) * 1e3)
 print("update ms per step (step 0 includes the root recompute):", [round(x, 1) for x in times])
+# throughput without a host sync per step (how a training loop runs it)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for t in range(20):
+  upd, st = opt.update(grads, st, params)
+t_host = (time.perf_counter() - t0) / 20
+torch.cuda.synchronize(); t_all = (time.perf_counter() - t0) / 20
+print(f"20 unsynchronised steps: host {t_host*1e3:.2f} ms/step, wall {t_all*1e3:.2f} ms/step")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for t in range(3):
