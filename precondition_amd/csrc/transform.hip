@@ -42,6 +42,19 @@ struct TParam {
 
 struct TChunk { int param; int idx; };
 
+// chunk -> (parameter, chunk within it) from the per-parameter prefix chunk0: a binary
+// search per workgroup instead of a host-built table of one entry per 4096 elements
+// (21k entries for a ViT-B tree, rebuilt and uploaded every step).  Parameters without
+// elements add no chunks; equal keys resolve to the last one, which owns the chunk.
+__device__ inline TChunk find_chunk(const TParam* params, int count, int chunk) {
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (params[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+  }
+  return {lo, chunk - params[lo].chunk0};
+}
+
 __device__ inline bool has_diag(int g) {
   return g == G_ADAGRAD || g == G_RMSPROP || g == G_RMSPROP_N || g == G_ADAGRAD_N;
 }
@@ -63,10 +76,10 @@ __device__ inline float param_sum(const float* slab, int col, const TParam& p, f
 }
 
 // pass A: slab[.][0] = sum (graft base)^2 ; slab[.][1] = sum pgrad^2
-__global__ __launch_bounds__(256) void transform_pass_a(const TParam* params, const TChunk* chunks,
+__global__ __launch_bounds__(256) void transform_pass_a(const TParam* params, int count,
                                                         float* slab, ps_transform_config cfg) {
   __shared__ float red[4];
-  const TChunk ch = chunks[blockIdx.x];
+  const TChunk ch = find_chunk(params, count, blockIdx.x);
   const TParam p = params[ch.param];
   const int64_t lo = (int64_t)ch.idx * TCHUNK;
   const int64_t hi = lo + TCHUNK < p.numel ? lo + TCHUNK : p.numel;
@@ -96,10 +109,10 @@ __device__ inline float diag_graft(float g, float gden, float diag, int graft, f
 }
 
 // pass B (Adagrad/RMSProp only): slab[.][2] = sum u^2 of the unclipped update
-__global__ __launch_bounds__(256) void transform_pass_b(const TParam* params, const TChunk* chunks,
+__global__ __launch_bounds__(256) void transform_pass_b(const TParam* params, int count,
                                                         float* slab, ps_transform_config cfg) {
   __shared__ float red[4];
-  const TChunk ch = chunks[blockIdx.x];
+  const TChunk ch = find_chunk(params, count, blockIdx.x);
   const TParam p = params[ch.param];
   float gscale = 1.f;
   if (normalized(cfg.graft_type)) gscale = sqrtf(param_sum(slab, 0, p, red)) + T_EPS;
@@ -117,10 +130,10 @@ __global__ __launch_bounds__(256) void transform_pass_b(const TParam* params, co
 }
 
 // pass C: everything else, elementwise
-__global__ __launch_bounds__(256) void transform_pass_c(const TParam* params, const TChunk* chunks,
+__global__ __launch_bounds__(256) void transform_pass_c(const TParam* params, int count,
                                                         const float* slab, ps_transform_config cfg) {
   __shared__ float red[4];
-  const TChunk ch = chunks[blockIdx.x];
+  const TChunk ch = find_chunk(params, count, blockIdx.x);
   const TParam p = params[ch.param];
   const int graft = cfg.graft_type;
   const float r0 = param_sum(slab, 0, p, red);
@@ -190,7 +203,7 @@ extern "C" size_t ps_transform_grads_workspace_bytes(const ps_transform_desc* de
   if (!desc || count <= 0) return 0;
   size_t chunks = 0;
   for (int i = 0; i < count; ++i) chunks += (size_t)((desc[i].numel + TCHUNK - 1) / TCHUNK);
-  return psh::align_up(sizeof(TParam) * count, 256) + psh::align_up(sizeof(TChunk) * chunks, 256) +
+  return psh::align_up(sizeof(TParam) * count, 256) +
          psh::align_up(sizeof(float) * 4 * chunks, 256) + 1024;
 }
 
@@ -203,8 +216,7 @@ extern "C" int ps_transform_grads_f32(void* stream, const ps_transform_desc* des
   const bool diag = cfg->graft_type == G_ADAGRAD || cfg->graft_type == G_RMSPROP ||
                     cfg->graft_type == G_RMSPROP_N || cfg->graft_type == G_ADAGRAD_N;
   std::vector<TParam> hp(count);
-  std::vector<TChunk> hc;
-  int chunk0 = 0;
+  long long chunk0 = 0;
   for (int i = 0; i < count; ++i) {
     const ps_transform_desc& d = desc[i];
     if (!d.grad || !d.mom_in || !d.mom_out || !d.dmom_in || !d.dmom_out || !d.upd_out ||
@@ -216,24 +228,22 @@ extern "C" int ps_transform_grads_f32(void* stream, const ps_transform_desc* des
     p.diag_out = d.diag_out; p.mom_in = d.mom_in; p.mom_out = d.mom_out;
     p.dmom_in = d.dmom_in; p.dmom_out = d.dmom_out; p.upd_out = d.upd_out;
     p.numel = d.numel;
-    p.chunk0 = chunk0;
+    p.chunk0 = (int)chunk0;
     p.nchunks = (int)((d.numel + TCHUNK - 1) / TCHUNK);
-    for (int c = 0; c < p.nchunks; ++c) hc.push_back({i, c});
     chunk0 += p.nchunks;
+    if (chunk0 > 0x7fffffffLL) return PS_EUNSUPPORTED;
   }
-  if (hc.empty()) return PS_OK;
+  if (chunk0 == 0) return PS_OK;
   hipStream_t st = (hipStream_t)stream;
   psh::Arena ar(workspace, workspace_bytes);
   TParam* dp = ar.take<TParam>(count);
-  TChunk* dc = ar.take<TChunk>(hc.size());
-  float* slab = ar.take<float>(4 * hc.size());
+  float* slab = ar.take<float>(4 * (size_t)chunk0);
   if (ar.overflow) return PS_EWORKSPACE;
   PS_RC(psh::upload_async(st, dp, hp.data(), sizeof(TParam) * count));
-  PS_RC(psh::upload_async(st, dc, hc.data(), sizeof(TChunk) * hc.size()));
-  const dim3 grid((unsigned)hc.size()), blk(256);
-  hipLaunchKernelGGL(transform_pass_a, grid, blk, 0, st, dp, dc, slab, *cfg);
-  if (diag) hipLaunchKernelGGL(transform_pass_b, grid, blk, 0, st, dp, dc, slab, *cfg);
-  hipLaunchKernelGGL(transform_pass_c, grid, blk, 0, st, dp, dc, slab, *cfg);
+  const dim3 grid((unsigned)chunk0), blk(256);
+  hipLaunchKernelGGL(transform_pass_a, grid, blk, 0, st, dp, count, slab, *cfg);
+  if (diag) hipLaunchKernelGGL(transform_pass_b, grid, blk, 0, st, dp, count, slab, *cfg);
+  hipLaunchKernelGGL(transform_pass_c, grid, blk, 0, st, dp, count, slab, *cfg);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
