@@ -70,12 +70,12 @@ class Workload:
                      if self.multi else None)
     self.metrics = None
 
-  def _roots(self, lo, hi):
+  def _roots(self, lo, hi, max_ev=None):
     from precondition_amd import kernels as K
     _, m = K.matrix_inverse_pth_root_batched(
         list(self.stats[lo:hi].unbind(0)), [self.p] * (hi - lo),
         padding_starts=[self.n] * (hi - lo), out=list(self.roots[lo:hi].unbind(0)),
-        eigh=self.name.startswith("eigh"))
+        eigh=self.name.startswith("eigh"), max_ev=max_ev)
     return m
 
   def compute(self):
@@ -89,15 +89,24 @@ class Workload:
     # N > 1: the batch is rooted in two halves so that the RCCL all-gather of the
     # first half's roots (NCCL-side stream, async) runs under the second half's
     # Newton iterations (measured cost of the split on one GPU: +3 % at 512^2,
-    # +7 % at 1024^2).  `gathered` is laid out [half][rank][block].
+    # +4 % at 1024^2).  `gathered` is laid out [half][rank][block].
+    # The power iteration (100 short HBM-bound launches) runs ONCE over the whole batch
+    # and both halves take their largest eigenvalue from it: split halves of it would
+    # sit on the launch-latency floor (split cost 1.4 -> 0.5 ms at 512^2; results are
+    # bit-identical, same kernels).
     import torch.distributed as dist
+    from precondition_amd import kernels as K
     h = self.nb // 2
     per = self.n * self.n
     g = self.gathered.view(-1)
     handles = []
     ms = []
+    lam = None
+    if not self.name.startswith("eigh"):
+      lam, _ = K.power_iteration_batched(list(self.stats.unbind(0)),
+                                         padding_starts=[self.n] * self.nb)
     for k, (lo, hi) in enumerate(((0, h), (h, self.nb))):
-      ms.append(self._roots(lo, hi))
+      ms.append(self._roots(lo, hi, None if lam is None else lam[lo:hi]))
       off = k * self.world * h * per
       out = g[off: off + self.world * (hi - lo) * per]
       inp = self.roots[lo:hi].reshape(-1)
@@ -172,7 +181,7 @@ class VitBWorkload:
     self.stats_step()
     flat = [s for st in self.stats for s in st]
     _, self.metrics = comm.sharded_inverse_pth_roots(
-        flat, self.exps, group=self.group, ownership="lpt")
+        flat, self.exps, group=self.group, ownership="lpt", pi_first=True)
 
   def flops(self):
     m = self.metrics.cpu().numpy()

@@ -97,6 +97,7 @@ def sharded_inverse_pth_roots(
     overlap_min_bytes: int = 32 << 20,
     payload_elems: Optional[Sequence[int]] = None,
     sizes: Optional[Sequence[int]] = None,
+    pi_first: bool = False,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
 
@@ -112,6 +113,10 @@ def sharded_inverse_pth_roots(
   bucket sizes, DS:3102-3127); `outs` and the returned roots are then flat views.
   `sizes[i]` (default statistics[i].shape[0]): with owner-only statistics
   (`shard_statistics`) the entries this rank does not own are placeholders.
+  `pi_first` (HIP Newton root only): in the two-phase layout the power iteration runs
+  once over all of this rank's statistics and each phase's root call gets its largest
+  eigenvalues from it (`max_ev=`): halves of the 100 short launches would sit on the
+  launch-latency floor.  Same kernels, bit-identical results.
   """
   n_stats = len(statistics)
   world, rank = world_and_rank(group)
@@ -157,6 +162,15 @@ def sharded_inverse_pth_roots(
     slot[i] = count[ph][r]
     count[ph][r] += 1
 
+  lam_of = None
+  if (pi_first and n_phases == 2 and compute_fn is None and not eigh and
+      relative_matrix_epsilon):
+    from . import kernels
+    all_mine = [i for i in range(n_stats) if owner[i] == rank]
+    if all_mine:
+      lam, _ = kernels.power_iteration_batched([statistics[i] for i in all_mine],
+                                               padding_starts=[sizes[i] for i in all_mine])
+      lam_of = {i: k for k, i in enumerate(all_mine)}
   gathered, gathered_metrics, handles = [], [], []
   for ph in range(n_phases):
     buf_elems = max(max(fill[ph]), 1)
@@ -171,10 +185,13 @@ def sharded_inverse_pth_roots(
       if compute_fn is not None:
         m = compute_fn(mine, outs)
       else:
+        extra = {}
+        if lam_of is not None:
+          extra["max_ev"] = lam[[lam_of[i] for i in mine]]
         _, m = root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
                        [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
                        relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
-                       out=outs)
+                       out=outs, **extra)
       send_metrics[:len(mine)] = m
     if group is None:
       gathered.append(send.unsqueeze(0))

@@ -551,7 +551,8 @@ def distributed_shampoo(
         statistics, exponents, group=group, ridge_epsilon=matrix_epsilon,
         relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
         ownership=block_ownership, root_fn=root_fn, out_cols=out_cols,
-        compute_fn=compute_fn, payload_elems=payload_elems, sizes=sizes)
+        compute_fn=compute_fn, payload_elems=payload_elems, sizes=sizes,
+        pi_first=(_backend_for_testing is None and not lobpcg_topk_precondition))
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
     if quantize_second_moment:
       roots = [QuantizedValue(*_unpack(r, n), qdt_second_moment, True, [n, n])

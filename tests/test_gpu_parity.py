@@ -723,3 +723,24 @@ def test_fd_update_root_subspace_path_matches_full_eigh(device, monkeypatch):
   assert len(calls) == 3
   for a, b in zip(fast, full):
     assert packed_matches(a, b, rank, tol=1e-3)
+
+
+def test_sharded_roots_two_phase_pi_first_bit_identical(device):
+  """comm.sharded_inverse_pth_roots over a one-rank RCCL group, two-phase layout with the
+  power iteration hoisted (pi_first): bit-identical to the plain single call."""
+  from precondition_amd import comm
+  from tests.conftest import single_rank_group
+  rng = np.random.default_rng(21)
+  stats, exps = [], []
+  for n, p in ((256, 4), (130, 2), (256, 4), (384, 4), (64, 8), (256, 2), (200, 4)):
+    g = rng.standard_normal((n, 3 * n)).astype(np.float32)
+    stats.append(torch.tensor(g @ g.T, device=device))
+    exps.append(p)
+  base_roots, base_m = comm.sharded_inverse_pth_roots(stats, exps, group=None)
+  group = single_rank_group("nccl")
+  for pi_first in (False, True):
+    roots, m = comm.sharded_inverse_pth_roots(stats, exps, group=group, overlap_min_bytes=0,
+                                              pi_first=pi_first, ownership="lpt")
+    for a, b in zip(roots, base_roots):
+      assert torch.equal(a, b)
+    assert torch.equal(m[:, :5], base_m[:, :5])
