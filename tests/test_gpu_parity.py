@@ -744,3 +744,62 @@ def test_sharded_roots_two_phase_pi_first_bit_identical(device):
     for a, b in zip(roots, base_roots):
       assert torch.equal(a, b)
     assert torch.equal(m[:, :5], base_m[:, :5])
+
+
+def test_newton_root_fuzz_vs_oracle_and_fp64(device):
+  """96 random blocks per call mix: sizes 1..384 (incl. 127/128/129), p in {1,2,3,4,6,8},
+  Wishart / rank-deficient / 6-decade / diagonal / zero spectra, scales 1e-3..1e3, garbage
+  in the padding.  Iteration and retry counts equal the oracle's (+-1 at the threshold);
+  the root is no further from the float64 closed form than 4x the oracle's own float32
+  error; failures are flagged the same way; padding rows/columns are exactly zero."""
+  rng = np.random.default_rng(20260)
+  for _ in range(4):
+    mats, ps, pads = [], [], []
+    for _ in range(24):
+      n = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 127, 128, 129, 200, 257, 300, 384]))
+      p = int(rng.choice([1, 2, 3, 4, 6, 8]))
+      kind = rng.integers(0, 5)
+      if kind == 0:
+        g = rng.standard_normal((n, 2 * n + 3)); a = g @ g.T
+      elif kind == 1:
+        g = rng.standard_normal((n, max(1, n // 3))); a = g @ g.T
+      elif kind == 2:
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        a = (q * (10.0 ** rng.uniform(-4, 2, n))) @ q.T
+      elif kind == 3:
+        a = np.diag(rng.uniform(0.0, 3.0, n))
+      else:
+        a = np.zeros((n, n))
+      a = ((a + a.T) / 2 * 10.0 ** rng.uniform(-3, 3)).astype(np.float32)
+      full = n + int(rng.choice([0, 0, 1, 7, 64]))
+      m = np.zeros((full, full), np.float32)
+      if full > n:
+        m[:] = rng.standard_normal((full, full)); m = ((m + m.T) / 2).astype(np.float32)
+      m[:n, :n] = a
+      mats.append(m); ps.append(p); pads.append(n if rng.uniform() < 0.9 else 0)
+    roots, met = K().matrix_inverse_pth_root_batched(
+        [torch.tensor(m, device=device) for m in mats], ps, pads)
+    met = met.cpu().numpy()
+    for i, (m, p, pad) in enumerate(zip(mats, ps, pads)):
+      with np.errstate(all="ignore"):
+        h, mm = orc.matrix_inverse_pth_root(m, p, padding_start=pad)
+      got = roots[i].cpu().numpy()
+      tag = (m.shape[0], pad, p)
+      failed_ref = not (mm["inverse_pth_root_errors"] < 0.1)
+      failed_got = not (met[i, 0] < 0.1)
+      assert failed_ref == failed_got, tag
+      if failed_ref or pad == 0:
+        if pad == 0:
+          assert np.all(got == 0) and met[i, 0] == 0
+        continue
+      assert abs(met[i, 1] - mm["inverse_pth_root_iters"]) <= 1, tag
+      assert met[i, 4] == mm["total_retries"], tag
+      a64 = m[:pad, :pad].astype(np.float64)
+      ridge = 1e-6 * max(float(mm["max_eigen_value"]), 1e-25) * 10.0 ** (mm["total_retries"] - 1)
+      w, v = np.linalg.eigh(a64 + ridge * np.eye(pad))
+      truth = (v * np.maximum(w, 1e-300) ** (-1.0 / p)) @ v.T
+      tn = max(np.linalg.norm(truth), 1e-30)
+      e_ref = np.linalg.norm(h[:pad, :pad] - truth) / tn
+      e_got = np.linalg.norm(got[:pad, :pad] - truth) / tn
+      assert e_got <= 4 * e_ref + 2e-5, (tag, e_got, e_ref)
+      assert np.all(got[pad:] == 0) and np.all(got[:, pad:] == 0), tag

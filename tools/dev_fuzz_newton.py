@@ -1,0 +1,77 @@
+"""Dev: random sizes / exponents / paddings / spectra, HIP batched root vs the oracle."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import shampoo_oracle as orc
+from precondition_amd import kernels as K
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(int(os.environ.get("SEED", "0")))
+bad = 0
+total = 0
+worst = 0.0
+for rnd in range(int(os.environ.get("ROUNDS", "12"))):
+  mats, ps, pads, refs = [], [], [], []
+  for _ in range(24):
+    n = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 127, 128, 129, 200, 257, 300, 384]))
+    p = int(rng.choice([1, 2, 3, 4, 6, 8]))
+    kind = rng.integers(0, 5)
+    if kind == 0:
+      g = rng.standard_normal((n, 2 * n + 3)); a = g @ g.T
+    elif kind == 1:
+      g = rng.standard_normal((n, max(1, n // 3))); a = g @ g.T            # rank deficient
+    elif kind == 2:
+      q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+      a = (q * (10.0 ** rng.uniform(-4, 2, n))) @ q.T
+    elif kind == 3:
+      a = np.diag(rng.uniform(0.0, 3.0, n))
+    else:
+      a = np.zeros((n, n))
+    a = ((a + a.T) / 2 * 10.0 ** rng.uniform(-3, 3)).astype(np.float32)
+    full = n + int(rng.choice([0, 0, 1, 7, 64]))
+    m = np.zeros((full, full), np.float32); m[:n, :n] = a
+    if full > n:  # garbage in the padding must be masked out
+      m[n:, :] = rng.standard_normal((full - n, full)); m[:, n:] = rng.standard_normal((full, full - n))
+      m = ((m + m.T) / 2).astype(np.float32); m[:n, :n] = a
+    pad = n if rng.uniform() < 0.9 else 0
+    mats.append(m); ps.append(p); pads.append(pad)
+  roots, met = K.matrix_inverse_pth_root_batched([torch.tensor(m, device=dev) for m in mats], ps, pads)
+  met = met.cpu().numpy()
+  for i, (m, p, pad) in enumerate(zip(mats, ps, pads)):
+    with np.errstate(all="ignore"):
+      h, mm = orc.matrix_inverse_pth_root(m, p, padding_start=pad)
+    got = roots[i].cpu().numpy()
+    total += 1
+    ok = True
+    why = ""
+    if not np.isfinite(h).all() or not np.isfinite(got).all():
+      ok = (np.isnan(h) == np.isnan(got)).all() or (mm["inverse_pth_root_errors"] != mm["inverse_pth_root_errors"]) == (met[i, 0] != met[i, 0])
+      why = f"nan pattern: ref err {mm['inverse_pth_root_errors']} got err {met[i,0]} a={m.ravel()[:4]} ref={h.ravel()[:3]} got={got.ravel()[:3]}"
+    else:
+      den = max(np.linalg.norm(h), 1e-30)
+      rel = np.linalg.norm(got - h) / den
+      iters_ok = abs(met[i, 1] - mm["inverse_pth_root_iters"]) <= 1 and met[i, 4] == mm["total_retries"]
+      # conditioning-scaled tolerance: failed / ill-posed cases only need matching flags
+      failed_ref = not (mm["inverse_pth_root_errors"] < 0.1)
+      failed_got = not (met[i, 0] < 0.1)
+      if failed_ref or failed_got:
+        ok = failed_ref == failed_got or rel < 1e-2
+        why = f"failure flag ref {mm['inverse_pth_root_errors']:.3g} got {met[i,0]:.3g}"
+      else:
+        # both against the float64 closed form with the oracle's ridge: the HIP root may
+        # not be further from it than a few times the oracle's own float32 error
+        a64 = m[:pad, :pad].astype(np.float64)
+        ridge = 1e-6 * max(float(mm["max_eigen_value"]), 1e-25) * 10.0 ** (mm["total_retries"] - 1)
+        w, v = np.linalg.eigh(a64 + ridge * np.eye(pad))
+        truth = (v * np.maximum(w, 1e-300) ** (-1.0 / p)) @ v.T
+        tn = max(np.linalg.norm(truth), 1e-30)
+        e_ref = np.linalg.norm(h[:pad, :pad] - truth) / tn
+        e_got = np.linalg.norm(got[:pad, :pad] - truth) / tn
+        ok = e_got <= 4 * e_ref + 2e-5 and iters_ok
+        worst = max(worst, e_got / max(e_ref, 1e-7))
+        why = f"err vs fp64: hip {e_got:.2e} oracle {e_ref:.2e}; rel {rel:.2e} iters {met[i,1]} vs {mm['inverse_pth_root_iters']} retries {met[i,4]} vs {mm['total_retries']}"
+      if pad < m.shape[0] and ok:
+        ok = np.all(got[pad:] == 0) and np.all(got[:, pad:] == 0); why += " padding"
+    if not ok:
+      bad += 1
+      print("MISMATCH n_full", m.shape[0], "pad", pad, "p", p, why)
+print("cases", total, "mismatches", bad, "worst hip/oracle error ratio", worst)
