@@ -456,6 +456,13 @@ def main():
         "step_breakdown_ms": {"product_stages": round(stage_ms, 3),
                               "power_iteration": round(pi_ms, 3),
                               "init_control_copyout": round(other_ms, 3)},
+        # the HBM-bound part of the step (reported separately): 100 matrix-vector
+        # passes; algorithmic = the whole matrix per pass, the kernel reads the upper block
+        # triangle only ((T+1)/(2T) of it)
+        "power_iteration_hbm": {
+            "bound": "hbm", "peak": 8000, "unit": "GB/s",
+            "algorithmic_GBps": round(nb * n * n * 4 * 100 / max(pi_ms, 1e-9) / 1e6, 1),
+            "read_GBps": round(nb * n * n * 4 * 100 * ex / max(pi_ms, 1e-9) / 1e6, 1)},
     }
   if multi:
     import torch.distributed as dist
