@@ -333,6 +333,23 @@ def pmc_traffic(workload, kernel):
   return None
 
 
+def parity_sample(work, count=8):
+  """rel-Fro error of the GPU roots against the oracle (the checker, SURVEY 8d
+  'Accuracy') on the first `count` blocks of the workload, same inputs; also iteration
+  counts.  north_star bar: 1e-4."""
+  from oracle import shampoo_oracle as orc
+  errs, iters_equal = [], True
+  m = work.metrics.cpu().numpy()
+  for i in range(min(count, work.nb)):
+    a = work.stats[i].cpu().numpy()
+    h, mm = orc.matrix_inverse_pth_root(a, work.p, padding_start=work.n)
+    got = work.roots[i].cpu().numpy()
+    errs.append(float(np.linalg.norm(got - h) / np.linalg.norm(h)))
+    iters_equal &= bool(m[i, 1] == mm["inverse_pth_root_iters"] and m[i, 4] == mm["total_retries"])
+  return {"blocks": len(errs), "rel_fro_max": max(errs), "rel_fro_median": float(np.median(errs)),
+          "iteration_and_retry_counts_equal": iters_equal, "bar": 1e-4}
+
+
 def cpu_baseline(name, budget_s=12.0):
   """The oracle executing the reference's op sequence (its 6 products per step
   at p=4) on the host cores, on a bounded sample of the same workload."""
@@ -432,6 +449,8 @@ def main():
       },
   }
 
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.workload.startswith("eigh"):
+    line["parity_vs_oracle"] = parity_sample(work)
   if rank == 0:
     stage_ms, launches, pi_ms, other_ms = profile_stage_kernel(work)
     fl1 = work.flops()
