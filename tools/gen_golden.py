@@ -521,6 +521,44 @@ def gen_e2e_quant():
   _run_e2e_configs(configs, None, "e2e_quant.npz", "e2e_quant_index.json")
 
 
+def gen_e2e_more():
+  """More option combinations of the optimizer surface (grafting variants, clipping,
+  skip rules, OUTPUT preconditioners, decoupled learning rate off, beta2 = 1)."""
+
+  def tree(shapes, seed):
+    r = np.random.default_rng(seed)
+    return tuple(r.standard_normal(s).astype(F32) for s in shapes)
+
+  shapes_a = ([40, 24], [24], [6, 10, 8], [70, 33])
+  shapes_b = ([40, 24], [70, 33], [6, 10, 8])
+  G = ds.GraftingType
+  configs = [
+      ("more_adagrad_normalized_nonesterov", tree(shapes_a, 31), None, dict(
+          block_size=32, graft_type=G.ADAGRAD_NORMALIZED, nesterov=False,
+          preconditioning_compute_steps=2, start_preconditioning_step=1), 4, "fresh"),
+      ("more_rmsprop_clip_decoupled_lr_off", tree(shapes_a, 32), None, dict(
+          block_size=32, graft_type=G.RMSPROP, clip_by_scaled_gradient_norm=0.05, beta2=0.95,
+          decoupled_learning_rate=False, weight_decay=0.02, decoupled_weight_decay=True,
+          preconditioning_compute_steps=1, start_preconditioning_step=2), 4, "fresh"),
+      ("more_graft_none_beta2_one", tree(shapes_a, 33), None, dict(
+          block_size=32, graft_type=G.NONE, beta2=1.0, beta1=0.5,
+          preconditioning_compute_steps=2, start_preconditioning_step=1), 4, "fresh"),
+      ("more_sqrt_n_skip_rank_lt2", tree(shapes_a, 34), None, dict(
+          block_size=32, graft_type=G.SQRT_N, skip_preconditioning_rank_lt=2,
+          skip_preconditioning_dim_size_gt=64, preconditioning_compute_steps=1,
+          start_preconditioning_step=1), 4, "fresh"),
+      ("more_output_only_exponent_override", tree(shapes_b, 35), None, dict(
+          block_size=32, precondtioner_type=ds.PreconditionerType.OUTPUT,
+          merge_small_dims_block_size=32, exponent_override=2, moving_average_for_momentum=True,
+          preconditioning_compute_steps=1, start_preconditioning_step=1), 4, "fresh"),
+      ("more_no_shape_interpretation_bs16", tree(shapes_a, 36), None, dict(
+          block_size=16, best_effort_shape_interpretation=False, matrix_epsilon=1e-4,
+          relative_matrix_epsilon=False, preconditioning_compute_steps=3,
+          start_preconditioning_step=1, inverse_failure_threshold=0.05), 5, "fresh"),
+  ]
+  _run_e2e_configs(configs, None, "e2e_more.npz", "e2e_more_index.json")
+
+
 def gen_quant():
   """QuantizedValue.quantize / to_float goldens (quantization_utils.py:45-113)."""
   from precondition.quantization_utils import QuantizedValue
@@ -641,7 +679,7 @@ def gen_lowrank():
 
 if __name__ == "__main__":
   which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e", "lowrank", "quant",
-                           "e2e_quant"]
+                           "e2e_quant", "e2e_more"]
   if "newton" in which:
     gen_newton()
   if "pi" in which:
@@ -658,6 +696,8 @@ if __name__ == "__main__":
     gen_quant()
   if "e2e_quant" in which:
     gen_e2e_quant()
+  if "e2e_more" in which:
+    gen_e2e_more()
   if "lowrank" in which:
     gen_lowrank()
   print("golden fixtures written to", OUT)
