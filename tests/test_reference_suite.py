@@ -332,3 +332,43 @@ def test_optimizer_with_topk_deflation_tracks_plain_optimizer():
       assert np.linalg.norm(x - y) <= 2e-2 * np.linalg.norm(x)
   tm = st.stats[0].training_metrics
   assert float(tm.inverse_pth_root_errors.max()) < 0.1
+
+
+@pytest.mark.gpu
+def test_known_answer_against_float64_closed_form():
+  """Independent known answer (in the spirit of tearfree/shampoo_test.py:147-200): without
+  grafting, momentum or decay the update is -lr * P_L g P_R with
+  P = (sum_t g_t g_t^T + eps I)^(-1/(2 rank)), checked against numpy float64."""
+  if not torch.cuda.is_available():
+    pytest.skip("no GPU")
+  dev = torch.device("cuda:0")
+  rng = np.random.default_rng(5)
+  shapes = ([6, 4], [5], [3, 7])
+  params = tuple(torch.zeros(s, device=dev) for s in shapes)
+  eps, lr = 1e-3, 0.1
+  opt = pa.distributed_shampoo(lr, 16, graft_type=pa.GraftingType.NONE, beta1=0.0, beta2=1.0,
+                               nesterov=False, matrix_epsilon=eps, start_preconditioning_step=0,
+                               preconditioning_compute_steps=1, merge_small_dims_block_size=1)
+  st = opt.init(params)
+  lstat = [eps * np.eye(s[0]) for s in shapes]
+  rstat = [eps * np.eye(s[1]) if len(s) == 2 else None for s in shapes]
+
+  def root(a, p):
+    w, v = np.linalg.eigh(a)
+    return (v * (w + eps * w.max()) ** (-1.0 / p)) @ v.T
+
+  for t in range(4):
+    grads_np = [rng.standard_normal(s) for s in shapes]
+    grads = tuple(torch.tensor(g.astype(np.float32), device=dev) for g in grads_np)
+    upd, st = opt.update(grads, st, params)
+    for i, (g, s) in enumerate(zip(grads_np, shapes)):
+      g = g.astype(np.float32).astype(np.float64)
+      if len(s) == 1:
+        lstat[i] = lstat[i] + np.multiply.outer(g, g)
+        want = -lr * root(lstat[i], 2) @ g
+      else:
+        lstat[i] = lstat[i] + g @ g.T
+        rstat[i] = rstat[i] + g.T @ g
+        want = -lr * root(lstat[i], 4) @ g @ root(rstat[i], 4)
+      got = upd[i].cpu().numpy().astype(np.float64)
+      assert np.linalg.norm(got - want) <= 1e-3 * np.linalg.norm(want), (t, i)
