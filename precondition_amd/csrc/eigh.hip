@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void eigh_scale_kernel(EighBlock* blocks,
 // float64 accumulation is accurate to the vectors' second-order error.  One workgroup per
 // (matrix, 64 eigenvectors): X = D V_I in 64-row panels, 4x4 float64 accumulators per
 // thread, operands staged through LDS as float32; n^3 DFMA per matrix on the vector pipe
-// (~4 % of the sweeps' time at 2048^2).  The refined values replace diag(A).
+// (3 % of the time at 64 x 2048^2).  The refined values replace diag(A).
 constexpr int RQ = 64;   // panel: 64 rows x 64 eigenvectors
 constexpr int RK = 16;   // k chunk
 __global__ __launch_bounds__(256) void eigh_rayleigh_f64_kernel(EighBlock* blocks,
