@@ -45,14 +45,16 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 100 /* 0.1.0 */
+#define PS_VERSION 200 /* 0.2.0 */
 
 enum {
   PS_OK = 0,
   PS_EINVAL = -1,     /* bad pointer / size / exponent */
   PS_EWORKSPACE = -2, /* workspace too small */
   PS_EUNSUPPORTED = -3,
-  PS_EINTERNAL = -4
+  PS_EINTERNAL = -4,
+  PS_EDEVICE = -5     /* called with a HIP device current that is not the one this
+                         process first used the library on (one process per GPU) */
 };
 
 /* Columns of the per-block metrics table written by the root functions.

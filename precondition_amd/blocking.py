@@ -243,10 +243,24 @@ class Preconditioner:
     """DS:1540-1591 (dense branch): new_stats[i] = w1*stats[i] + w2*Gram_i."""
     from . import kernels  # HIP path; raises without the library / a GPU
     del precision
-    if frequent_directions:
-      raise NotImplementedError("frequent_directions (config 5) is not built yet")
     to_float = to_float or (lambda x: x)
     from_float = from_float or (lambda x: x)
+    if frequent_directions:
+      # DS:1585-1588: blocks whose axis is compressed take frequent_directions_update
+      # (a square factor R with R R^T = Gram), the others the dense weighted update.
+      from . import low_rank
+      dims = [i for i, p in enumerate(self.should_precondition_dims()) if p]
+      new_stats, index = [], 0
+      for g in self.partitioned_blocks(grad):
+        for axis in dims:
+          old = to_float(stats[index]).contiguous()
+          if _should_compress(self._compression_rank, g.shape[axis]):
+            new = low_rank.frequent_directions_update(old, g, axis, w1, w2)
+          else:
+            new = kernels.gram_weighted_update(old, g, axis, w1, w2)
+          new_stats.append(from_float(new))
+          index += 1
+      return new_stats
     olds = [to_float(s).contiguous() for s in stats]
     news = [torch.empty_like(s) for s in olds]
     kernels.stats_update_grouped(self.statistics_update_items(olds, grad, news),

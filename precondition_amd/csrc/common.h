@@ -21,6 +21,12 @@
     if (rc__ != 0) return rc__;               \
   } while (0)
 
+#define PS_DEVICE_CHECK()                     \
+  do {                                        \
+    int rc__ = psh::bind_device();            \
+    if (rc__ != 0) return rc__;               \
+  } while (0)
+
 #define PS_LAUNCH_CHECK()                     \
   do {                                        \
     hipError_t e__ = hipGetLastError();       \
@@ -28,6 +34,23 @@
   } while (0)
 
 namespace psh {
+
+// One process drives ONE device (one process per GPU, RCCL-style): the library keeps a
+// few per-process resources that are bound to a device (the pinned upload ring's
+// events, kernel attributes such as the dynamic-LDS limit, the mapped status rings).
+// The first compute call binds the process to the current HIP device; a later call made
+// with another device current is refused with PS_EDEVICE instead of enqueuing kernels
+// on a stream of the wrong device.
+inline int bind_device() {
+  static std::mutex mu;
+  static int bound = -1;
+  int d = -1;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess) return 0;  // no device at all: the first HIP call below reports it
+  std::lock_guard<std::mutex> lk(mu);
+  if (bound < 0) bound = d;
+  return bound == d ? 0 : PS_EDEVICE;
+}
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }

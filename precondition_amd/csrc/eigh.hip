@@ -689,6 +689,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                        int relative_matrix_epsilon, float* const* out, const int32_t* ldo,
                        float* const* evals_out, float* metrics, void* workspace,
                        size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
   if (batch <= 0 || !a || !n || !lda || !out || !ldo || !workspace) return PS_EINVAL;
   if (mode == 0 && (!p || !metrics)) return PS_EINVAL;
   if (mode == 1 && !evals_out) return PS_EINVAL;

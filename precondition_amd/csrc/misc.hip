@@ -18,6 +18,7 @@ extern "C" const char* ps_error_string(int code) {
     case PS_EWORKSPACE: return "workspace too small";
     case PS_EUNSUPPORTED: return "unsupported size or exponent";
     case PS_EINTERNAL: return "internal error";
+    case PS_EDEVICE: return "wrong HIP device current (the library serves one device per process)";
     default:
       return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
@@ -99,6 +100,7 @@ extern "C" int ps_gemm_f32(void* stream, int transa, int transb, const float* a,
                            const float* b, float* c, int m, int n, int k, int lda,
                            int ldb, int ldc, int batch, int64_t stride_a,
                            int64_t stride_b, int64_t stride_c) {
+  PS_DEVICE_CHECK();
   if (!a || !b || !c || m < 1 || n < 1 || k < 1 || batch < 1 || ldc < n ||
       lda < (transa ? m : k) || ldb < (transb ? k : n))
     return PS_EINVAL;
@@ -169,6 +171,7 @@ extern "C" size_t ps_gemm_grouped_workspace_bytes(const ps_gemm_desc* desc, int 
 
 extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count,
                                    void* workspace, size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
   if (!desc || count <= 0 || !workspace) return PS_EINVAL;
   if (workspace_bytes < grouped_gemm_bytes(desc, count)) return PS_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -233,6 +236,7 @@ extern "C" size_t ps_mat_power_workspace_bytes(int n, int p) {
 extern "C" int ps_mat_power_f32(void* stream, const float* m, int n, int ldm, int p,
                                 float* out, int ldo, void* workspace,
                                 size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
   if (!m || !out || n < 1 || p < 0 || ldm < n || ldo < n) return PS_EINVAL;
   if (workspace_bytes < ps_mat_power_workspace_bytes(n, p) || !workspace)
     return PS_EWORKSPACE;

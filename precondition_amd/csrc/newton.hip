@@ -589,6 +589,7 @@ static int newton_driver(
     float ridge_epsilon, float error_tolerance, int relative_matrix_epsilon,
     const float* max_ev_given, float* const* out, const int32_t* ldo, float* metrics,
     void* workspace, size_t workspace_bytes, int32_t* iters_executed_host) {
+  PS_DEVICE_CHECK();
   if (batch <= 0 || !a || !n || !lda || !p || !out || !ldo || !metrics || !workspace ||
       num_iters < 1)
     return PS_EINVAL;
@@ -782,6 +783,7 @@ extern "C" int ps_power_iteration_batched_f32(
     const int32_t* padding_start, int batch, int num_iters, float error_tolerance,
     float* out_lambda, int32_t* out_iters, float* out_v, int32_t ldv, void* workspace,
     size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
   if (batch <= 0 || !a || !n || !lda || !out_lambda || !workspace || num_iters < 1)
     return PS_EINVAL;
   for (int b = 0; b < batch; ++b)

@@ -289,6 +289,7 @@ extern "C" size_t ps_quantize_workspace_bytes(const ps_quant_desc* desc, int cou
 
 extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int count, void* workspace,
                                size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
   if (!desc || count <= 0 || !workspace) return PS_EINVAL;
   if (workspace_bytes < ps_quantize_workspace_bytes(desc, count)) return PS_EWORKSPACE;
   std::vector<QTensor> ht;
@@ -322,6 +323,7 @@ extern "C" size_t ps_dequantize_workspace_bytes(const ps_quant_desc* desc, int c
 
 extern "C" int ps_dequantize_f32(void* stream, const ps_quant_desc* desc, int count, void* workspace,
                                  size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
   if (!desc || count <= 0 || !workspace) return PS_EINVAL;
   if (workspace_bytes < ps_dequantize_workspace_bytes(desc, count)) return PS_EWORKSPACE;
   std::vector<QTensor> ht;

@@ -165,6 +165,7 @@ extern "C" size_t ps_stats_update_grouped_workspace_bytes(const ps_stats_desc* d
 extern "C" int ps_stats_update_grouped_f32(void* stream, const ps_stats_desc* desc,
                                            int count, float w1, float w2,
                                            void* workspace, size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
   if (!desc || count <= 0 || !workspace) return PS_EINVAL;
   if (workspace_bytes < grouped_bytes(desc, count)) return PS_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -211,6 +212,7 @@ extern "C" int ps_stats_update_f32(void* stream, const float* g, int64_t rows,
                                    int64_t cols, int64_t ldg, int axis,
                                    const float* stat_in, float* stat_out, int64_t lds,
                                    float w1, float w2) {
+  PS_DEVICE_CHECK();
   if (rows < 1 || cols < 1 || (axis != 0 && axis != 1) || rows > 0x7fffffff ||
       cols > 0x7fffffff || ldg < cols)
     return PS_EINVAL;

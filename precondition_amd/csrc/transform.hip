@@ -210,6 +210,7 @@ extern "C" size_t ps_transform_grads_workspace_bytes(const ps_transform_desc* de
 extern "C" int ps_transform_grads_f32(void* stream, const ps_transform_desc* desc, int count,
                                       const ps_transform_config* cfg, void* workspace,
                                       size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
   if (!desc || !cfg || count <= 0 || !workspace) return PS_EINVAL;
   if (workspace_bytes < ps_transform_grads_workspace_bytes(desc, count)) return PS_EWORKSPACE;
   if (cfg->graft_type < 0 || cfg->graft_type > 6) return PS_EINVAL;

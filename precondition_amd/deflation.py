@@ -77,7 +77,12 @@ def matrix_inverse_pth_root_deflated_batched(
   inverse_pth_root_diagnostics (DS:915-928)."""
   from . import kernels as K, subspace
   from .distributed_shampoo import _EPSILON, _pth_root_difference
-  del max_iter  # the block method iterates to its residual tolerance instead
+  # jax's lobpcg_standard (third party, absent here: parity unpinned) runs at most
+  # `topk if lobpcg_max_iter == 0 else lobpcg_max_iter` iterations (DS:795-797).  The block
+  # method below is a different iteration (Chebyshev-filtered subspace iteration, one outer
+  # round = up to 12 filtered products + Rayleigh-Ritz); the same number is honoured as
+  # the cap on its outer rounds, and `lobpcg_iters` reports the rounds it ran.
+  outer_cap = max(1, min(50, int(topk) if not max_iter else int(max_iter)))
   batch = len(matrices)
   dev = matrices[0].device
   k = int(topk)
@@ -112,6 +117,7 @@ def matrix_inverse_pth_root_deflated_batched(
     groups.setdefault(pads[b], []).append(j)
   for n, js in groups.items():
     e, v, conv, info = subspace.top_eigenpairs_batched([a_eff[j] for j in js], k,
+                                                       max_outer=outer_cap,
                                                        oversample=max(8, min(31, n - k)))
     for t, j in enumerate(js):
       theta[j], vecs[j], iters[j] = e[t], v[t], info["outer_iterations"]

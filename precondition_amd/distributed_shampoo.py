@@ -561,6 +561,11 @@ def distributed_shampoo(
     for i, (root, old) in enumerate(zip(roots, prev)):
       err = errors[i]
       bad = np.isnan(err) or err >= inverse_failure_threshold  # DS:2936-2943
+      if bad and isinstance(old, torch.Tensor) and old._base is not None:
+        # `old` is a view into the PREVIOUS recompute's gathered buffer: keeping the view
+        # would pin that whole buffer (every preconditioner of the model) for as long as
+        # this block keeps failing, and torch.save would serialise it.  Detach it.
+        old = old.clone()
       new_p.append(old if bad else root)
 
     out, idx = [], 0
@@ -753,6 +758,14 @@ def distributed_shampoo(
     stats_flat = treedef.flatten_up_to(state.stats)
     grads_flat = treedef.flatten_up_to(grads)
     step = int(state.count)
+    # Mixed-precision training hands over bf16 / fp16 gradients: the reference promotes
+    # them inside its float32 arithmetic; the kernels here take float32 only, so promote
+    # at the door and hand the updates back in the gradient's dtype.
+    grad_dtypes = [g.dtype for g in grads_flat]
+    grads_flat = [g if g.dtype == torch.float32 else g.to(torch.float32) for g in grads_flat]
+    if any(p.dtype != torch.float32 for p in params_flat):
+      params_flat = [p if p.dtype == torch.float32 else p.to(torch.float32)
+                     for p in params_flat]
 
     new_stats = _compute_stats_all(grads_flat, stats_flat, params_flat, step)
     new_stats = _compute_preconditioners(new_stats, params_flat, step)
@@ -769,7 +782,8 @@ def distributed_shampoo(
     else:  # host-logic test seam: the same arithmetic as torch elementwise ops
       outs = [_transform_grad(g, s, p, step, pg)
               for g, s, p, pg in zip(grads_flat, new_stats, params_flat, pgs)]
-    updates_flat = [o[0] for o in outs]
+    updates_flat = [o[0] if o[0].dtype == dt else o[0].to(dt)
+                    for o, dt in zip(outs, grad_dtypes)]
     new_stats = [o[1] for o in outs]
     if best_effort_memory_usage_reduction:  # _quantize_momentum, DS:3617-3619
       moms = _quantize_momentum_many([s.momentum.to_float() for s in new_stats], params_flat)

@@ -28,7 +28,51 @@ def _require_gpu(t: torch.Tensor, what: str):
 
 
 def _stream() -> int:
+  """HIP stream of the CURRENT device; every entry point below runs under
+  `_device_guarded`, which makes the tensors' device current first."""
   return torch.cuda.current_stream().cuda_stream
+
+
+def _first_cuda_device(obj, depth=0):
+  if isinstance(obj, torch.Tensor):
+    return obj.device if obj.is_cuda else None
+  if depth < 3 and isinstance(obj, (list, tuple)):
+    for x in obj:
+      d = _first_cuda_device(x, depth + 1)
+      if d is not None:
+        return d
+  if depth < 3 and isinstance(obj, dict):
+    for x in obj.values():
+      d = _first_cuda_device(x, depth + 1)
+      if d is not None:
+        return d
+  return None
+
+
+def _device_guarded(fn):
+  """Runs `fn` with the device of its first device-tensor argument current, so that the
+  stream handed to the library (_stream()), the workspaces and the outputs all belong to
+  the device the pointers live on (kernels enqueued on a cuda:0 stream with cuda:1
+  pointers fault or race with the caching allocator).  The library itself serves one
+  device per process (PS_EDEVICE otherwise)."""
+  import functools
+
+  @functools.wraps(fn)
+  def wrapper(*args, **kwargs):
+    dev = _first_cuda_device(args) or _first_cuda_device(list(kwargs.values()))
+    if dev is None:
+      return fn(*args, **kwargs)
+    with torch.cuda.device(dev):
+      return fn(*args, **kwargs)
+
+  return wrapper
+
+
+def _same_device(tensors, what: str):
+  devs = {t.device for t in tensors if isinstance(t, torch.Tensor)}
+  if len(devs) > 1:
+    raise ValueError(f"{what}: all tensors of one call must live on one device, got "
+                     f"{sorted(str(d) for d in devs)}")
 
 
 def _i32(xs) -> np.ndarray:
@@ -58,6 +102,7 @@ def _as_2d_ld(t: torch.Tensor) -> int:
 # ---------------------------------------------------------------------------
 # inverse p-th root
 # ---------------------------------------------------------------------------
+@_device_guarded
 def matrix_inverse_pth_root_batched(
     matrices: Sequence[torch.Tensor],
     ps: Sequence[int],
@@ -85,6 +130,8 @@ def matrix_inverse_pth_root_batched(
     _require_gpu(m, "matrix_inverse_pth_root")
     if m.dim() != 2 or m.shape[0] != m.shape[1]:
       raise ValueError(f"expected square matrices, got {tuple(m.shape)}")
+  _same_device(list(matrices) + (list(out) if out is not None else []),
+               "matrix_inverse_pth_root")
   n = _i32([m.shape[0] for m in matrices])
   lda = _i32([_as_2d_ld(m) for m in matrices])
   p = _i32(list(ps))
@@ -179,6 +226,7 @@ def matrix_inverse_pth_root_deflated_batched(*args, **kwargs):
   return deflation.matrix_inverse_pth_root_deflated_batched(*args, **kwargs)
 
 
+@_device_guarded
 def eigh_batched(matrices: Sequence[torch.Tensor]):
   """jnp.linalg.eigh for a batch of symmetric matrices (blocked Jacobi on the
   GPU).  Returns (eigenvalues ascending [n], eigenvectors [n, n] in columns) per
@@ -209,6 +257,7 @@ def eigh_batched(matrices: Sequence[torch.Tensor]):
   return out_e, out_v
 
 
+@_device_guarded
 def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
                     error_tolerance: float = 1e-6,
                     padding_start: Optional[int] = None):
@@ -232,6 +281,7 @@ def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
   return v[0], lam[0]
 
 
+@_device_guarded
 def power_iteration_batched(matrices: Sequence[torch.Tensor], num_iters=100,
                             error_tolerance=1e-6, padding_starts=None):
   """Returns (lambda[batch], iters[batch])."""
@@ -256,6 +306,7 @@ def power_iteration_batched(matrices: Sequence[torch.Tensor], num_iters=100,
   return lam, its
 
 
+@_device_guarded
 def mat_power(mat_m: torch.Tensor, p: int) -> torch.Tensor:
   """DS:655-678: M^p with the reference's multiplication order."""
   _require_gpu(mat_m, "mat_power")
@@ -269,6 +320,7 @@ def mat_power(mat_m: torch.Tensor, p: int) -> torch.Tensor:
   return out
 
 
+@_device_guarded
 def matmul(a: torch.Tensor, b: torch.Tensor, transa: bool = False,
            transb: bool = False) -> torch.Tensor:
   """op(a) @ op(b) in float32 on the MFMA core (2-D, or 3-D batched)."""
@@ -304,6 +356,7 @@ def _ld_2d(shapes: np.ndarray, strides: np.ndarray) -> np.ndarray:
   return np.where(shapes[:, 0] > 1, strides[:, 0], np.maximum(shapes[:, 1], 1))
 
 
+@_device_guarded
 def gemm_grouped(items):
   """items: list of (a, b, c, transa, transb) with 2-D row-contiguous (possibly
   strided) tensors; c = op(a) @ op(b) for all of them in one launch per layout pair.
@@ -320,6 +373,7 @@ def gemm_grouped(items):
     if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2:
       _require_gpu(t, "gemm_grouped")
       raise ValueError("gemm_grouped expects 2-D tensors")
+  _same_device(A + B + Cm, "gemm_grouped")
   sa = np.array([t.shape for t in A], np.int64)
   sb = np.array([t.shape for t in B], np.int64)
   sc = np.array([t.shape for t in Cm], np.int64)
@@ -430,6 +484,7 @@ _SDESC_DT = np.dtype([("g", "u8"), ("layout", "i4"), ("d", "i4"), ("k", "i4"), (
                       ("stat_out", "u8"), ("lds", "i8")], align=True)
 
 
+@_device_guarded
 def stats_update_grouped(items, w1: float, w2: float):
   """items: list of (g_block, axis, stat_in, stat_out). One launch per layout.  Row-
   contiguous 2-D blocks (the common case) are described column-wise with NumPy; other
@@ -439,6 +494,7 @@ def stats_update_grouped(items, w1: float, w2: float):
   n_items = len(items)
   dev = items[0][0].device
   assert _SDESC_DT.itemsize == C.sizeof(StatsDesc)
+  _same_device([t for it in items for t in (it[0], it[2], it[3])], "gram_weighted_update")
   tbl = np.zeros(n_items, _SDESC_DT)
   keep = []
   fast = [i for i, it in enumerate(items)
@@ -522,6 +578,7 @@ def fd_update_root_batched(calls):
 # ---------------------------------------------------------------------------
 # fused _transform_grad for a whole tree (DS:3496-3625)
 # ---------------------------------------------------------------------------
+@_device_guarded
 def transform_grads_fused(items, cfg: dict):
   """items: list of dicts with contiguous float32 device tensors
   {grad, pgrad|None, param|None, diag_in|None, mom_in, dmom_in}; returns per item
@@ -636,6 +693,7 @@ def _quant_desc_table(n):
   return tbl, C.cast(tbl.ctypes.data, C.POINTER(QuantDesc))
 
 
+@_device_guarded
 def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False, out=None):
   """QuantizedValue.quantize (QU:45-95) for a list of float32 device tensors in one
   ps_quantize_f32 call.  Returns a list of (codes, diagonal | [], bucket_size);
@@ -694,6 +752,7 @@ def quantize_grouped(fvalues, quantized_dtype, extract_diagonal=False, out=None)
   return outs
 
 
+@_device_guarded
 def dequantize_grouped(items, out=None):
   """QuantizedValue.to_float (QU:97-113) for a list of (codes, diagonal | [], bucket_size)
   in one ps_dequantize_f32 call.  Returns float32 tensors of the codes' shapes."""
