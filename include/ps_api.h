@@ -28,10 +28,10 @@
  *     the *_workspace_bytes functions.  No hidden device allocation happens inside
  *     a compute call (a few KB of pinned host memory are allocated once per
  *     process for convergence flags).
- *   - Calls are stream-ordered.  ps_newton_root_batched_f32 additionally polls a
- *     pinned convergence flag (one event wait per Newton iteration, lagging the
- *     GPU by one iteration) because iteration counts are data dependent
- *     (DS:836-848, 862-864); all other entry points only enqueue work.
+ *   - Calls are stream-ordered and only enqueue work.  Data-dependent iteration counts
+ *     (DS:836-848, 862-864) are resolved on the device; the only entry points that wait
+ *     for the GPU are ps_eigh_* (one wait per Jacobi sweep) and any call made while
+ *     ps_profile_enable(1) is in force.
  *   - Numerical failure is data, not an error (DS:2936-2950): it is reported in
  *     the metrics table and the function still returns 0.
  */
@@ -70,6 +70,17 @@ enum {
   PS_M_RESERVED = 7,
   PS_METRICS_STRIDE = 8
 };
+
+/* Symmetry contract of the matrices handed to the power iteration / Newton root.
+ * The reference's functions take ANY square matrix (power_iteration DS:595-652 is a
+ * plain mat-vec loop, matrix_inverse_pth_root DS:845-846 plain products); symmetric
+ * inputs — which statistics are, except after int16 dequantization (DS:2746-2772) —
+ * allow computing only the upper tile triangle of every product / mat-vec pass.
+ *   PS_SYMMETRY_VERIFY  (default) every block is tested on the device, a_ij == a_ji bit
+ *                       for bit; blocks that fail take the full products.
+ *   PS_SYMMETRY_ASSUME  the caller guarantees exact symmetry (skips the test pass).
+ *   PS_SYMMETRY_GENERAL full products for every block. */
+enum { PS_SYMMETRY_VERIFY = 0, PS_SYMMETRY_ASSUME = 1, PS_SYMMETRY_GENERAL = 2 };
 
 int ps_version(void);
 const char* ps_error_string(int code);
@@ -124,15 +135,15 @@ int ps_stats_update_f32(void* stream, const float* g, int64_t rows, int64_t cols
  * out_lambda[b] (device) receives s of the last executed step, out_iters[b]
  * (device, may be NULL) the number of steps executed.  out_v (device, may be
  * NULL) receives the normalised vector, n_max floats per block.  Host arrays:
- * a, n, lda, padding_start. */
+ * a, n, lda, padding_start.  symmetry: PS_SYMMETRY_* (the matrix need not be symmetric). */
 size_t ps_power_iteration_workspace_bytes(int batch, const int32_t* n);
 int ps_power_iteration_batched_f32(void* stream, const float* const* a,
                                    const int32_t* n, const int32_t* lda,
                                    const int32_t* padding_start, int batch,
                                    int num_iters, float error_tolerance,
                                    float* out_lambda, int32_t* out_iters,
-                                   float* out_v, int32_t ldv, void* workspace,
-                                   size_t workspace_bytes);
+                                   float* out_v, int32_t ldv, int symmetry,
+                                   void* workspace, size_t workspace_bytes);
 
 /* ---- mat_power (DS:655-678): out = m^p, same multiplication order ------------ */
 size_t ps_mat_power_workspace_bytes(int n, int p);
@@ -149,16 +160,29 @@ int ps_mat_power_f32(void* stream, const float* m, int n, int ldm, int p,
  * diverged, all-padding blocks forced to 0.  A 1x1 block runs the same iteration
  * (as it does in the reference whenever it is padded to max_size, DS:2841-2843;
  * the reference's unpadded matrix_size == 1 branch raises, DS:850-855/907).
- * iters_executed_host (may be NULL): total Newton steps the host loop enqueued. */
+ * symmetry: PS_SYMMETRY_* above.
+ * The call only enqueues work (no host synchronisation): the whole iteration — init,
+ * products, loop control, retries, copy-out — runs in ONE persistent kernel whose
+ * workgroups pull (block, product, tile) items from device-side queues; a block's next
+ * product is released by the last tile of the products it depends on (DS:844-846), the
+ * loop condition of DS:836-848 is evaluated on the device by the last tile of a step.
+ * iters_executed_host (may be NULL) is set to -1 (the host no longer knows; per-block
+ * counts are in the metrics table). */
 size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
                                       const int32_t* p,
                                       const int32_t* padding_start);
+/* Number of leading Newton steps of every try in which the M update (DS:845) of an exactly
+ * symmetric block is computed in full and averaged with its transpose instead of being
+ * mirrored from its upper tile triangle (default 4; PS_NEWTON_AVG_STEPS overrides; see
+ * csrc/newton.hip TileFlags: mirrored everywhere is 3-5x less accurate than the reference's
+ * full products at cond ~1e4, averaged leading steps match them).  For FLOP accounting. */
+int ps_newton_averaged_steps(void);
 int ps_newton_root_batched_f32(void* stream, const float* const* a,
                                const int32_t* n, const int32_t* lda,
                                const int32_t* p, const int32_t* padding_start,
                                int batch, int num_iters, float ridge_epsilon,
                                float error_tolerance, int relative_matrix_epsilon,
-                               float* const* out, const int32_t* ldo,
+                               int symmetry, float* const* out, const int32_t* ldo,
                                float* metrics, void* workspace,
                                size_t workspace_bytes, int32_t* iters_executed_host);
 
@@ -171,7 +195,7 @@ int ps_newton_root_batched_maxev_f32(void* stream, const float* const* a,
                                      const int32_t* p, const int32_t* padding_start,
                                      int batch, int num_iters, float ridge_epsilon,
                                      float error_tolerance, const float* max_ev,
-                                     float* const* out, const int32_t* ldo,
+                                     int symmetry, float* const* out, const int32_t* ldo,
                                      float* metrics, void* workspace,
                                      size_t workspace_bytes, int32_t* iters_executed_host);
 

@@ -14,6 +14,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprecondition_amd.so")
 
 PS_METRICS_STRIDE = 8
+PS_SYMMETRY_VERIFY, PS_SYMMETRY_ASSUME, PS_SYMMETRY_GENERAL = 0, 1, 2
+_SYMMETRY = {"verify": PS_SYMMETRY_VERIFY, "assume": PS_SYMMETRY_ASSUME,
+             "general": PS_SYMMETRY_GENERAL}
+
+
+def symmetry_code(symmetry) -> int:
+  """'verify' (default: each block is tested on the device, a_ij == a_ji bit for bit, and
+  blocks that fail take the full products), 'assume' (caller guarantees exact symmetry) or
+  'general' (full products everywhere); see PS_SYMMETRY_* in include/ps_api.h."""
+  if isinstance(symmetry, str):
+    try:
+      return _SYMMETRY[symmetry]
+    except KeyError:
+      raise ValueError(f"symmetry must be one of {sorted(_SYMMETRY)}, got {symmetry!r}")
+  return int(symmetry)
 (PS_M_ERROR, PS_M_ITERS, PS_M_ERROR_RATIO, PS_M_MAX_EV, PS_M_RETRIES,
  PS_M_TOTAL_ITERS, PS_M_POWER_ITERS, PS_M_RESERVED) = range(8)
 
@@ -91,21 +106,22 @@ _SIGNATURES = {
     "ps_power_iteration_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
-                   C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+                   C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_size_t]),
     "ps_mat_power_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ps_mat_power_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                    C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "ps_newton_root_workspace_bytes":
         (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ps_newton_averaged_steps": (C.c_int, []),
     "ps_newton_root_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                    C.c_void_p]),
     "ps_newton_root_batched_maxev_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                    C.c_void_p]),
     "ps_eigh_root_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p]),

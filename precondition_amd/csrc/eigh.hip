@@ -747,7 +747,11 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       (rc = up(lo.rq, pl.rq_tiles.data(), sizeof(ETile) * pl.rq_tiles.size())))
     return rc;
   PS_HIP(hipStreamSynchronize(st));
-  if (relative_matrix_epsilon && (rc = pl.pip.upload(st, a, lda))) return rc;
+  if (relative_matrix_epsilon) {
+    if ((rc = pl.pip.upload(st, a, lda))) return rc;
+    // the reference's power iteration is a plain mat-vec loop on the raw input (DS:996-1001)
+    if ((rc = pl.pip.enqueue_symmetry(st, PS_SYMMETRY_VERIFY))) return rc;
+  }
 
   const int nsq = (int)pl.sq_tiles.size();
   const int npair = (int)pl.pair_tiles.size();

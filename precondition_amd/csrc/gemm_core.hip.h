@@ -44,6 +44,16 @@ __device__ inline f32x4 gload4(const float* p) {
 }
 __device__ inline float gload1(const float* p) { return *(const float PS_GLOBAL*)(p); }
 __device__ inline void gstore1(float* p, float v) { *(float PS_GLOBAL*)(p) = v; }
+// Write-through (sc1) store: the bytes leave this XCD's L2 at once, so a workgroup on
+// another CU / XCD can be handed the data inside a launch after the storing waves have
+// drained (s_waitcnt vmcnt(0)) and one lane has signalled (cdna_hip_programming.md G16 R1).
+__device__ inline void gstore1_wt(float* p, float v) {
+  __hip_atomic_store((float PS_GLOBAL*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool WT>
+__device__ inline void tstore1(float* p, float v) {
+  if (WT) gstore1_wt(p, v); else gstore1(p, v);
+}
 
 template <int BK>
 struct SmemCfg {
@@ -53,7 +63,10 @@ struct SmemCfg {
   static constexpr int MC_SIZE = BK * MC_LD;
   static constexpr int OP_SIZE = KC_SIZE > MC_SIZE ? KC_SIZE : MC_SIZE;
   static constexpr int STAGE_SIZE = 2 * OP_SIZE;    // A + B
-  static constexpr int TOTAL = 2 * STAGE_SIZE;      // double buffered (floats)
+  static constexpr int TOTAL = 2 * STAGE_SIZE;      // double buffered (floats): any layout pair
+  // exact footprint of one layout pair (the K loop packs A and B images back to back)
+  static constexpr int op_size(int layout) { return layout == 0 ? KC_SIZE : MC_SIZE; }
+  static constexpr int total(int la, int lb) { return 2 * (op_size(la) + op_size(lb)); }
 };
 
 struct Operand {
@@ -199,13 +212,22 @@ __device__ inline void zero_acc(f32x16 (&acc)[2][2]) {
 }
 
 // Accumulating form: acc += A * B over k in [0, Kext).
-template <int LA, int LB, int BK, bool GUARD>
+// DEEP = false: the global loads of K-tile t+1 are issued at the top of iteration t and
+//   written to the other LDS buffer at its bottom (one K-tile of MFMAs covers their latency).
+// DEEP = true: two register sets; the loads of K-tile t+2 are issued at the top of iteration
+//   t and the set holding tile t+1 (issued one iteration earlier) is written at its bottom, so
+//   a load has two K-tiles of MFMA time to land.  With BK = 16 one K-tile is only 2048
+//   MFMA-cycles per wavefront, less than the loaded-HBM latency: without the second set a
+//   workgroup's K loop cannot go faster than one memory round trip per K-tile even when the
+//   MFMA pipe is free (measured: 6900 cycles per K-tile whether 2 or 3 workgroups shared
+//   the CU).  Same summation order, bit-identical results.
+template <int LA, int LB, int BK, bool GUARD, bool DEEP = false>
 __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int Kext,
                                        float* smem, f32x16 (&acc)[2][2]) {
   using LdA = TileLoader<LA, BK, GUARD>;
   using LdB = TileLoader<LB, BK, GUARD>;
-  constexpr int OPS = SmemCfg<BK>::OP_SIZE;
-  constexpr int STG = SmemCfg<BK>::STAGE_SIZE;
+  constexpr int OPS = SmemCfg<BK>::op_size(LA);
+  constexpr int STG = SmemCfg<BK>::op_size(LA) + SmemCfg<BK>::op_size(LB);
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
@@ -213,34 +235,75 @@ __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int K
   const int wn = wave & 1;
 
   const int nk = (Kext + BK - 1) / BK;
-  f32x4 ra[LdA::NV], rb[LdB::NV];
-  LdA::load(A, 0, tid, ra);
-  LdB::load(B, 0, tid, rb);
-  LdA::store(smem, tid, ra);
-  LdB::store(smem + OPS, tid, rb);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    float* cur = smem + (kt & 1) * STG;
-    float* nxt = smem + ((kt + 1) & 1) * STG;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      LdA::load(A, (kt + 1) * BK, tid, ra);
-      LdB::load(B, (kt + 1) * BK, tid, rb);
+  if (!DEEP) {
+    f32x4 ra[LdA::NV], rb[LdB::NV];
+    LdA::load(A, 0, tid, ra);
+    LdB::load(B, 0, tid, rb);
+    LdA::store(smem, tid, ra);
+    LdB::store(smem + OPS, tid, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      float* cur = smem + (kt & 1) * STG;
+      float* nxt = smem + ((kt + 1) & 1) * STG;
+      const bool more = kt + 1 < nk;
+      if (more) {
+        LdA::load(A, (kt + 1) * BK, tid, ra);
+        LdB::load(B, (kt + 1) * BK, tid, rb);
+      }
+      compute_ktile<LA, LB, BK>(cur, cur + OPS, acc, wm, wn, lane);
+      if (more) {
+        LdA::store(nxt, tid, ra);
+        LdB::store(nxt + OPS, tid, rb);
+      }
+      __syncthreads();
     }
-    compute_ktile<LA, LB, BK>(cur, cur + OPS, acc, wm, wn, lane);
-    if (more) {
-      LdA::store(nxt, tid, ra);
-      LdB::store(nxt + OPS, tid, rb);
+    return;
+  }
+  // ---- two register sets, loop unrolled by two so that the set indices are static ----
+  f32x4 ra0[LdA::NV], rb0[LdB::NV], ra1[LdA::NV], rb1[LdB::NV];
+  LdA::load(A, 0, tid, ra0);
+  LdB::load(B, 0, tid, rb0);
+  if (nk > 1) {
+    LdA::load(A, BK, tid, ra1);
+    LdB::load(B, BK, tid, rb1);
+  }
+  LdA::store(smem, tid, ra0);
+  LdB::store(smem + OPS, tid, rb0);
+  __syncthreads();
+  float* s0 = smem;
+  float* s1 = smem + STG;
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even iteration: tile kt in s0; set 1 holds tile kt+1; set 0 is free -> tile kt+2
+    if (kt + 2 < nk) {
+      LdA::load(A, (kt + 2) * BK, tid, ra0);
+      LdB::load(B, (kt + 2) * BK, tid, rb0);
+    }
+    compute_ktile<LA, LB, BK>(s0, s0 + OPS, acc, wm, wn, lane);
+    if (kt + 1 < nk) {
+      LdA::store(s1, tid, ra1);
+      LdB::store(s1 + OPS, tid, rb1);
+    }
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd iteration: tile kt+1 in s1; set 0 holds tile kt+2; set 1 is free -> tile kt+3
+    if (kt + 3 < nk) {
+      LdA::load(A, (kt + 3) * BK, tid, ra1);
+      LdB::load(B, (kt + 3) * BK, tid, rb1);
+    }
+    compute_ktile<LA, LB, BK>(s1, s1 + OPS, acc, wm, wn, lane);
+    if (kt + 2 < nk) {
+      LdA::store(s0, tid, ra0);
+      LdB::store(s0 + OPS, tid, rb0);
     }
     __syncthreads();
   }
 }
 
-template <int LA, int LB, int BK, bool GUARD>
+template <int LA, int LB, int BK, bool GUARD, bool DEEP = false>
 __device__ inline void gemm_tile(const Operand& A, const Operand& B, int Kext,
                                  float* smem, f32x16 (&acc)[2][2]) {
   zero_acc(acc);
-  gemm_tile_accum<LA, LB, BK, GUARD>(A, B, Kext, smem, acc);
+  gemm_tile_accum<LA, LB, BK, GUARD, DEEP>(A, B, Kext, smem, acc);
 }
 
 // Accumulator element -> (row, col) inside the 128x128 tile (C/D layout of the
@@ -258,6 +321,7 @@ __device__ inline int acc_col(int wn, int tn, int lane) {
 // in two 64-row halves (stride 129: conflict-free both ways) so that the global
 // stores are contiguous 256-byte runs.  smem must hold 64*129 floats and be free
 // (gemm_tile ends with a barrier).  All 256 threads must call.
+template <bool WT = false>
 __device__ inline void store_tile_transposed(const f32x16 (&acc)[2][2], float* smem,
                                              float* dst, float* dst2, float alpha, int ld,
                                              int row0, int col0) {
@@ -284,8 +348,66 @@ __device__ inline void store_tile_transposed(const f32x16 (&acc)[2][2], float* s
       const int c = e >> 6, lr = e & 63;
       const float v = smem[lr * TLD + c];
       const int64_t o = (int64_t)(row0 + c) * ld + col0 + h * 64 + lr;
-      gstore1(dst + o, v);
-      if (dst2 != nullptr) gstore1(dst2 + o, __fmul_rn(alpha, v));
+      tstore1<WT>(dst + o, v);
+      if (dst2 != nullptr) tstore1<WT>(dst2 + o, __fmul_rn(alpha, v));
+    }
+    __syncthreads();
+  }
+}
+
+// Vectorised mirror store (16-byte LDS and global accesses).  Same contract as
+// store_tile_transposed; smem must hold 64*132 floats.  The accumulator layout gives every
+// lane 4 CONSECUTIVE tile rows per register quad at one tile column, i.e. 4 consecutive
+// elements of a row of the TRANSPOSED tile: the transposed image T[c][r] is written with
+// ds_write_b128 (row stride 132 floats: 8 lanes x 16 B cover the 32 banks), read back with
+// ds_read_b128 along r, and stored as 512-byte runs of the mirrored tile's rows.  The tile is
+// staged in two halves by accumulator column block tn (64 tile columns each, all four
+// wavefronts take part in both).
+template <bool WT = false>
+__device__ inline void store_tile_transposed_v4(const f32x16 (&acc)[2][2], float* smem,
+                                                float* dst, float* dst2, float alpha, int ld,
+                                                int row0, int col0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int TLD = 132;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    // T row ci = wn*32 + (lane&31)  <->  tile column wn*64 + h*32 + (lane&31)
+    float* trow = smem + (wn * 32 + (lane & 31)) * TLD + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {acc[tm][h][4 * g + 0], acc[tm][h][4 * g + 1], acc[tm][h][4 * g + 2],
+                   acc[tm][h][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(trow + tm * 32 + 8 * g) = v;
+      }
+    __syncthreads();
+    // thread -> (T row ci = (tid>>5) + 8k, 4 consecutive r = 4*(tid&31)..)
+    const int r4 = (tid & 31) * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ci = (tid >> 5) + 8 * k;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(smem + ci * TLD + r4);
+      const int c = (ci >> 5) * 64 + h * 32 + (ci & 31);  // tile column = mirrored tile's row
+      const int64_t o = (int64_t)(row0 + c) * ld + col0 + r4;
+      if (WT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gstore1_wt(dst + o + e, v[e]);
+      } else {
+        *(f32x4 PS_GLOBAL*)(dst + o) = v;
+      }
+      if (dst2 != nullptr) {
+        f32x4 w = {__fmul_rn(alpha, v[0]), __fmul_rn(alpha, v[1]), __fmul_rn(alpha, v[2]),
+                   __fmul_rn(alpha, v[3])};
+        if (WT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gstore1_wt(dst2 + o + e, w[e]);
+        } else {
+          *(f32x4 PS_GLOBAL*)(dst2 + o) = w;
+        }
+      }
     }
     __syncthreads();
   }

@@ -9,18 +9,36 @@
 // checks and is the reference's own padding semantics (identity and matrix are
 // masked at DS:777-783).
 //
-// Per host iteration the stream receives, for the whole batch at once:
-//   stage 0..S-1 : newton_stage_kernel — one 128x128 output tile per workgroup,
-//                  products of the binary-powering chain of mat_power (DS:655-678,
-//                  same multiplication order, minus the exact "@ I" and the unused
-//                  trailing square), H <- H Mi (DS:846) in stage 0, and as the last
-//                  product of each block M <- Mi^p M (DS:845) whose epilogue also
-//                  writes the next Mi (DS:844) and max|M - I| (DS:847);
-//   control      : one thread per block advances the loop state of DS:836-848 /
-//                  DS:858-885 (ratio guard, retry with ridge*10^i) on the device.
-// Finished blocks cost nothing (their tiles exit at once).  The host only polls
-// "how many blocks are still running" one iteration behind the GPU.
+// One Newton step of a block is a small dependency graph of n^3 products
+// (DS:844-846; mat_power DS:655-678 with the same multiplication order, minus the
+// exact "@ I" and the unused trailing square):
+//     P0 : H' = H Mi                                  (needs Mi of this step)
+//     P1..P(L-1) : binary-powering chain Mi^p          (each needs the previous one)
+//     PL : M' = Mi^p M; epilogue writes the next Mi and max|M' - I|   (needs P(L-1), P0)
+// followed by the loop control of DS:836-848 / DS:858-885 (ratio guard, retry with
+// ridge*10^i).  Blocks are independent of each other.
+//
+// Execution A (PS_NEWTON_PERSISTENT=1) = ONE persistent kernel for the whole call
+// (newton_persistent_kernel):
+// a resident grid of workgroups pulls (block, product, 128x128 tile) items from
+// per-XCD device queues.  The last tile of a product to arrive (an agent-scope counter)
+// releases the products that depend on it; the last tile of a step evaluates the loop
+// control for its block and releases the next step, a retry (re-initialisation with a
+// larger ridge) or the copy-out.  There is no global barrier and no host round trip:
+// a block advances as fast as its own tiles complete, blocks that converge early simply
+// stop producing items, and the tail of one product overlaps the head of others.
+// Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16: payload tiles
+// are stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), the
+// workgroup's barrier, one lane's agent-scope release + counter add; the consumer
+// pops an item (relaxed agent atomics), ONE agent-scope acquire, then plain loads.
+// Mutable per-block loop state is only touched through agent-scope atomics.
+//
+// Execution B (default, the faster one today — see persistent_mode() below) = staged: one
+// launch per product stage for the whole batch + a control launch per step, the host
+// polling "blocks still running" one iteration behind the GPU.  Both run the same tile
+// code and produce bit-identical results (tests/test_gpu_round2.py).
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,11 +54,14 @@ namespace psk {
 constexpr int NBK = 16;        // K-tile depth of the Newton products
 constexpr int MAX_PROD = 8;    // products per Newton step (p <= 64)
 constexpr int NTEMP = 5;
+constexpr int NQ = 8;          // item queues (one per XCD)
+constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 4;
+
 
 enum Phase { PH_INIT = 0, PH_ACTIVE = 1, PH_DONE = 2 };
 enum BufId { ID_MI = 0, ID_MCUR, ID_MNEXT, ID_HCUR, ID_HNEXT, ID_T0 };
-enum Epi { EPI_PLAIN = 0, EPI_NEWM = 1 };
 
+// Immutable after upload.
 struct NewtonBlock {
   const float* a;
   float* out;
@@ -49,21 +70,32 @@ struct NewtonBlock {
   float* Mi;
   float* T[NTEMP];
   float* sumsq_partial;  // [npad/128 * npad/128] partial sums of ||D||_F^2
+  const int* asym;       // *asym != 0: not exactly symmetric -> full products
   int n;        // effective size
   int n_full;   // rows/cols of a and out
   int lda, ldo, npad, p;
   float alpha, one_minus_alpha, inv_p;
-  // loop state
+  int nprod;    // products per step (L + 1)
+  int queue;    // item queue of this block (persistent execution)
+  short pa[MAX_PROD], pb[MAX_PROD], pc[MAX_PROD];  // operand / result buffer ids
+};
+
+// Mutable loop state (DS:836-848 carry + DS:858-885 retry state).  Staged execution:
+// plain accesses ordered by kernel boundaries.  Persistent execution: agent-scope
+// atomics only.
+struct NewtonState {
   int phase, cur, it, tries, total_iters, result_sel;
   float err, ratio, max_ev, ridge, ridge_try;
   unsigned err_bits;
   int power_iters;
-  int symmetric;  // products are computed on the upper tile triangle and mirrored
+  // arrival counters of the persistent execution
+  unsigned c_init1, c_init2, c_join, c_copy;
+  unsigned c_prod[MAX_PROD];
 };
 
 struct NewtonTask {
   int block;
-  short a_id, b_id, c_id, epi;
+  int prod;
 };
 
 struct TileEntry {
@@ -78,72 +110,160 @@ struct HostStatus {
   int pad;
 };
 
-__device__ inline float* resolve(NewtonBlock* nb, int id) {
+// Mi = (1-alpha) I + alpha M.  For p = 1 the M update multiplies by Mi itself (the
+// powering chain is empty) while its epilogue writes the next Mi: those blocks alternate
+// Mi between nb->Mi and the (otherwise unused) last powering temporary by step parity.
+__device__ inline float* mi_buf(const NewtonBlock* nb, int cur) {
+  return (nb->p == 1 && cur) ? nb->T[NTEMP - 1] : nb->Mi;
+}
+
+// z^(1/p) of DS:873.  One out-of-line copy, so that every kernel that initialises a try
+// (staged and persistent execution) rounds it identically.
+__device__ __attribute__((noinline)) float pth_root_of_scale(float z, float inv_p) {
+  return powf(z, inv_p);
+}
+
+__device__ inline float* resolve(const NewtonBlock* nb, int id, int cur) {
   switch (id) {
-    case ID_MI: return nb->Mi;
-    case ID_MCUR: return nb->M[nb->cur];
-    case ID_MNEXT: return nb->M[nb->cur ^ 1];
-    case ID_HCUR: return nb->H[nb->cur];
-    case ID_HNEXT: return nb->H[nb->cur ^ 1];
+    case ID_MI: return mi_buf(nb, cur);
+    case ID_MCUR: return nb->M[cur];
+    case ID_MNEXT: return nb->M[cur ^ 1];
+    case ID_HCUR: return nb->H[cur];
+    case ID_HNEXT: return nb->H[cur ^ 1];
     default: return nb->T[id - ID_T0];
   }
 }
 
-// ---- products -----------------------------------------------------------------
-template <int BK>
-__global__ __launch_bounds__(256, 2) void newton_stage_kernel(
-    NewtonBlock* blocks, const NewtonTask* tasks, const TileEntry* tiles,
-    int ntiles) {
-  extern __shared__ __align__(16) float smem[];  // SmemCfg<BK>::TOTAL floats
-  const TileEntry te = tiles[xcd_remap(blockIdx.x, ntiles)];
-  const NewtonTask tk = tasks[te.task];
-  NewtonBlock* nb = &blocks[tk.block];
-  if (nb->phase != PH_ACTIVE) return;
-  const int n = nb->n, ld = nb->npad;
-  Operand A{resolve(nb, tk.a_id), ld, te.tm * TILE, ld, ld, true};
-  Operand B{resolve(nb, tk.b_id), ld, te.tn * TILE, ld, ld, true};
-  float* C = resolve(nb, tk.c_id);
-  f32x16 acc[2][2];
-  gemm_tile<KC, MC, BK, false>(A, B, n, smem, acc);
+// ---- one 128x128 tile of one product --------------------------------------------
+// WT: write-through stores (see PERSIST_WT).  flags:
+//   TF_MIRROR   also store the transposed tile (symmetric products: only tiles tm <= tn run)
+//   TF_RAW      store the product tile to C only (no M-update epilogue): first pass of an
+//               averaged M update
+//   TF_AVG      before the epilogue, replace the accumulators X by (X + Y^T) / 2 where Y is
+//               the tile at the transposed position (tn, tm) of C, written by a TF_RAW pass
+//   TF_SELFAVG  diagonal tile of an averaged M update: X is stored raw, then averaged with
+//               its own transpose
+// All 256 threads; ends without a barrier.
+//
+// Why an averaged M update (M' = (X + X^T)/2, X = Mi^p M computed in full): the iterates
+// commute only up to rounding, so X carries an antisymmetric part K ~ [Mi^p, M]/2.  Copying
+// the upper triangle over the lower (TF_MIRROR) turns K into a SYMMETRIC perturbation of the
+// same size, which moves eigenvalues at first order, while K itself is harmless (x^T K x = 0)
+// and averaging removes it.  Measured (tools/dev_sym_accuracy.py, cond 7e3, p = 4, float32):
+// full products (the reference) 1.2e-4 from the float64 root, mirrored everywhere 3.6e-4,
+// averaged M update in the first 2 steps 1.5e-4, in the first 4 or in all steps 1.0e-4; the
+// H update and the squares (exactly symmetric for symmetric input) can stay mirrored.
+enum TileFlags { TF_MIRROR = 1, TF_RAW = 2, TF_AVG = 4, TF_SELFAVG = 8 };
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// acc <- (acc + P^T) / 2 with P the 128x128 tile of C at (prow0, pcol0) (the transposed
+// position of the accumulator tile).  P's rows are staged through LDS in two halves with the
+// layout of store_tile_transposed_v4's image (T row = accumulator column), so that global
+// reads are 512-byte runs and every LDS access is 16 bytes.  smem: 64*132 floats.
+__device__ inline void average_with_transposed_tile(f32x16 (&acc)[2][2], float* smem,
+                                                     const float* C, int ld, int prow0,
+                                                     int pcol0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  if (tk.epi == EPI_PLAIN) {
+  constexpr int TLD = 132;
+  const int r4 = (tid & 31) * 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ci = (tid >> 5) + 8 * k;
+      const int c = (ci >> 5) * 64 + h * 32 + (ci & 31);
+      *reinterpret_cast<f32x4*>(smem + ci * TLD + r4) =
+          gload4(C + (int64_t)(prow0 + c) * ld + pcol0 + r4);
+    }
+    __syncthreads();
+    const float* trow = smem + (wn * 32 + (lane & 31)) * TLD + wm * 64 + 4 * (lane >> 5);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(trow + tm * 32 + 8 * g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = te.tm * TILE + acc_row(wm, tm, r, lane);
-          const int col = te.tn * TILE + acc_col(wn, tn, lane);
-          gstore1(C + (int64_t)row * ld + col, acc[tm][tn][r]);
-        }
-    if (te.tm != te.tn && nb->symmetric)
-      store_tile_transposed(acc, smem, C, nullptr, 0.f, ld, te.tn * TILE, te.tm * TILE);
-    return;
+        for (int j = 0; j < 4; ++j)
+          acc[tm][h][4 * g + j] = __fmul_rn(0.5f, __fadd_rn(acc[tm][h][4 * g + j], pv[j]));
+      }
+    __syncthreads();
   }
-  // EPI_NEWM: C = new M; Mi = (1-alpha) I + alpha M (DS:844, two roundings as
+}
+
+template <int BK, bool WT, bool DEEP>
+__device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, NewtonState* st, int prod,
+                                           int cur, int tm_, int tn_, int flags,
+                                           float* smem, unsigned long long* stamp = nullptr) {
+  const bool mirror = (flags & TF_MIRROR) != 0;
+  const int n = nb->n, ld = nb->npad;
+  Operand A{resolve(nb, nb->pa[prod], cur), ld, tm_ * TILE, ld, ld, true};
+  Operand B{resolve(nb, nb->pb[prod], cur), ld, tn_ * TILE, ld, ld, true};
+  float* C = resolve(nb, nb->pc[prod], cur);
+  f32x16 acc[2][2];
+  gemm_tile<KC, MC, BK, false, DEEP>(A, B, n, smem, acc);
+
+  // Addressing of the direct stores: everything but a per-lane 32-bit offset is wave-uniform
+  // (kept in SGPRs), so the 64 (or 128) stores of the epilogue need no per-store address
+  // registers: element r of block (tm, tn) of this wavefront lies at
+  //   C[(tile_row0 + wm*64 + tm*32 + (r&3) + 8*(r>>2)) * ld + tile_col0 + wn*64 + tn*32] + lane_off
+  // with lane_off = 4*(lane>>5)*ld + (lane&31).
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lane_off = 4 * (lane >> 5) * ld + (lane & 31);
+  const int lane_row = 4 * (lane >> 5), lane_col = lane & 31;
+  if (stamp != nullptr && tid == 0) *stamp = __builtin_amdgcn_s_memrealtime();  // dev profile
+  const bool plain = prod != nb->nprod - 1 || (flags & TF_RAW) != 0;
+  if (plain || (flags & TF_SELFAVG) != 0) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        float* blk = C + (int64_t)(tm_ * TILE + wm * 64 + tm * 32) * ld + tn_ * TILE + wn * 64 + tn * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tstore1<WT>(blk + (int64_t)((r & 3) + 8 * (r >> 2)) * ld + lane_off, acc[tm][tn][r]);
+      }
+    if (plain) {
+      if (mirror)
+        store_tile_transposed_v4<WT>(acc, smem, C, nullptr, 0.f, ld, tn_ * TILE, tm_ * TILE);
+      return;
+    }
+    // TF_SELFAVG: the raw tile is in C; every lane's stores must have landed before the
+    // transposed read-back (same CU: workgroup-scope visibility through its own L1/L2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if ((flags & (TF_AVG | TF_SELFAVG)) != 0)
+    average_with_transposed_tile(acc, smem, C, ld, tn_ * TILE, tm_ * TILE);
+  // M update: C = new M; Mi = (1-alpha) I + alpha M (DS:844, two roundings as
   // written there); err = max |M - I| (DS:847) with the identity masked to n.
-  float* Mi = nb->Mi;
+  float* Mi = mi_buf(nb, cur ^ 1);  // the Mi of the NEXT step
   const float alpha = nb->alpha, oma = nb->one_minus_alpha;
   unsigned emax = 0;
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int tn = 0; tn < 2; ++tn) {
+      const int brow = tm_ * TILE + wm * 64 + tm * 32, bcol = tn_ * TILE + wn * 64 + tn * 32;
+      float* blk = C + (int64_t)brow * ld + bcol;
+      float* blk_i = Mi + (int64_t)brow * ld + bcol;
+      // the identity touches this block only if it straddles the diagonal (uniform test)
+      const bool on_diag = brow == bcol;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = te.tm * TILE + acc_row(wm, tm, r, lane);
-        const int col = te.tn * TILE + acc_col(wn, tn, lane);
+        const int rr = (r & 3) + 8 * (r >> 2);
         const float v = acc[tm][tn][r];
-        const float ident = (row == col && row < n) ? 1.f : 0.f;
-        gstore1(C + (int64_t)row * ld + col, v);
-        gstore1(Mi + (int64_t)row * ld + col,
-                __fadd_rn(__fmul_rn(oma, ident), __fmul_rn(alpha, v)));
+        const float ident =
+            (on_diag && rr + lane_row == lane_col && brow + rr + lane_row < n) ? 1.f : 0.f;
+        tstore1<WT>(blk + (int64_t)rr * ld + lane_off, v);
+        tstore1<WT>(blk_i + (int64_t)rr * ld + lane_off,
+                    __fadd_rn(__fmul_rn(oma, ident), __fmul_rn(alpha, v)));
         const unsigned e = abs_bits(__fsub_rn(v, ident));
         emax = e > emax ? e : emax;
       }
+    }
   emax = wave_max_u32(emax);
   unsigned* red = reinterpret_cast<unsigned*>(smem);
   if (lane == 0) red[wave] = emax;
@@ -153,32 +273,59 @@ __global__ __launch_bounds__(256, 2) void newton_stage_kernel(
     m = red[1] > m ? red[1] : m;
     m = red[2] > m ? red[2] : m;
     m = red[3] > m ? red[3] : m;
-    atomicMax(&nb->err_bits, m);
+    atomicMax(&st->err_bits, m);
   }
-  if (te.tm != te.tn && nb->symmetric) {
+  if (mirror) {
     __syncthreads();  // red[] lives in smem
     // off-diagonal tile: identity is 0 there, so Mi = fl(alpha * M)
-    store_tile_transposed(acc, smem, C, Mi, alpha, ld, te.tn * TILE, te.tm * TILE);
+    store_tile_transposed_v4<WT>(acc, smem, C, Mi, alpha, ld, tn_ * TILE, tm_ * TILE);
   }
 }
 
-// ---- (re)initialisation of a try (DS:866-875) -----------------------------------
-// pass 1: per 128x128 tile, partial sum of squares of D = A + ridge_try * I.
-__global__ __launch_bounds__(256) void newton_init1_kernel(NewtonBlock* blocks,
-                                                           const TileEntry* tiles) {
-  __shared__ float red[4];
-  const TileEntry te = tiles[blockIdx.x];
-  NewtonBlock* nb = &blocks[te.task];
-  if (nb->phase != PH_INIT) return;
+// Tile (tm <= tn) of a product, both executions.  Blocks that are not exactly symmetric
+// compute the transposed position as a product of its own; symmetric blocks mirror it, except
+// the M update of the first steps of a try (avg), which is computed in full and averaged
+// with its transpose (see TileFlags).
+template <int BK, bool WT, bool DEEP>
+__device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, NewtonState* st, int prod,
+                                           int cur, int avg, int tm, int tn, float* smem,
+                                           unsigned long long* stamp = nullptr) {
+  const bool sym = *nb->asym == 0;
+  int passes = 1, f0 = 0, f1 = 0;
+  if (!sym) {
+    passes = tm != tn ? 2 : 1;
+  } else if (!(avg && prod == nb->nprod - 1)) {
+    f0 = tm != tn ? TF_MIRROR : 0;
+  } else if (tm == tn) {
+    f0 = TF_SELFAVG;
+  } else {
+    passes = 2; f0 = TF_RAW; f1 = TF_AVG | TF_MIRROR;
+  }
+  // one copy of the tile code (a rolled loop): two inlined copies cost 90 VGPRs
+#pragma unroll 1
+  for (int pass = 0; pass < passes; ++pass) {
+    if (pass) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first pass's tile is re-read
+      __syncthreads();
+    }
+    newton_product_tile<BK, WT, DEEP>(nb, st, prod, cur, pass ? tn : tm, pass ? tm : tn,
+                                      pass ? f1 : f0, smem, stamp);
+  }
+}
+
+// ---- (re)initialisation of a try (DS:866-875), tile bodies ----------------------------
+// pass 1: partial sum of squares of D = A + ridge_try * I over one 128x128 tile.
+template <bool WT>
+__device__ inline void newton_init1_tile(const NewtonBlock* nb, float ridge_try, int tm,
+                                         int tn, float* red) {
   const int n = nb->n, tid = threadIdx.x;
-  const float rt = nb->ridge_try;
   float ss = 0.f;
   const int tpr = nb->npad / TILE;
   for (int e = tid; e < TILE * TILE; e += 256) {
-    const int row = te.tm * TILE + e / TILE, col = te.tn * TILE + e % TILE;
+    const int row = tm * TILE + e / TILE, col = tn * TILE + e % TILE;
     if (row < n && col < n) {
-      float d = nb->a[(int64_t)row * nb->lda + col];
-      if (row == col) d = __fadd_rn(d, rt);
+      float d = gload1(nb->a + (int64_t)row * nb->lda + col);
+      if (row == col) d = __fadd_rn(d, ridge_try);
       ss += d * d;
     }
   }
@@ -186,33 +333,32 @@ __global__ __launch_bounds__(256) void newton_init1_kernel(NewtonBlock* blocks,
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
   if (tid == 0)
-    nb->sumsq_partial[te.tm * tpr + te.tn] = ((red[0] + red[1]) + red[2]) + red[3];
+    tstore1<WT>(nb->sumsq_partial + tm * tpr + tn, ((red[0] + red[1]) + red[2]) + red[3]);
 }
 
 // pass 2: z, M0 = D z, H0 = I z^(1/p), Mi0, err0 = max|M0 - I|.
-__global__ __launch_bounds__(256) void newton_init2_kernel(NewtonBlock* blocks,
-                                                           const TileEntry* tiles) {
-  __shared__ float bc;
-  __shared__ unsigned red[4];
-  const TileEntry te = tiles[blockIdx.x];
-  NewtonBlock* nb = &blocks[te.task];
-  if (nb->phase != PH_INIT) return;
+template <bool WT>
+__device__ inline void newton_init2_tile(const NewtonBlock* nb, NewtonState* st,
+                                         float ridge_try, int cur, int tm, int tn,
+                                         float* scratch) {
+  float* bc = scratch;
+  unsigned* red = reinterpret_cast<unsigned*>(scratch + 4);
   const int n = nb->n, ld = nb->npad, tid = threadIdx.x;
   const int tpr = ld / TILE;
-  const float sumsq = fixed_order_sum_wave0(nb->sumsq_partial, tpr * tpr, tid, &bc);
+  const float sumsq = fixed_order_sum_wave0(nb->sumsq_partial, tpr * tpr, tid, bc);
   const float z = __fdiv_rn((float)(1 + nb->p), __fmul_rn(2.f, sqrtf(sumsq)));  // DS:870
-  const float h0 = powf(z, nb->inv_p);                                          // DS:873
-  const float rt = nb->ridge_try, alpha = nb->alpha, oma = nb->one_minus_alpha;
-  float* M = nb->M[nb->cur];
-  float* H0 = nb->H[nb->cur];
-  float* H1 = nb->H[nb->cur ^ 1];
-  float* Mi = nb->Mi;
+  const float h0 = pth_root_of_scale(z, nb->inv_p);                             // DS:873
+  const float rt = ridge_try, alpha = nb->alpha, oma = nb->one_minus_alpha;
+  float* M = nb->M[cur];
+  float* H0 = nb->H[cur];
+  float* H1 = nb->H[cur ^ 1];
+  float* Mi = mi_buf(nb, cur);
   unsigned emax = 0;
   for (int e = tid; e < TILE * TILE; e += 256) {
-    const int row = te.tm * TILE + e / TILE, col = te.tn * TILE + e % TILE;
+    const int row = tm * TILE + e / TILE, col = tn * TILE + e % TILE;
     float m = 0.f, mi = 0.f, h = 0.f;
     if (row < n && col < n) {
-      float d = nb->a[(int64_t)row * nb->lda + col];
+      float d = gload1(nb->a + (int64_t)row * nb->lda + col);
       const float ident = row == col ? 1.f : 0.f;
       if (row == col) d = __fadd_rn(d, rt);                 // DS:869
       m = __fmul_rn(d, z);                                   // DS:871
@@ -222,10 +368,10 @@ __global__ __launch_bounds__(256) void newton_init2_kernel(NewtonBlock* blocks,
       emax = eb > emax ? eb : emax;
     }
     const int64_t o = (int64_t)row * ld + col;
-    M[o] = m;
-    Mi[o] = mi;
-    H0[o] = h;
-    H1[o] = h;
+    tstore1<WT>(M + o, m);
+    tstore1<WT>(Mi + o, mi);
+    tstore1<WT>(H0 + o, h);
+    tstore1<WT>(H1 + o, h);
   }
   emax = wave_max_u32(emax);
   if ((tid & 63) == 0) red[tid >> 6] = emax;
@@ -235,56 +381,112 @@ __global__ __launch_bounds__(256) void newton_init2_kernel(NewtonBlock* blocks,
     m = red[1] > m ? red[1] : m;
     m = red[2] > m ? red[2] : m;
     m = red[3] > m ? red[3] : m;
-    atomicMax(&nb->err_bits, m);
+    atomicMax(&st->err_bits, m);
   }
 }
 
+// Copy-out of one 128x128 tile of the result (DS:902-907): H[sel] cropped to n, zero
+// beyond it up to n_full.
+__device__ inline void newton_copy_tile(const NewtonBlock* nb, int sel, int tm, int tn) {
+  const int n = nb->n, nf = nb->n_full, tid = threadIdx.x;
+  const float* H = nb->H[sel];
+  for (int e = tid; e < TILE * TILE; e += 256) {
+    const int row = tm * TILE + e / TILE, col = tn * TILE + e % TILE;
+    if (row < nf && col < nf)
+      gstore1(nb->out + (int64_t)row * nb->ldo + col,
+              (row < n && col < n) ? gload1(H + (int64_t)row * nb->npad + col) : 0.f);
+  }
+}
+
+__device__ inline void write_metrics(float* metrics, int b, float err, int it, float ratio,
+                                     int tries, int total_iters, float max_ev, int pit) {
+  float* m = metrics + (int64_t)b * PS_METRICS_STRIDE;
+  m[PS_M_ERROR] = err; m[PS_M_ITERS] = (float)it; m[PS_M_ERROR_RATIO] = ratio;
+  m[PS_M_RETRIES] = (float)tries; m[PS_M_TOTAL_ITERS] = (float)total_iters;
+  m[PS_M_MAX_EV] = max_ev; m[PS_M_POWER_ITERS] = (float)pit; m[PS_M_RESERVED] = 0.f;
+}
+
+// ==================================================================================
+// staged execution (PS_NEWTON_PERSISTENT=0)
+// ==================================================================================
+template <int BK>
+__global__ __launch_bounds__(256, 3) void newton_stage_kernel(
+    const NewtonBlock* blocks, NewtonState* states, const NewtonTask* tasks,
+    const TileEntry* tiles, int ntiles, int navg) {
+  extern __shared__ __align__(16) float smem[];  // SmemCfg<BK>::TOTAL floats
+  const TileEntry te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  const NewtonTask tk = tasks[te.task];
+  const NewtonBlock* nb = &blocks[tk.block];
+  NewtonState* st = &states[tk.block];
+  if (st->phase != PH_ACTIVE) return;
+  newton_product_item<BK, false, false>(nb, st, tk.prod, st->cur, st->it < navg, te.tm, te.tn, smem);
+}
+
+__global__ __launch_bounds__(256) void newton_init1_kernel(const NewtonBlock* blocks,
+                                                           const NewtonState* states,
+                                                           const TileEntry* tiles) {
+  __shared__ float red[4];
+  const TileEntry te = tiles[blockIdx.x];
+  if (states[te.task].phase != PH_INIT) return;
+  newton_init1_tile<false>(&blocks[te.task], states[te.task].ridge_try, te.tm, te.tn, red);
+}
+
+__global__ __launch_bounds__(256) void newton_init2_kernel(const NewtonBlock* blocks,
+                                                           NewtonState* states,
+                                                           const TileEntry* tiles) {
+  __shared__ float scratch[8];
+  const TileEntry te = tiles[blockIdx.x];
+  NewtonState* st = &states[te.task];
+  if (st->phase != PH_INIT) return;
+  newton_init2_tile<false>(&blocks[te.task], st, st->ridge_try, st->cur, te.tm, te.tn, scratch);
+}
+
 // ---- loop control (single workgroup, one thread per block, grid-stride) --------
-__device__ inline void finish_try(NewtonBlock* nb, float ridge_eps_unused) {
+__device__ inline void finish_try(NewtonState* st) {
   // DS:878-882: error, is_converged select, retry decision.
-  const bool conv = nb->ratio < 1.2f;
-  nb->result_sel = conv ? nb->cur : (nb->cur ^ 1);
-  nb->tries += 1;
-  if (nb->err > 0.05f && nb->tries < 6) {
-    nb->phase = PH_INIT;
+  const bool conv = st->ratio < 1.2f;
+  st->result_sel = conv ? st->cur : (st->cur ^ 1);
+  st->tries += 1;
+  if (st->err > 0.05f && st->tries < 6) {
+    st->phase = PH_INIT;
     const float pow10[6] = {1.f, 10.f, 100.f, 1000.f, 10000.f, 100000.f};
-    nb->ridge_try = __fmul_rn(nb->ridge, pow10[nb->tries]);  // DS:869
+    st->ridge_try = __fmul_rn(st->ridge, pow10[st->tries]);  // DS:869
   } else {
-    nb->phase = PH_DONE;
+    st->phase = PH_DONE;
   }
 }
 
 // mode 0: after init2 (enter the inner loop, DS:874-877); mode 1: after one
 // Newton step (DS:848 carry + DS:836-840 condition).
 __global__ __launch_bounds__(256) void newton_control_kernel(
-    NewtonBlock* blocks, int nblocks, int mode, int num_iters, float tol, int gen,
+    NewtonState* states, int nblocks, int mode, int num_iters, float tol, int gen,
     HostStatus* status) {
   __shared__ int s_nd, s_ni;
   if (threadIdx.x == 0) { s_nd = 0; s_ni = 0; }
   __syncthreads();
   int nd = 0, ni = 0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    NewtonBlock* nb = &blocks[b];
-    if (mode == 0 && nb->phase == PH_INIT) {
-      nb->err = __uint_as_float(nb->err_bits);
-      nb->err_bits = 0;
-      nb->ratio = 1.f;
-      nb->it = 0;
-      const bool cont = nb->it < num_iters && nb->err > tol && nb->ratio < 1.2f;
-      if (cont) nb->phase = PH_ACTIVE; else finish_try(nb, 0.f);
-    } else if (mode == 1 && nb->phase == PH_ACTIVE) {
-      const float new_err = __uint_as_float(nb->err_bits);
-      nb->err_bits = 0;
-      nb->ratio = __fdiv_rn(new_err, nb->err);
-      nb->err = new_err;
-      nb->it += 1;
-      nb->total_iters += 1;
-      nb->cur ^= 1;
-      const bool cont = nb->it < num_iters && nb->err > tol && nb->ratio < 1.2f;
-      if (!cont) finish_try(nb, 0.f);
+    NewtonState* st = &states[b];
+    if (mode == 0 && st->phase == PH_INIT) {
+      st->err = __uint_as_float(st->err_bits);
+      st->err_bits = 0;
+      st->ratio = 1.f;
+      st->it = 0;
+      const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
+      if (cont) st->phase = PH_ACTIVE; else finish_try(st);
+    } else if (mode == 1 && st->phase == PH_ACTIVE) {
+      const float new_err = __uint_as_float(st->err_bits);
+      st->err_bits = 0;
+      st->ratio = __fdiv_rn(new_err, st->err);
+      st->err = new_err;
+      st->it += 1;
+      st->total_iters += 1;
+      st->cur ^= 1;
+      const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
+      if (!cont) finish_try(st);
     }
-    nd += nb->phase != PH_DONE;
-    ni += nb->phase == PH_INIT;
+    nd += st->phase != PH_DONE;
+    ni += st->phase == PH_INIT;
   }
   atomicAdd(&s_nd, nd);
   atomicAdd(&s_ni, ni);
@@ -298,30 +500,32 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
 }
 
 // After the power iteration: ridge = ridge_epsilon * max(max_ev, 1e-25) (DS:830).
-__global__ void newton_setup_kernel(NewtonBlock* blocks, const PiBlock* pis,
-                                    int nblocks, float ridge_epsilon, int relative,
+__global__ void newton_setup_kernel(NewtonState* states, const PiBlock* pis, int nblocks,
+                                    float ridge_epsilon, int relative,
                                     const float* max_ev_given) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblocks) return;
-  NewtonBlock* nb = &blocks[b];
+  NewtonState* st = &states[b];
   float max_ev = 1.f;
   int pit = 0;
   if (relative) {
     if (max_ev_given) max_ev = max_ev_given[b];  // DS:815-817: lobpcg already has it
     else { max_ev = pis[b].lambda; pit = pis[b].iters; }
   }
-  nb->max_ev = max_ev;
-  nb->power_iters = pit;
-  nb->ridge = __fmul_rn(ridge_epsilon, fmaxf(max_ev, 1e-25f));
+  st->max_ev = max_ev;
+  st->power_iters = pit;
+  st->ridge = __fmul_rn(ridge_epsilon, fmaxf(max_ev, 1e-25f));
   // fmaxf drops a NaN max_ev; jnp.maximum propagates it.
-  if (max_ev != max_ev) nb->ridge = max_ev;
-  nb->ridge_try = nb->ridge;  // * 10^0
+  if (max_ev != max_ev) st->ridge = max_ev;
+  st->ridge_try = st->ridge;  // * 10^0
 }
 
-// ---- result copy-out + metrics table (DS:902-907, 930-939) -----------------------
-__global__ __launch_bounds__(256) void newton_final_kernel(NewtonBlock* blocks,
+// ---- result copy-out + metrics table (DS:902-907, 930-939), staged execution ------
+__global__ __launch_bounds__(256) void newton_final_kernel(const NewtonBlock* blocks,
+                                                           const NewtonState* states,
                                                            float* metrics) {
-  NewtonBlock* nb = &blocks[blockIdx.x];
+  const NewtonBlock* nb = &blocks[blockIdx.x];
+  const NewtonState* st = &states[blockIdx.x];
   const int n = nb->n, nf = nb->n_full;
   const int tid = blockIdx.y * 256 + threadIdx.x, nth = gridDim.y * 256;
   float* out = nb->out;
@@ -331,7 +535,7 @@ __global__ __launch_bounds__(256) void newton_final_kernel(NewtonBlock* blocks,
       out[(int64_t)row * nb->ldo + col] = 0.f;
     }
   } else {
-    const float* H = nb->H[nb->result_sel];
+    const float* H = nb->H[st->result_sel];
     for (int64_t e = tid; e < (int64_t)nf * nf; e += nth) {
       const int row = e / nf, col = e % nf;
       out[(int64_t)row * nb->ldo + col] =
@@ -339,18 +543,352 @@ __global__ __launch_bounds__(256) void newton_final_kernel(NewtonBlock* blocks,
     }
   }
   if (tid == 0) {
-    float* m = metrics + (int64_t)blockIdx.x * PS_METRICS_STRIDE;
-    if (n == 0) {  // all padding: DS:930-937 (error forced to 0)
-      m[PS_M_ERROR] = 0.f; m[PS_M_ITERS] = 0.f; m[PS_M_ERROR_RATIO] = 1.f;
-      m[PS_M_RETRIES] = 1.f; m[PS_M_TOTAL_ITERS] = 0.f;
-    } else {
-      m[PS_M_ERROR] = nb->err; m[PS_M_ITERS] = (float)nb->it;
-      m[PS_M_ERROR_RATIO] = nb->ratio; m[PS_M_RETRIES] = (float)nb->tries;
-      m[PS_M_TOTAL_ITERS] = (float)nb->total_iters;
+    if (n == 0)  // all padding: DS:930-937 (error forced to 0)
+      write_metrics(metrics, blockIdx.x, 0.f, 0, 1.f, 1, 0, st->max_ev, st->power_iters);
+    else
+      write_metrics(metrics, blockIdx.x, st->err, st->it, st->ratio, st->tries,
+                    st->total_iters, st->max_ev, st->power_iters);
+  }
+}
+
+// ==================================================================================
+// persistent dataflow execution
+// ==================================================================================
+enum ItemKind { IT_INIT1 = 1, IT_INIT2 = 2, IT_PROD = 3, IT_COPY = 4, IT_EXIT = 5 };
+
+// Queue slot = one 8-byte granule {tag, payload}, written by ONE agent-scope store:
+//   [63:48] tag = (index / capacity + 1) & 0xffff     (0 = never written)
+//   [47:32] block   [31:28] kind   [27:24] product   [23:16] tm   [15:8] tn   [1] averaged
+//   M update in this step   [0] cur / sel
+typedef unsigned long long u64;
+
+struct PControl {
+  unsigned head[NQ * 32];   // one 128-byte line per word
+  unsigned tail[NQ * 32];
+  unsigned blocks_done[32];
+  unsigned abort_flag[32];
+};
+
+struct PArgs {
+  const NewtonBlock* blocks;
+  NewtonState* states;
+  PControl* ctl;
+  u64* slots;         // [NQ][qcap]
+  float* metrics;
+  unsigned qcap;      // power of two
+  int nblocks;
+  int nlive;          // blocks with n >= 1
+  int num_iters;
+  float tol;
+  int navg;           // leading steps of a try whose M update is averaged (TileFlags)
+  int grid;           // workgroups of the persistent launch (exit tokens per queue)
+  int nq;             // queues in use (1..NQ); workgroup w serves queue w % nq
+  u64* prof;          // dev (PS_NEWTON_PROF=1): [grid][8] per-workgroup time split, else NULL
+};
+
+#define PS_RLX __ATOMIC_RELAXED
+#define PS_AGENT __HIP_MEMORY_SCOPE_AGENT
+template <typename T>
+__device__ inline T ald(T* p) { return __hip_atomic_load(p, PS_RLX, PS_AGENT); }
+template <typename T>
+__device__ inline void ast(T* p, T v) { __hip_atomic_store(p, v, PS_RLX, PS_AGENT); }
+
+__device__ inline u64 make_item(int block, int kind, int prod, int tm, int tn, int bit) {
+  return ((u64)(unsigned)block << 32) | ((u64)kind << 28) | ((u64)prod << 24) |
+         ((u64)tm << 16) | ((u64)tn << 8) | (u64)(bit & 3);
+}
+
+// Everything this lane stored before (state words, and — through the barrier that
+// precedes every call site — the workgroup's drained payload tiles) becomes visible at
+// agent scope before anything stored afterwards (the queue slots).
+__device__ inline void release_agent() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop its own wait
+}
+
+// Reserve `count` consecutive slots of queue q; one lane.
+__device__ inline unsigned q_reserve(const PArgs& pa, int q, unsigned count) {
+  return __hip_atomic_fetch_add(&pa.ctl->tail[q * 32], count, PS_RLX, PS_AGENT);
+}
+__device__ inline void q_put(const PArgs& pa, int q, unsigned pos, u64 payload) {
+  const u64 tag = (u64)(((pos / pa.qcap) + 1u) & 0xffffu);
+  ast(pa.slots + (size_t)q * pa.qcap + (pos & (pa.qcap - 1)), (tag << 48) | payload);
+}
+
+// Push every tile of one work unit of block b (one lane).  upper: tiles with tm <= tn only.
+__device__ inline void push_tiles(const PArgs& pa, const NewtonBlock* nb, int b, int kind,
+                                  int prod, int t, bool upper, int bit) {
+  const unsigned count = upper ? (unsigned)(t * (t + 1) / 2) : (unsigned)(t * t);
+  unsigned pos = q_reserve(pa, nb->queue, count);
+  for (int tm = 0; tm < t; ++tm)
+    for (int tn = upper ? tm : 0; tn < t; ++tn)
+      q_put(pa, nb->queue, pos++, make_item(b, kind, prod, tm, tn, bit));
+}
+
+__device__ inline void push_product(const PArgs& pa, const NewtonBlock* nb, int b, int prod,
+                                    int cur) {
+  push_tiles(pa, nb, b, IT_PROD, prod, nb->npad / TILE, true, cur);
+}
+
+constexpr u64 ITEM_EXIT = ~0ull;
+constexpr unsigned long long SPIN_LIMIT_TICKS = 400000000ull;  // 4 s of s_memrealtime (100 MHz)
+
+// Dequeue = ONE returning agent-scope add on the queue's head word (a ticket), then the
+// ticket's slot is polled until its tag says "published".  No compare-and-swap loop: with
+// ~100 workgroups per queue finishing tiles in bursts a CAS dequeue spent 28 us per item in
+// retries.  A ticket commits the workgroup to its queue; it is released at the end of the
+// call by the exit tokens that the last block to finish pushes into every queue.
+__device__ inline u64 q_pop_wait(const PArgs& pa, int q) {
+  const unsigned t = __hip_atomic_fetch_add(&pa.ctl->head[q * 32], 1u, PS_RLX, PS_AGENT);
+  u64* slot = pa.slots + (size_t)q * pa.qcap + (t & (pa.qcap - 1));
+  const unsigned want = ((t / pa.qcap) + 1u) & 0xffffu;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const u64 s = ald(slot);
+    if ((unsigned)(s >> 48) == want) return s;
+    if (ald(&pa.ctl->abort_flag[0]) != 0u) return ITEM_EXIT;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
+      ast(&pa.ctl->abort_flag[0], 1u);  // give up: never hang the device
+      return ITEM_EXIT;
     }
-    m[PS_M_MAX_EV] = nb->max_ev;
-    m[PS_M_POWER_ITERS] = (float)nb->power_iters;
-    m[PS_M_RESERVED] = 0.f;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+// ---- loop control of one block, run by the lane whose tile arrived last -----------------
+__device__ inline void p_block_done(const PArgs& pa, const NewtonBlock* nb, NewtonState* st,
+                                    int b, float err, int it, float ratio, int tries,
+                                    int total_iters, int sel) {
+  write_metrics(pa.metrics, b, err, it, ratio, tries, total_iters, ald(&st->max_ev),
+                ald(&st->power_iters));
+  ast(&st->phase, (int)PH_DONE);
+  release_agent();
+  push_tiles(pa, nb, b, IT_COPY, 0, (nb->n_full + TILE - 1) / TILE, false, sel);
+}
+
+__device__ inline void p_finish_try(const PArgs& pa, const NewtonBlock* nb, NewtonState* st,
+                                    int b, float err, int it, float ratio, int cur,
+                                    int total_iters) {
+  // DS:878-882
+  const bool conv = ratio < 1.2f;
+  const int sel = conv ? cur : (cur ^ 1);
+  const int tries = ald(&st->tries) + 1;
+  ast(&st->tries, tries);
+  ast(&st->result_sel, sel);
+  if (err > 0.05f && tries < 6) {
+    const float pow10[6] = {1.f, 10.f, 100.f, 1000.f, 10000.f, 100000.f};
+    ast(&st->ridge_try, __fmul_rn(ald(&st->ridge), pow10[tries]));  // DS:869
+    ast(&st->phase, (int)PH_INIT);
+    release_agent();
+    push_tiles(pa, nb, b, IT_INIT1, 0, nb->npad / TILE, false, cur);
+  } else {
+    p_block_done(pa, nb, st, b, err, it, ratio, tries, total_iters, sel);
+  }
+}
+
+__device__ inline void p_start_step(const PArgs& pa, const NewtonBlock* nb, int b, int cur,
+                                    int it) {
+  const int bits = (cur & 1) | (it < pa.navg ? 2 : 0);
+  release_agent();
+  push_product(pa, nb, b, 0, bits);
+  if (nb->nprod >= 3) push_product(pa, nb, b, 1, bits);
+}
+
+// after init2 (DS:874-877)
+__device__ inline void p_control_init(const PArgs& pa, const NewtonBlock* nb, NewtonState* st,
+                                      int b, int cur) {
+  const float err = __uint_as_float(ald(&st->err_bits));
+  ast(&st->err_bits, 0u);
+  ast(&st->err, err);
+  ast(&st->ratio, 1.f);
+  ast(&st->it, 0);
+  const bool cont = 0 < pa.num_iters && err > pa.tol;
+  if (cont) { ast(&st->phase, (int)PH_ACTIVE); p_start_step(pa, nb, b, cur, 0); }
+  else p_finish_try(pa, nb, st, b, err, 0, 1.f, cur, ald(&st->total_iters));
+}
+
+// after the M update of a step (DS:848 carry + DS:836-840 condition)
+__device__ inline void p_control_step(const PArgs& pa, const NewtonBlock* nb, NewtonState* st,
+                                      int b, int cur) {
+  const float new_err = __uint_as_float(ald(&st->err_bits));
+  ast(&st->err_bits, 0u);
+  const float ratio = __fdiv_rn(new_err, ald(&st->err));
+  const int it = ald(&st->it) + 1;
+  const int total = ald(&st->total_iters) + 1;
+  const int ncur = cur ^ 1;
+  ast(&st->ratio, ratio);
+  ast(&st->err, new_err);
+  ast(&st->it, it);
+  ast(&st->total_iters, total);
+  ast(&st->cur, ncur);
+  const bool cont = it < pa.num_iters && new_err > pa.tol && ratio < 1.2f;
+  if (cont) p_start_step(pa, nb, b, ncur, it);
+  else p_finish_try(pa, nb, st, b, new_err, it, ratio, ncur, total);
+}
+
+// Arrival of one finished item (one lane, after the workgroup's drain + barrier).
+__device__ inline void p_complete(const PArgs& pa, u64 item) {
+  const int b = (int)((item >> 32) & 0xffffu), kind = (int)((item >> 28) & 0xfu);
+  const int prod = (int)((item >> 24) & 0xfu), bits = (int)(item & 3u), bit = bits & 1;
+  const NewtonBlock* nb = &pa.blocks[b];
+  NewtonState* st = &pa.states[b];
+  const unsigned t = (unsigned)(nb->npad / TILE);
+  release_agent();
+  if (kind == IT_PROD) {
+    const unsigned want = t * (t + 1) / 2;
+    if (__hip_atomic_fetch_add(&st->c_prod[prod], 1u, PS_RLX, PS_AGENT) + 1u != want) return;
+    ast(&st->c_prod[prod], 0u);
+    const int L = nb->nprod - 1;
+    if (prod == L) { p_control_step(pa, nb, st, b, bit); return; }
+    if (prod >= 1 && prod < L - 1) { release_agent(); push_product(pa, nb, b, prod + 1, bits); }
+    if (prod == 0 || prod == L - 1) {
+      const unsigned target = L >= 2 ? 2u : 1u;
+      if (__hip_atomic_fetch_add(&st->c_join, 1u, PS_RLX, PS_AGENT) + 1u == target) {
+        ast(&st->c_join, 0u);
+        release_agent();
+        push_product(pa, nb, b, L, bits);
+      }
+    }
+  } else if (kind == IT_INIT1) {
+    if (__hip_atomic_fetch_add(&st->c_init1, 1u, PS_RLX, PS_AGENT) + 1u != t * t) return;
+    ast(&st->c_init1, 0u);
+    release_agent();
+    push_tiles(pa, nb, b, IT_INIT2, 0, (int)t, false, bit);
+  } else if (kind == IT_INIT2) {
+    if (__hip_atomic_fetch_add(&st->c_init2, 1u, PS_RLX, PS_AGENT) + 1u != t * t) return;
+    ast(&st->c_init2, 0u);
+    p_control_init(pa, nb, st, b, bit);
+  } else {  // IT_COPY
+    const unsigned tc = (unsigned)((nb->n_full + TILE - 1) / TILE);
+    if (__hip_atomic_fetch_add(&st->c_copy, 1u, PS_RLX, PS_AGENT) + 1u != tc * tc) return;
+    if (__hip_atomic_fetch_add(&pa.ctl->blocks_done[0], 1u, PS_RLX, PS_AGENT) + 1u !=
+        (unsigned)pa.nlive)
+      return;
+    // the last block of the call: one exit token per workgroup in every queue
+    for (int q = 0; q < pa.nq; ++q) {
+      unsigned pos = q_reserve(pa, q, (unsigned)pa.grid);
+      for (int k = 0; k < pa.grid; ++k) q_put(pa, q, pos++, make_item(0, IT_EXIT, 0, 0, 0, 0));
+    }
+  }
+}
+
+// Seeds the queues: the first initialisation pass of every live block.
+__global__ void newton_seed_kernel(PArgs pa) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= pa.nblocks) return;
+  const NewtonBlock* nb = &pa.blocks[b];
+  if (nb->n < 1) return;
+  push_tiles(pa, nb, b, IT_INIT1, 0, nb->npad / TILE, false, pa.states[b].cur);
+}
+
+// Payload stores of the persistent execution: plain (write-back L2, made visible by the
+// agent-scope release that precedes every arrival) or write-through (sc1).  4-byte sc1
+// stores are one fabric write each (MI355X_MICROARCH.md: ~6x the time per byte of a
+// 16-byte one) and were measured slower here: epilogues 46 -> ? us per tile.
+constexpr bool PERSIST_WT = false;
+// LDS of a product workgroup: the A (k-contiguous) and B (mn-contiguous) images, double
+// buffered, and at least the 64 x 129 floats of the mirror-store staging.
+template <int BK>
+constexpr int PSMEM = SmemCfg<BK>::total(KC, MC) > 64 * 132 ? SmemCfg<BK>::total(KC, MC) : 64 * 132;
+
+// DEEP = false: 3 workgroups per CU (<= 168 VGPRs).  DEEP = true: two-K-tile-deep register
+// prefetch in the K loop, 2 workgroups per CU (the second register set does not fit in 168).
+template <int BK, bool DEEP>
+__global__ __launch_bounds__(256, DEEP ? 2 : 3) void newton_persistent_kernel(PArgs pa) {
+  extern __shared__ __align__(16) float smem[];  // PSMEM<BK> floats + 16
+  float* scratch = smem + PSMEM<BK>;             // 16 floats of control scratch
+  u64* s_item = reinterpret_cast<u64*>(scratch + 12);
+  const int tid = threadIdx.x;
+  // Queue of this workgroup.  Workgroups are dealt round-robin over the XCDs, so blockIdx % 8
+  // keeps a queue's blocks in one XCD's L2 (speed only); unlike the XCC id it also
+  // guarantees that every queue is served whatever the partition mode of the device.
+  const int my_q = (int)(blockIdx.x % (unsigned)pa.nq);
+  // dev profile (tid 0 only; 100 MHz ticks): pop, acquire, K loops, epilogues, drain,
+  // completion, items, product items
+  u64 pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  u64* s_stamp = reinterpret_cast<u64*>(scratch + 8);
+  u64 t_pop_end = 0, t_work = 0;
+  for (;;) {
+    if (tid == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      u64 it = q_pop_wait(pa, my_q);
+      if (it != ITEM_EXIT && (int)((it >> 28) & 0xfu) == IT_EXIT) it = ITEM_EXIT;
+      if (pa.prof) t_pop_end = __builtin_amdgcn_s_memrealtime();
+      if (it != ITEM_EXIT) {
+        // ONE agent-scope acquire after the successful pop: drops this CU's stale L1 lines;
+        // the wait holds the barrier below until the invalidate has completed.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (pa.prof) {
+        t_work = __builtin_amdgcn_s_memrealtime();
+        pf[0] += t_pop_end - t0; pf[1] += t_work - t_pop_end;
+        *s_stamp = 0;
+      }
+      *s_item = it;
+    }
+    __syncthreads();
+    const u64 item = *s_item;
+    if (item == ITEM_EXIT) {
+      if (pa.prof && tid == 0) {
+        pf[10] = (u64)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);  // XCC id
+        for (int k = 0; k < 12; ++k) pa.prof[(size_t)blockIdx.x * 12 + k] = pf[k];
+      }
+      return;
+    }
+    const int b = (int)((item >> 32) & 0xffffu), kind = (int)((item >> 28) & 0xfu);
+    const int prod = (int)((item >> 24) & 0xfu), tm = (int)((item >> 16) & 0xffu);
+    const int tn = (int)((item >> 8) & 0xffu), bit = (int)(item & 1u);
+    const int avg = (int)((item >> 1) & 1u);
+    const NewtonBlock* nb = &pa.blocks[b];
+    NewtonState* st = &pa.states[b];
+    if (kind == IT_PROD) {
+      newton_product_item<BK, PERSIST_WT, DEEP>(nb, st, prod, bit, avg, tm, tn, smem,
+                                    pa.prof ? s_stamp : nullptr);
+    } else if (kind == IT_INIT1) {
+      newton_init1_tile<PERSIST_WT>(nb, ald(&st->ridge_try), tm, tn, scratch);
+    } else if (kind == IT_INIT2) {
+      newton_init2_tile<PERSIST_WT>(nb, st, ald(&st->ridge_try), bit, tm, tn, scratch);
+    } else {
+      newton_copy_tile(nb, bit, tm, tn);
+    }
+    // every storing wave drains its write-through stores, then the workgroup's barrier,
+    // then ONE lane signals (G16 R1)
+    u64 t_epi_end = 0;
+    if (pa.prof && tid == 0) t_epi_end = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      u64 t_drain_end = 0;
+      if (pa.prof) t_drain_end = __builtin_amdgcn_s_memrealtime();
+      p_complete(pa, item);
+      if (pa.prof) {
+        const u64 t_end = __builtin_amdgcn_s_memrealtime();
+        const u64 t_k = *s_stamp;  // end of the (last) K loop of a product item, else 0
+        if (t_k != 0) { pf[2] += t_k - t_work; pf[3] += t_epi_end - t_k; pf[7] += 1; }
+        else pf[3] += t_epi_end - t_work;
+        pf[4] += t_drain_end - t_epi_end; pf[5] += t_end - t_drain_end; pf[6] += 1;
+      }
+    }
+  }
+}
+
+// All-padding blocks (zero result, error 0, DS:930-937) and, if the persistent kernel
+// gave up (a bounded spin expired: must never happen), NaN errors for unfinished blocks
+// so that the caller's failure select keeps the previous preconditioners.
+__global__ __launch_bounds__(256) void newton_persist_epilogue_kernel(PArgs pa) {
+  const int b = blockIdx.x;
+  const NewtonBlock* nb = &pa.blocks[b];
+  NewtonState* st = &pa.states[b];
+  const int nf = nb->n_full;
+  if (nb->n == 0) {
+    for (int64_t e = threadIdx.x; e < (int64_t)nf * nf; e += 256)
+      nb->out[(e / nf) * nb->ldo + e % nf] = 0.f;
+    if (threadIdx.x == 0)
+      write_metrics(pa.metrics, b, 0.f, 0, 1.f, 1, 0, st->max_ev, st->power_iters);
+  } else if (st->phase != PH_DONE && threadIdx.x == 0) {
+    write_metrics(pa.metrics, b, __uint_as_float(0x7fc00000u), st->it, st->ratio, st->tries,
+                  st->total_iters, st->max_ev, st->power_iters);
   }
 }
 
@@ -394,6 +932,11 @@ struct Plan {
   int batch = 0;
   std::vector<int> n_eff, npad;
   std::vector<std::vector<Product>> chains;  // per block, incl. H and M products
+  std::vector<int> queue_of;                 // persistent execution
+  size_t qcap = 0;
+  int nq = 1;
+  int nlive = 0;
+  // staged execution
   int nstages = 0;
   std::vector<std::vector<NewtonTask>> stage_tasks;
   std::vector<std::vector<TileEntry>> stage_tiles;
@@ -403,27 +946,25 @@ struct Plan {
   bool ok = true;
 };
 
-// All iterates of the coupled Newton iteration are polynomials in the (symmetric)
-// input, hence symmetric and commuting: in symmetric mode only the tiles with
-// tm <= tn of every product are computed and the strict upper ones are mirrored,
-// which removes (T-1)/(2T) of the MFMA work (T = tiles per side).  The result
-// differs from the full products of DS:845-846 only by which of the two rounded
-// values x_ij / x_ji is kept.  PS_NEWTON_SYMMETRIC=0 restores the full products.
-bool symmetric_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("PS_NEWTON_SYMMETRIC");
-    mode = e ? (atoi(e) != 0) : 1;
-  }
-  return mode != 0;
+// Which execution a call takes (read per call: tests and A/B runs flip it inside one
+// process).  Default = staged: measured on MI355X (profiles/r02_*), cfg2 256 x 512^2:
+// staged product launches 13.5 ms vs persistent 15.6 ms — the dataflow kernel removes the
+// 24 grid drains, but every tile then pays a software dequeue + acquire + release/arrival
+// (~10 us of 143 us) that the hardware dispatcher does for free, and the MFMA pipe of a CU
+// stays shared by only 3 workgroups either way.  PS_NEWTON_PERSISTENT=1 selects the
+// persistent kernel (no host round trip at all: the call only enqueues).
+bool persistent_mode() {
+  const char* e = getenv("PS_NEWTON_PERSISTENT");
+  return e ? (atoi(e) != 0) : false;
 }
 
 void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
-               const int32_t* padding_start) {
+               const int32_t* padding_start, bool staged) {
   pl.batch = batch;
   pl.n_eff.resize(batch);
   pl.npad.resize(batch);
   pl.chains.resize(batch);
+  pl.queue_of.assign(batch, 0);
   for (int b = 0; b < batch; ++b) {
     int ne = n[b];
     if (padding_start) ne = std::max(0, std::min(ne, (int)padding_start[b]));
@@ -431,10 +972,11 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
     pl.npad[b] = ne >= 1 ? psh::round_up(ne, TILE) : 0;
     pl.max_n = std::max(pl.max_n, ne);
     if (ne >= 1) {
+      ++pl.nlive;
       std::vector<Product> ch;
       int power_id;
       if (p[b] < 1 || !build_chain(p[b], ch, power_id)) { pl.ok = false; return; }
-      // H <- H Mi rides in the first stage; M <- power @ M is last.
+      // H <- H Mi first; M <- power @ M is last.
       std::vector<Product> full;
       full.push_back({ID_HCUR, ID_MI, ID_HNEXT});
       for (auto& q : ch) full.push_back(q);
@@ -443,8 +985,52 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
     }
   }
   pl.pip.build(batch, pl.n_eff);
-  // Stage s runs product s+1 of every block (product 0, the H update, joins
-  // stage 0); the M update of a block runs as soon as its chain is done.
+
+  // ---- persistent execution: block -> queue, queue capacity.  A workgroup serves ONE queue
+  // (blockIdx % nq), so the queues must carry equal work: blocks are dealt by longest-
+  // processing-time on c(p) * T^3 for every queue count 1..8 and the count with the smallest
+  // makespan (max queue load x queue count; ties -> more queues, for L2 locality) is used.
+  {
+    std::vector<int> order;
+    for (int b = 0; b < batch; ++b) if (pl.n_eff[b] >= 1) order.push_back(b);
+    auto cost = [&](int b) {
+      const double t = pl.npad[b] / (double)TILE;
+      return (double)pl.chains[b].size() * t * t * t;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) > cost(y); });
+    double best = -1.0;
+    std::vector<int> assign(batch, 0);
+    for (int nq = NQ; nq >= 1; --nq) {
+      double load[NQ] = {0};
+      for (int b : order) {
+        int q = 0;
+        for (int k = 1; k < nq; ++k) if (load[k] < load[q]) q = k;
+        assign[b] = q;
+        load[q] += cost(b);
+      }
+      double mx = 0;
+      for (int k = 0; k < nq; ++k) mx = std::max(mx, load[k]);
+      if (best < 0 || mx * nq < best * (1.0 - 1e-9)) {
+        best = mx * nq;
+        pl.nq = nq;
+        pl.queue_of = assign;
+      }
+    }
+    size_t cap[NQ] = {0};
+    for (int b : order) {
+      const size_t t = pl.npad[b] / TILE, tc = (n[b] + TILE - 1) / TILE;
+      cap[pl.queue_of[b]] += std::max(2 * t * t, tc * tc);  // most items a block can have outstanding
+    }
+    size_t need = 64;
+    for (int k = 0; k < NQ; ++k) need = std::max(need, cap[k] + 64 + 4096);  // + exit tokens
+    size_t c = 64;
+    while (c < need) c <<= 1;
+    pl.qcap = c;
+  }
+  if (!staged) return;
+
+  // ---- staged execution: stage s runs product s+1 of every block (product 0, the H
+  // update, joins stage 0); the M update of a block runs as soon as its chain is done.
   // (A block whose step is only {H update, M update} (p = 1) keeps them in
   // different stages: the M update's epilogue rewrites Mi, which H reads.)
   auto stage_of = [](size_t k, size_t len) {
@@ -466,13 +1052,10 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
       for (int tn = 0; tn < t; ++tn) pl.init_tiles.push_back({b, (short)tm, (short)tn});
     for (size_t k = 0; k < c.size(); ++k) {
       const int s = stage_of(k, c.size());
-      const bool last = k + 1 == c.size();
-      NewtonTask tk{b, (short)c[k].a, (short)c[k].b, (short)c[k].c,
-                    (short)(last ? EPI_NEWM : EPI_PLAIN)};
       const int tid = (int)pl.stage_tasks[s].size();
-      pl.stage_tasks[s].push_back(tk);
+      pl.stage_tasks[s].push_back({b, (int)k});
       for (int tm = 0; tm < t; ++tm)
-        for (int tn = (symmetric_mode() ? tm : 0); tn < t; ++tn)
+        for (int tn = tm; tn < t; ++tn)
           pl.stage_tiles[s].push_back({tid, (short)tm, (short)tn});
     }
   }
@@ -480,6 +1063,10 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
 
 struct WsLayout {
   NewtonBlock* blocks;
+  NewtonState* states;
+  PControl* ctl;
+  u64* slots;
+  u64* prof;
   NewtonTask* tasks[MAX_PROD];
   TileEntry* tiles[MAX_PROD];
   TileEntry* init_tiles;
@@ -487,18 +1074,25 @@ struct WsLayout {
   std::vector<float*> sumsq;
 };
 
-size_t carve(Plan& pl, Arena& ar, WsLayout* lo) {
+size_t carve(Plan& pl, Arena& ar, WsLayout* lo, bool staged) {
   const int B = pl.batch;
   NewtonBlock* blocks = ar.take<NewtonBlock>(B);
+  NewtonState* states = ar.take<NewtonState>(B);
+  PControl* ctl = ar.take<PControl>(1);
+  u64* slots = ar.take<u64>(NQ * pl.qcap);
+  u64* prof = ar.take<u64>(12 * 4096);  // dev profile of up to 4096 workgroups
   pl.pip.carve(ar, lo != nullptr);
-  if (lo) { lo->blocks = blocks; }
-  for (int s = 0; s < pl.nstages; ++s) {
-    NewtonTask* t = ar.take<NewtonTask>(pl.stage_tasks[s].size());
-    TileEntry* e = ar.take<TileEntry>(pl.stage_tiles[s].size());
-    if (lo) { lo->tasks[s] = t; lo->tiles[s] = e; }
+  if (lo) { lo->blocks = blocks; lo->states = states; lo->ctl = ctl; lo->slots = slots;
+            lo->prof = prof; }
+  if (staged) {
+    for (int s = 0; s < pl.nstages; ++s) {
+      NewtonTask* t = ar.take<NewtonTask>(pl.stage_tasks[s].size());
+      TileEntry* e = ar.take<TileEntry>(pl.stage_tiles[s].size());
+      if (lo) { lo->tasks[s] = t; lo->tiles[s] = e; }
+    }
+    TileEntry* it = ar.take<TileEntry>(pl.init_tiles.size());
+    if (lo) { lo->init_tiles = it; }
   }
-  TileEntry* it = ar.take<TileEntry>(pl.init_tiles.size());
-  if (lo) { lo->init_tiles = it; }
   for (int b = 0; b < B; ++b) {
     const size_t sq = (size_t)pl.npad[b] * pl.npad[b];
     for (int k = 0; k < 10; ++k) {
@@ -521,7 +1115,7 @@ Profile g_prof;
 
 // Event pairs recorded on the caller's stream; resolved after the call.
 struct ProfRun {
-  struct Span { hipEvent_t a, b; int kind; };  // kind 0 stage, 1 power iter, 2 other
+  struct Span { hipEvent_t a, b; int kind; };  // kind 0 products, 1 power iter, 2 other
   std::vector<Span> spans;
   bool active;
   hipStream_t st;
@@ -566,52 +1160,92 @@ HostStatus* pinned_status() {
   return st;
 }
 
-bool vec_ok(const float* p, int ld) {
-  return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0);
+// Resident grid of the persistent kernel (workgroups per CU from the occupancy query x
+// CUs).  Correctness does not depend on residency (no workgroup ever waits for a specific
+// other workgroup: waits are for queue items, which only running workgroups produce),
+// so the query is for speed only.
+bool deep_mode() {  // dev A/B: PS_NEWTON_DEEP=1 selects the deep-prefetch / 2-per-CU variant
+  const char* e = getenv("PS_NEWTON_DEEP");
+  return e && atoi(e) != 0;
+}
+
+int persistent_grid(size_t lds_bytes, bool deep) {
+  static int grid[2] = {0, 0};
+  if (grid[deep] == 0) {
+    int dev = 0, cus = 256, occ = deep ? 2 : 3;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    const void* fn = deep ? (const void*)newton_persistent_kernel<NBK, true>
+                          : (const void*)newton_persistent_kernel<NBK, false>;
+    int q = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, 256, lds_bytes) == hipSuccess && q >= 1)
+      occ = q;
+    const char* e = getenv("PS_NEWTON_WG_PER_CU");
+    if (e && atoi(e) > 0) occ = atoi(e);
+    grid[deep] = cus * occ;
+  }
+  return grid[deep];
 }
 
 }  // namespace
+
+extern "C" int ps_newton_averaged_steps(void) {
+  const char* e = getenv("PS_NEWTON_AVG_STEPS");
+  return e ? std::max(0, atoi(e)) : PS_NEWTON_AVG_STEPS_DEFAULT;
+}
 
 extern "C" size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
                                                  const int32_t* p,
                                                  const int32_t* padding_start) {
   if (batch <= 0 || !n || !p) return 0;
   Plan pl;
-  make_plan(pl, batch, n, p, padding_start);
+  make_plan(pl, batch, n, p, padding_start, true);  // staged tables included: upper bound
   if (!pl.ok) return 0;
   Arena ar(nullptr, 0);
-  return carve(pl, ar, nullptr) + 256;
+  return carve(pl, ar, nullptr, true) + 256;
 }
 
 static int newton_driver(
     void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
     const int32_t* p, const int32_t* padding_start, int batch, int num_iters,
     float ridge_epsilon, float error_tolerance, int relative_matrix_epsilon,
-    const float* max_ev_given, float* const* out, const int32_t* ldo, float* metrics,
-    void* workspace, size_t workspace_bytes, int32_t* iters_executed_host) {
+    const float* max_ev_given, int symmetry, float* const* out, const int32_t* ldo,
+    float* metrics, void* workspace, size_t workspace_bytes, int32_t* iters_executed_host) {
   PS_DEVICE_CHECK();
   if (batch <= 0 || !a || !n || !lda || !p || !out || !ldo || !metrics || !workspace ||
-      num_iters < 1)
+      num_iters < 1 || symmetry < PS_SYMMETRY_VERIFY || symmetry > PS_SYMMETRY_GENERAL)
     return PS_EINVAL;
+  if (batch > 65535) return PS_EUNSUPPORTED;  // 16-bit block field of a queue item
   for (int b = 0; b < batch; ++b)
     if (n[b] < 1 || lda[b] < n[b] || ldo[b] < n[b] || !a[b] || !out[b]) return PS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const bool staged = !persistent_mode();
+  {
+    const char* e = getenv("PS_NEWTON_SYMMETRIC");  // dev: 0 forces the full products
+    if (e && atoi(e) == 0) symmetry = PS_SYMMETRY_GENERAL;
+  }
+  // Leading steps of every try whose M update is computed in full and averaged with its
+  // transpose (TileFlags above).  PS_NEWTON_AVG_STEPS overrides (0 = mirrored everywhere).
+  const int navg = ps_newton_averaged_steps();
   Plan pl;
-  make_plan(pl, batch, n, p, padding_start);
+  make_plan(pl, batch, n, p, padding_start, staged);
   if (!pl.ok) return PS_EUNSUPPORTED;
   if (pl.max_n > 16384) return PS_EUNSUPPORTED;
   Arena ar(workspace, workspace_bytes);
   WsLayout lo;
-  carve(pl, ar, &lo);
+  carve(pl, ar, &lo, staged);
   if (ar.overflow) return PS_EWORKSPACE;
-  HostStatus* status = pinned_status();
-  if (!status) return PS_EINTERNAL;
 
-  // ---- upload plan ----------------------------------------------------------
+  // ---- upload plan (pinned staging ring: no stream synchronisation) ------------------
   std::vector<NewtonBlock> hb(batch);
+  std::vector<NewtonState> hs(batch);
   for (int b = 0; b < batch; ++b) {
     NewtonBlock& nb = hb[b];
+    NewtonState& ns = hs[b];
     memset(&nb, 0, sizeof(nb));
+    memset(&ns, 0, sizeof(ns));
     nb.a = a[b]; nb.out = out[b];
     nb.M[0] = lo.mat[0][b]; nb.M[1] = lo.mat[1][b];
     nb.H[0] = lo.mat[2][b]; nb.H[1] = lo.mat[3][b];
@@ -623,32 +1257,31 @@ static int newton_driver(
     nb.alpha = (float)(-1.0 / p[b]);        // DS:774 (float32 of the exact quotient)
     nb.one_minus_alpha = 1.0f - nb.alpha;   // DS:844, float32 subtraction
     nb.inv_p = (float)(1.0 / p[b]);
-    nb.phase = pl.n_eff[b] >= 1 ? PH_INIT : PH_DONE;
-    nb.ratio = 1.f;
-    nb.symmetric = symmetric_mode() ? 1 : 0;
+    nb.nprod = (int)pl.chains[b].size();
+    nb.queue = pl.queue_of[b];
+    for (size_t k = 0; k < pl.chains[b].size(); ++k) {
+      nb.pa[k] = (short)pl.chains[b][k].a;
+      nb.pb[k] = (short)pl.chains[b][k].b;
+      nb.pc[k] = (short)pl.chains[b][k].c;
+    }
+    ns.phase = pl.n_eff[b] >= 1 ? PH_INIT : PH_DONE;
+    ns.ratio = 1.f;
   }
-
-  PS_HIP(hipMemcpyAsync(lo.blocks, hb.data(), sizeof(NewtonBlock) * batch,
-                        hipMemcpyHostToDevice, st));
-  for (int s = 0; s < pl.nstages; ++s) {
-    PS_HIP(hipMemcpyAsync(lo.tasks[s], pl.stage_tasks[s].data(),
-                          sizeof(NewtonTask) * pl.stage_tasks[s].size(),
-                          hipMemcpyHostToDevice, st));
-    PS_HIP(hipMemcpyAsync(lo.tiles[s], pl.stage_tiles[s].data(),
-                          sizeof(TileEntry) * pl.stage_tiles[s].size(),
-                          hipMemcpyHostToDevice, st));
+  PS_RC(pl.pip.upload(st, a, lda));  // also fixes pl.pip.d_asym
+  for (int b = 0; b < batch; ++b) hb[b].asym = pl.pip.d_asym + b;
+  PS_RC(psh::upload_async(st, lo.blocks, hb.data(), sizeof(NewtonBlock) * batch));
+  PS_RC(psh::upload_async(st, lo.states, hs.data(), sizeof(NewtonState) * batch));
+  if (staged) {
+    for (int s = 0; s < pl.nstages; ++s) {
+      PS_RC(psh::upload_async(st, lo.tasks[s], pl.stage_tasks[s].data(),
+                              sizeof(NewtonTask) * pl.stage_tasks[s].size()));
+      PS_RC(psh::upload_async(st, lo.tiles[s], pl.stage_tiles[s].data(),
+                              sizeof(TileEntry) * pl.stage_tiles[s].size()));
+    }
+    PS_RC(psh::upload_async(st, lo.init_tiles, pl.init_tiles.data(),
+                            sizeof(TileEntry) * pl.init_tiles.size()));
   }
-  if (!pl.init_tiles.empty())
-    PS_HIP(hipMemcpyAsync(lo.init_tiles, pl.init_tiles.data(),
-                          sizeof(TileEntry) * pl.init_tiles.size(),
-                          hipMemcpyHostToDevice, st));
-  // The host vectors above must outlive the async copies (pageable memory is
-  // staged synchronously by the runtime, but do not rely on it).
-  PS_HIP(hipStreamSynchronize(st));
-  {
-    int rc = pl.pip.upload(st, a, lda);
-    if (rc) return rc;
-  }
+  PS_RC(pl.pip.enqueue_symmetry(st, symmetry));
 
   ProfRun prof(st);
   // ---- power iteration -> ridge epsilon --------------------------------------
@@ -659,11 +1292,71 @@ static int newton_driver(
   }
   prof.end();
   hipLaunchKernelGGL(newton_setup_kernel, dim3((batch + 255) / 256), dim3(256), 0, st,
-                     lo.blocks, pl.pip.d_blocks, batch, ridge_epsilon,
+                     lo.states, pl.pip.d_blocks, batch, ridge_epsilon,
                      relative_matrix_epsilon, max_ev_given);
   PS_LAUNCH_CHECK();
 
-  // ---- Newton loop -------------------------------------------------------------
+  if (!staged) {
+    // ---- persistent dataflow execution: one launch, no host round trip ------------
+    PArgs pa;
+    pa.blocks = lo.blocks; pa.states = lo.states; pa.ctl = lo.ctl; pa.slots = lo.slots;
+    pa.metrics = metrics; pa.qcap = (unsigned)pl.qcap; pa.nblocks = batch;
+    pa.nlive = pl.nlive; pa.num_iters = num_iters; pa.tol = error_tolerance;
+    const size_t lds = (PSMEM<NBK> + 16) * sizeof(float);
+    const bool deep = deep_mode();
+    const int grid = std::min(persistent_grid(lds, deep), 4096);
+    const bool dev_prof = getenv("PS_NEWTON_PROF") != nullptr;
+    pa.prof = dev_prof ? lo.prof : nullptr;
+    pa.grid = grid;
+    pa.navg = navg;
+    pa.nq = pl.nq;
+    if (dev_prof) PS_HIP(hipMemsetAsync(lo.prof, 0, sizeof(u64) * 12 * 4096, st));
+    if (pl.nlive > 0) {
+      prof.begin(2);
+      // every polled word (heads, tails, counters, slot tags) is zeroed before EVERY launch
+      PS_HIP(hipMemsetAsync(lo.ctl, 0, sizeof(PControl), st));
+      PS_HIP(hipMemsetAsync(lo.slots, 0, sizeof(u64) * NQ * pl.qcap, st));
+      hipLaunchKernelGGL(newton_seed_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, pa);
+      prof.end();
+      PS_LAUNCH_CHECK();
+      prof.begin(0);
+      if (deep)
+        hipLaunchKernelGGL((newton_persistent_kernel<NBK, true>), dim3(grid), dim3(256), lds, st, pa);
+      else
+        hipLaunchKernelGGL((newton_persistent_kernel<NBK, false>), dim3(grid), dim3(256), lds, st, pa);
+      prof.end();
+      PS_LAUNCH_CHECK();
+    }
+    prof.begin(2);
+    hipLaunchKernelGGL(newton_persist_epilogue_kernel, dim3(batch), dim3(256), 0, st, pa);
+    prof.end();
+    PS_LAUNCH_CHECK();
+    prof.finish();
+    if (dev_prof && pl.nlive > 0) {  // dev only: per-workgroup time split of the persistent kernel
+      std::vector<u64> h(12 * (size_t)grid);
+      PS_HIP(hipStreamSynchronize(st));
+      PS_HIP(hipMemcpy(h.data(), lo.prof, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
+      double sum[12] = {0};
+      int per_xcd[8] = {0};
+      for (int w = 0; w < grid; ++w) {
+        for (int k = 0; k < 10; ++k) sum[k] += (double)h[12 * w + k];
+        per_xcd[h[12 * w + 10] & 7] += 1;
+      }
+      const double us = 0.01 / grid;  // 100 MHz ticks -> microseconds, mean per workgroup
+      fprintf(stderr, "[newton persistent] grid %d  per workgroup: items %.1f (products %.1f, stolen %.1f, "
+              "empty sweeps %.1f)  pop %.0f us  acquire %.0f us  K-loops %.0f us  epilogues+other bodies "
+              "%.0f us  drain %.0f us  completion %.0f us  | workgroups per XCC id: %d %d %d %d %d %d %d %d\n",
+              grid, sum[6] / grid, sum[7] / grid, sum[8] / grid, sum[9] / grid, sum[0] * us, sum[1] * us,
+              sum[2] * us, sum[3] * us, sum[4] * us, sum[5] * us, per_xcd[0], per_xcd[1], per_xcd[2],
+              per_xcd[3], per_xcd[4], per_xcd[5], per_xcd[6], per_xcd[7]);
+    }
+    if (iters_executed_host) *iters_executed_host = -1;
+    return PS_OK;
+  }
+
+  // ---- staged execution --------------------------------------------------------------
+  HostStatus* status = pinned_status();
+  if (!status) return PS_EINTERNAL;
   // K-tile depth of the product kernel: 32 (73.7 KB LDS => exactly 2 workgroups per
   // CU, half the barriers) or 16 (40 KB, 3 per CU).  PS_NEWTON_BK overrides.
   static int stage_bk = 0;
@@ -693,10 +1386,10 @@ static int newton_driver(
       if (need_init) {
         prof.begin(2);
         hipLaunchKernelGGL(newton_init1_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
-                           lo.init_tiles);
+                           lo.states, lo.init_tiles);
         hipLaunchKernelGGL(newton_init2_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
-                           lo.init_tiles);
-        hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.blocks,
+                           lo.states, lo.init_tiles);
+        hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
                            batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr);
         prof.end();
       }
@@ -705,15 +1398,15 @@ static int newton_driver(
         prof.begin(0);
         if (stage_bk == 32)
           hipLaunchKernelGGL(newton_stage_kernel<32>, dim3(nt), dim3(256),
-                             SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.tasks[s],
-                             lo.tiles[s], nt);
+                             SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
+                             lo.tasks[s], lo.tiles[s], nt, navg);
         else
           hipLaunchKernelGGL(newton_stage_kernel<16>, dim3(nt), dim3(256),
-                             SmemCfg<16>::TOTAL * sizeof(float), st, lo.blocks, lo.tasks[s],
-                             lo.tiles[s], nt);
+                             SmemCfg<16>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
+                             lo.tasks[s], lo.tiles[s], nt, navg);
         prof.end();
       }
-      hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.blocks,
+      hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
                          batch, 1, num_iters, error_tolerance, g, slot);
       if ((rc = (int)hipGetLastError()) != 0) break;
       if ((rc = (int)hipEventRecord(ev[g & 1], st)) != 0) break;
@@ -734,7 +1427,7 @@ static int newton_driver(
   }
   prof.begin(2);
   hipLaunchKernelGGL(newton_final_kernel, dim3(batch, 32), dim3(256), 0, st, lo.blocks,
-                     metrics);
+                     lo.states, metrics);
   prof.end();
   PS_LAUNCH_CHECK();
   prof.finish();
@@ -781,10 +1474,11 @@ extern "C" size_t ps_power_iteration_workspace_bytes(int batch, const int32_t* n
 extern "C" int ps_power_iteration_batched_f32(
     void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
     const int32_t* padding_start, int batch, int num_iters, float error_tolerance,
-    float* out_lambda, int32_t* out_iters, float* out_v, int32_t ldv, void* workspace,
-    size_t workspace_bytes) {
+    float* out_lambda, int32_t* out_iters, float* out_v, int32_t ldv, int symmetry,
+    void* workspace, size_t workspace_bytes) {
   PS_DEVICE_CHECK();
-  if (batch <= 0 || !a || !n || !lda || !out_lambda || !workspace || num_iters < 1)
+  if (batch <= 0 || !a || !n || !lda || !out_lambda || !workspace || num_iters < 1 ||
+      symmetry < PS_SYMMETRY_VERIFY || symmetry > PS_SYMMETRY_GENERAL)
     return PS_EINVAL;
   for (int b = 0; b < batch; ++b)
     if (n[b] < 1 || lda[b] < n[b] || !a[b]) return PS_EINVAL;
@@ -798,6 +1492,8 @@ extern "C" int ps_power_iteration_batched_f32(
   if (ar.overflow) return PS_EWORKSPACE;
   int rc = pp.upload(st, a, lda);
   if (rc) return rc;
+  rc = pp.enqueue_symmetry(st, symmetry);
+  if (rc) return rc;
   rc = pp.enqueue(st, num_iters, error_tolerance);
   if (rc) return rc;
   hipLaunchKernelGGL(pi_output_kernel, dim3(batch), dim3(256), 0, st, pp.d_blocks, batch,
@@ -809,22 +1505,22 @@ extern "C" int ps_power_iteration_batched_f32(
 extern "C" int ps_newton_root_batched_f32(
     void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
     const int32_t* p, const int32_t* padding_start, int batch, int num_iters,
-    float ridge_epsilon, float error_tolerance, int relative_matrix_epsilon,
+    float ridge_epsilon, float error_tolerance, int relative_matrix_epsilon, int symmetry,
     float* const* out, const int32_t* ldo, float* metrics, void* workspace,
     size_t workspace_bytes, int32_t* iters_executed_host) {
   return newton_driver(stream, a, n, lda, p, padding_start, batch, num_iters, ridge_epsilon,
-                       error_tolerance, relative_matrix_epsilon, nullptr, out, ldo, metrics,
-                       workspace, workspace_bytes, iters_executed_host);
+                       error_tolerance, relative_matrix_epsilon, nullptr, symmetry, out, ldo,
+                       metrics, workspace, workspace_bytes, iters_executed_host);
 }
 
 extern "C" int ps_newton_root_batched_maxev_f32(
     void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
     const int32_t* p, const int32_t* padding_start, int batch, int num_iters,
-    float ridge_epsilon, float error_tolerance, const float* max_ev, float* const* out,
-    const int32_t* ldo, float* metrics, void* workspace, size_t workspace_bytes,
-    int32_t* iters_executed_host) {
+    float ridge_epsilon, float error_tolerance, const float* max_ev, int symmetry,
+    float* const* out, const int32_t* ldo, float* metrics, void* workspace,
+    size_t workspace_bytes, int32_t* iters_executed_host) {
   if (!max_ev) return PS_EINVAL;
   return newton_driver(stream, a, n, lda, p, padding_start, batch, num_iters, ridge_epsilon,
-                       error_tolerance, 1, max_ev, out, ldo, metrics, workspace,
+                       error_tolerance, 1, max_ev, symmetry, out, ldo, metrics, workspace,
                        workspace_bytes, iters_executed_host);
 }

@@ -13,9 +13,14 @@
 //                   forms s = v.(A v) and ||A v||, takes the stop decision of
 //                   DS:639 and writes the normalised iterate for the next step.
 // No float atomics, no inter-workgroup traffic inside a launch: results are
-// bit-reproducible.  (Only the upper block triangle of the input is read; for an
-// input that is symmetric only to rounding this differs from the reference's
-// full mat-vec by that rounding.)
+// bit-reproducible.
+//
+// Symmetry is a per-call contract (ps_api.h PS_SYMMETRY_*), never assumed silently: the
+// reference's power_iteration (DS:595) takes any square matrix, and in the int16 state
+// mode the dequantized statistics are NOT symmetric (per-column scales).  sym_check_kernel
+// compares a_ij with a_ji bit for bit (one pass over the matrices, before the first step)
+// and sets a per-block flag; blocks that are not exactly symmetric read BOTH tiles (I,J)
+// and (J,I) in their off-diagonal workgroups and form the full mat-vec.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -44,6 +49,7 @@ struct PiBlock {
   int stop_iter;  // -1 while running, else the step after which the loop ended
   float lambda;   // s_out
   int iters;      // steps executed
+  const int* asym;  // *asym != 0: the block is not exactly symmetric (full mat-vec)
 };
 
 struct PiTile {
@@ -64,6 +70,81 @@ static __global__ __launch_bounds__(256) void pi_init_kernel(PiBlock* blocks,
   __syncthreads();
   const float nrm = sqrtf(((red[0] + red[1]) + red[2]) + red[3]);
   for (int j = tid; j < pb->t * PT; j += 256) pb->vn[j] = j < n ? v0[j] / nrm : 0.f;
+}
+
+// ---- exact symmetry test: a_ij == a_ji on every element of the unpadded part --------
+// One workgroup per tile (I, J >= I); 64x64 sub-blocks, the partner block staged
+// transposed through LDS so that both global reads are row-contiguous.
+static __global__ __launch_bounds__(256) void sym_check_kernel(const PiBlock* blocks,
+                                                              const PiTile* tiles,
+                                                              int* asym) {
+  __shared__ float tb[64][65];
+  const PiTile te = tiles[blockIdx.x];
+  const PiBlock* pb = &blocks[te.block];
+  const int n = pb->n, lda = pb->lda, tid = threadIdx.x;
+  const float* a = pb->a;
+  int bad = 0;
+  for (int sub = 0; sub < 4; ++sub) {
+    const int r0 = te.I * PT + 64 * (sub >> 1), c0 = te.J * PT + 64 * (sub & 1);
+    if (r0 >= n || c0 >= n || (te.I == te.J && r0 > c0)) continue;  // uniform
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int rr = e >> 6, cc = e & 63;
+      const int gr = c0 + rr, gc = r0 + cc;
+      tb[rr][cc] = (gr < n && gc < n) ? gload1(a + (int64_t)gr * lda + gc) : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      const int gr = r0 + r, gc = c0 + c;
+      const float x = (gr < n && gc < n) ? gload1(a + (int64_t)gr * lda + gc) : 0.f;
+      if (!(x == tb[c][r])) bad = 1;  // a NaN counts as asymmetric: full products, NaN out
+    }
+    __syncthreads();
+  }
+  if (bad) asym[te.block] = 1;  // racing writers all store 1
+}
+
+static __global__ void sym_fill_kernel(int* asym, int count, int value) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) asym[i] = value;
+}
+
+// Row dot products of one 128x128 tile with a 128-vector: u[r] = sum_c A[r0+r][c0+c] v[c],
+// written to P_out[r].  Register streaming: lane = (row parity rh, float4 column group c4),
+// a wavefront walks 32 rows two at a time with all 16 loads in flight.
+__device__ inline void pi_tile_rowdot(const float* a, int lda, int n, int r0, int c0, bool fast,
+                                      f32x4 vc, int wave, int c4, int rh, float* P_out) {
+  f32x4 x[16];
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int r = 32 * wave + 2 * it + rh;
+      x[it] = gload4(a + (int64_t)(r0 + r) * lda + c0 + 4 * c4);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int r = 32 * wave + 2 * it + rh;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + 4 * c4 + e < n) t[e] = gload1(a + (int64_t)(r0 + r) * lda + c0 + 4 * c4 + e);
+      }
+      x[it] = t;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int r = 32 * wave + 2 * it + rh;
+    float u = x[it][0] * vc[0];
+    u += x[it][1] * vc[1];
+    u += x[it][2] * vc[2];
+    u += x[it][3] * vc[3];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) u += __shfl_xor(u, off, 64);  // within the half
+    if (c4 == 0) P_out[r] = u;
+  }
 }
 
 // ---- one tile of A v (and of A^T v for off-diagonal tiles) ------------------------
@@ -126,7 +207,12 @@ static __global__ __launch_bounds__(256) void pi_mv_kernel(PiBlock* blocks,
     const float vi = vI[r];
     w[0] += x[it][0] * vi; w[1] += x[it][1] * vi; w[2] += x[it][2] * vi; w[3] += x[it][3] * vi;
   }
-  if (offdiag) {
+  if (offdiag && *pb->asym != 0) {
+    // not symmetric: the contribution of v_I to y_J needs the tile (J, I) itself
+    const f32x4 vi4 = *reinterpret_cast<const f32x4*>(vI + 4 * c4);
+    pi_tile_rowdot(a, lda, n, c0, r0, fast, vi4, wave, c4, rh,
+                   P + ((int64_t)te.J * t + te.I) * PT);
+  } else if (offdiag) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] += __shfl_xor(w[e], 32, 64);  // the two row parities
     if (rh == 0) {
@@ -215,6 +301,7 @@ struct PiPlan {
   PiBlock* d_blocks = nullptr;
   PiTile* d_tiles = nullptr;
   float* d_v0 = nullptr;
+  int* d_asym = nullptr;   // [batch] 1 = not exactly symmetric
   std::vector<float*> d_vn, d_P;
 
   void build(int b, const std::vector<int>& ne) {
@@ -234,7 +321,8 @@ struct PiPlan {
     PiBlock* blk = ar.take<PiBlock>(batch);
     PiTile* tl = ar.take<PiTile>(std::max<size_t>(tiles.size(), 1));
     float* v0 = ar.take<float>(std::max(max_n, 1));
-    if (assign) { d_blocks = blk; d_tiles = tl; d_v0 = v0; d_vn.clear(); d_P.clear(); }
+    int* asym = ar.take<int>(std::max(batch, 1));
+    if (assign) { d_blocks = blk; d_tiles = tl; d_v0 = v0; d_asym = asym; d_vn.clear(); d_P.clear(); }
     for (int i = 0; i < batch; ++i) {
       const int t = (n_eff[i] + PT - 1) / PT;
       float* vn = ar.take<float>(std::max(t * PT, 1));
@@ -243,7 +331,7 @@ struct PiPlan {
     }
   }
 
-  // Uploads the descriptors (synchronises the stream: host vectors are temporary).
+  // Uploads the descriptors through the pinned staging ring (no stream synchronisation).
   int upload(hipStream_t st, const float* const* a, const int32_t* lda) {
     std::vector<PiBlock> h(batch);
     for (int i = 0; i < batch; ++i) {
@@ -257,15 +345,29 @@ struct PiPlan {
       pb.vn = d_vn[i];
       pb.P = d_P[i];
       pb.stop_iter = -1;
+      pb.asym = d_asym + i;
     }
     std::vector<float> v0(std::max(max_n, 1));
     ps_power_iteration_v0(max_n, v0.data());
-    PS_HIP(hipMemcpyAsync(d_blocks, h.data(), sizeof(PiBlock) * batch, hipMemcpyHostToDevice, st));
-    PS_HIP(hipMemcpyAsync(d_v0, v0.data(), sizeof(float) * v0.size(), hipMemcpyHostToDevice, st));
+    PS_RC(psh::upload_async(st, d_blocks, h.data(), sizeof(PiBlock) * batch));
+    PS_RC(psh::upload_async(st, d_v0, v0.data(), sizeof(float) * v0.size()));
     if (!tiles.empty())
-      PS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(PiTile) * tiles.size(),
-                            hipMemcpyHostToDevice, st));
-    PS_HIP(hipStreamSynchronize(st));
+      PS_RC(psh::upload_async(st, d_tiles, tiles.data(), sizeof(PiTile) * tiles.size()));
+    return 0;
+  }
+
+  // Fills the per-block asymmetry flags according to the call's symmetry contract
+  // (PS_SYMMETRY_VERIFY: test every block; _ASSUME: caller guarantees exact symmetry;
+  // _GENERAL: full products everywhere).  Must follow upload().
+  int enqueue_symmetry(hipStream_t st, int symmetry) {
+    if (batch == 0) return 0;
+    const int fill = symmetry == PS_SYMMETRY_GENERAL ? 1 : 0;
+    hipLaunchKernelGGL(sym_fill_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, d_asym,
+                       batch, fill);
+    if (symmetry == PS_SYMMETRY_VERIFY && !tiles.empty())
+      hipLaunchKernelGGL(sym_check_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, st,
+                         d_blocks, d_tiles, d_asym);
+    PS_LAUNCH_CHECK();
     return 0;
   }
 

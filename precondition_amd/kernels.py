@@ -114,6 +114,7 @@ def matrix_inverse_pth_root_batched(
     eigh: bool = False,
     out: Optional[Sequence[torch.Tensor]] = None,
     max_ev: Optional[torch.Tensor] = None,
+    symmetry="verify",
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """vmap(matrix_inverse_pth_root) over independent blocks (DS:2742-2744).
 
@@ -121,6 +122,8 @@ def matrix_inverse_pth_root_batched(
   (0..4 = TrainingMetrics fields of DS:902-907).  Blocks may differ in size.
   `max_ev` (float32 device tensor [batch]): the largest eigenvalue is given instead of
   being found by the power iteration (the lobpcg branch, DS:813-817).
+  `symmetry`: 'verify' | 'assume' | 'general' (_lib.symmetry_code): the reference takes
+  any square matrix; exactly symmetric blocks get the half-work symmetric products.
   """
   batch = len(matrices)
   if batch == 0:
@@ -170,7 +173,7 @@ def matrix_inverse_pth_root_batched(
       rc = L.ps_newton_root_batched_maxev_f32(
           _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
           p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
-          error_tolerance, mev.data_ptr(), o_ptrs.ctypes.data,
+          error_tolerance, mev.data_ptr(), _lib.symmetry_code(symmetry), o_ptrs.ctypes.data,
           ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
           C.addressof(iters))
       check(rc, "ps_newton_root_batched_maxev_f32")
@@ -178,7 +181,8 @@ def matrix_inverse_pth_root_batched(
       rc = L.ps_newton_root_batched_f32(
           _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
           p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
-          error_tolerance, int(relative_matrix_epsilon), o_ptrs.ctypes.data,
+          error_tolerance, int(relative_matrix_epsilon), _lib.symmetry_code(symmetry),
+          o_ptrs.ctypes.data,
           ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
           C.addressof(iters))
       check(rc, "ps_newton_root_batched_f32")
@@ -260,8 +264,9 @@ def eigh_batched(matrices: Sequence[torch.Tensor]):
 @_device_guarded
 def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
                     error_tolerance: float = 1e-6,
-                    padding_start: Optional[int] = None):
-  """DS:595-652.  Returns (eigenvector, eigenvalue) as device tensors."""
+                    padding_start: Optional[int] = None, symmetry="verify"):
+  """DS:595-652.  Returns (eigenvector, eigenvalue) as device tensors.  Any square
+  matrix (the reference's is a plain mat-vec loop); see `symmetry` above."""
   _require_gpu(matrix, "power_iteration")
   n = int(matrix.shape[-1])
   dev = matrix.device
@@ -276,14 +281,15 @@ def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
   rc = L.ps_power_iteration_batched_f32(
       _stream(), a_ptrs.ctypes.data, na.ctypes.data, lda.ctypes.data,
       None if pad is None else pad.ctypes.data, 1, num_iters, error_tolerance,
-      lam.data_ptr(), its.data_ptr(), v.data_ptr(), n, ws.data_ptr(), ws.numel())
+      lam.data_ptr(), its.data_ptr(), v.data_ptr(), n, _lib.symmetry_code(symmetry),
+      ws.data_ptr(), ws.numel())
   check(rc, "ps_power_iteration_batched_f32")
   return v[0], lam[0]
 
 
 @_device_guarded
 def power_iteration_batched(matrices: Sequence[torch.Tensor], num_iters=100,
-                            error_tolerance=1e-6, padding_starts=None):
+                            error_tolerance=1e-6, padding_starts=None, symmetry="verify"):
   """Returns (lambda[batch], iters[batch])."""
   batch = len(matrices)
   dev = matrices[0].device
@@ -300,8 +306,8 @@ def power_iteration_batched(matrices: Sequence[torch.Tensor], num_iters=100,
   rc = L.ps_power_iteration_batched_f32(
       _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
       None if pad is None else pad.ctypes.data, batch, num_iters,
-      error_tolerance, lam.data_ptr(), its.data_ptr(), None, 0, ws.data_ptr(),
-      ws.numel())
+      error_tolerance, lam.data_ptr(), its.data_ptr(), None, 0,
+      _lib.symmetry_code(symmetry), ws.data_ptr(), ws.numel())
   check(rc, "ps_power_iteration_batched_f32")
   return lam, its
 

@@ -1,0 +1,229 @@
+"""Round-2 parity tests of the HIP path (through the C-ABI):
+
+* inputs that are NOT symmetric (dequantized int16 statistics, DS:2746-2772) through
+  the power iteration and the Newton root against the oracle's full products — the
+  reference's functions take any square matrix (DS:595, DS:845-846);
+* the persistent dataflow execution of the Newton root against the staged one
+  (bit-identical: same tile code, same summation orders);
+* BASELINE.json configs[3]: the ViT-B/16 parameter tree (395 statistics of sizes
+  768 / 1024 / 1000 / 197, p = 2 and 4 in ONE batch) through
+  comm.sharded_inverse_pth_roots with LPT ownership (DS:2816-2950).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import quantization_oracle as qorc
+from oracle import shampoo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def K():
+  from precondition_amd import kernels
+  return kernels
+
+
+def wishart(n, k, seed):
+  g = np.random.default_rng(seed).standard_normal((n, k)).astype(np.float32)
+  return (g @ g.T).astype(np.float32)
+
+
+def dequantized_int16(a):
+  """What the reference roots in the int16 state mode: to_float(quantize(A)) with the
+  diagonal kept aside (DS:2746-2772).  Column scales make it asymmetric."""
+  q, d, b = qorc.quantize(a, np.int16, True)
+  return np.ascontiguousarray(qorc.to_float(q, d, b, np.int16, True), dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,p,seed", [(96, 4, 1), (200, 2, 2), (384, 4, 3), (130, 4, 4)])
+def test_asymmetric_input_power_iteration_and_newton_vs_oracle(n, p, seed, device):
+  a = dequantized_int16(wishart(n, 4 * n, seed))
+  assert np.abs(a - a.T).max() > 0, "the test input must not be symmetric"
+  a_d = torch.tensor(a, device=device)
+  # power iteration: full mat-vec (DS:631-639)
+  _, lam_ref, _ = orc.power_iteration(a)
+  lam, its = K().power_iteration_batched([a_d])
+  assert np.isclose(float(lam[0]), float(lam_ref), rtol=2e-5), (float(lam[0]), float(lam_ref))
+  # Newton root: full products (DS:845-846)
+  h_ref, m_ref = orc.matrix_inverse_pth_root(a, p)
+  roots, met = K().matrix_inverse_pth_root_batched([a_d], [p])
+  met = met.cpu().numpy()
+  h = roots[0].cpu().numpy()
+  rel = np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref)
+  assert rel < 5e-5, rel
+  assert met[0, 1] == m_ref["inverse_pth_root_iters"], (met[0], m_ref)
+  assert met[0, 4] == m_ref["total_retries"]
+  # 'general' = the same full products: bit-identical to what 'verify' decided
+  roots_g, met_g = K().matrix_inverse_pth_root_batched([a_d], [p], symmetry="general")
+  assert torch.equal(roots_g[0], roots[0]) and torch.equal(met_g, torch.tensor(met, device=device))
+  # the symmetric fast path on this input would be a different (wrong) computation
+  if n > 128:  # (a single 128x128 tile has nothing to mirror)
+    roots_s, _ = K().matrix_inverse_pth_root_batched([a_d], [p], symmetry="assume")
+    assert not torch.equal(roots_s[0], roots[0])
+
+
+def test_symmetry_verify_equals_assume_on_symmetric_input_and_mixed_batch(device):
+  """A batch mixing exactly symmetric and asymmetric blocks: each block takes its own
+  path, and the symmetric ones are bit-identical to a call that assumes symmetry."""
+  sym = [wishart(n, 4 * n, 10 + i) for i, n in enumerate((64, 257, 300))]
+  asym = [dequantized_int16(wishart(n, 4 * n, 20 + i)) for i, n in enumerate((130, 256))]
+  mats = [sym[0], asym[0], sym[1], asym[1], sym[2]]
+  ps = [4, 4, 2, 4, 4]
+  mats_d = [torch.tensor(m, device=device) for m in mats]
+  roots, met = K().matrix_inverse_pth_root_batched(mats_d, ps)
+  roots_a, met_a = K().matrix_inverse_pth_root_batched(
+      [mats_d[0], mats_d[2], mats_d[4]], [4, 2, 4], symmetry="assume")
+  for i, j in enumerate((0, 2, 4)):
+    assert torch.equal(roots[j], roots_a[i])
+    assert torch.equal(met[j], met_a[i])
+  for j in (1, 3):
+    h_ref, m_ref = orc.matrix_inverse_pth_root(mats[j], ps[j])
+    h = roots[j].cpu().numpy()
+    assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 5e-5
+    assert float(met[j, 1]) == m_ref["inverse_pth_root_iters"]
+
+
+# ---------------------------------------------------------------------------
+def _mixed_batch():
+  sizes = [16, 130, 64, 257, 96, 512, 33, 200, 1, 48, 640, 24]
+  ps = [4, 2, 4, 4, 8, 4, 6, 2, 4, 3, 4, 4]
+  mats = [wishart(n, 4 * n, 100 + i) for i, n in enumerate(sizes)]
+  pads = list(sizes)
+  mats[2] = orc.pad_square_matrix(mats[2], 80); pads[2] = 64
+  mats[6] = orc.pad_square_matrix(mats[6], 40); pads[6] = 33
+  # an all-padding block (DST:400-408) and an indefinite one that walks the retry ladder
+  mats.append(np.eye(10, dtype=np.float32)); ps.append(4); pads.append(0)
+  rng = np.random.default_rng(7)
+  q, _ = np.linalg.qr(rng.standard_normal((24, 24)))
+  e = np.linspace(1, 0.1, 24); e[-1] = -1e-3
+  bad = (q * e) @ q.T
+  mats[11] = ((bad + bad.T) / 2).astype(np.float32)
+  return mats, ps, pads
+
+
+def test_persistent_execution_bit_identical_to_staged(device):
+  mats, ps, pads = _mixed_batch()
+  mats_d = [torch.tensor(m, device=device) for m in mats]
+  out = {}
+  old = os.environ.get("PS_NEWTON_PERSISTENT")
+  try:
+    for mode in ("1", "0"):
+      os.environ["PS_NEWTON_PERSISTENT"] = mode
+      roots, met = K().matrix_inverse_pth_root_batched(mats_d, ps, pads)
+      torch.cuda.synchronize()
+      out[mode] = ([r.clone() for r in roots], met.clone())
+  finally:
+    if old is None:
+      os.environ.pop("PS_NEWTON_PERSISTENT", None)
+    else:
+      os.environ["PS_NEWTON_PERSISTENT"] = old
+  for i in range(len(mats)):
+    assert torch.equal(out["1"][0][i], out["0"][0][i]), i
+  # NaN-safe comparison of the metrics tables
+  a, b = out["1"][1].cpu().numpy(), out["0"][1].cpu().numpy()
+  assert np.array_equal(a, b, equal_nan=True), (a, b)
+  assert a[11, 4] == 5.0  # the retry ladder ran inside the persistent kernel
+  assert a[12, 0] == 0.0 and not out["1"][0][12].any()
+
+
+@pytest.fixture
+def persistent_mode():
+  old = os.environ.get("PS_NEWTON_PERSISTENT")
+  os.environ["PS_NEWTON_PERSISTENT"] = "1"
+  yield
+  if old is None:
+    os.environ.pop("PS_NEWTON_PERSISTENT", None)
+  else:
+    os.environ["PS_NEWTON_PERSISTENT"] = old
+
+
+def test_persistent_execution_repeated_calls_and_many_small_blocks(device, persistent_mode):
+  """Queue state is re-initialised by every call; 600 small blocks of mixed exponents
+  keep every queue busy with many more blocks than resident workgroups per queue."""
+  rng = np.random.default_rng(5)
+  sizes = rng.integers(1, 200, size=600)
+  ps = rng.choice([1, 2, 3, 4, 6, 8], size=600)
+  mats = [wishart(int(n), int(2 * n + 8), 1000 + i) for i, n in enumerate(sizes)]
+  mats_d = [torch.tensor(m, device=device) for m in mats]
+  r1, m1 = K().matrix_inverse_pth_root_batched(mats_d, [int(p) for p in ps])
+  r2, m2 = K().matrix_inverse_pth_root_batched(mats_d, [int(p) for p in ps])
+  assert torch.equal(m1, m2)
+  for x, y in zip(r1, r2):
+    assert torch.equal(x, y)
+  m1 = m1.cpu().numpy()
+  n_off = 0
+  for i in rng.choice(600, size=24, replace=False):
+    h_ref, m_ref = orc.matrix_inverse_pth_root(mats[i], int(ps[i]))
+    h = r1[i].cpu().numpy()
+    assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 5e-5, (i, sizes[i], ps[i])
+    # iteration counts exact, +-1 where the 1e-6 threshold is within rounding
+    d_it = abs(m1[i, 1] - m_ref["inverse_pth_root_iters"])
+    assert d_it == 0 or (d_it == 1 and max(m1[i, 0], m_ref["inverse_pth_root_errors"]) < 3e-6), (
+        i, m1[i], m_ref)
+    n_off += int(d_it)
+    assert m1[i, 4] == m_ref["total_retries"]
+  assert n_off <= 2
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("persistent", ["0", "1"])
+def test_vit_b_tree_recompute(device, persistent, monkeypatch):
+  """BASELINE.json configs[3] on one rank: bench.py's VitBWorkload (the 200-leaf ViT-B/16
+  tree, block_size 1024 -> 395 statistics, 4 warm statistics steps) through
+  comm.sharded_inverse_pth_roots(ownership="lpt").  Every block: the root's own
+  residual max|H^p (A + ridge I) - I| (float64 check of the float32 result), symmetry,
+  finiteness; a 1000^2, a 197^2, a 768^2 / p = 2 and a 1024^2 / p = 4 block against the
+  oracle with equal iteration and retry counts (reference: DS:2816-2950)."""
+  import bench
+  from precondition_amd import comm
+  monkeypatch.setenv("PS_NEWTON_PERSISTENT", persistent)
+  vw = bench.VitBWorkload(0, 1, device, None)
+  assert vw.n_stats == 395
+  vw.stats_step()
+  flat = [s for st in vw.stats for s in st]
+  roots, metrics = comm.sharded_inverse_pth_roots(flat, vw.exps, group=None, ownership="lpt",
+                                                 pi_first=True)
+  torch.cuda.synchronize()
+  met = metrics.cpu().numpy()
+  assert met.shape == (395, 8)
+  census = {}
+  for s, p in zip(flat, vw.exps):
+    census[(int(s.shape[0]), p)] = census.get((int(s.shape[0]), p), 0) + 1
+  assert census == {(768, 4): 172, (768, 2): 112, (1024, 4): 72, (1024, 2): 36,
+                    (1000, 4): 1, (1000, 2): 1, (197, 4): 1}
+  assert np.isfinite(met[:, 0]).all() and (met[:, 0] < 0.1).all(), "a block failed"
+  worst = 0.0
+  for i, (a, h, p) in enumerate(zip(flat, roots, vw.exps)):
+    assert torch.isfinite(h).all()
+    # off-diagonal tiles are mirrored exactly; inside the 128x128 diagonal tiles h_ij and
+    # h_ji are separately rounded dot products
+    assert (h - h.T).abs().max() <= 1e-4 * h.abs().max(), (i, float((h - h.T).abs().max()), float(h.abs().max()))
+    ridge = 1e-6 * max(float(met[i, 3]), 1e-25) * 10.0 ** (met[i, 4] - 1)
+    d = a.double() + ridge * torch.eye(a.shape[0], dtype=torch.float64, device=device)
+    hp = torch.linalg.matrix_power(h.double(), p)
+    res = (hp @ d - torch.eye(a.shape[0], dtype=torch.float64, device=device)).abs().max()
+    worst = max(worst, float(res))
+    # the metric the kernel reports is max|M - I| of its own iterate; the float64
+    # residual of the float32 root adds the rounding of H^p D at this conditioning
+    assert float(res) < 2e-2, (i, tuple(a.shape), p, float(res), met[i])
+  sample = {}
+  for i, (s, p) in enumerate(zip(flat, vw.exps)):
+    sample.setdefault((int(s.shape[0]), p), i)
+  for key in ((1000, 4), (197, 4), (768, 2), (1024, 4)):
+    i = sample[key]
+    a = flat[i].cpu().numpy()
+    h_ref, m_ref = orc.matrix_inverse_pth_root(a, key[1])
+    h = roots[i].cpu().numpy()
+    rel = np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref)
+    # These statistics come from 5 steps on ONE gradient: rank 768 in up to 1024 dimensions
+    # plus the 1e-6 initial diagonal, cond ~7e3 at p = 4.  Two float32 evaluations of the
+    # coupled iteration (the oracle's full products are themselves 1.2e-4 from the float64
+    # root there, this build 1.8e-4) agree to a few 1e-4; well-conditioned blocks to 1e-6.
+    assert rel < (5e-4 if key[1] == 4 and key[0] >= 768 else 1e-4), (key, rel)
+    assert met[i, 1] == m_ref["inverse_pth_root_iters"], (key, met[i], m_ref)
+    assert met[i, 4] == m_ref["total_retries"], (key, met[i], m_ref)
+    assert np.isclose(met[i, 3], m_ref["max_eigen_value"], rtol=2e-5)
