@@ -211,10 +211,13 @@ int ps_eigh_root_batched_f32(void* stream, const float* const* a, const int32_t*
 
 /* ---- plain batched symmetric eigendecomposition (jnp.linalg.eigh, DS:1007/1071) ----
  * a[b]: symmetric [n[b], n[b]].  evals[b]: n[b] floats; evecs[b]: [n[b], n[b]] with
- * eigenvectors in COLUMNS (ld = ldv[b]).  Order is the Jacobi order (NOT sorted):
- * callers that need LAPACK's ascending order sort the pairs.  Used by the low-rank /
+ * eigenvectors in COLUMNS (ld = ldv[b]).  Matrices with n <= ps_eigh_sorted_max_n() (128:
+ * solved by the LDS-resident single-launch kernel, the whole call only enqueues work) come
+ * back in LAPACK's ASCENDING order; larger ones in the Jacobi order (NOT sorted): callers
+ * that need ascending order sort those pairs.  Used by the low-rank /
  * Frequent-Directions branch (_low_rank_root DS:1033-1120, _fd_update_root DS:1123-1290).
  * Workspace: ps_eigh_root_workspace_bytes. */
+int ps_eigh_sorted_max_n(void);
 int ps_eigh_batched_f32(void* stream, const float* const* a, const int32_t* n,
                         const int32_t* lda, int batch, float* const* evals,
                         float* const* evecs, const int32_t* ldv, void* workspace,

@@ -145,6 +145,7 @@ _SIGNATURES = {
     "ps_eigh_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ps_eigh_sorted_max_n": (C.c_int, []),
     "ps_profile_enable": (C.c_int, [C.c_int]),
     "ps_profile_reset": (C.c_int, []),
     "ps_profile_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

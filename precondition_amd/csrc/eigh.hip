@@ -58,6 +58,7 @@ struct EighBlock {
   int n, n_full, lda, ldo, npad, nb, npairs, p;
   float alpha, ridge, max_ev, normD;
   int active, sweeps;
+  int small;   // n <= 128: solved by the LDS-resident one-sided Jacobi kernel, never swept
   float off_rel;
   unsigned err_bits;
   int power_iters;
@@ -88,9 +89,15 @@ __device__ __host__ inline void rr_pair(int m, int r, int k, int& I, int& J) {
 
 // Same tournament without ordering the two players (the in-LDS pivot sweep walks
 // the first players (r+k) % (m-1) and the second players (r-k) % (m-1) with lanes).
+// 0 <= r < m-1 and 0 <= k < m/2, so the reductions are one conditional subtraction each
+// (an integer division by a run-time value costs ~40 instructions per lane and round).
 __device__ inline void rr_pair_raw(int m, int r, int k, int& a, int& b) {
-  if (k == 0) { a = m - 1; b = r % (m - 1); }
-  else { a = (r + k) % (m - 1); b = (r - k + (m - 1)) % (m - 1); }
+  const int mm = m - 1;
+  if (k == 0) { a = mm; b = r; }
+  else {
+    a = r + k; if (a >= mm) a -= mm;
+    b = r - k; if (b < 0) b += mm;
+  }
 }
 
 // ---- init: D = A_in masked + ridge I, A = D, V = I; ||D||_F partials -------------
@@ -258,6 +265,230 @@ __global__ __launch_bounds__(JT) void jacobi_pair_kernel(EighBlock* blocks,
   }
 }
 
+// ---- LDS-resident eigensolver for n <= 128: the whole decomposition in ONE launch ------
+// One 1024-thread workgroup per matrix; G = A V (starts as A) and V (starts as I) live in
+// LDS column-major (column stride 132 floats: 16-byte aligned, 2 x 66 KB), and all sweeps
+// and the convergence test run inside the kernel (no host round trip, any batch size).
+// One-sided (Hestenes) Jacobi: a rotation of the column pair (p, q) of G and V makes g_p
+// and g_q orthogonal; when all pairs are, the columns of V are the eigenvectors of the
+// symmetric input and lambda_j = v_j . g_j (its Rayleigh quotient, sign included).  Unlike the
+// two-sided form a rotation touches only its own two columns, so a round of m/2 disjoint
+// pairs (round-robin tournament) needs a single barrier, every LDS access is a 16-byte read
+// or write of a contiguous column piece, and the three dot products of a pair are reduced
+// inside a quarter-wavefront: 16 lanes own one pair (8 elements of each column per lane), a
+// wavefront 4 pairs, the 16 wavefronts the 64 pairs of a round at n = 128.
+// LDS traffic per round = G and V read and written once (2 x 64 KB at n = 128), the bound of
+// the kernel (ds_write_b128 ~79 B/clk): ~2.2k cycles per round, ~8 sweeps of n-1 rounds.
+// Replaces, for small matrices, the multi-launch blocked driver below (jnp.linalg.eigh at
+// DS:1007 / DS:1071 and the b x b problems of subspace.py).
+constexpr int SE_T = 1024;          // threads
+constexpr int SE_LD = 132;          // column stride (floats)
+constexpr int SE_MAXN = 128;
+constexpr int SE_MAX_SWEEPS = 24;
+
+// x + (x rotated right by N lanes inside its row of 16 lanes): one v_add_f32 with a DPP
+// operand.  Rotations by 8, 4, 2, 1 leave the sum of the 16 lanes in every lane.
+template <int N>
+__device__ inline float row16_add_ror(float x) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xf, 0xf, false);
+  return x + __int_as_float(r);
+}
+__device__ inline float row16_sum(float x) {
+  x = row16_add_ror<8>(x);
+  x = row16_add_ror<4>(x);
+  x = row16_add_ror<2>(x);
+  return row16_add_ror<1>(x);
+}
+
+__global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, const int* ids) {
+  extern __shared__ __align__(16) float sem[];
+  float* G = sem;                       // [128][132] column-major: G[col * SE_LD + row]
+  float* V = sem + SE_MAXN * SE_LD;
+  float* s_red = sem + 2 * SE_MAXN * SE_LD;                 // [16] per-wavefront partials
+  int* s_rot = reinterpret_cast<int*>(s_red + 16);          // [2]
+  EighBlock* eb = &blocks[ids[blockIdx.x]];
+  const int n = eb->n, ld = eb->npad, tid = threadIdx.x;
+  if (n == 0) return;
+  const int m = (n + 1) & ~1;           // players of the tournament (a dummy column if n is odd)
+  const bool tall = n > 64;             // rows 64.. exist (else that half of every column is zero)
+  const float* A = eb->A;               // regularised input D (eigh_init_kernel), stride npad
+  const int lane = tid & 63, wave = tid >> 6;
+  const int sub = lane >> 4, l = lane & 15;     // 16 lanes per pair, 4 pairs per wavefront
+  const int k = 4 * wave + sub;                 // pair index within the round
+  const bool has_pair = k < (m >> 1);
+  float shift = 0.f;
+  int sweeps_total = 0;
+  // One-sided Jacobi yields the SVD: for an indefinite matrix with eigenvalues +x and -x of
+  // close magnitude the singular subspace mixes their eigenvectors.  Such inputs (detected
+  // from the Rayleigh quotients) are solved again as A + shift I, which is positive definite.
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // G = (D + D^T)/2 + shift I column-major, zero padded to 128 rows / m columns; V = I
+    for (int e = tid; e < SE_MAXN * SE_MAXN; e += SE_T) {
+      const int col = e >> 7, row = e & 127;
+      float g = 0.f;
+      if (row < n && col < n) {
+        g = 0.5f * (gload1(A + (int64_t)col * ld + row) + gload1(A + (int64_t)row * ld + col));
+        if (row == col) g += shift;
+      }
+      G[col * SE_LD + row] = g;
+      V[col * SE_LD + row] = row == col ? 1.f : 0.f;
+    }
+    if (tid < 2) s_rot[tid] = 0;
+    __syncthreads();
+
+    for (int sweeps = 0; sweeps < SE_MAX_SWEEPS; ++sweeps, ++sweeps_total) {
+      int rotated = 0;
+      for (int round = 0; round < m - 1; ++round) {
+        if (has_pair) {
+          int p, q;
+          rr_pair_raw(m, round, k, p, q);
+          float* gp = G + p * SE_LD + 4 * l;
+          float* gq = G + q * SE_LD + 4 * l;
+          float* vp = V + p * SE_LD + 4 * l;
+          float* vq = V + q * SE_LD + 4 * l;
+          // elements 4l..4l+3 and 64+4l..64+4l+3 of each column (16 lanes x 16 B contiguous);
+          // all eight reads are issued before anything waits on them
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+          f32x4 a0 = *reinterpret_cast<f32x4*>(gp), b0 = *reinterpret_cast<f32x4*>(gq);
+          f32x4 w0 = *reinterpret_cast<f32x4*>(vp), x0 = *reinterpret_cast<f32x4*>(vq);
+          f32x4 a1 = zero4, b1 = zero4, w1 = zero4, x1 = zero4;
+          if (tall) {
+            a1 = *reinterpret_cast<f32x4*>(gp + 64); b1 = *reinterpret_cast<f32x4*>(gq + 64);
+            w1 = *reinterpret_cast<f32x4*>(vp + 64); x1 = *reinterpret_cast<f32x4*>(vq + 64);
+          }
+          float aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            aa += a0[j] * a0[j] + a1[j] * a1[j];
+            bb += b0[j] * b0[j] + b1[j] * b1[j];
+            ab += a0[j] * b0[j] + a1[j] * b1[j];
+          }
+          aa = row16_sum(aa); bb = row16_sum(bb); ab = row16_sum(ab);
+          // rotate unless the columns are already orthogonal to working precision
+          if (fabsf(ab) > 3e-7f * __builtin_amdgcn_sqrtf(aa * bb)) {
+            const float zeta = (bb - aa) * __builtin_amdgcn_rcpf(2.f * ab);
+            const float t = copysignf(1.f, zeta) *
+                            __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta));
+            const float c = __builtin_amdgcn_rsqf(1.f + t * t), sn = c * t;
+            if (c == c && sn == sn) {
+              f32x4 na0, nb0, nw0, nx0;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                na0[j] = c * a0[j] - sn * b0[j]; nb0[j] = sn * a0[j] + c * b0[j];
+                nw0[j] = c * w0[j] - sn * x0[j]; nx0[j] = sn * w0[j] + c * x0[j];
+              }
+              *reinterpret_cast<f32x4*>(gp) = na0; *reinterpret_cast<f32x4*>(gq) = nb0;
+              *reinterpret_cast<f32x4*>(vp) = nw0; *reinterpret_cast<f32x4*>(vq) = nx0;
+              if (tall) {
+                f32x4 na1, nb1, nw1, nx1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  na1[j] = c * a1[j] - sn * b1[j]; nb1[j] = sn * a1[j] + c * b1[j];
+                  nw1[j] = c * w1[j] - sn * x1[j]; nx1[j] = sn * w1[j] + c * x1[j];
+                }
+                *reinterpret_cast<f32x4*>(gp + 64) = na1; *reinterpret_cast<f32x4*>(gq + 64) = nb1;
+                *reinterpret_cast<f32x4*>(vp + 64) = nw1; *reinterpret_cast<f32x4*>(vq + 64) = nx1;
+              }
+              rotated = 1;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      // a sweep without a single rotation: converged (s_rot is double buffered by parity)
+      if (rotated && l == 0) s_rot[sweeps & 1] = 1;
+      __syncthreads();
+      const int any = s_rot[sweeps & 1];
+      __syncthreads();
+      if (tid == 0) s_rot[sweeps & 1] = 0;   // re-armed for sweep + 2 (after the next barriers)
+      if (!any) { ++sweeps_total; break; }
+    }
+    __syncthreads();
+    // The approximate rcp / rsq of the rotation parameters scale a rotation by 1 + O(eps):
+    // renormalise the eigenvectors (and g_j with them, G = A V), then the Rayleigh quotients.
+    float lo_ev = 0.f, hi_abs = 0.f;
+    for (int j = wave; j < m; j += SE_T / 64) {
+      const float v0 = V[j * SE_LD + lane], v1 = V[j * SE_LD + 64 + lane];
+      const float nn = wave_sum_f32(v0 * v0 + v1 * v1);
+      const float inv = nn > 0.f ? 1.f / sqrtf(nn) : 0.f;
+      const float g0 = G[j * SE_LD + lane] * inv, g1 = G[j * SE_LD + 64 + lane] * inv;
+      V[j * SE_LD + lane] = v0 * inv; V[j * SE_LD + 64 + lane] = v1 * inv;
+      G[j * SE_LD + lane] = g0; G[j * SE_LD + 64 + lane] = g1;
+      const float ev = wave_sum_f32(v0 * inv * g0 + v1 * inv * g1) - shift;
+      // ||g_j|| = the singular value |lambda_j + shift|: exact even when eigenvectors of +x and
+      // -x are mixed, so 1.01 max_j ||g_j|| is a safe shift
+      const float gn = sqrtf(wave_sum_f32(g0 * g0 + g1 * g1));
+      if (j < n) { lo_ev = fminf(lo_ev, ev); hi_abs = fmaxf(hi_abs, gn); }
+    }
+    if (lane == 0) { s_red[wave] = lo_ev; }
+    __syncthreads();
+    float lo_all = 0.f;
+    for (int w = 0; w < SE_T / 64; ++w) lo_all = fminf(lo_all, s_red[w]);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = hi_abs;
+    __syncthreads();
+    float hi_all = 0.f;
+    for (int w = 0; w < SE_T / 64; ++w) hi_all = fmaxf(hi_all, s_red[w]);
+    __syncthreads();
+    // positive semi-definite (the statistics, Gram and Rayleigh-Ritz matrices of this
+    // library): done.  Clearly indefinite: once more on A + 1.01 max|lambda| I.
+    if (attempt == 1 || !(lo_all < -1e-5f * hi_all)) break;
+    shift = 1.01f * hi_all;
+  }
+  if (eb->evals_out != nullptr) {
+    // plain eigenpairs (ps_eigh_batched_f32): straight to the caller's arrays in LAPACK's
+    // ASCENDING order.  rank_j = #{i : lambda_i < lambda_j or (equal and i < j)}; the
+    // eigenvalue of column j sits in s_ev[j], its rank in s_rank[j] (both alias G's padding
+    // rows... no: they live behind V, G is still needed for the quotients).
+    float* s_ev = s_red + 32;                           // [128]
+    int* s_rank = reinterpret_cast<int*>(s_ev + 128);   // [128]
+    for (int j = wave; j < n; j += SE_T / 64) {
+      float d = V[j * SE_LD + lane] * G[j * SE_LD + lane] +
+                V[j * SE_LD + 64 + lane] * G[j * SE_LD + 64 + lane];
+      d = wave_sum_f32(d);
+      if (lane == 0) s_ev[j] = d - shift;
+    }
+    __syncthreads();
+    if (tid < n) {
+      const float mine = s_ev[tid];
+      int rank = 0;
+      for (int i = 0; i < n; ++i) {
+        const float o = s_ev[i];
+        rank += (o < mine || (o == mine && i < tid) || (o != o && mine == mine)) ? 1 : 0;
+      }
+      if (mine != mine) {   // NaNs last, in index order
+        rank = 0;
+        for (int i = 0; i < n; ++i) rank += (s_ev[i] == s_ev[i] || i < tid) ? 1 : 0;
+      }
+      s_rank[tid] = rank;
+      gstore1(eb->evals_out + rank, mine);
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += SE_T) {
+      const int col = e / n, row = e - col * n;   // LDS walks a column; the store scatters rows
+      gstore1(eb->out + (int64_t)row * eb->ldo + s_rank[col], V[col * SE_LD + row]);
+    }
+    if (tid == 0) { eb->sweeps = sweeps_total; eb->active = 0; eb->off_rel = 0.f; }
+    return;
+  }
+  // results to the block's workspace: V row-major (eigenvectors in columns), A = diag(lambda)
+  float* Aout = eb->A;
+  float* Vout = eb->V;
+  for (int e = tid; e < SE_MAXN * SE_MAXN; e += SE_T) {
+    const int row = e >> 7, col = e & 127;   // consecutive threads: consecutive columns of a row
+    const bool in = row < n && col < n;
+    gstore1(Vout + (int64_t)row * ld + col, in ? V[col * SE_LD + row] : (row == col ? 1.f : 0.f));
+    if (row != col) gstore1(Aout + (int64_t)row * ld + col, 0.f);
+  }
+  for (int j = wave; j < n; j += SE_T / 64) {
+    float d = V[j * SE_LD + lane] * G[j * SE_LD + lane] +
+              V[j * SE_LD + 64 + lane] * G[j * SE_LD + 64 + lane];
+    d = wave_sum_f32(d);
+    if (lane == 0) gstore1(Aout + (int64_t)j * ld + j, d - shift);
+  }
+  if (tid == 0) { eb->sweeps = sweeps_total; eb->active = 0; eb->off_rel = 0.f; }
+}
+
 // ---- A <- J^T A on block rows {I, J}; tile = 128 gathered rows x 128 columns -----
 __global__ __launch_bounds__(256, 2) void jacobi_row_kernel(EighBlock* blocks,
                                                             const ETile* tiles, int ntiles,
@@ -376,7 +607,7 @@ __global__ void eigh_set_active_kernel(EighBlock* blocks, int nblocks, int swap_
   if (b >= nblocks) return;
   EighBlock* eb = &blocks[b];
   if (eb->n == 0) return;
-  eb->active = 1;
+  eb->active = eb->small ? 0 : 1;
   if (swap_vw) { float* t = eb->V; eb->V = eb->W; eb->W = t; }
 }
 
@@ -553,6 +784,7 @@ __global__ __launch_bounds__(256) void eigh_copy_pairs_kernel(EighBlock* blocks,
                                                               const ETile* tiles) {
   const ETile te = tiles[blockIdx.x];
   EighBlock* eb = &blocks[te.block];
+  if (eb->small) return;  // eigh_small_kernel wrote the (sorted) pairs itself
   const int ld = eb->npad, n = eb->n, tid = threadIdx.x;
   for (int e = tid; e < TILE * TILE; e += 256) {
     const int row = te.k * TILE + e / TILE, col = te.t * TILE + e % TILE;
@@ -591,8 +823,14 @@ using psh::Arena;
 
 namespace {
 
+bool small_eigh_enabled() {  // dev A/B: PS_EIGH_SMALL=0 sends every size through the blocked driver
+  const char* e = getenv("PS_EIGH_SMALL");
+  return !e || atoi(e) != 0;
+}
+
 struct EPlan {
   int batch = 0, max_n = 0, max_nb = 0;
+  std::vector<int> small_ids;     // blocks solved by eigh_small_kernel
   std::vector<int> n_eff, npad;
   std::vector<ETile> sq_tiles;    // (block, tm, tn) over npad^2
   std::vector<ETile> pair_tiles;  // (block, k)
@@ -615,10 +853,14 @@ void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_s
     pl.npad[b] = ne >= 1 ? psh::round_up(ne, TILE) : 0;
     pl.max_n = std::max(pl.max_n, ne);
     const int t = pl.npad[b] / TILE, nb = pl.npad[b] / JB, np = nb / 2;
-    pl.max_nb = std::max(pl.max_nb, nb);
     for (int i = 0; i < t; ++i)
       for (int j = 0; j < t; ++j) pl.sq_tiles.push_back({b, (short)i, (short)j, 0, 0});
     for (int c = 0; c < (ne + 63) / 64; ++c) pl.rq_tiles.push_back({b, (short)c, 0, 0, 0});
+    if (ne >= 1 && ne <= SE_MAXN && small_eigh_enabled()) {  // LDS-resident solver, never swept
+      pl.small_ids.push_back(b);
+      continue;
+    }
+    pl.max_nb = std::max(pl.max_nb, nb);
     for (int k = 0; k < np; ++k) {
       pl.pair_tiles.push_back({b, (short)k, 0, 0, 0});
       for (int c = 0; c < t; ++c) {
@@ -632,6 +874,7 @@ void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_s
 
 struct ELayout {
   EighBlock* blocks;
+  int* small_ids;
   ETile *sq, *pair, *row, *col, *rq;
   std::vector<float*> mat[5], Q, offp, ssq, evals;
 };
@@ -645,8 +888,9 @@ size_t ecarve(EPlan& pl, Arena& ar, ELayout* lo) {
   ETile* rw = ar.take<ETile>(pl.row_tiles.size());
   ETile* cl = ar.take<ETile>(pl.col_tiles.size());
   ETile* rq = ar.take<ETile>(std::max<size_t>(pl.rq_tiles.size(), 1));
+  int* sid = ar.take<int>(std::max<size_t>(pl.small_ids.size(), 1));
   if (lo) { lo->blocks = blocks; lo->sq = sq; lo->pair = pr; lo->row = rw; lo->col = cl;
-            lo->rq = rq; }
+            lo->rq = rq; lo->small_ids = sid; }
   for (int b = 0; b < B; ++b) {
     const size_t sq_e = (size_t)pl.npad[b] * pl.npad[b];
     for (int k = 0; k < 5; ++k) { float* m = ar.take<float>(sq_e); if (lo) lo->mat[k].push_back(m); }
@@ -733,9 +977,9 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     eb.active = eb.n > 0 ? 1 : 0;
     eb.off_rel = 1.f;
   }
+  for (int b : pl.small_ids) hb[b].small = 1;
   auto up = [&](void* d, const void* h, size_t bytes) -> int {
-    if (bytes == 0) return 0;
-    return (int)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
+    return psh::upload_async(st, d, h, bytes);  // pinned staging ring: no stream synchronisation
   };
   int rc;
   if ((rc = up(lo.blocks, hb.data(), sizeof(EighBlock) * batch))) return rc;
@@ -746,7 +990,9 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   if (!pl.rq_tiles.empty() &&
       (rc = up(lo.rq, pl.rq_tiles.data(), sizeof(ETile) * pl.rq_tiles.size())))
     return rc;
-  PS_HIP(hipStreamSynchronize(st));
+  if (!pl.small_ids.empty() &&
+      (rc = up(lo.small_ids, pl.small_ids.data(), sizeof(int) * pl.small_ids.size())))
+    return rc;
   if (relative_matrix_epsilon) {
     if ((rc = pl.pip.upload(st, a, lda))) return rc;
     // the reference's power iteration is a plain mat-vec loop on the raw input (DS:996-1001)
@@ -800,8 +1046,22 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       }
       return 0;
     };
+    const bool any_big = npair > 0;
+    if (!pl.small_ids.empty()) {  // n <= 128: whole decomposition in one launch, no host wait
+      const size_t small_lds = (size_t)(2 * SE_MAXN * SE_LD + 32 + 256) * sizeof(float);
+      static bool small_attr = false;
+      if (!small_attr) {
+        PS_HIP(hipFuncSetAttribute((const void*)eigh_small_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+        small_attr = true;
+      }
+      hipLaunchKernelGGL(eigh_small_kernel, dim3((unsigned)pl.small_ids.size()), dim3(SE_T),
+                         small_lds, st, lo.blocks, lo.small_ids);
+      PS_LAUNCH_CHECK();
+    }
+    if (mode == 1 && !any_big) return PS_OK;  // the kernel wrote sorted pairs to the outputs
     // phase 1: sweep until the pivot off-norm at the start of a sweep < 1e-3 ||D||
-    if ((rc = run_phase(1e-3f, 30))) return rc;
+    if (any_big && (rc = run_phase(1e-3f, 30))) return rc;
     // polish: V <- V (1.5 I - 0.5 V^T V);  A <- V^T D V
     hipLaunchKernelGGL((eigh_gemm_kernel<MC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
                        (int)GB_V, (int)GB_V, (int)GB_X, (int)GE_POLISH);
@@ -815,7 +1075,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                        (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_STORE);
     PS_LAUNCH_CHECK();
     // phase 2: finish (quadratic): stop once a sweep STARTED below 1e-4
-    if ((rc = run_phase(1e-4f, 4))) return rc;
+    if (any_big && (rc = run_phase(1e-4f, 4))) return rc;
     {
       static int refine = -1;
       if (refine < 0) { const char* e = getenv("PS_EIGH_REFINE"); refine = e ? atoi(e) != 0 : 1; }
@@ -860,6 +1120,8 @@ extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
                      error_tolerance, relative_matrix_epsilon, out, ldo, nullptr, metrics,
                      workspace, workspace_bytes);
 }
+
+extern "C" int ps_eigh_sorted_max_n(void) { return small_eigh_enabled() ? SE_MAXN : 0; }
 
 extern "C" int ps_eigh_batched_f32(void* stream, const float* const* a, const int32_t* n,
                                    const int32_t* lda, int batch, float* const* evals,

@@ -253,8 +253,13 @@ def eigh_batched(matrices: Sequence[torch.Tensor]):
                              v_ptrs.ctypes.data, ldv.ctypes.data, ws.data_ptr(),
                              ws.numel())
   check(rc, "ps_eigh_batched_f32")
+  sorted_n = L.ps_eigh_sorted_max_n()  # small matrices come back ascending already
   out_e, out_v = [], []
   for e, v in zip(evals, evecs):
+    if e.shape[0] <= sorted_n:
+      out_e.append(e)
+      out_v.append(v)
+      continue
     order = torch.argsort(e)  # pure permutation (data movement, no arithmetic)
     out_e.append(e[order])
     out_v.append(v[:, order])
