@@ -227,3 +227,43 @@ def test_vit_b_tree_recompute(device, persistent, monkeypatch):
     assert met[i, 1] == m_ref["inverse_pth_root_iters"], (key, met[i], m_ref)
     assert met[i, 4] == m_ref["total_retries"], (key, met[i], m_ref)
     assert np.isclose(met[i, 3], m_ref["max_eigen_value"], rtol=2e-5)
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["d1024_r8", "d2048_r64"])
+def test_fd_update_root_subspace_path_vs_reference_golden(name, device, monkeypatch):
+  """Full-size Frequent-Directions chains (BASELINE configs[4] path): at d >= 1024
+  _fd_update_root takes the leading rank+1 eigenpairs from the block subspace method
+  (MFMA products) instead of the reference's SVD of [sqrt(decay) W | R] (DS:1193).  Every
+  step is replayed from the REFERENCE's previous sketch and compared with its packed
+  result as DST:770-885 do: inverted / deflated eigenvalues, tail and const by value,
+  eigenvectors through the projector they span (tests/golden/low_rank_big.npz, generated by
+  tools/gen_golden.py from the reference's own _fd_update_root)."""
+  import json
+  from precondition_amd import low_rank, subspace
+  from tests.test_oracle_golden import GOLD, fd_big_grad
+  from tests.test_optimizer_host_logic import packed_matches
+  z = np.load(os.path.join(GOLD, "low_rank_big.npz"))
+  with open(os.path.join(GOLD, "low_rank_big_index.json")) as f:
+    c = [c for c in json.load(f) if c["name"] == name][0]
+  calls = []
+  real = subspace.top_eigenpairs_batched
+  monkeypatch.setattr(subspace, "top_eigenpairs_batched",
+                      lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+  rng = np.random.default_rng(c["seed"])
+  d, r = c["d"], c["rank"]
+  prev = torch.zeros((d, r + 2), device=device)
+  for t in range(c["steps"]):
+    g = torch.tensor(fd_big_grad(d, r, t, rng), device=device)
+    gram = low_rank.gram_of_block(g, 0)
+    new, _ = low_rank._fd_update_root(
+        gram, c["p"], rank=r, ridge_epsilon=c["ridge"], error_tolerance=0.0,
+        relative_matrix_epsilon=c["rel"], decay=c["decay"], padding_start=d, prev=prev,
+        new_grad_is_gram=True)
+    ref = z[f"fd_{name}__new{t}"]
+    got = new.cpu().numpy()
+    assert packed_matches(got, ref, r, tol=2e-3), (name, t)
+    # tail ~ cutoff^2 accumulates exactly as in the reference (DST:829-885)
+    assert np.isclose(got[1, -1], ref[1, -1], rtol=1e-3)
+    prev = torch.tensor(ref, device=device)
+  assert len(calls) == c["steps"], "the block subspace method must have run"

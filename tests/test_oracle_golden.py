@@ -206,3 +206,50 @@ def test_quantization_oracle_errors():
     qorc.quantize(np.zeros((3, 4, 5), np.float32), np.int16, True)   # QU:67-69
   with pytest.raises(ValueError):
     qorc.quantize(np.zeros((3, 3), np.float32), np.int32, False)     # QU:64
+
+
+# ---------------------------------------------------------------------------
+# Frequent-Directions sketch update (config 5, DS:1123-1290): the oracle's fd_update_root
+# against the reference's own packed sketches, small chains and the d = 1024 / rank 8
+# full-size chain (inputs rebuilt from the seed, tools/gen_golden.py fd_big_grad).
+def fd_big_grad(ps, rank, t, rng):
+  g = rng.standard_normal((ps, 3 * ps)).astype(np.float32) * np.float32(1.0 + 0.3 * t)
+  g[:rank + 2] *= np.linspace(6.0, 2.0, rank + 2)[:, None].astype(np.float32)
+  return g
+
+
+def test_oracle_fd_update_root_vs_reference_golden():
+  from tests.test_optimizer_host_logic import packed_matches
+  z = np.load(os.path.join(GOLD, "low_rank.npz"))
+  with open(os.path.join(GOLD, "low_rank_index.json")) as f:
+    idx = [c for c in json.load(f) if c["kind"] == "fd_chain"]
+  assert idx
+  for c in idx:
+    nm, r = c["name"], c["rank"]
+    for t in range(c["steps"]):
+      got = orc.fd_update_root(z[f"fd_{nm}__factor{t}"], c["p"], r, ridge_epsilon=c["ridge"],
+                               error_tolerance=0.0, relative_matrix_epsilon=c["rel"],
+                               decay=c["decay"], padding_start=c["padding_start"],
+                               prev=z[f"fd_{nm}__prev{t}"])
+      assert packed_matches(got, z[f"fd_{nm}__new{t}"], r, tol=1e-4), (nm, t)
+
+
+def test_oracle_fd_update_root_full_size_chain_vs_reference_golden():
+  from tests.test_optimizer_host_logic import packed_matches
+  z = np.load(os.path.join(GOLD, "low_rank_big.npz"))
+  with open(os.path.join(GOLD, "low_rank_big_index.json")) as f:
+    c = [c for c in json.load(f) if c["name"] == "d1024_r8"][0]
+  rng = np.random.default_rng(c["seed"])
+  d, r = c["d"], c["rank"]
+  prev = np.zeros((d, r + 2), np.float32)
+  for t in range(c["steps"]):
+    g = fd_big_grad(d, r, t, rng)
+    gram = (g.astype(np.float64) @ g.astype(np.float64).T)
+    w, v = np.linalg.eigh(gram)   # any factor R with R R^T = Gram is equivalent (DS:1179-1193)
+    fac = (v * np.sqrt(np.maximum(w, 0))).astype(np.float32)
+    got = orc.fd_update_root(fac, c["p"], r, ridge_epsilon=c["ridge"], error_tolerance=0.0,
+                             relative_matrix_epsilon=c["rel"], decay=c["decay"],
+                             padding_start=d, prev=prev)
+    ref = z[f"fd_d1024_r8__new{t}"]
+    assert packed_matches(got, ref, r, tol=1e-3), t
+    prev = ref

@@ -677,9 +677,46 @@ def gen_lowrank():
     json.dump(index, f, indent=1)
 
 
+def fd_big_grad(ps, rank, t, rng):
+  """Gradient block of step t of a full-size FD chain (shared with the tests, which rebuild
+  the inputs from the seed instead of storing d x 3d arrays)."""
+  g = rng.standard_normal((ps, 3 * ps)).astype(F32) * F32(1.0 + 0.3 * t)
+  g[:rank + 2] *= np.linspace(6.0, 2.0, rank + 2)[:, None].astype(F32)
+  return g
+
+
+def gen_lowrank_big():
+  """Full-size Frequent-Directions chains (BASELINE configs[4] sizes that the CPU reference
+  finishes in seconds): d = 1024 / rank 8 and d = 2048 / rank 64, the sizes at which the
+  build takes the leading eigenpairs from the block subspace method instead of the reference's
+  SVD (DS:1193).  Only seeds and the reference's packed sketches are stored."""
+  out, index = {}, []
+  for name, d, rank, p, decay, steps, seed in (("d1024_r8", 1024, 8, 4, 0.999, 2, 21),
+                                               ("d2048_r64", 2048, 64, 4, 0.999, 2, 22)):
+    rng = np.random.default_rng(seed)
+    prev = jnp.zeros((d, rank + 2), jnp.float32)
+    for t in range(steps):
+      g = fd_big_grad(d, rank, t, rng)
+      fac = ds.frequent_directions_update(None, jnp.array(g), 0, 0.0, 0.0)
+      with np.errstate(all="ignore"):
+        new, _ = ds._fd_update_root(fac, p, rank=rank, ridge_epsilon=1e-6,
+                                    relative_matrix_epsilon=True, decay=decay,
+                                    padding_start=d, prev=prev, error_tolerance=0.0)
+      assert np.asarray(new).dtype == np.float32
+      out[f"fd_{name}__new{t}"] = npy(new)
+      prev = new
+      print("fd_big", name, "step", t, "tail", float(np.asarray(new)[1, -1]),
+            "const", float(np.asarray(new)[0, -1]))
+    index.append(dict(kind="fd_chain_big", name=name, d=d, rank=rank, p=p, padding_start=d,
+                      decay=decay, rel=True, ridge=1e-6, steps=steps, seed=seed))
+  np.savez_compressed(os.path.join(OUT, "low_rank_big.npz"), **out)
+  with open(os.path.join(OUT, "low_rank_big_index.json"), "w") as f:
+    json.dump(index, f, indent=1)
+
+
 if __name__ == "__main__":
   which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e", "lowrank", "quant",
-                           "e2e_quant", "e2e_more"]
+                           "e2e_quant", "e2e_more", "lowrank_big"]
   if "newton" in which:
     gen_newton()
   if "pi" in which:
@@ -700,4 +737,6 @@ if __name__ == "__main__":
     gen_e2e_more()
   if "lowrank" in which:
     gen_lowrank()
+  if "lowrank_big" in which:
+    gen_lowrank_big()
   print("golden fixtures written to", OUT)
