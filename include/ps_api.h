@@ -263,6 +263,32 @@ size_t ps_gemm_grouped_workspace_bytes(const ps_gemm_desc* desc, int count);
 int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count, void* workspace,
                         size_t workspace_bytes);
 
+/* ---- bf16-MFMA products of the Frequent-Directions branch (BASELINE configs[4]) --------
+ * _fd_update_root (DS:1123-1290) needs the leading rank+1 singular pairs of the d x (rank+d)
+ * update; the reference takes a full SVD (DS:1193), this build a block subspace iteration
+ * whose cost is d x d @ d x b products (b ~ rank + 32).  Those run on the bf16 MFMA with
+ * float32 accumulation: C = A * Bt^T with both operands K-CONTIGUOUS bf16 arrays, A [m][k]
+ * and Bt [n][k].  Each operand is either one bf16 array (a_lo / b_lo NULL: 2^-9 relative
+ * operand precision) or a hi/lo pair x = hi + lo (2^-17: hi*hi + lo*hi + hi*lo are
+ * accumulated).  Requirements: k % 32 == 0, lda % 8 == 0, ldb % 8 == 0, 16-byte aligned
+ * bases (PS_EUNSUPPORTED otherwise).
+ * ps_convert_f32_to_bf16 produces the operands: dst_hi[r][c] = bf16(src[r][c]) (round to
+ * nearest even), dst_lo (may be NULL) = bf16(src - hi); transpose != 0 writes dst[c][r]. */
+typedef struct {
+  const void* a_hi; const void* a_lo;   /* bf16 [m][k], leading dimension lda (elements) */
+  const void* b_hi; const void* b_lo;   /* bf16 [n][k], leading dimension ldb */
+  float* c;                             /* float32 [m][n], leading dimension ldc */
+  int32_t m, n, k;
+  int64_t lda, ldb, ldc;
+} ps_gemm_bf16_desc;
+
+int ps_convert_f32_to_bf16(void* stream, const float* src, void* dst_hi, void* dst_lo,
+                           int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
+                           int transpose);
+size_t ps_gemm_bf16_grouped_workspace_bytes(const ps_gemm_bf16_desc* desc, int count);
+int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc, int count,
+                         void* workspace, size_t workspace_bytes);
+
 /* ---- fused _transform_grad for a whole parameter tree (DS:3496-3625) -------------
  * Grafting, norm matching of the preconditioned gradient, weight decay, momentum /
  * Nesterov for every parameter in three launches.  All arrays of one parameter are

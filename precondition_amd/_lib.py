@@ -47,6 +47,13 @@ class GemmDesc(C.Structure):
   ]
 
 
+class GemmBf16Desc(C.Structure):
+  """Mirror of ps_gemm_bf16_desc."""
+  _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("b_hi", C.c_void_p),
+              ("b_lo", C.c_void_p), ("c", C.c_void_p), ("m", C.c_int32), ("n", C.c_int32),
+              ("k", C.c_int32), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64)]
+
+
 class TransformDesc(C.Structure):
   """Mirror of ps_transform_desc."""
   _fields_ = [(n, C.c_void_p) for n in ("grad", "pgrad", "param", "diag_in", "diag_out",
@@ -132,6 +139,12 @@ _SIGNATURES = {
     "ps_gemm_grouped_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc), C.c_int]),
     "ps_gemm_grouped_f32":
         (C.c_int, [C.c_void_p, C.POINTER(GemmDesc), C.c_int, C.c_void_p, C.c_size_t]),
+    "ps_convert_f32_to_bf16":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                   C.c_int64, C.c_int64, C.c_int]),
+    "ps_gemm_bf16_grouped_workspace_bytes": (C.c_size_t, [C.POINTER(GemmBf16Desc), C.c_int]),
+    "ps_gemm_bf16_grouped":
+        (C.c_int, [C.c_void_p, C.POINTER(GemmBf16Desc), C.c_int, C.c_void_p, C.c_size_t]),
     "ps_transform_grads_workspace_bytes": (C.c_size_t, [C.POINTER(TransformDesc), C.c_int]),
     "ps_transform_grads_f32":
         (C.c_int, [C.c_void_p, C.POINTER(TransformDesc), C.c_int, C.POINTER(TransformConfig),

@@ -1,0 +1,277 @@
+// gemm_bf16.hip — grouped C = A * B^T on the bf16 MFMA (v_mfma_f32_32x32x16_bf16), float32
+// accumulation and output, for the Frequent-Directions branch (BASELINE configs[4]: "rank-64
+// updates on 4096-dim factors, bf16 MFMA"; reference: _fd_update_root DS:1123-1290, whose SVD
+// at DS:1193 this build replaces by a block subspace iteration made of d x d @ d x b
+// products, precondition_amd/subspace.py).
+//
+// Both operands are K-CONTIGUOUS bf16 arrays: A [m][k] and Bt [n][k] (the caller converts the
+// float32 covariance once per update and the tall-skinny iterate once per product with
+// ps_convert_f32_to_bf16, which can also transpose).  Each operand may come as ONE bf16
+// array (relative precision 2^-9) or as a hi/lo PAIR (x = hi + lo, hi = bf16(x), lo =
+// bf16(x - hi): 2^-17); the kernel accumulates hi*hi (+ lo*hi + hi*lo when split) into the
+// same float32 accumulators.  The product is HBM-bound (a 4096 x 4096 covariance is read
+// once per product, n <= 128 columns): what matters is bytes, not MFMA passes — the split
+// form reads the same bytes as float32 and is ~3.4x faster than the float32 MFMA product,
+// the single form halves them again.
+//
+// One workgroup = 256 threads = 2x2 wavefronts, 128 x 128 output tile, BK = 32 k per LDS
+// stage, double buffered; LDS rows are 32 + 8 bf16 (80 bytes: 16-lane fragment reads and
+// 8-lane row writes touch every bank once).  Fragments: lane l of a wavefront holds
+// A[row l&31][k = 8(l>>5) + j] (j = 0..7) = one ds_read_b128 per 32x32x16 step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "gemm_core.hip.h"
+
+namespace psk {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HBK = 32;           // k per stage
+constexpr int HLD = HBK + 8;      // LDS row stride in bf16 elements (80 bytes)
+constexpr int HOP = TILE * HLD;   // bf16 elements of one operand image
+
+struct HTask {
+  const uint16_t* a_hi; const uint16_t* a_lo;   // [m][k], lo may be null
+  const uint16_t* b_hi; const uint16_t* b_lo;   // [n][k], lo may be null
+  float* c;
+  int m, n, k;
+  int64_t lda, ldb, ldc;
+};
+struct HTile { int task; short tm, tn; };
+
+__device__ inline u32x4 gload16(const uint16_t* p) { return *(const u32x4 PS_GLOBAL*)(p); }
+
+// 128 rows x 32 k of one operand array -> registers (2 x 16 bytes per thread)
+__device__ inline void hload(const uint16_t* base, int64_t ld, int row0, int rows, int k0,
+                             int tid, u32x4 (&r)[2]) {
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int f = tid + 256 * v;          // 512 chunks of 8 bf16
+    const int row = f >> 2, kc = (f & 3) * 8;
+    u32x4 t = {0u, 0u, 0u, 0u};
+    if (row0 + row < rows) t = gload16(base + (int64_t)(row0 + row) * ld + k0 + kc);
+    r[v] = t;
+  }
+}
+__device__ inline void hstore(uint16_t* s, int tid, const u32x4 (&r)[2]) {
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int f = tid + 256 * v;
+    const int row = f >> 2, kc = (f & 3) * 8;
+    *reinterpret_cast<u32x4*>(s + row * HLD + kc) = r[v];
+  }
+}
+__device__ inline bf16x8 hfrag(const uint16_t* s, int row, int k) {
+  return *reinterpret_cast<const bf16x8*>(s + row * HLD + k);
+}
+
+// SA / SB: 1 = single bf16 array, 2 = hi/lo pair.
+template <int SA, int SB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* tasks,
+                                                                   const HTile* tiles,
+                                                                   int ntiles) {
+  extern __shared__ __align__(16) uint16_t hs[];   // 2 stages x (SA + SB) images
+  constexpr int STG = (SA + SB) * HOP;
+  const HTile te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  const HTask tk = tasks[te.task];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int row0 = te.tm * TILE, col0 = te.tn * TILE;
+  const int nk = (tk.k + HBK - 1) / HBK;   // k is a multiple of 8 (checked on the host);
+                                           // a ragged last tile reads zeros past k? no: k % 32
+                                           // is also required, see ps_gemm_bf16_grouped
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  u32x4 ra[SA][2], rb[SB][2];
+  hload(tk.a_hi, tk.lda, row0, tk.m, 0, tid, ra[0]);
+  if (SA == 2) hload(tk.a_lo, tk.lda, row0, tk.m, 0, tid, ra[SA - 1]);
+  hload(tk.b_hi, tk.ldb, col0, tk.n, 0, tid, rb[0]);
+  if (SB == 2) hload(tk.b_lo, tk.ldb, col0, tk.n, 0, tid, rb[SB - 1]);
+  hstore(hs, tid, ra[0]);
+  if (SA == 2) hstore(hs + HOP, tid, ra[SA - 1]);
+  hstore(hs + SA * HOP, tid, rb[0]);
+  if (SB == 2) hstore(hs + (SA + 1) * HOP, tid, rb[SB - 1]);
+  __syncthreads();
+  const int fr = lane & 31, fk = 8 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    uint16_t* cur = hs + (kt & 1) * STG;
+    uint16_t* nxt = hs + ((kt + 1) & 1) * STG;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      const int k0 = (kt + 1) * HBK;
+      hload(tk.a_hi, tk.lda, row0, tk.m, k0, tid, ra[0]);
+      if (SA == 2) hload(tk.a_lo, tk.lda, row0, tk.m, k0, tid, ra[SA - 1]);
+      hload(tk.b_hi, tk.ldb, col0, tk.n, k0, tid, rb[0]);
+      if (SB == 2) hload(tk.b_lo, tk.ldb, col0, tk.n, k0, tid, rb[SB - 1]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = hfrag(cur, wm * 64 + t * 32 + fr, ks * 16 + fk);
+        if (SA == 2) al[t] = hfrag(cur + HOP, wm * 64 + t * 32 + fr, ks * 16 + fk);
+        bh[t] = hfrag(cur + SA * HOP, wn * 64 + t * 32 + fr, ks * 16 + fk);
+        if (SB == 2) bl[t] = hfrag(cur + (SA + 1) * HOP, wn * 64 + t * 32 + fr, ks * 16 + fk);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          // small terms first: lo*hi + hi*lo, then hi*hi (lo*lo ~ 2^-18 relative is dropped)
+          if (SA == 2)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          if (SB == 2)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    if (more) {
+      hstore(nxt, tid, ra[0]);
+      if (SA == 2) hstore(nxt + HOP, tid, ra[SA - 1]);
+      hstore(nxt + SA * HOP, tid, rb[0]);
+      if (SB == 2) hstore(nxt + (SA + 1) * HOP, tid, rb[SB - 1]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + acc_row(wm, i, r, lane);
+        const int col = col0 + acc_col(wn, j, lane);
+        if (row < tk.m && col < tk.n) gstore1(tk.c + (int64_t)row * tk.ldc + col, acc[i][j][r]);
+      }
+}
+
+// ---- float32 -> bf16 (round to nearest even), optionally hi/lo split and transposed -------
+// dst_hi[r][c] = bf16(src[r][c]); dst_lo[r][c] = bf16(src[r][c] - float(dst_hi[r][c])).
+// transpose: dst[c][r] instead (64 x 64 tiles through LDS, both sides coalesced).
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* src, uint16_t* hi,
+                                                       uint16_t* lo, int rows, int cols,
+                                                       int64_t lds, int64_t ldd, int transpose,
+                                                       int tiles_c) {
+  __shared__ float t[64][65];
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64, tid = threadIdx.x;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    t[r][c] = (r0 + r < rows && c0 + c < cols) ? gload1(src + (int64_t)(r0 + r) * lds + c0 + c) : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int a = e >> 6, b = e & 63;          // output tile coordinates (row a, col b)
+    const int r = transpose ? b : a, c = transpose ? a : b;
+    if (r0 + r >= rows || c0 + c >= cols) continue;
+    const float x = t[r][c];
+    const __bf16 h = (__bf16)x;                 // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    const int64_t o = transpose ? (int64_t)(c0 + c) * ldd + r0 + r : (int64_t)(r0 + r) * ldd + c0 + c;
+    hi[o] = __builtin_bit_cast(uint16_t, h);
+    if (lo != nullptr) {
+      const __bf16 l = (__bf16)(x - (float)h);
+      lo[o] = __builtin_bit_cast(uint16_t, l);
+    }
+  }
+}
+
+}  // namespace psk
+
+using namespace psk;
+
+extern "C" int ps_convert_f32_to_bf16(void* stream, const float* src, void* dst_hi,
+                                      void* dst_lo, int64_t rows, int64_t cols, int64_t lds,
+                                      int64_t ldd, int transpose) {
+  PS_DEVICE_CHECK();
+  if (!src || !dst_hi || rows < 1 || cols < 1 || lds < cols || ldd < (transpose ? rows : cols))
+    return PS_EINVAL;
+  const int64_t tr = (rows + 63) / 64, tc = (cols + 63) / 64;
+  if (tr * tc > 0x7fffffff) return PS_EUNSUPPORTED;
+  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)(tr * tc)), dim3(256), 0,
+                     (hipStream_t)stream, src, (uint16_t*)dst_hi, (uint16_t*)dst_lo, (int)rows,
+                     (int)cols, lds, ldd, transpose, (int)tc);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+static size_t hbytes(const ps_gemm_bf16_desc* d, int count) {
+  size_t tiles = 0;
+  for (int i = 0; i < count; ++i)
+    tiles += (size_t)((d[i].m + TILE - 1) / TILE) * ((d[i].n + TILE - 1) / TILE);
+  return 4 * (psh::align_up(sizeof(HTask) * count, 256) + 256) +
+         4 * (psh::align_up(sizeof(HTile) * tiles, 256) + 256) + 1024;
+}
+
+extern "C" size_t ps_gemm_bf16_grouped_workspace_bytes(const ps_gemm_bf16_desc* desc, int count) {
+  if (!desc || count <= 0) return 0;
+  return hbytes(desc, count);
+}
+
+extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc, int count,
+                                    void* workspace, size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
+  if (!desc || count <= 0 || !workspace) return PS_EINVAL;
+  if (workspace_bytes < hbytes(desc, count)) return PS_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  // groups by (split of A, split of B)
+  std::vector<HTask> tasks[4];
+  std::vector<HTile> tiles[4];
+  for (int i = 0; i < count; ++i) {
+    const ps_gemm_bf16_desc& d = desc[i];
+    if (!d.a_hi || !d.b_hi || !d.c || d.m < 1 || d.n < 1 || d.k < 1 || d.lda < d.k ||
+        d.ldb < d.k || d.ldc < d.n)
+      return PS_EINVAL;
+    // 16-byte loads of 8 consecutive k: k, both leading dimensions and the bases aligned
+    if (d.k % HBK != 0 || d.lda % 8 != 0 || d.ldb % 8 != 0 || ((uintptr_t)d.a_hi % 16) != 0 ||
+        ((uintptr_t)d.b_hi % 16) != 0 || (d.a_lo && ((uintptr_t)d.a_lo % 16) != 0) ||
+        (d.b_lo && ((uintptr_t)d.b_lo % 16) != 0))
+      return PS_EUNSUPPORTED;
+    const int g = (d.a_lo ? 2 : 0) + (d.b_lo ? 1 : 0);
+    const int tid = (int)tasks[g].size();
+    tasks[g].push_back({(const uint16_t*)d.a_hi, (const uint16_t*)d.a_lo, (const uint16_t*)d.b_hi,
+                        (const uint16_t*)d.b_lo, d.c, d.m, d.n, d.k, d.lda, d.ldb, d.ldc});
+    for (int tm = 0; tm < (d.m + TILE - 1) / TILE; ++tm)
+      for (int tn = 0; tn < (d.n + TILE - 1) / TILE; ++tn) tiles[g].push_back({tid, (short)tm, (short)tn});
+  }
+  psh::Arena ar(workspace, workspace_bytes);
+  for (int g = 0; g < 4; ++g) {
+    if (tasks[g].empty()) continue;
+    HTask* dt = ar.take<HTask>(tasks[g].size());
+    HTile* dl = ar.take<HTile>(tiles[g].size());
+    if (ar.overflow) return PS_EWORKSPACE;
+    PS_RC(psh::upload_async(st, dt, tasks[g].data(), sizeof(HTask) * tasks[g].size()));
+    PS_RC(psh::upload_async(st, dl, tiles[g].data(), sizeof(HTile) * tiles[g].size()));
+    const int nt = (int)tiles[g].size();
+    const int sa = (g & 2) ? 2 : 1, sb = (g & 1) ? 2 : 1;
+    const size_t lds = (size_t)2 * (sa + sb) * HOP * sizeof(uint16_t);  // 40 .. 80 KiB
+    static bool attr_done = false;
+    if (!attr_done) {
+      const int big = (int)((size_t)2 * 4 * HOP * sizeof(uint16_t));
+      PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 2>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
+      PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<2, 1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
+      PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<2, 2>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
+      attr_done = true;
+    }
+    if (g == 0)
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 1>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
+    else if (g == 1)
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 2>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
+    else if (g == 2)
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<2, 1>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
+    else
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<2, 2>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
+    PS_LAUNCH_CHECK();
+  }
+  return PS_OK;
+}

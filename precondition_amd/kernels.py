@@ -413,6 +413,57 @@ def gemm_grouped(items):
   check(rc, "ps_gemm_grouped_f32")
 
 
+@_device_guarded
+def to_bf16(x: torch.Tensor, split: bool = False, transpose: bool = False):
+  """float32 [r, c] -> bfloat16 operand(s) for gemm_bf16_grouped: (hi, lo | None), each
+  [r, c] (or [c, r] with transpose), round to nearest even; lo = bf16(x - hi)."""
+  _require_gpu(x, "to_bf16")
+  if x.dim() != 2:
+    raise ValueError("to_bf16 expects a 2-D tensor")
+  r, c = int(x.shape[0]), int(x.shape[1])
+  shape = (c, r) if transpose else (r, c)
+  hi = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+  lo = torch.empty(shape, dtype=torch.bfloat16, device=x.device) if split else None
+  rc = lib().ps_convert_f32_to_bf16(_stream(), x.data_ptr(), hi.data_ptr(),
+                                    lo.data_ptr() if split else None, r, c, _as_2d_ld(x),
+                                    shape[1], int(transpose))
+  check(rc, "ps_convert_f32_to_bf16")
+  return hi, lo
+
+
+@_device_guarded
+def gemm_bf16_grouped(items):
+  """items: list of ((a_hi, a_lo | None), (bt_hi, bt_lo | None), c): c [m, n] float32 =
+  a [m, k] @ bt [n, k]^T on the bf16 MFMA with float32 accumulation (hi/lo pairs: three
+  accumulated products).  Operands are contiguous bfloat16 tensors from to_bf16."""
+  if not items:
+    return
+  from ._lib import GemmBf16Desc
+  descs = (GemmBf16Desc * len(items))()
+  dev = items[0][2].device
+  for d, ((a_hi, a_lo), (b_hi, b_lo), c) in zip(descs, items):
+    for t in (a_hi, a_lo, b_hi, b_lo):
+      if t is not None and (t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 2 or
+                            (t.shape[1] > 1 and t.stride(1) != 1)):
+        raise ValueError("gemm_bf16_grouped expects row-contiguous 2-D bfloat16 device tensors")
+    _require_gpu(c, "gemm_bf16_grouped")
+    m, k = int(a_hi.shape[0]), int(a_hi.shape[1])
+    n = int(b_hi.shape[0])
+    if int(b_hi.shape[1]) != k or tuple(c.shape) != (m, n):
+      raise ValueError("gemm_bf16_grouped shape mismatch")
+    if (a_lo is not None and a_lo.stride() != a_hi.stride()) or (
+        b_lo is not None and b_lo.stride() != b_hi.stride()):
+      raise ValueError("hi and lo parts must share their layout")
+    d.a_hi, d.a_lo = a_hi.data_ptr(), (a_lo.data_ptr() if a_lo is not None else None)
+    d.b_hi, d.b_lo = b_hi.data_ptr(), (b_lo.data_ptr() if b_lo is not None else None)
+    d.c, d.m, d.n, d.k = c.data_ptr(), m, n, k
+    d.lda, d.ldb, d.ldc = _as_2d_ld(a_hi), _as_2d_ld(b_hi), _as_2d_ld(c)
+  L = lib()
+  ws = _workspace(L.ps_gemm_bf16_grouped_workspace_bytes(descs, len(items)), dev)
+  check(L.ps_gemm_bf16_grouped(_stream(), descs, len(items), ws.data_ptr(), ws.numel()),
+        "ps_gemm_bf16_grouped")
+
+
 def tensordot_axis0(g: torch.Tensor, pc: torch.Tensor) -> torch.Tensor:
   """tensordot(g, pc, axes=[[0],[0]]) (DS:1707): contracts g's leading axis
   with pc's rows; result shape = g.shape[1:] + (pc.shape[1],)."""

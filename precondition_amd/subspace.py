@@ -79,6 +79,24 @@ def _rayleigh_ritz(c: Sequence[torch.Tensor], x: torch.Tensor, z: torch.Tensor,
   return theta, res
 
 
+def _filter_precision(n: int) -> str:
+  """Arithmetic of the Chebyshev filter's C @ Y products (the bulk of the work; the
+  Rayleigh-Ritz products and residuals are always float32 MFMA):
+    "f32"    exact-f32 MFMA (v_mfma_f32_32x32x2_f32);
+    "bf16x3" bf16 MFMA on hi/lo pairs of C and Y (hi*hi + lo*hi + hi*lo, float32
+             accumulation): ~2^-17 operand precision at the byte traffic of float32, i.e.
+             HBM-bound instead of MFMA-bound;
+    "bf16"   plain bf16 operands while the residuals are above the bf16 floor, then bf16x3
+             (BASELINE configs[4] names bf16 MFMA for this branch).
+  Default bf16x3 where the bf16 kernel's alignment rules hold (n % 32 == 0);
+  PS_FD_FILTER overrides."""
+  import os
+  mode = os.environ.get("PS_FD_FILTER", "bf16x3")
+  if mode not in ("f32", "bf16x3", "bf16"):
+    raise ValueError(f"PS_FD_FILTER must be f32, bf16x3 or bf16, got {mode!r}")
+  return mode if n % 32 == 0 else "f32"
+
+
 def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e-5,
                            degree: int = 12, max_outer: int = 14, oversample: int = 31,
                            seed: int = 1729):
@@ -90,6 +108,25 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   dev = mats[0].device
   b = min(n, ((k + oversample + 31) // 32) * 32)
   c = [m if m.is_contiguous() else m.contiguous() for m in mats]
+  mode = _filter_precision(n)
+  c16 = None
+  if mode != "f32":  # the covariance is converted ONCE per call (hi/lo pair)
+    c16 = [_K().to_bf16(m, split=True) for m in c]
+
+  def filter_product(y, z, plain):
+    """z[j] = C_j @ y[j] for all j (y, z: [B, n, b])."""
+    if c16 is None:
+      _gemm([(c[j], y[j], z[j], False, False) for j in range(bsz)])
+      return
+    # one conversion launch for the whole stack: [B*n, b] -> [b, B*n] (k-contiguous per factor)
+    yt_hi, yt_lo = _K().to_bf16(y.view(bsz * n, b), split=not plain, transpose=True)
+    items = []
+    for j in range(bsz):
+      bt = (yt_hi[:, j * n:(j + 1) * n], None if plain else yt_lo[:, j * n:(j + 1) * n])
+      a = (c16[j][0], None if plain else c16[j][1])
+      items.append((a, bt, z[j]))
+    _K().gemm_bf16_grouped(items)
+
   gen = torch.Generator(device=dev).manual_seed(seed)
   x = torch.randn((bsz, n, b), generator=gen, device=dev, dtype=torch.float32)
   z = torch.empty_like(x)
@@ -129,8 +166,10 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
     # z = C x is current from the Rayleigh-Ritz step
     y_prev = x.clone()
     y = (z - ctr * x) * (sigma1 / e)
+    # plain bf16 operands only while the wanted residuals are far above its 2^-9 floor
+    plain = mode == "bf16" and float((res[:, :k] / top).max()) > 2e-2
     for step in range(2, max_deg + 1):
-      _gemm([(c[j], y[j], z[j], False, False) for j in range(bsz)])
+      filter_product(y, z, plain)
       gemms += 1
       sigma_new = 1.0 / (2.0 / sigma1 - sigma)
       y_next = (z - ctr * y) * (2.0 * sigma_new / e) - (sigma * sigma_new) * y_prev
@@ -146,6 +185,6 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
     top = theta[:, :1].clamp_min(1e-30)
     wanted = theta[:, :k] > n * 2.4e-7 * top
     converged = ((res[:, :k] <= tol * top) | ~wanted).all(dim=1)
-  info = {"outer_iterations": outer, "big_gemms": gemms, "block": b,
+  info = {"outer_iterations": outer, "big_gemms": gemms, "block": b, "filter_precision": mode,
           "max_residual_rel": float((res[:, :k] / theta[:, :1].clamp_min(1e-30)).max())}
   return theta[:, :k].contiguous(), x[:, :, :k].contiguous(), converged, info

@@ -267,3 +267,29 @@ def test_fd_update_root_subspace_path_vs_reference_golden(name, device, monkeypa
     assert np.isclose(got[1, -1], ref[1, -1], rtol=1e-3)
     prev = torch.tensor(ref, device=device)
   assert len(calls) == c["steps"], "the block subspace method must have run"
+
+
+# ---------------------------------------------------------------------------
+def test_gemm_bf16_grouped_vs_fp64(device):
+  """bf16-MFMA products of the FD branch: single bf16 operands (2^-9) and hi/lo pairs
+  (2^-17) against float64, asymmetric operands, ragged n, several problems in one launch."""
+  rng = np.random.default_rng(3)
+  items, refs, tols = [], [], []
+  for (m, n, k), split in (((256, 96, 512), True), ((128, 128, 64), False), ((384, 40, 1024), True),
+                           ((200, 96, 256), False)):
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)   # the tall-skinny iterate [k, n]
+    a_d, b_d = torch.tensor(a, device=device), torch.tensor(b, device=device)
+    c = torch.full((m, n), float("nan"), device=device)
+    items.append((K().to_bf16(a_d, split=split), K().to_bf16(b_d, split=split, transpose=True), c))
+    refs.append(a.astype(np.float64) @ b.astype(np.float64))
+    tols.append(3e-5 if split else 8e-3)
+  # the conversion itself: hi = RNE bf16, hi + lo reproduces x to 2^-17
+  hi, lo = items[0][0]
+  a0 = torch.tensor(rng.standard_normal((4, 4)).astype(np.float32), device=device)
+  assert torch.equal(K().to_bf16(a0)[0], a0.to(torch.bfloat16))
+  K().gemm_bf16_grouped(items)
+  for (_, _, c), ref, tol in zip(items, refs, tols):
+    got = c.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, tol

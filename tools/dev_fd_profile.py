@@ -1,0 +1,4 @@
+import sys, os, json, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+print(json.dumps(bench.fd_cfg5(torch.device("cuda:0"))["ms_per_factor_update"]))
