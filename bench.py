@@ -214,8 +214,10 @@ class VitBWorkload:
 def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
   """BASELINE.json configs[4]: Frequent-Directions sketch updates (rank 64) of
   4096-dim factors: Gram of a [4096, 4096] gradient block + _fd_update_root, three
-  consecutive updates from a zero sketch.  float32 throughout (exact-f32 MFMA)."""
-  from precondition_amd import low_rank
+  consecutive updates from a zero sketch.  Arithmetic of the large products (Gram, the
+  Chebyshev filter's C @ Y): PS_FD_FILTER = bf16x3 (default: bf16 MFMA on hi/lo pairs),
+  bf16 (plain bf16 operands first) or f32 (exact-f32 MFMA); Rayleigh-Ritz always float32."""
+  from precondition_amd import low_rank, subspace
   gen = torch.Generator(device=dev).manual_seed(64)
   prevs = [torch.zeros((d, rank + 2), dtype=torch.float32, device=dev) for _ in range(factors)]
   times = []
@@ -234,11 +236,13 @@ def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
   tails = [float(p[1, -1]) for p in prevs]
   return {"workload": f"{factors} factors of dim {d}, rank {rank}, {updates} FD updates from a "
                       "zero sketch, grad blocks ~N(0,1) [4096x4096], fp32",
+          "products": subspace._filter_precision(d),
           "ms_per_factor_update": [round(t * 1e3, 1) for t in times],
           "tail_after_updates": round(float(np.mean(tails)), 1),
-          "note": "Gram on the fp32 MFMA statistics kernel + leading rank+1 eigenpairs of the "
-                  "4096x4096 covariance update by Chebyshev-filtered subspace iteration on the "
-                  "fp32 MFMA GEMM (all factors batched), full Jacobi eigh as the fallback"}
+          "note": "Gram + leading rank+1 eigenpairs of the 4096x4096 covariance update by "
+                  "Chebyshev-filtered subspace iteration (all factors batched): large products on "
+                  "the bf16 MFMA (hi/lo split operands, fp32 accumulation) or the fp32 MFMA, "
+                  "b x b problems in the LDS-resident eigensolver, fp32 Rayleigh-Ritz"}
 
 
 def quant_f3(dev):
@@ -647,8 +651,19 @@ def main():
                                        "MFMA-busy share is in profiles/"},
         }
 
-      for key, fn in (("fd_cfg5", lambda: fd_cfg5(dev)), ("quant_f3", lambda: quant_f3(dev)),
-                      ("eigh_cfg3", eigh_cfg3)):
+      def fd_f32():
+        old = os.environ.get("PS_FD_FILTER")
+        os.environ["PS_FD_FILTER"] = "f32"
+        try:
+          return fd_cfg5(dev)
+        finally:
+          if old is None:
+            os.environ.pop("PS_FD_FILTER", None)
+          else:
+            os.environ["PS_FD_FILTER"] = old
+
+      for key, fn in (("fd_cfg5", lambda: fd_cfg5(dev)), ("fd_cfg5_f32_products", fd_f32),
+                      ("quant_f3", lambda: quant_f3(dev)), ("eigh_cfg3", eigh_cfg3)):
         torch.cuda.empty_cache()
         try:
           line[key] = fn()

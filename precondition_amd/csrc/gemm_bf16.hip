@@ -42,8 +42,10 @@ struct HTask {
   float* c;
   int m, n, k;
   int64_t lda, ldb, ldc;
+  int ksplit, kchunk;   // split-K (deterministic two-pass), as in ps_gemm_grouped_f32
+  float* partial;       // [ksplit][m][n] when ksplit > 1
 };
-struct HTile { int task; short tm, tn; };
+struct HTile { int task; short tm, tn; int ks; };
 
 __device__ inline u32x4 gload16(const uint16_t* p) { return *(const u32x4 PS_GLOBAL*)(p); }
 
@@ -84,16 +86,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int row0 = te.tm * TILE, col0 = te.tn * TILE;
-  const int nk = (tk.k + HBK - 1) / HBK;   // k is a multiple of 8 (checked on the host);
-                                           // a ragged last tile reads zeros past k? no: k % 32
-                                           // is also required, see ps_gemm_bf16_grouped
+  const int kbeg = te.ks * tk.kchunk;                 // k % 32 == 0 and kchunk % 32 == 0
+  const int nk = (min(tk.kchunk, tk.k - kbeg) + HBK - 1) / HBK;   // (checked on the host)
   f32x16 acc[2][2];
   zero_acc(acc);
   u32x4 ra[SA][2], rb[SB][2];
-  hload(tk.a_hi, tk.lda, row0, tk.m, 0, tid, ra[0]);
-  if (SA == 2) hload(tk.a_lo, tk.lda, row0, tk.m, 0, tid, ra[SA - 1]);
-  hload(tk.b_hi, tk.ldb, col0, tk.n, 0, tid, rb[0]);
-  if (SB == 2) hload(tk.b_lo, tk.ldb, col0, tk.n, 0, tid, rb[SB - 1]);
+  hload(tk.a_hi, tk.lda, row0, tk.m, kbeg, tid, ra[0]);
+  if (SA == 2) hload(tk.a_lo, tk.lda, row0, tk.m, kbeg, tid, ra[SA - 1]);
+  hload(tk.b_hi, tk.ldb, col0, tk.n, kbeg, tid, rb[0]);
+  if (SB == 2) hload(tk.b_lo, tk.ldb, col0, tk.n, kbeg, tid, rb[SB - 1]);
   hstore(hs, tid, ra[0]);
   if (SA == 2) hstore(hs + HOP, tid, ra[SA - 1]);
   hstore(hs + SA * HOP, tid, rb[0]);
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
     uint16_t* nxt = hs + ((kt + 1) & 1) * STG;
     const bool more = kt + 1 < nk;
     if (more) {
-      const int k0 = (kt + 1) * HBK;
+      const int k0 = kbeg + (kt + 1) * HBK;
       hload(tk.a_hi, tk.lda, row0, tk.m, k0, tid, ra[0]);
       if (SA == 2) hload(tk.a_lo, tk.lda, row0, tk.m, k0, tid, ra[SA - 1]);
       hload(tk.b_hi, tk.ldb, col0, tk.n, k0, tid, rb[0]);
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
     }
     __syncthreads();
   }
+  float* out = tk.ksplit > 1 ? tk.partial + (int64_t)te.ks * tk.m * tk.n : tk.c;
+  const int64_t ldo = tk.ksplit > 1 ? tk.n : tk.ldc;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -149,8 +152,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + acc_row(wm, i, r, lane);
         const int col = col0 + acc_col(wn, j, lane);
-        if (row < tk.m && col < tk.n) gstore1(tk.c + (int64_t)row * tk.ldc + col, acc[i][j][r]);
+        if (row < tk.m && col < tk.n) gstore1(out + (int64_t)row * ldo + col, acc[i][j][r]);
       }
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_splitk_reduce_kernel(const HTask* tasks) {
+  const HTask tk = tasks[blockIdx.x];
+  if (tk.ksplit <= 1) return;
+  const int64_t mn = (int64_t)tk.m * tk.n;
+  for (int64_t e = blockIdx.y * 256 + threadIdx.x; e < mn; e += (int64_t)gridDim.y * 256) {
+    float v = 0.f;
+    for (int s = 0; s < tk.ksplit; ++s) v += tk.partial[s * mn + e];
+    tk.c[(e / tk.n) * tk.ldc + e % tk.n] = v;
+  }
 }
 
 // ---- float32 -> bf16 (round to nearest even), optionally hi/lo split and transposed -------
@@ -202,12 +216,30 @@ extern "C" int ps_convert_f32_to_bf16(void* stream, const float* src, void* dst_
   return PS_OK;
 }
 
-static size_t hbytes(const ps_gemm_bf16_desc* d, int count) {
+static int hsplit_for(size_t total_tiles, int k) {
+  if (total_tiles >= 512 || k < 1024) return 1;
+  int s = (int)((512 + total_tiles - 1) / total_tiles);   // 2 resident workgroups per CU
+  s = std::min(s, k / 512);
+  return std::max(1, std::min(s, 16));
+}
+
+static size_t htiles(const ps_gemm_bf16_desc* d, int count) {
   size_t tiles = 0;
   for (int i = 0; i < count; ++i)
     tiles += (size_t)((d[i].m + TILE - 1) / TILE) * ((d[i].n + TILE - 1) / TILE);
+  return tiles;
+}
+
+static size_t hbytes(const ps_gemm_bf16_desc* d, int count) {
+  const size_t tiles = htiles(d, count);
+  size_t split_tiles = 0, partial = 0;
+  for (int i = 0; i < count; ++i) {
+    const int s = hsplit_for(tiles, d[i].k);
+    split_tiles += (size_t)s * ((d[i].m + TILE - 1) / TILE) * ((d[i].n + TILE - 1) / TILE);
+    if (s > 1) partial += psh::align_up((size_t)s * d[i].m * d[i].n * sizeof(float), 256) + 256;
+  }
   return 4 * (psh::align_up(sizeof(HTask) * count, 256) + 256) +
-         4 * (psh::align_up(sizeof(HTile) * tiles, 256) + 256) + 1024;
+         4 * (psh::align_up(sizeof(HTile) * split_tiles, 256) + 256) + partial + 1024;
 }
 
 extern "C" size_t ps_gemm_bf16_grouped_workspace_bytes(const ps_gemm_bf16_desc* desc, int count) {
@@ -224,6 +256,8 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
   // groups by (split of A, split of B)
   std::vector<HTask> tasks[4];
   std::vector<HTile> tiles[4];
+  psh::Arena ar(workspace, workspace_bytes);
+  const size_t total_tiles = htiles(desc, count);
   for (int i = 0; i < count; ++i) {
     const ps_gemm_bf16_desc& d = desc[i];
     if (!d.a_hi || !d.b_hi || !d.c || d.m < 1 || d.n < 1 || d.k < 1 || d.lda < d.k ||
@@ -236,12 +270,20 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
       return PS_EUNSUPPORTED;
     const int g = (d.a_lo ? 2 : 0) + (d.b_lo ? 1 : 0);
     const int tid = (int)tasks[g].size();
-    tasks[g].push_back({(const uint16_t*)d.a_hi, (const uint16_t*)d.a_lo, (const uint16_t*)d.b_hi,
-                        (const uint16_t*)d.b_lo, d.c, d.m, d.n, d.k, d.lda, d.ldb, d.ldc});
+    HTask t{(const uint16_t*)d.a_hi, (const uint16_t*)d.a_lo, (const uint16_t*)d.b_hi,
+            (const uint16_t*)d.b_lo, d.c, d.m, d.n, d.k, d.lda, d.ldb, d.ldc, 1, d.k, nullptr};
+    const int sp = hsplit_for(total_tiles, d.k);
+    if (sp > 1) {
+      t.kchunk = psh::round_up((d.k + sp - 1) / sp, HBK);
+      t.ksplit = (d.k + t.kchunk - 1) / t.kchunk;
+      if (t.ksplit > 1) t.partial = ar.take<float>((size_t)t.ksplit * d.m * d.n);
+      else t.kchunk = d.k;
+    }
+    tasks[g].push_back(t);
     for (int tm = 0; tm < (d.m + TILE - 1) / TILE; ++tm)
-      for (int tn = 0; tn < (d.n + TILE - 1) / TILE; ++tn) tiles[g].push_back({tid, (short)tm, (short)tn});
+      for (int tn = 0; tn < (d.n + TILE - 1) / TILE; ++tn)
+        for (int ks = 0; ks < t.ksplit; ++ks) tiles[g].push_back({tid, (short)tm, (short)tn, ks});
   }
-  psh::Arena ar(workspace, workspace_bytes);
   for (int g = 0; g < 4; ++g) {
     if (tasks[g].empty()) continue;
     HTask* dt = ar.take<HTask>(tasks[g].size());
@@ -271,6 +313,11 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
       hipLaunchKernelGGL((gemm_bf16_grouped_kernel<2, 1>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
     else
       hipLaunchKernelGGL((gemm_bf16_grouped_kernel<2, 2>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
+    bool any_split = false;
+    for (auto& t : tasks[g]) any_split |= t.ksplit > 1;
+    if (any_split)
+      hipLaunchKernelGGL(gemm_bf16_splitk_reduce_kernel, dim3((unsigned)tasks[g].size(), 16),
+                         dim3(256), 0, st, dt);
     PS_LAUNCH_CHECK();
   }
   return PS_OK;

@@ -128,8 +128,10 @@ namespace psk {
 struct GTask {
   const float* a; const float* b; float* c;
   int m, n, k, lda, ldb, ldc, veca, vecb;
+  int ksplit, kchunk;   // split-K: tile (tm, tn, ks) covers k in [ks*kchunk, (ks+1)*kchunk)
+  float* partial;       // [ksplit][m][n] when ksplit > 1
 };
-struct GTile { int task; short tm, tn; };
+struct GTile { int task; short tm, tn; int ks; };
 
 template <int LA, int LB>
 __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GTask* tasks,
@@ -137,12 +139,19 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GTask* tasks
   __shared__ __align__(16) float smem[SmemCfg<GBK>::TOTAL];
   const GTile te = tiles[xcd_remap(blockIdx.x, ntiles)];
   const GTask tk = tasks[te.task];
-  Operand A{tk.a, tk.lda, te.tm * TILE, tk.m, tk.k, tk.veca != 0};
-  Operand B{tk.b, tk.ldb, te.tn * TILE, tk.n, tk.k, tk.vecb != 0};
+  const int k0 = te.ks * tk.kchunk;
+  const int kext = min(tk.kchunk, tk.k - k0);
+  // element (mn, k) of a KC operand lies at p[mn*ld + k], of an MC operand at p[k*ld + mn]
+  const float* ap = tk.a + (LA == KC ? (int64_t)k0 : (int64_t)k0 * tk.lda);
+  const float* bp = tk.b + (LB == KC ? (int64_t)k0 : (int64_t)k0 * tk.ldb);
+  Operand A{ap, tk.lda, te.tm * TILE, tk.m, kext, tk.veca != 0};
+  Operand B{bp, tk.ldb, te.tn * TILE, tk.n, kext, tk.vecb != 0};
   f32x16 acc[2][2];
-  gemm_tile<LA, LB, GBK, true>(A, B, tk.k, smem, acc);
+  gemm_tile<LA, LB, GBK, true>(A, B, kext, smem, acc);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
+  float* out = tk.ksplit > 1 ? tk.partial + (int64_t)te.ks * tk.m * tk.n : tk.c;
+  const int ldo = tk.ksplit > 1 ? tk.n : tk.ldc;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -151,17 +160,53 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GTask* tasks
       for (int r = 0; r < 16; ++r) {
         const int row = te.tm * TILE + acc_row(wm, i, r, lane);
         const int col = te.tn * TILE + acc_col(wn, j, lane);
-        if (row < tk.m && col < tk.n) gstore1(tk.c + (int64_t)row * tk.ldc + col, acc[i][j][r]);
+        if (row < tk.m && col < tk.n) gstore1(out + (int64_t)row * ldo + col, acc[i][j][r]);
       }
+}
+
+// c = sum over the K splits of the partial products, in split order (deterministic).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GTask* tasks,
+                                                                 const int* task_ids) {
+  const GTask tk = tasks[task_ids[blockIdx.x]];
+  const int64_t mn = (int64_t)tk.m * tk.n;
+  for (int64_t e = blockIdx.y * 256 + threadIdx.x; e < mn; e += (int64_t)gridDim.y * 256) {
+    float v = 0.f;
+    for (int s = 0; s < tk.ksplit; ++s) v += tk.partial[s * mn + e];
+    tk.c[(e / tk.n) * tk.ldc + e % tk.n] = v;
+  }
 }
 }  // namespace psk
 
-static size_t grouped_gemm_bytes(const ps_gemm_desc* d, int count) {
+// Split-K plan of one grouped call: products whose output has far fewer tiles than the GPU
+// has CUs but a long contraction (the b x n @ n x b Gram / Rayleigh-Ritz products of the
+// subspace iteration: ONE 128 x 128 tile with k = 4096) are cut along k into `ksplit`
+// partial products, each in its own workgroup, summed by gemm_splitk_reduce_kernel.
+// Calls with enough tiles (the per-step application of the preconditioners) are unchanged.
+static int splitk_for(int total_tiles, int k) {
+  if (total_tiles >= 256 || k < 512) return 1;
+  int s = (512 + total_tiles - 1) / total_tiles;   // aim at ~2 workgroups per CU
+  s = std::min(s, k / 256);                        // at least 256 k per split
+  return std::max(1, std::min(s, 64));
+}
+
+static size_t grouped_total_tiles(const ps_gemm_desc* d, int count) {
   size_t tiles = 0;
   for (int i = 0; i < count; ++i)
     tiles += (size_t)((d[i].m + TILE - 1) / TILE) * ((d[i].n + TILE - 1) / TILE);
+  return tiles;
+}
+
+static size_t grouped_gemm_bytes(const ps_gemm_desc* d, int count) {
+  const size_t tiles = grouped_total_tiles(d, count);
+  size_t split_tiles = 0, partial = 0;
+  for (int i = 0; i < count; ++i) {
+    const int s = splitk_for((int)std::min<size_t>(tiles, 1 << 30), d[i].k);
+    split_tiles += (size_t)s * ((d[i].m + TILE - 1) / TILE) * ((d[i].n + TILE - 1) / TILE);
+    if (s > 1) partial += psh::align_up((size_t)s * d[i].m * d[i].n * sizeof(float), 256) + 256;
+  }
   return 4 * (psh::align_up(sizeof(GTask) * count, 256) + 256) +
-         4 * (psh::align_up(sizeof(GTile) * tiles, 256) + 256) + 1024;
+         4 * (psh::align_up(sizeof(GTile) * split_tiles, 256) + 256) +
+         psh::align_up(sizeof(int) * count, 256) + 256 + partial + 1024;
 }
 
 extern "C" size_t ps_gemm_grouped_workspace_bytes(const ps_gemm_desc* desc, int count) {
@@ -177,6 +222,9 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
   hipStream_t st = (hipStream_t)stream;
   std::vector<GTask> tasks[4];
   std::vector<GTile> tiles[4];
+  std::vector<int> split_ids[4];
+  psh::Arena ar(workspace, workspace_bytes);
+  const int total_tiles = (int)std::min<size_t>(grouped_total_tiles(desc, count), 1 << 30);
   for (int i = 0; i < count; ++i) {
     const ps_gemm_desc& d = desc[i];
     if (!d.a || !d.b || !d.c || d.m < 1 || d.n < 1 || d.k < 1 || d.ldc < d.n ||
@@ -185,31 +233,47 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
       return PS_EINVAL;
     const int g = (d.transa ? 2 : 0) + (d.transb ? 1 : 0);
     GTask t{d.a, d.b, d.c, d.m, d.n, d.k, (int)d.lda, (int)d.ldb, (int)d.ldc,
-            vec_ok(d.a, (int)d.lda, 0) ? 1 : 0, vec_ok(d.b, (int)d.ldb, 0) ? 1 : 0};
+            vec_ok(d.a, (int)d.lda, 0) ? 1 : 0, vec_ok(d.b, (int)d.ldb, 0) ? 1 : 0, 1, d.k,
+            nullptr};
+    const int s = splitk_for(total_tiles, d.k);
+    if (s > 1) {
+      t.kchunk = psh::round_up((d.k + s - 1) / s, 128);   // keeps 16-byte load alignment
+      t.ksplit = (d.k + t.kchunk - 1) / t.kchunk;
+      if (t.ksplit > 1) t.partial = ar.take<float>((size_t)t.ksplit * d.m * d.n);
+      else t.kchunk = d.k;
+    }
     const int id = (int)tasks[g].size();
     tasks[g].push_back(t);
+    if (t.ksplit > 1) split_ids[g].push_back(id);
     const int tm = (d.m + TILE - 1) / TILE, tn = (d.n + TILE - 1) / TILE;
     for (int a = 0; a < tm; ++a)
-      for (int b = 0; b < tn; ++b) tiles[g].push_back({id, (short)a, (short)b});
+      for (int b = 0; b < tn; ++b)
+        for (int ks = 0; ks < t.ksplit; ++ks) tiles[g].push_back({id, (short)a, (short)b, ks});
   }
-  psh::Arena ar(workspace, workspace_bytes);
   GTask* dt[4];
   GTile* dl[4];
+  int* di[4];
   for (int g = 0; g < 4; ++g) {
     dt[g] = ar.take<GTask>(std::max<size_t>(tasks[g].size(), 1));
     dl[g] = ar.take<GTile>(std::max<size_t>(tiles[g].size(), 1));
+    di[g] = ar.take<int>(std::max<size_t>(split_ids[g].size(), 1));
   }
   if (ar.overflow) return PS_EWORKSPACE;
   for (int g = 0; g < 4; ++g) {
     if (tasks[g].empty()) continue;
     PS_RC(psh::upload_async(st, dt[g], tasks[g].data(), sizeof(GTask) * tasks[g].size()));
     PS_RC(psh::upload_async(st, dl[g], tiles[g].data(), sizeof(GTile) * tiles[g].size()));
+    PS_RC(psh::upload_async(st, di[g], split_ids[g].data(), sizeof(int) * split_ids[g].size()));
   }
   const dim3 blk(256);
 #define PS_GG(G, LA, LB)                                                                   \
-  if (!tasks[G].empty())                                                                   \
+  if (!tasks[G].empty()) {                                                                 \
     hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB>), dim3((unsigned)tiles[G].size()), blk, \
-                       0, st, dt[G], dl[G], (int)tiles[G].size())
+                       0, st, dt[G], dl[G], (int)tiles[G].size());                         \
+    if (!split_ids[G].empty())                                                             \
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)split_ids[G].size(), 16), \
+                         blk, 0, st, dt[G], di[G]);                                        \
+  }
   PS_GG(0, KC, MC);
   PS_GG(1, KC, KC);
   PS_GG(2, MC, MC);

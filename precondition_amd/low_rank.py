@@ -131,8 +131,21 @@ def _low_rank_root(matrix: torch.Tensor, p: int, compression_rank: int = 0,
 
 # ---- frequent_directions_update (DS:1473-1505) -------------------------------------
 def gram_of_block(g: torch.Tensor, axis: int) -> torch.Tensor:
-  """tensordot(g, g, all axes but `axis`) on the MFMA statistics kernel."""
+  """tensordot(g, g, all axes but `axis`): the covariance update of one Frequent-Directions
+  step.  Large 2-D blocks take it from the bf16 MFMA on hi/lo pairs of g (bf16x3: 2^-17
+  operand precision, float32 accumulation — BASELINE configs[4] names bf16 MFMA for this
+  branch; PS_FD_FILTER=f32 keeps the exact-f32 statistics kernel); everything else, and
+  the dense statistics of the optimizer, always use the float32 MFMA statistics kernel."""
+  from . import subspace
   d = g.shape[axis]
+  if (g.dim() == 2 and d >= 1024 and d % 32 == 0 and g.shape[1 - axis] % 32 == 0 and
+      subspace._filter_precision(d) != "f32"):
+    gt = g if axis == 0 else g.t()
+    hi, lo = kernels.to_bf16(gt.contiguous() if not gt.is_contiguous() else gt, split=True)
+    out = torch.empty((d, d), dtype=torch.float32, device=g.device)
+    kernels.gemm_bf16_grouped([((hi, lo), (hi, lo), out)])
+    # (symmetric up to the order of the two cross terms in the float32 accumulation chain)
+    return out
   zero = torch.zeros((d, d), dtype=torch.float32, device=g.device)
   out = torch.empty_like(zero)
   kernels.stats_update_grouped([(g, axis, zero, out)], 0.0, 1.0)
