@@ -98,6 +98,7 @@ def sharded_inverse_pth_roots(
     payload_elems: Optional[Sequence[int]] = None,
     sizes: Optional[Sequence[int]] = None,
     pi_first: bool = False,
+    metrics_cols: int = METRICS_STRIDE,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
 
@@ -117,6 +118,8 @@ def sharded_inverse_pth_roots(
   once over all of this rank's statistics and each phase's root call gets its largest
   eigenvalues from it (`max_ev=`): halves of the 100 short launches would sit on the
   launch-latency floor.  Same kernels, bit-identical results.
+  `metrics_cols` (needs `compute_fn`): width of the gathered metrics rows when the
+  per-statistic diagnostics are wider than the 8 PS_M_* columns (FDDiagnostics).
   """
   n_stats = len(statistics)
   world, rank = world_and_rank(group)
@@ -177,7 +180,7 @@ def sharded_inverse_pth_roots(
     max_count = max(max(count[ph]), 1)
     send = torch.empty((buf_elems,), dtype=torch.float32, device=dev)
     mine = [i for i in range(n_stats) if owner[i] == rank and phase_of[i] == ph]
-    send_metrics = torch.zeros((max_count, METRICS_STRIDE), dtype=torch.float32, device=dev)
+    send_metrics = torch.zeros((max_count, metrics_cols), dtype=torch.float32, device=dev)
     if mine:
       outs = [send[offsets[i]:offsets[i] + elems[i]] for i in mine]
       if not raw:
@@ -200,7 +203,7 @@ def sharded_inverse_pth_roots(
     import torch.distributed as dist
     # flat outputs (concatenation form) are accepted by both RCCL and gloo
     g = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
-    gm = torch.empty((world * max_count * METRICS_STRIDE,), dtype=torch.float32, device=dev)
+    gm = torch.empty((world * max_count * metrics_cols,), dtype=torch.float32, device=dev)
     if dist.get_backend(group) == "gloo" and send.is_cuda:
       # gloo has no device all-gather: stage through the host (functional fallback
       # for single-GPU debugging; the production backend is RCCL)
@@ -219,7 +222,7 @@ def sharded_inverse_pth_roots(
       dist.all_gather_into_tensor(g, send, group=group)
       dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group)
     gathered.append(g.view(world, buf_elems))
-    gathered_metrics.append(gm.view(world, max_count, METRICS_STRIDE))
+    gathered_metrics.append(gm.view(world, max_count, metrics_cols))
   for h in handles:
     if hasattr(h, "wait"):
       h.wait()

@@ -31,8 +31,8 @@ import torch
 from . import comm
 from . import pytree
 from .blocking import Preconditioner, _precond_dim, _should_compress
-from .state import (GradientTransformation, GraftingType, MaskedNode,
-                    ParameterStats, PreconditionerType, QuantizedValue,
+from .state import (_FD_FIELDS, FDDiagnostics, GradientTransformation, GraftingType,
+                    MaskedNode, ParameterStats, PreconditionerType, QuantizedValue,
                     ShampooState, TrainingMetrics, init_training_metrics)
 
 _EPSILON = 1e-25  # DS:41
@@ -149,8 +149,6 @@ def distributed_shampoo(
     raise NotImplementedError("shard_optimizer_states (pjit mode) is out of scope")
   if lobpcg_topk_precondition and (eigh or compression_rank != 0):
     raise NotImplementedError("lobpcg_topk_precondition is built for the dense Newton branch")
-  if generate_fd_metrics:
-    raise NotImplementedError("FDDiagnostics (generate_fd_metrics) are not built")
   reset_frequency = None
   if reset_preconditioner:  # DS:2022-2024
     reset_frequency = int(np.round(1 / (1 - beta2))) if beta2 != 1 else None
@@ -431,6 +429,8 @@ def distributed_shampoo(
     # this rank does not own are empty placeholders
     sizes = [int(p.shape[0]) for p in prev]
     compute_fn, out_cols = None, None
+    fd_cols = len(_FD_FIELDS) if (generate_fd_metrics and generate_training_metrics) else 0
+    metrics_cols = comm.METRICS_STRIDE + fd_cols
     if compression_rank != 0:
       max_size = max(sizes)
       assert _precond_dim(compression_rank, max_size) < max_size, (
@@ -446,7 +446,7 @@ def distributed_shampoo(
         return pp
 
       def compute_fn(indices, outs):  # new_mi_pth_root dispatch, DS:2706-2738
-        rows = torch.zeros((len(indices), comm.METRICS_STRIDE), dtype=torch.float32,
+        rows = torch.zeros((len(indices), metrics_cols), dtype=torch.float32,
                            device=statistics[0].device)
         dense = [k for k, i in enumerate(indices)
                  if not _should_compress(compression_rank, sizes[i])]
@@ -456,7 +456,7 @@ def distributed_shampoo(
               [sizes[indices[k]] for k in dense], ridge_epsilon=matrix_epsilon,
               relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
               out=[outs[k] for k in dense])
-          rows[dense] = m
+          rows[dense, :comm.METRICS_STRIDE] = m
         fd_calls, fd_slots = [], []
         for k, i in enumerate(indices):
           if k in dense:
@@ -480,7 +480,9 @@ def distributed_shampoo(
                 new_grad=stat_i, p=exponents[i], rank=compression_rank,
                 ridge_epsilon=matrix_epsilon,
                 relative_matrix_epsilon=relative_matrix_epsilon, decay=beta2,
-                padding_start=n_i, prev=prev_i, new_grad_is_gram=True))
+                padding_start=n_i, prev=prev_i, new_grad_is_gram=True,
+                generate_training_metrics=generate_training_metrics,
+                generate_fd_metrics=generate_fd_metrics))
             fd_slots.append((k, n_i))
           else:
             val, tm = backend.low_rank_root(
@@ -493,6 +495,10 @@ def distributed_shampoo(
           for (k, n_i), (val, tm) in zip(fd_slots, backend.fd_update_root_batched(fd_calls)):
             outs[k].copy_(val[:n_i])
             rows[k, 0] = tm.inverse_pth_root_errors
+            if fd_cols:  # FDDiagnostics ride behind the 8 PS_M_* columns of the gathered row
+              rows[k, comm.METRICS_STRIDE:] = torch.stack(
+                  [torch.as_tensor(getattr(tm.fd, name), dtype=torch.float32).to(rows.device)
+                   for name in _FD_FIELDS])
         return rows
 
     root_fn = backend.matrix_inverse_pth_root_batched
@@ -552,7 +558,8 @@ def distributed_shampoo(
         relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
         ownership=block_ownership, root_fn=root_fn, out_cols=out_cols,
         compute_fn=compute_fn, payload_elems=payload_elems, sizes=sizes,
-        pi_first=(_backend_for_testing is None and not lobpcg_topk_precondition))
+        pi_first=(_backend_for_testing is None and not lobpcg_topk_precondition),
+        metrics_cols=metrics_cols if compute_fn is not None else comm.METRICS_STRIDE)
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
     if quantize_second_moment:
       roots = [QuantizedValue(*_unpack(r, n), qdt_second_moment, True, [n, n])
@@ -586,6 +593,9 @@ def distributed_shampoo(
             final_error_ratio=m[:, 2].clone(),
             max_eigen_value=m[:, 3].clone(),
             total_retries=m[:, 4].clone())
+        if fd_cols and m.shape[1] > comm.METRICS_STRIDE:
+          tm = tm.replace(fd=FDDiagnostics(**{
+              name: m[:, comm.METRICS_STRIDE + j].clone() for j, name in enumerate(_FD_FIELDS)}))
       out.append(ParameterStats(state.diagonal_statistics, state.statistics,
                                 new_p[idx:idx + num], state.diagonal_momentum,
                                 state.momentum, state.avg_grad, tm))

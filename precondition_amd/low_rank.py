@@ -198,10 +198,12 @@ def _fd_update_root_batched(calls) -> list:
   results = [None] * n_calls
   preps = [None] * n_calls
   for i, kw in enumerate(calls):
-    if kw.get("generate_fd_metrics"):
-      raise NotImplementedError("FDDiagnostics are not built")
     preps[i] = _fd_prepare(**{k: v for k, v in kw.items()
                               if k not in ("generate_training_metrics", "generate_fd_metrics")})
+    preps[i]["want_fd"] = bool(kw.get("generate_fd_metrics") and
+                               kw.get("generate_training_metrics", True))
+    if preps[i]["want_fd"] and preps[i]["ps"] != 0:
+      _fd_keep_for_diagnostics(preps[i], kw)
     if preps[i]["ps"] == 0:  # DS:1284-1288
       results[i] = (torch.zeros_like(kw["prev"]), _metrics(0.0))
   todo = [i for i in range(n_calls) if results[i] is None]
@@ -263,7 +265,63 @@ def _fd_prepare(new_grad, p, rank=0, ridge_epsilon=1e-6, error_tolerance=1e-6,
   c = decay * kernels.matmul(weighted, weighted, transb=True) + gram
   st["c"] = 0.5 * (c + c.T)
   st["tail"] = tail
+  st["weighted"] = weighted
   return st
+
+
+def _fd_keep_for_diagnostics(st, kw):
+  """What FDDiagnostics (DS:197-335) needs besides the decomposition."""
+  st["new_grad"] = kw["new_grad"]
+  st["new_grad_is_gram"] = bool(kw.get("new_grad_is_gram"))
+
+
+def _fd_diagnostics(st, rho_t, new_tail, deflated, eigvecs, num_neg, num_zero_init,
+                    num_unsafe, num_has_padding, top_sq):
+  """FDDiagnostics.create (DS:262-335) + the fit errors of DS:1232-1241.
+  The reference measures the fit on its SVD factors; here `updated updated^T = C`, so
+  total_frob = ||updated||_F^2 = trace(C), and the top-k residual of an exact SVD is
+  sum_{i >= k} s_i^2 = trace(C) - sum_{i < k} s_i^2 (square_frob and heuristic_frob, which the
+  reference evaluates separately in float32, coincide).  Quantities that depend on WHICH
+  square factor R of the Gram matrix was passed (entrywise_err, new_grad_abs_max and the
+  two sparsities — R is not unique in the reference either, it is a QR factor) are computed
+  from R when the caller passed one and are NaN when the slot holds the Gram matrix itself
+  (`new_grad_is_gram`, this build's optimizer mode)."""
+  from .state import FDDiagnostics
+  ps, rank, max_size, dev = st["ps"], st["rank"], st["max_size"], st["dev"]
+  f32 = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev)
+  nan = f32(float("nan"))
+  nz = deflated != 0
+  eig_max = deflated.max()
+  eig_min = torch.where(nz, deflated, eig_max).min()
+  c = st["c"]
+  total_frob = torch.diagonal(c).sum()
+  resid = torch.clamp(total_frob - top_sq.sum(), min=0.0)
+  g = st["new_grad"][:ps, :ps]
+  if st["new_grad_is_gram"]:
+    gram = g
+    abs_max = sparsity = col_sparsity = entrywise = nan
+  else:
+    gram = kernels.matmul(g.contiguous(), g.contiguous(), transb=True)
+    abs_max = g.abs().max()
+    sparsity = (g == 0).sum().to(torch.float32) / float(ps * ps)
+    col_sparsity = (g.abs().sum(dim=0) == 0).sum().to(torch.float32) / float(ps)
+    # ||updated - U_k U_k^T updated||_1 / (ps^2 + ps rank), updated = [sqrt(decay) W | R]
+    upd = torch.cat([st["weighted"] * (st["decay"] ** 0.5), g], dim=1).contiguous()
+    uk = st["u_top"]
+    proj = kernels.matmul(uk, kernels.matmul(uk, upd, transa=True))
+    entrywise = (upd - proj).abs().sum() / float(ps * ps + ps * rank)
+  _, ggt_max = kernels.power_iteration(gram.contiguous(), 100, 1e-6)
+  cross = kernels.matmul(eigvecs.contiguous(), eigvecs.contiguous(), transa=True)
+  ortho = (cross - torch.diag(torch.diagonal(cross))).abs().max()
+  return FDDiagnostics(
+      size_max_size=f32(max_size), size_rank=f32(rank), size_padding_start=f32(ps),
+      rho=f32(rho_t), tail=f32(new_tail), eig_sparsity=(deflated == 0).to(torch.float32).mean(),
+      eig_max=eig_max, eig_min=eig_min, new_grad_abs_max=abs_max, new_grad_sparsity=sparsity,
+      new_grad_col_sparsity=col_sparsity, ggt_eig_max=ggt_max,
+      ggt_intrinsic_dimension=torch.diagonal(gram).sum() / ggt_max, max_ortho_err=ortho,
+      num_neg_eigs=f32(num_neg), num_zero_initial_eigs=f32(num_zero_init),
+      num_unsafe_norms=f32(num_unsafe), num_has_padding=f32(num_has_padding),
+      square_frob=resid, heuristic_frob=resid, entrywise_err=entrywise, total_frob=total_frob)
 
 
 def _fd_finish(st, e, u):
@@ -296,10 +354,13 @@ def _fd_finish(st, e, u):
   alpha = -1.0 / p
   new_const = torch.where(new_tail <= 0, torch.zeros_like(new_tail), new_tail ** alpha)
   new_tail = torch.where(new_tail <= 0, torch.zeros_like(new_tail), new_tail)
+  num_neg = (deflated < 0).sum()
+  num_zero_init = (deflated == 0.0).sum()
   deflated = torch.where(deflated <= 0, torch.zeros_like(deflated), deflated)
   eigvecs = eigvecs * (deflated > 0)
   norms = torch.linalg.vector_norm(eigvecs, dim=0)
   safe = (0.99 <= norms) & (norms <= 1.01)
+  num_unsafe = (~safe).sum() - (num_neg + num_zero_init)   # DS:1217-1219
   eigvecs = eigvecs * safe
   deflated = deflated * safe
   eigvecs = eigvecs / torch.where(safe, norms, torch.ones_like(norms))
@@ -315,4 +376,10 @@ def _fd_finish(st, e, u):
   has_zeros = bool((deflated <= 0).any()) or bool((new_tail <= 0).any())
   packed = _fd_low_rank_pack(eigvecs, deflated, inverted, new_const, new_tail,
                              has_zeros, rank)
-  return packed, _metrics(0.0)
+  metrics = _metrics(0.0)
+  if st.get("want_fd"):
+    st["u_top"] = u[:, :k].contiguous()
+    metrics = metrics.replace(fd=_fd_diagnostics(
+        st, rho_t, new_tail, deflated, eigvecs, num_neg, num_zero_init, num_unsafe,
+        has_pad.sum(), torch.square(top_eigs)))
+  return packed, metrics

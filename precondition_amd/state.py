@@ -73,6 +73,45 @@ class InversePthRootDiagnostics:
     return dataclasses.replace(self, **kw)
 
 
+_FD_FIELDS = ("size_max_size", "size_rank", "size_padding_start", "rho", "tail", "eig_sparsity",
+              "eig_max", "eig_min", "new_grad_abs_max", "new_grad_sparsity",
+              "new_grad_col_sparsity", "ggt_eig_max", "ggt_intrinsic_dimension",
+              "max_ortho_err", "num_neg_eigs", "num_zero_initial_eigs", "num_unsafe_norms",
+              "num_has_padding", "square_frob", "heuristic_frob", "entrywise_err",
+              "total_frob")
+
+
+@dataclasses.dataclass(frozen=True)
+class FDDiagnostics:
+  """Diagnostics of a Frequent-Directions update (DS:197-335), same fields in the same
+  order; filled by low_rank._fd_update_root when generate_fd_metrics is set."""
+  size_max_size: Any = dataclasses.field(default_factory=_zero)
+  size_rank: Any = dataclasses.field(default_factory=_zero)
+  size_padding_start: Any = dataclasses.field(default_factory=_zero)
+  rho: Any = dataclasses.field(default_factory=_zero)
+  tail: Any = dataclasses.field(default_factory=_zero)
+  eig_sparsity: Any = dataclasses.field(default_factory=_zero)
+  eig_max: Any = dataclasses.field(default_factory=_zero)
+  eig_min: Any = dataclasses.field(default_factory=_zero)
+  new_grad_abs_max: Any = dataclasses.field(default_factory=_zero)
+  new_grad_sparsity: Any = dataclasses.field(default_factory=_zero)
+  new_grad_col_sparsity: Any = dataclasses.field(default_factory=_zero)
+  ggt_eig_max: Any = dataclasses.field(default_factory=_zero)
+  ggt_intrinsic_dimension: Any = dataclasses.field(default_factory=_zero)
+  max_ortho_err: Any = dataclasses.field(default_factory=_zero)
+  num_neg_eigs: Any = dataclasses.field(default_factory=_zero)
+  num_zero_initial_eigs: Any = dataclasses.field(default_factory=_zero)
+  num_unsafe_norms: Any = dataclasses.field(default_factory=_zero)
+  num_has_padding: Any = dataclasses.field(default_factory=_zero)
+  square_frob: Any = dataclasses.field(default_factory=_zero)
+  heuristic_frob: Any = dataclasses.field(default_factory=_zero)
+  entrywise_err: Any = dataclasses.field(default_factory=_zero)
+  total_frob: Any = dataclasses.field(default_factory=_zero)
+
+  def replace(self, **kw):
+    return dataclasses.replace(self, **kw)
+
+
 @dataclasses.dataclass(frozen=True)
 class TrainingMetrics:
   """Per-statistic diagnostics kept inside the optimizer state (DS:338-363)."""
@@ -98,6 +137,7 @@ pytree.register_dataclass(LOBPCGDiagnostics,
 pytree.register_dataclass(
     InversePthRootDiagnostics,
     [f.name for f in dataclasses.fields(InversePthRootDiagnostics)])
+pytree.register_dataclass(FDDiagnostics, list(_FD_FIELDS))
 pytree.register_dataclass(TrainingMetrics,
                           [f.name for f in dataclasses.fields(TrainingMetrics)])
 
@@ -172,7 +212,9 @@ class ShampooState(NamedTuple):
 
 
 def default_training_metrics(generate_fd_metrics: bool = False) -> TrainingMetrics:
-  del generate_fd_metrics  # FD diagnostics: config 5, not built yet
+  """DS:429-436."""
+  if generate_fd_metrics:
+    return TrainingMetrics(fd=FDDiagnostics())
   return TrainingMetrics()
 
 

@@ -293,3 +293,42 @@ def test_gemm_bf16_grouped_vs_fp64(device):
     got = c.cpu().numpy()
     assert np.isfinite(got).all()
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, tol
+
+
+# ---------------------------------------------------------------------------
+def test_fd_diagnostics_vs_reference_golden(device):
+  """FDDiagnostics (DS:197-335) of _fd_update_root in factor mode against the values the
+  reference's own code produced (tests/golden/fd_metrics.npz), and the Gram-matrix mode of
+  the optimizer: the same numbers where they are defined, NaN for the four quantities that
+  depend on which factor R of the Gram matrix the caller holds."""
+  import json
+  from precondition_amd import low_rank
+  from tests.test_oracle_golden import GOLD
+  z = np.load(os.path.join(GOLD, "fd_metrics.npz"))
+  with open(os.path.join(GOLD, "fd_metrics_index.json")) as f:
+    idx = json.load(f)
+  factor_only = {"new_grad_abs_max", "new_grad_sparsity", "new_grad_col_sparsity", "entrywise_err"}
+  for c in idx:
+    nm, r = c["name"], c["rank"]
+    for t in range(c["steps"]):
+      fac = torch.tensor(z[f"{nm}__factor{t}"], device=device)
+      prev = torch.tensor(z[f"{nm}__prev{t}"], device=device)
+      ref = dict(zip(c["fields"], z[f"{nm}__fd{t}"].tolist()))
+      for use_gram in (False, True):
+        src = low_rank.kernels.matmul(fac, fac, transb=True) if use_gram else fac
+        new, tm = low_rank._fd_update_root(
+            src, c["p"], rank=r, ridge_epsilon=1e-6, error_tolerance=0.0,
+            relative_matrix_epsilon=True, decay=c["decay"], padding_start=c["padding_start"],
+            prev=prev, generate_training_metrics=True, generate_fd_metrics=True,
+            new_grad_is_gram=use_gram)
+        got = {k: float(getattr(tm.fd, k)) for k in c["fields"]}
+        for k, v in ref.items():
+          if use_gram and k in factor_only:
+            assert np.isnan(got[k]), (k, got[k])
+          elif k == "max_ortho_err":
+            assert got[k] < 1e-5
+          elif k in ("square_frob", "heuristic_frob"):
+            # trace(C) - sum of the kept s_i^2: a difference of large numbers in float32
+            assert np.isclose(got[k], v, rtol=2e-3, atol=1e-4 * ref["total_frob"]), (k, got[k], v)
+          else:
+            assert np.isclose(got[k], v, rtol=2e-3, atol=1e-6), (nm, t, use_gram, k, got[k], v)

@@ -12,6 +12,7 @@ sequence); the flag is stored in each fixture as ``oracle_bitexact_at_gen``.
 
 Usage:  python tools/gen_golden.py            (writes tests/golden/)
 """
+import dataclasses
 import json
 import os
 import sys
@@ -677,6 +678,39 @@ def gen_lowrank():
     json.dump(index, f, indent=1)
 
 
+def gen_fd_metrics():
+  """FDDiagnostics (DS:197-335) of the reference's _fd_update_root on a short chain, factor
+  mode (new_grad = the QR factor R) so that every field is defined."""
+  out, index = {}, []
+  for name, d, rank, p, ps, decay, seed in (("d24_r4", 24, 4, 4, 24, 0.9, 2),
+                                            ("d32_r5_pad26", 32, 5, 2, 26, 0.999, 3)):
+    r = np.random.default_rng(seed)
+    prev = jnp.zeros((d, rank + 2), jnp.float32)
+    for t in range(2):
+      g = r.standard_normal((ps, 3 * ps)).astype(F32) * (1.0 + 0.3 * t)
+      g[:rank + 2] *= np.linspace(6.0, 2.0, rank + 2)[:, None].astype(F32)
+      gfull = np.zeros((d, g.shape[1]), F32); gfull[:ps] = g
+      fac = ds.frequent_directions_update(None, jnp.array(gfull), 0, 0.0, 0.0)
+      with np.errstate(all="ignore"):
+        new, m = ds._fd_update_root(fac, p, rank=rank, ridge_epsilon=1e-6,
+                                    relative_matrix_epsilon=True, decay=decay,
+                                    padding_start=ps, prev=prev, error_tolerance=0.0,
+                                    generate_training_metrics=True, generate_fd_metrics=True)
+      out[f"{name}__factor{t}"] = npy(fac)
+      out[f"{name}__prev{t}"] = npy(prev)
+      out[f"{name}__new{t}"] = npy(new)
+      fd = m.fd
+      names = [f.name for f in dataclasses.fields(fd)]
+      out[f"{name}__fd{t}"] = np.array([float(np.asarray(getattr(fd, n))) for n in names], F32)
+      prev = new
+    index.append(dict(name=name, d=d, rank=rank, p=p, padding_start=ps, decay=decay, steps=2,
+                      fields=names))
+    print("fd_metrics", name, dict(zip(names, out[f"{name}__fd1"].tolist())))
+  np.savez_compressed(os.path.join(OUT, "fd_metrics.npz"), **out)
+  with open(os.path.join(OUT, "fd_metrics_index.json"), "w") as f:
+    json.dump(index, f, indent=1)
+
+
 def fd_big_grad(ps, rank, t, rng):
   """Gradient block of step t of a full-size FD chain (shared with the tests, which rebuild
   the inputs from the seed instead of storing d x 3d arrays)."""
@@ -716,7 +750,7 @@ def gen_lowrank_big():
 
 if __name__ == "__main__":
   which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e", "lowrank", "quant",
-                           "e2e_quant", "e2e_more", "lowrank_big"]
+                           "e2e_quant", "e2e_more", "lowrank_big", "fd_metrics"]
   if "newton" in which:
     gen_newton()
   if "pi" in which:
@@ -739,4 +773,6 @@ if __name__ == "__main__":
     gen_lowrank()
   if "lowrank_big" in which:
     gen_lowrank_big()
+  if "fd_metrics" in which:
+    gen_fd_metrics()
   print("golden fixtures written to", OUT)
