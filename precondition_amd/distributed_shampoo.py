@@ -31,9 +31,11 @@ import torch
 from . import comm
 from . import pytree
 from .blocking import Preconditioner, _precond_dim, _should_compress
-from .state import (_FD_FIELDS, FDDiagnostics, GradientTransformation, GraftingType,
-                    MaskedNode, ParameterStats, PreconditionerType, QuantizedValue,
-                    ShampooState, TrainingMetrics, init_training_metrics)
+from .state import (_FD_FIELDS, FDDiagnostics, GlobalShardedParameterStats,
+                    GradientTransformation, GraftingType, InitFnState,
+                    LocalShardedParameterStats, MaskedNode, ParameterStats, PreconditionerType,
+                    QuantizedValue, ShampooState, ShardedShampooStats, TrainingMetrics,
+                    init_training_metrics)
 
 _EPSILON = 1e-25  # DS:41
 
@@ -127,7 +129,9 @@ def distributed_shampoo(
 ):
   """Returns GradientTransformation(init_fn, update_fn); see module docstring."""
   del precision, tensordot_precision  # always exact-f32 MFMA
-  del statistics_partition_spec, preconditioner_partition_spec, num_devices_for_pjit
+  # (the partition specs describe XLA shardings; here the stacked statistics are always
+  # split along their leading axis over the ranks of the process group)
+  del statistics_partition_spec, preconditioner_partition_spec
 
   # ---- construction-time validation: same conditions and messages as DS:2019-2040
   if reset_preconditioner and not frequent_directions:
@@ -145,8 +149,10 @@ def distributed_shampoo(
                      "to equal != preconditioning_compute_steps "
                      f"({preconditioning_compute_steps})")
   # ---- scope of this build
-  if shard_optimizer_states:
-    raise NotImplementedError("shard_optimizer_states (pjit mode) is out of scope")
+  if shard_optimizer_states and best_effort_memory_usage_reduction:
+    raise NotImplementedError("shard_optimizer_states with quantized state is not built")
+  if shard_optimizer_states and block_ownership != "reference":
+    raise ValueError("shard_optimizer_states keeps the reference's batch() ownership")
   if lobpcg_topk_precondition and (eigh or compression_rank != 0):
     raise NotImplementedError("lobpcg_topk_precondition is built for the dense Newton branch")
   reset_frequency = None
@@ -155,7 +161,13 @@ def distributed_shampoo(
     beta2 = 1.0
 
   group = comm.resolve_group(batch_axis_name)
-  shard_stats = bool(shard_statistics and group is not None)
+  # sharded optimizer state (DS:2162-2583) = owner-only statistics behind the stacked-array API
+  shard_stats = bool((shard_statistics or shard_optimizer_states) and group is not None)
+  if shard_optimizer_states and num_devices_for_pjit is not None:
+    if int(num_devices_for_pjit) != comm.world_and_rank(group)[0]:
+      raise ValueError(
+          f"num_devices_for_pjit={num_devices_for_pjit} but the process group has "
+          f"{comm.world_and_rank(group)[0]} rank(s): one process per GPU")
   if shard_stats and (frequent_directions or compression_rank != 0):
     raise NotImplementedError("shard_statistics supports the dense preconditioner mode")
 
@@ -804,4 +816,197 @@ def distributed_shampoo(
     return (treedef.unflatten(updates_flat),
             ShampooState(count=state.count + 1, stats=treedef.unflatten(new_stats)))
 
+  # ---------------------------------------------------------------------------
+  # Sharded optimizer state: the reference's pjit mode (DS:2162-2583).  Same state layout
+  # (ShardedShampooStats: GlobalShardedParameterStats with ONE stacked, padded array per kind
+  # + a LocalShardedParameterStats per parameter) and the same init-function triple; the
+  # XLA sharding of the stacked statistics along their leading axis becomes: rank r of the
+  # process group keeps rows [r*b, (r+1)*b) (b = padded count / ranks — the batch() chunks
+  # of DS:1827), updates and roots them in place at their TRUE sizes (views into the padded
+  # slots, padding_start semantics), and one RCCL all-gather replicates the roots.
+  def _pad_count(n_stats):
+    world, _ = comm.world_and_rank(group)
+    to_pad = -n_stats % world
+    return (world if n_stats == 0 else n_stats + to_pad), world
+
+  def _stat_sizes(params_flat):
+    sizes_per_param, exps = [], []
+    for param in params_flat:
+      sizes = []
+      if not _skip_preconditioning(param):
+        pc = preconditioner_from_params(param)
+        sizes = [int(sh[0]) for sh in pc.shapes_for_preconditioners()]
+        e = pc.exponent_for_preconditioner() if exponent_override == 0 else exponent_override
+        exps.extend([e] * len(sizes))
+      sizes_per_param.append(sizes)
+    return sizes_per_param, exps
+
+  def _padded_eye(n, max_size, scale, dev):
+    """pad_square_matrix(scale * I_n, max_size) (DS:1324-1350): [[scale I, 0], [0, I]]."""
+    m = torch.eye(max_size, dtype=torch.float32, device=dev)
+    if n > 0:
+      m[:n, :n] *= scale
+    return m
+
+  def sharded_init_fn(params):
+    """DS:2162-2255."""
+    params_flat, treedef = pytree.tree_flatten(params)
+    dev = params_flat[0].device if params_flat else None
+    sizes_per_param, exps = _stat_sizes(params_flat)
+    all_sizes = [n for sz in sizes_per_param for n in sz]
+    max_size = max(all_sizes) if all_sizes else block_size
+    n_pad, world = _pad_count(len(all_sizes))
+    _, rank = comm.world_and_rank(group)
+    b = n_pad // world
+    pd = _precond_dim(compression_rank, max_size)
+    local_flat, index = [], 0
+    for param, sizes in zip(params_flat, sizes_per_param):
+      zeros_q = _quantize_momentum_many([torch.zeros_like(param), torch.zeros_like(param)],
+                                        [param, param])
+      diag = torch.zeros_like(param) if _graft_type_has_diagonal_statistics() else []
+      local_flat.append(LocalShardedParameterStats(
+          _quantize(diag), zeros_q[0], zeros_q[1],
+          torch.zeros_like(param) if (frequent_directions and average_grad) else MaskedNode(),
+          init_training_metrics(len(sizes), generate_training_metrics, generate_fd_metrics,
+                                device=dev),
+          index, tuple(sizes)))
+      index += len(sizes)
+    # this rank's chunk of the stacked statistics; entries past the real ones are the
+    # identity matrices the reference pads the list with (exponent 1, DS:2237-2249)
+    mine = range(rank * b, (rank + 1) * b)
+    stats = torch.stack([
+        _padded_eye(all_sizes[i], max_size, matrix_epsilon, dev) if i < len(all_sizes)
+        else torch.eye(max_size, dtype=torch.float32, device=dev) for i in mine])
+    eye_p = torch.eye(max_size, pd, dtype=torch.float32, device=dev) * float(pd == max_size)
+    preconds = eye_p.unsqueeze(0).repeat(n_pad, 1, 1)
+    exponents = torch.tensor(exps + [1] * (n_pad - len(exps)), dtype=torch.int32, device=dev)
+    return ShampooState(
+        count=torch.zeros([], dtype=torch.int32),
+        stats=ShardedShampooStats(GlobalShardedParameterStats(stats, preconds, exponents),
+                                  treedef.unflatten(local_flat)))
+
+  def sharded_init_partition_spec_fn(params, params_partition_spec,
+                                     partition_spec_for_statistics):
+    """DS:2275-2342: the state tree with the caller's partition specs in place of arrays
+    (kept for API parity: checkpointing code walks it; nothing here consumes it)."""
+    pspec_flat, _ = pytree.tree_flatten(params_partition_spec, is_leaf=lambda x: x is None)
+    params_flat, treedef = pytree.tree_flatten(params)
+    assert pspec_flat and params_flat
+    sizes_per_param, _ = _stat_sizes(params_flat)
+    local_flat, index = [], 0
+    for param, pspec, sizes in zip(params_flat, pspec_flat, sizes_per_param):
+      qdtype = quantized_dtype_for_momentum_buffers(param)
+      scale = [] if qdtype == torch.float32 else (list(pspec[1:]) if pspec and len(pspec) > 1 else [])
+      local_flat.append(LocalShardedParameterStats(
+          QuantizedValue(pspec, [], [], torch.float32, False, list(param.shape)),
+          QuantizedValue(pspec, [], scale, qdtype, False, list(param.shape)),
+          QuantizedValue(pspec, [], scale, qdtype, False, list(param.shape)),
+          pspec if (frequent_directions and average_grad) else MaskedNode(),
+          pytree.tree_map(lambda _: None, init_training_metrics(
+              1, generate_training_metrics, generate_fd_metrics)),
+          index, tuple(sizes)))
+      index += len(sizes)
+    g = GlobalShardedParameterStats(partition_spec_for_statistics,
+                                    partition_spec_for_statistics, None)
+    return ShampooState(count=None, stats=ShardedShampooStats(g, treedef.unflatten(local_flat)))
+
+  def sharded_init_shape_and_dtype_fn(params):
+    """DS:2344-2418: the state tree with [shape, dtype] in place of arrays.  Shapes are the
+    GLOBAL ones of the reference (statistics [N_padded, max, max]); a rank holds N_padded /
+    ranks rows of the statistics."""
+    params_flat, treedef = pytree.tree_flatten(params)
+    sizes_per_param, _ = _stat_sizes(params_flat)
+    all_sizes = [n for sz in sizes_per_param for n in sz]
+    max_size = max(all_sizes) if all_sizes else block_size
+    n_pad, _ = _pad_count(len(all_sizes))
+    local_flat, index = [], 0
+    for param, sizes in zip(params_flat, sizes_per_param):
+      qdtype = quantized_dtype_for_momentum_buffers(param)
+      shp = list(param.shape)
+      scale = [] if qdtype == torch.float32 else [shp[1:], torch.float32]
+      local_flat.append(LocalShardedParameterStats(
+          QuantizedValue([shp, torch.float32], [], [], torch.float32, False, shp),
+          QuantizedValue([shp, qdtype], [], scale, qdtype, False, shp),
+          QuantizedValue([shp, qdtype], [], scale, qdtype, False, shp),
+          [shp, param.dtype] if (frequent_directions and average_grad) else MaskedNode(),
+          pytree.tree_map(lambda _: [[len(sizes)], torch.float32], init_training_metrics(
+              len(sizes), generate_training_metrics, generate_fd_metrics)),
+          index, tuple(sizes)))
+      index += len(sizes)
+    pd = _precond_dim(compression_rank, max_size)
+    g = GlobalShardedParameterStats([[n_pad, max_size, max_size], torch.float32],
+                                    [[n_pad, max_size, pd], torch.float32],
+                                    [[n_pad], torch.int32])
+    return ShampooState(count=[[], torch.float32],
+                        stats=ShardedShampooStats(g, treedef.unflatten(local_flat)))
+
+  def sharded_update_fn(grads, state, params):
+    """DS:2420-2583."""
+    params_flat, treedef = pytree.tree_flatten(params)
+    grads_flat = treedef.flatten_up_to(grads)
+    grad_dtypes = [g.dtype for g in grads_flat]
+    grads_flat = [g if g.dtype == torch.float32 else g.to(torch.float32) for g in grads_flat]
+    step = int(state.count)
+    gstats = state.stats.global_stats
+    local_flat = treedef.flatten_up_to(state.stats.local_stats)
+    world, rank = comm.world_and_rank(group)
+    b = int(gstats.statistics.shape[0])
+    lo = rank * b
+    # _convert_to_parameter_stats (DS:1762-1788): true-size views into the padded slots;
+    # statistics another rank owns are empty placeholders
+    stats_flat = []
+    for loc in local_flat:
+      st, pcs = [], []
+      for j, n in enumerate(loc.sizes):
+        i = loc.index_start + j
+        st.append(gstats.statistics[i - lo, :n, :n] if lo <= i < lo + b
+                  else torch.empty((0, 0), dtype=torch.float32, device=gstats.statistics.device))
+        pcs.append(gstats.preconditioners[i, :n, :_precond_dim(compression_rank, n)])
+      stats_flat.append(ParameterStats(loc.diagonal_statistics, st, pcs, loc.diagonal_momentum,
+                                       loc.momentum, loc.avg_grad, loc.training_metrics))
+    new_stats = _compute_stats_all(grads_flat, stats_flat, params_flat, step)
+    new_stats = _compute_preconditioners(new_stats, params_flat, step)
+    pgs = _preconditioned_grads_all(grads_flat, new_stats, params_flat)
+    if hasattr(backend, "transform_grads_fused"):
+      outs = _transform_grads_fused(grads_flat, new_stats, params_flat, pgs, step)
+    else:
+      outs = [_transform_grad(g, s, p, step, pg)
+              for g, s, p, pg in zip(grads_flat, new_stats, params_flat, pgs)]
+    updates_flat = [o[0] if o[0].dtype == dt else o[0].to(dt) for o, dt in zip(outs, grad_dtypes)]
+    new_stats = [o[1] for o in outs]
+    # back into the stacked arrays (pad_square_matrix semantics: the padding of a slot is
+    # the identity for statistics, DS:2461-2465, and zero for the roots, DST:367-398)
+    new_statistics = gstats.statistics.clone()
+    recomputed = any(ns.preconditioners is not os.preconditioners and
+                     any(a is not c for a, c in zip(ns.preconditioners, os.preconditioners))
+                     for ns, os in zip(new_stats, stats_flat))
+    new_preconds = gstats.preconditioners
+    if recomputed:
+      new_preconds = torch.zeros_like(gstats.preconditioners)
+    new_local = []
+    for loc, ns in zip(local_flat, new_stats):
+      for j, n in enumerate(loc.sizes):
+        i = loc.index_start + j
+        if lo <= i < lo + b and ns.statistics[j].numel():
+          new_statistics[i - lo, :n, :n] = ns.statistics[j]
+        if recomputed:
+          p_ij = ns.preconditioners[j]
+          new_preconds[i, :n, :p_ij.shape[1]] = p_ij
+      new_local.append(LocalShardedParameterStats(
+          ns.diagonal_statistics, ns.diagonal_momentum, ns.momentum, ns.avg_grad,
+          ns.training_metrics, loc.index_start, loc.sizes))
+    new_state = ShampooState(
+        count=state.count + 1,
+        stats=ShardedShampooStats(
+            GlobalShardedParameterStats(new_statistics, new_preconds, gstats.exponents),
+            treedef.unflatten(new_local)))
+    return treedef.unflatten(updates_flat), new_state
+
+  if shard_optimizer_states:
+    # DS:3661-3673: init() returns the three init functions instead of a state
+    def _init_fns(unused_params):
+      return InitFnState(init_fn=sharded_init_fn, pspec_fn=sharded_init_partition_spec_fn,
+                         shape_and_dtype_fn=sharded_init_shape_and_dtype_fn)
+
+    return GradientTransformation(_init_fns, sharded_update_fn)
   return GradientTransformation(init_fn, update_fn)

@@ -211,6 +211,57 @@ class ShampooState(NamedTuple):
   stats: Any
 
 
+# ---- sharded optimizer state (the reference's pjit mode, DS:376-399, 483-500) ----------
+@dataclasses.dataclass(frozen=True)
+class GlobalShardedParameterStats:
+  """One stacked array per kind for ALL statistics of the model (DS:381-385).  The leading
+  axis is the one the reference shards with pjit; here a rank keeps its own contiguous
+  chunk of `statistics` (rows rank*b .. (rank+1)*b-1 of the padded list, the batch() order
+  of DS:1827) and the whole of `preconditioners` and `exponents`."""
+  statistics: Any       # [b, max_size, max_size]
+  preconditioners: Any  # [N_padded, max_size, precond_dim(max_size)]
+  exponents: Any        # [N_padded] int32
+
+  def replace(self, **kw):
+    return dataclasses.replace(self, **kw)
+
+
+@dataclasses.dataclass(frozen=True)
+class LocalShardedParameterStats:
+  """Per-parameter state of the sharded mode (DS:390-399): everything that mirrors the
+  parameter, plus where its statistics sit in the global arrays."""
+  diagonal_statistics: Any
+  diagonal_momentum: Any
+  momentum: Any
+  avg_grad: Any
+  training_metrics: Any
+  index_start: int = 0     # static: index into the global statistics list
+  sizes: Any = ()          # static: sizes of this parameter's statistics
+
+  def replace(self, **kw):
+    return dataclasses.replace(self, **kw)
+
+
+class ShardedShampooStats(NamedTuple):
+  """DS:483-486."""
+  global_stats: Any
+  local_stats: Any
+
+
+class InitFnState(NamedTuple):
+  """DS:493-496: what init() returns in the sharded mode."""
+  init_fn: Any
+  pspec_fn: Any
+  shape_and_dtype_fn: Any
+
+
+pytree.register_dataclass(GlobalShardedParameterStats,
+                          ["statistics", "preconditioners", "exponents"])
+pytree.register_dataclass(LocalShardedParameterStats,
+                          ["diagonal_statistics", "diagonal_momentum", "momentum", "avg_grad",
+                           "training_metrics"], ["index_start", "sizes"])
+
+
 def default_training_metrics(generate_fd_metrics: bool = False) -> TrainingMetrics:
   """DS:429-436."""
   if generate_fd_metrics:

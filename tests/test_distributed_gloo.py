@@ -233,3 +233,103 @@ def test_owner_only_statistics_two_ranks(quant, ownership):
     assert np.array_equal(ret[holders[0]][1][j], ref)
     n_owned[holders[0]] += 1
   assert min(n_owned) > 0
+
+
+# ---------------------------------------------------------------------------
+# shard_optimizer_states: the reference's pjit-mode API (DS:2162-2583, DS:3661-3673)
+def _run_pjit_api(group, sharded):
+  """Four steps; returns (updates of the last step, true-size statistics by global index
+  or None where this rank does not hold them, true-size preconditioners)."""
+  import precondition_amd as pa
+  from tests import cpu_backend
+  params, grads, kw = _quant_problem()
+  kw = dict(kw)
+  kw["best_effort_memory_usage_reduction"] = False
+  opt = pa.distributed_shampoo(0.1, 8, batch_axis_name=group, _backend_for_testing=cpu_backend,
+                               shard_optimizer_states=sharded, **kw)
+  if not sharded:
+    st = opt.init(params)
+    for g in grads:
+      upd, st = opt.update(g, st, params)
+    stats = [x.numpy().copy() for s in st.stats for x in s.statistics]
+    precs = [p.numpy().copy() for s in st.stats for p in s.preconditioners]
+    return [u.numpy().copy() for u in upd], stats, precs, None
+  fns = opt.init(params)
+  assert isinstance(fns, pa.state.InitFnState)
+  st = fns.init_fn(params)
+  shapes = fns.shape_and_dtype_fn(params)
+  g0 = st.stats.global_stats
+  n_pad, max_size = shapes.stats.global_stats.statistics[0][0], shapes.stats.global_stats.statistics[0][1]
+  assert list(g0.preconditioners.shape) == shapes.stats.global_stats.preconditioners[0]
+  assert g0.statistics.shape[1:] == (max_size, max_size)
+  for g in grads:
+    upd, st = opt.update(g, st, params)
+  gs = st.stats.global_stats
+  import torch.distributed as dist
+  world = dist.get_world_size(group) if group is not None else 1
+  rank = dist.get_rank(group) if group is not None else 0
+  b = gs.statistics.shape[0]
+  assert b * world == n_pad
+  from precondition_amd import pytree
+  locs = [l for l in pytree.tree_flatten(
+      st.stats.local_stats, is_leaf=lambda x: isinstance(x, pa.state.LocalShardedParameterStats))[0]]
+  stats, precs = [], []
+  for loc in locs:
+    for j, n in enumerate(loc.sizes):
+      i = loc.index_start + j
+      stats.append(gs.statistics[i - rank * b, :n, :n].numpy().copy()
+                   if rank * b <= i < (rank + 1) * b else None)
+      precs.append(gs.preconditioners[i, :n, :n].numpy().copy())
+      # padding of a slot: identity for statistics, zero for roots (DS:1324-1350, DST:367-398)
+      if rank * b <= i < (rank + 1) * b and n < max_size:
+        assert np.array_equal(gs.statistics[i - rank * b, n:, n:].numpy(),
+                              np.eye(max_size - n, dtype=np.float32))
+        assert not gs.statistics[i - rank * b, :n, n:].any()
+      assert not gs.preconditioners[i, n:, :].any() and not gs.preconditioners[i, :, n:].any()
+  return [u.numpy().copy() for u in upd], stats, precs, int(st.count)
+
+
+def _pjit_worker(rank, world, port, ret):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    ret[rank] = _run_pjit_api(dist.group.WORLD, True)
+  finally:
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_state_api_matches_plain_optimizer():
+  """One process: the pjit-style state (stacked padded arrays + local stats, init-function
+  triple) must walk the same trajectory as the plain optimizer, bit for bit."""
+  base_upd, base_stats, base_precs, _ = _run_pjit_api(None, False)
+  upd, stats, precs, count = _run_pjit_api(None, True)
+  assert count == 4
+  for a, b in zip(upd, base_upd):
+    assert np.array_equal(a, b)
+  for a, b in zip(stats, base_stats):
+    assert np.array_equal(a, b)
+  for a, b in zip(precs, base_precs):
+    assert np.array_equal(a, b)
+
+
+def test_sharded_optimizer_state_api_two_ranks():
+  """Two ranks: every rank holds one chunk of the stacked statistics (batch() order,
+  DS:1827), all preconditioners; updates equal the single-process ones."""
+  world = 2
+  mgr = mp.Manager()
+  ret = mgr.dict()
+  mp.spawn(_pjit_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+  base_upd, base_stats, base_precs, _ = _run_pjit_api(None, False)
+  for rank in range(world):
+    upd, stats, precs, count = ret[rank]
+    assert count == 4
+    for a, b in zip(upd, base_upd):
+      assert np.array_equal(a, b)
+    for a, b in zip(precs, base_precs):
+      assert np.array_equal(a, b)
+  for j, ref in enumerate(base_stats):
+    holders = [r for r in range(world) if ret[r][1][j] is not None]
+    assert len(holders) == 1, (j, holders)
+    assert np.array_equal(ret[holders[0]][1][j], ref)

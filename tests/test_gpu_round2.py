@@ -332,3 +332,26 @@ def test_fd_diagnostics_vs_reference_golden(device):
             assert np.isclose(got[k], v, rtol=2e-3, atol=1e-4 * ref["total_frob"]), (k, got[k], v)
           else:
             assert np.isclose(got[k], v, rtol=2e-3, atol=1e-6), (nm, t, use_gram, k, got[k], v)
+
+
+# ---------------------------------------------------------------------------
+def test_sharded_optimizer_state_api_hip_matches_plain_optimizer(device):
+  """shard_optimizer_states (the reference's pjit-mode API, DS:2162-2583) on the HIP path:
+  the stacked padded state must walk the plain optimizer's trajectory bit for bit."""
+  import precondition_amd as pa
+  from tests.test_distributed_gloo import _quant_problem
+  params, grads, kw = _quant_problem()
+  kw = dict(kw)
+  kw["best_effort_memory_usage_reduction"] = False
+  params = tuple(p.to(device) for p in params)
+  grads = [tuple(g.to(device) for g in gs) for gs in grads]
+  plain = pa.distributed_shampoo(0.1, 8, batch_axis_name=None, **kw)
+  shard = pa.distributed_shampoo(0.1, 8, batch_axis_name=None, shard_optimizer_states=True, **kw)
+  st_p = plain.init(params)
+  st_s = shard.init(params).init_fn(params)
+  for g in grads:
+    up, st_p = plain.update(g, st_p, params)
+    us, st_s = shard.update(g, st_s, params)
+    for a, b in zip(up, us):
+      assert torch.equal(a, b)
+  assert int(st_s.count) == len(grads)
