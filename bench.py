@@ -27,6 +27,43 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
+# TESTS ONLY (tests/test_distributed_gloo.py): PS_BENCH_SELFTEST_CPU=1 runs the control flow of
+# this file — rank set-up, the two-phase async all-gather step, barriers, max-over-ranks
+# timing, the ViT-B strong-scaling leg, the JSON line — on CPU tensors over gloo with the
+# numerical kernels replaced by tests/cpu_backend (the oracle) and every size shrunk.  The
+# line it prints says "data": "selftest-cpu" and is never a measurement.
+SELFTEST = bool(os.environ.get("PS_BENCH_SELFTEST_CPU"))
+
+
+def _sync():
+  if not SELFTEST:
+    torch.cuda.synchronize()
+
+
+def _install_selftest_backend():
+  from oracle import shampoo_oracle as orc
+  from precondition_amd import kernels as K
+  from tests import cpu_backend
+
+  def roots(matrices, ps, padding_starts=None, out=None, max_ev=None, symmetry="verify",
+            eigh=False, **kw):
+    del max_ev, symmetry
+    kw.pop("num_iters", None)
+    return cpu_backend.matrix_inverse_pth_root_batched(matrices, ps, padding_starts, out=out,
+                                                       eigh=eigh, **kw)
+
+  def power(matrices, padding_starts=None, **kw):
+    lam = [orc.power_iteration(m.numpy(), padding_start=None if padding_starts is None
+                               else int(padding_starts[i]))[1] for i, m in enumerate(matrices)]
+    return torch.tensor(lam, dtype=torch.float32), torch.full((len(lam),), 100, dtype=torch.int32)
+
+  K.matrix_inverse_pth_root_batched = roots
+  K.power_iteration_batched = power
+  K.stats_update_grouped = cpu_backend.stats_update_grouped
+  WORKLOADS.update({"cfg2_256x512_p4": (8, 16, 64, 4, 1234),
+                    "headline_64x1024_p4": (4, 32, 128, 4, 1024),
+                    "eigh_cfg3_64x2048_p2": (2, 16, 32, 2, 2048)})
+
 WORKLOADS = {
     # name: (blocks per GPU, n, k of the Wishart factor, p, seed)
     "cfg2_256x512_p4": (256, 512, 2048, 4, 1234),
@@ -52,7 +89,7 @@ def make_blocks(name, rank, dev):
     g_d = torch.from_numpy(g).to(dev)
     items = [(g_d[i], 0, stats[b0 + i], stats[b0 + i]) for i in range(g_d.shape[0])]
     K.stats_update_grouped(items, 0.0, 1.0)  # S <- 0*S + 1*G G^T on the MFMA path
-    torch.cuda.synchronize()
+    _sync()
   return stats, p
 
 
@@ -120,6 +157,20 @@ class Workload:
       w.wait()
     self.metrics = torch.cat(ms, dim=0)
 
+  def check_gathered_order(self, rank):
+    """After step(): `gathered` is laid out [half][rank][block]; this rank's own roots must
+    sit in its rank's slots of both halves (DS:2876: all_gather returns rank order)."""
+    if self.gathered is None:
+      return True
+    h = self.nb // 2
+    per = self.n * self.n
+    g = self.gathered.view(-1)
+    ok = True
+    for k, (lo, hi) in enumerate(((0, h), (h, self.nb))):
+      off = k * self.world * h * per + rank * (hi - lo) * per
+      ok &= bool(torch.equal(g[off: off + (hi - lo) * per], self.roots[lo:hi].reshape(-1)))
+    return ok
+
   def flops(self):
     """Algorithmic FLOPs of the last step on this rank (c(p) * 2n^3 per
     Newton step)."""
@@ -152,9 +203,13 @@ class VitBWorkload:
     self.group, self.world = group, world
     self.pcs, self.grads, self.stats, self.exps = [], [], [], []
     rng = np.random.default_rng(7)
-    for shape in VIT_B_SHAPES:
+    shapes, bs, merge = VIT_B_SHAPES, 1024, 4096
+    if SELFTEST:  # same tree, every dimension / 32 (tests only)
+      shapes = [[max(1, d // 32) if d > 16 else d for d in sh] for sh in VIT_B_SHAPES]
+      bs, merge = 32, 128
+    for shape in shapes:
       g = torch.from_numpy((rng.standard_normal(shape) * 0.02).astype(np.float32)).to(dev)
-      pc = Preconditioner(g, 1024, 4096, True)
+      pc = Preconditioner(g, bs, merge, True)
       st = [1e-6 * torch.eye(s[0], dtype=torch.float32, device=dev)
             for s in pc.shapes_for_preconditioners()]
       self.pcs.append(pc); self.grads.append(g); self.stats.append(st)
@@ -224,13 +279,13 @@ def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
   for u in range(updates):
     grads = [torch.randn((d, d), generator=gen, device=dev, dtype=torch.float32)
              for _ in range(factors)]
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     calls = [dict(new_grad=low_rank.gram_of_block(grads[f], 0), p=4, rank=rank,
                   ridge_epsilon=1e-6, decay=0.999, padding_start=d, prev=prevs[f],
                   new_grad_is_gram=True) for f in range(factors)]
     prevs = [r[0] for r in low_rank._fd_update_root_batched(calls)]
-    torch.cuda.synchronize()
+    _sync()
     times.append((time.perf_counter() - t0) / factors)
     del grads
   tails = [float(p[1, -1]) for p in prevs]
@@ -262,11 +317,11 @@ def quant_f3(dev):
       stats.append(g @ g.T)
 
   def t(fn, reps=5):
-    out = fn(); torch.cuda.synchronize()
+    out = fn(); _sync()
     t0 = time.perf_counter()
     for _ in range(reps):
       out = fn()
-    torch.cuda.synchronize()
+    _sync()
     return (time.perf_counter() - t0) / reps, out
 
   ne = sum(x.numel() for x in stats)
@@ -289,14 +344,14 @@ def timed(work, steps, warmup, multi):
   import torch.distributed as dist
   for _ in range(warmup):
     work.step()
-  torch.cuda.synchronize()
+  _sync()
   if multi:
     dist.barrier()
-  torch.cuda.synchronize()
+  _sync()
   t0 = time.perf_counter()
   for _ in range(steps):
     work.step()
-  torch.cuda.synchronize()
+  _sync()
   if multi:
     dist.barrier()
   dt = time.perf_counter() - t0
@@ -323,7 +378,7 @@ def profile_stage_kernel(work):
   L.ps_profile_enable(1)
   try:
     work.compute()  # rank-local: no collective, so only rank 0 needs to run it
-    torch.cuda.synchronize()
+    _sync()
   finally:
     L.ps_profile_enable(0)
   stage_ms, pi_ms, other_ms = C.c_double(), C.c_double(), C.c_double()
@@ -436,15 +491,19 @@ def main():
     local = 0
   if world != args.gpus and world > 1:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-  if not torch.cuda.is_available():
-    raise SystemExit("bench.py needs an MI355X (no CPU path)")
-  torch.cuda.set_device(local)
-  dev = torch.device("cuda", local)
+  if SELFTEST:
+    _install_selftest_backend()
+    dev = torch.device("cpu")
+  else:
+    if not torch.cuda.is_available():
+      raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
   if multi:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if os.environ.get("PS_BENCH_ONE_DEVICE"):
-      # dev only: RCCL refuses two ranks on one GPU; gloo exercises the same control flow
+    if SELFTEST or os.environ.get("PS_BENCH_ONE_DEVICE"):
+      # tests / dev only: RCCL refuses two ranks on one GPU; gloo exercises the same control flow
       dist.init_process_group(backend="gloo")
     else:
       dist.init_process_group(backend="nccl", device_id=dev)
@@ -468,7 +527,7 @@ def main():
       "scaling": "weak",
       "vs_baseline": None,
       "dtype": "f32",
-      "data": "synthetic",
+      "data": "selftest-cpu" if SELFTEST else "synthetic",
       "config": {
           "workload": f"{args.workload}: {nb} blocks/GPU of {n}x{n} fp32, p={p}, "
                       f"A=GG^T with G~N(0,1) [{n}x{WORKLOADS[args.workload][2]}], "
@@ -530,6 +589,27 @@ def main():
     }
   if multi:
     import torch.distributed as dist
+    # self-diagnosis of a multi-GPU run: how many ranks answered, and one extra step split
+    # into this rank's root computation and the all-gather tail that is NOT hidden under it
+    rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    ones = torch.ones(1, dtype=torch.int32, device=rdev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    dist.barrier(); _sync()
+    t0 = time.perf_counter(); work.compute(); _sync()
+    t_compute = time.perf_counter() - t0
+    dist.barrier(); _sync()
+    t0 = time.perf_counter(); work.step(); _sync()
+    t_step = time.perf_counter() - t0
+    tt = torch.tensor([t_compute, t_step], dtype=torch.float64, device=rdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    line["multi_gpu"] = {
+        "backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(),
+        "rccl_ranks_seen": int(ones.item()), "world_size": world,
+        "roots_only_ms_max_over_ranks": round(tt[0].item() * 1e3, 3),
+        "roots_plus_gather_ms_max_over_ranks": round(tt[1].item() * 1e3, 3),
+        "gathered_bytes_per_rank": int(work.roots.numel() * 4),
+        "gathered_list_matches_rank_order": bool(work.check_gathered_order(rank)),
+    }
     dist.barrier()
 
   if not args.no_headline and args.workload != "headline_64x1024_p4":
@@ -575,13 +655,13 @@ def main():
     vsteps = 2
     for _ in range(1):
       vw.step()
-    torch.cuda.synchronize()
+    _sync()
     if multi:
       dist.barrier()
     t0 = time.perf_counter()
     for _ in range(vsteps):
       vw.step()
-    torch.cuda.synchronize()
+    _sync()
     if multi:
       dist.barrier()
     vdt = (time.perf_counter() - t0) / vsteps
@@ -594,13 +674,16 @@ def main():
     vfl = vw.flops()
     vfl_ex = vw.flops(executed=True)
     # statistics kernel alone (HIP events on the launch stream = torch's current stream)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    vw.stats_step(); torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(5):
-      vw.stats_step()
-    ev1.record(); torch.cuda.synchronize()
-    st_ms = ev0.elapsed_time(ev1) / 5
+    vw.stats_step(); _sync()
+    if SELFTEST:
+      t0 = time.perf_counter(); vw.stats_step(); st_ms = (time.perf_counter() - t0) * 1e3
+    else:
+      ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      ev0.record()
+      for _ in range(5):
+        vw.stats_step()
+      ev1.record(); _sync()
+      st_ms = ev0.elapsed_time(ev1) / 5
     st_fl = vw.stats_flops / (world if world > 1 else 1)  # owner-only statistics when sharded
     st_ex = vw.stats_executed_flops() / (world if world > 1 else 1)
     line["vit_b_cfg4"] = {
@@ -633,8 +716,8 @@ def main():
       # single-GPU side measurements: a failure in one of them must not cost the line
       def eigh_cfg3():
         ew = Workload("eigh_cfg3_64x2048_p2", rank, 1, dev)
-        ew.step(); torch.cuda.synchronize()
-        t0 = time.perf_counter(); ew.step(); torch.cuda.synchronize()
+        ew.step(); _sync()
+        t0 = time.perf_counter(); ew.step(); _sync()
         edt = time.perf_counter() - t0
         conv = (6 + 2.0 / 3 + 4) * 2048.0 ** 3 * 64
         return {

@@ -333,3 +333,132 @@ def test_sharded_optimizer_state_api_two_ranks():
     holders = [r for r in range(world) if ret[r][1][j] is not None]
     assert len(holders) == 1, (j, holders)
     assert np.array_equal(ret[holders[0]][1][j], ref)
+
+
+# ---------------------------------------------------------------------------
+def test_bench_multi_rank_control_flow_over_gloo(tmp_path):
+  """bench.py's N > 1 path end to end, launched exactly as the driver launches it
+  (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2), in its
+  tests-only CPU mode (oracle kernels, shrunk sizes, gloo): rank set-up, the two-phase
+  all-gather step, barriers, max-over-ranks timing, the ViT-B strong-scaling leg with LPT
+  ownership, ONE JSON line from rank 0 with the multi-GPU self-diagnosis."""
+  import json
+  import subprocess
+  env = dict(os.environ)
+  env["PS_BENCH_SELFTEST_CPU"] = "1"
+  env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout[-2000:]
+  line = json.loads(lines[0])
+  assert line["data"] == "selftest-cpu" and line["n_gpus"] == 2 and line["scaling"] == "weak"
+  assert line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
+  mg = line["multi_gpu"]
+  assert mg["rccl_ranks_seen"] == 2 and mg["world_size"] == 2
+  assert mg["gathered_list_matches_rank_order"] is True
+  assert line["headline_1024"]["value"] > 0
+  vb = line["vit_b_cfg4"]
+  assert vb["failed_blocks"] == 0 and vb["ms_per_step"] > 0
+  assert "cpu_baseline" not in line   # rank 0 at N = 1 only
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_vit_b_ownership_tables_and_gather_layout(world):
+  """The 395 statistics of the ViT-B tree (cfg4) over 2 / 4 / 8 ranks, no communication:
+  every rank derives the same ownership, phase and offset tables from shapes alone; the
+  reference ownership is batch()'s contiguous chunks (DS:1827-1831) and the gathered list
+  order is the statistics list order (DS:1834-1846); send buffers have the same size on
+  every rank (all_gather_into_tensor requires it) with both ownership modes."""
+  from precondition_amd import comm
+  sizes = [768] * 172 + [768] * 112 + [1024] * 72 + [1024] * 36 + [1000, 1000, 197]
+  exps = [4] * 172 + [2] * 112 + [4] * 72 + [2] * 36 + [4, 2, 4]
+  assert len(sizes) == 395
+  ref = comm.reference_ownership(395, world)
+  b = (395 + (-395 % world)) // world
+  assert ref == [i // b for i in range(395)] and max(ref) == world - 1
+  for mode in ("reference", "lpt"):
+    owner = comm.ownership_table(sizes, exps, world, mode)
+    assert len(owner) == 395 and set(owner) == set(range(world))
+    load = [0.0] * world
+    for o, n, p in zip(owner, sizes, exps):
+      load[o] += (4 if p == 4 else 3) * float(n) ** 3
+    if mode == "lpt":
+      assert max(load) / (sum(load) / world) < 1.02   # cost-balanced to 2 %
+  # the in-process emulation of the gather: each "rank" fills its flat buffer with the index
+  # of the statistic; after concatenation every statistic must be found at its own index
+  import torch
+  for mode in ("reference", "lpt"):
+    owner = comm.ownership_table(sizes, exps, world, mode)
+    seen = []
+    small = [max(1, n // 64) for n in sizes]
+
+    class FakeGroup:  # world/rank without a process group: run every rank in turn
+      pass
+
+    results = []
+    for rank in range(world):
+      calls = []
+
+      def root_fn(mats, ps, pads, out=None, **kw):
+        for m, o in zip(mats, out):
+          o.fill_(float(m[0, 0]))
+        calls.append(len(mats))
+        return out, torch.zeros((len(mats), 8))
+
+      stats = [torch.full((n, n), float(i)) for i, n in enumerate(small)]
+      # one rank's view: group=None roots everything; emulate ownership by masking
+      mine = [i for i in range(395) if owner[i] == rank]
+      roots, _ = comm.sharded_inverse_pth_roots([stats[i] for i in mine], [exps[i] for i in mine],
+                                                group=None, root_fn=root_fn)
+      results.append({i: float(r[0, 0]) for i, r in zip(mine, roots)})
+    merged = {}
+    for r in results:
+      merged.update(r)
+    assert [merged[i] for i in range(395)] == [float(i) for i in range(395)]
+
+
+def _vitb_worker(rank, world, port, ownership, ret):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    from precondition_amd import comm
+    sizes = [768] * 172 + [768] * 112 + [1024] * 72 + [1024] * 36 + [1000, 1000, 197]
+    exps = [4] * 172 + [2] * 112 + [4] * 72 + [2] * 36 + [4, 2, 4]
+    small = [max(2, n // 128) for n in sizes]
+    stats = [torch.full((n, n), float(i)) for i, n in enumerate(small)]
+    sent = []
+
+    def root_fn(mats, ps, pads, out=None, **kw):
+      for m, o in zip(mats, out):
+        o.fill_(float(m[0, 0]) + 0.5)
+      sent.append(len(mats))
+      rows = torch.zeros((len(mats), 8))
+      rows[:, 1] = torch.tensor([float(m[0, 0]) for m in mats])
+      return out, rows
+
+    roots, metrics = comm.sharded_inverse_pth_roots(
+        stats, exps, group=dist.group.WORLD, ownership=ownership, root_fn=root_fn,
+        overlap_min_bytes=0)   # force the two-phase (overlapped) layout
+    ok = all(float(r[0, 0]) == i + 0.5 and tuple(r.shape) == (small[i], small[i])
+             for i, r in enumerate(roots))
+    ok &= bool(torch.equal(metrics[:, 1], torch.arange(395, dtype=torch.float32)))
+    ret[rank] = (ok, sum(sent))
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ownership", [(4, "reference"), (4, "lpt")])
+def test_vit_b_statistics_gather_order_four_ranks(world, ownership):
+  """395 statistics over 4 gloo ranks, two-phase layout: every rank ends with every root and
+  metrics row at its list index (DS:1834-1846); each statistic is rooted exactly once."""
+  mgr = mp.Manager()
+  ret = mgr.dict()
+  mp.spawn(_vitb_worker, args=(world, _free_port(), ownership, ret), nprocs=world, join=True)
+  assert all(ret[r][0] for r in range(world))
+  assert sum(ret[r][1] for r in range(world)) == 395
