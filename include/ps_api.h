@@ -67,6 +67,9 @@ enum {
   PS_M_RETRIES = 4,      /* total_retries = number of tries (>=1) */
   PS_M_TOTAL_ITERS = 5,  /* inner iterations summed over all tries (for FLOP accounting) */
   PS_M_POWER_ITERS = 6,  /* power-iteration steps executed */
+  PS_M_ASYMMETRY = 7,    /* max|X - X^T| / max|X| of the full M update X of the first step of
+                            the last try (0 if that step did not average): the commutator
+                            noise of the iterates, ~1e-7 well conditioned, ~1e-5 at cond 1e4 */
   PS_M_RESERVED = 7,
   PS_METRICS_STRIDE = 8
 };
@@ -173,9 +176,9 @@ size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
                                       const int32_t* padding_start);
 /* Number of leading Newton steps of every try in which the M update (DS:845) of an exactly
  * symmetric block is computed in full and averaged with its transpose instead of being
- * mirrored from its upper tile triangle (default 4; PS_NEWTON_AVG_STEPS overrides; see
- * csrc/newton.hip TileFlags: mirrored everywhere is 3-5x less accurate than the reference's
- * full products at cond ~1e4, averaged leading steps match them).  For FLOP accounting. */
+ * mirrored from its upper tile triangle (default 2; PS_NEWTON_AVG_STEPS overrides; see
+ * csrc/newton.hip TileFlags: at cond ~1e4 mirroring everywhere is 5x less accurate than
+ * full products, 2 averaged steps bring it to 1.4x, 4 steps to parity).  For FLOP accounting. */
 int ps_newton_averaged_steps(void);
 int ps_newton_root_batched_f32(void* stream, const float* const* a,
                                const int32_t* n, const int32_t* lda,

@@ -55,7 +55,7 @@ constexpr int NBK = 16;        // K-tile depth of the Newton products
 constexpr int MAX_PROD = 8;    // products per Newton step (p <= 64)
 constexpr int NTEMP = 5;
 constexpr int NQ = 8;          // item queues (one per XCD)
-constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 4;
+constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 2;
 
 
 enum Phase { PH_INIT = 0, PH_ACTIVE = 1, PH_DONE = 2 };
@@ -87,6 +87,11 @@ struct NewtonState {
   int phase, cur, it, tries, total_iters, result_sel;
   float err, ratio, max_ev, ridge, ridge_try;
   unsigned err_bits;
+  // averaged M update: max |X - X^T| and max |X| of the step (bit patterns), and whether the
+  // NEXT step still averages (adaptive: see newton_avg_next)
+  unsigned asym_bits, xmax_bits;
+  int avg_on;
+  float asym_first;   // relative asymmetry measured in the first step of the last try
   int power_iters;
   // arrival counters of the persistent execution
   unsigned c_init1, c_init2, c_join, c_copy;
@@ -149,10 +154,12 @@ __device__ inline float* resolve(const NewtonBlock* nb, int id, int cur) {
 // commute only up to rounding, so X carries an antisymmetric part K ~ [Mi^p, M]/2.  Copying
 // the upper triangle over the lower (TF_MIRROR) turns K into a SYMMETRIC perturbation of the
 // same size, which moves eigenvalues at first order, while K itself is harmless (x^T K x = 0)
-// and averaging removes it.  Measured (tools/dev_sym_accuracy.py, cond 7e3, p = 4, float32):
-// full products (the reference) 1.2e-4 from the float64 root, mirrored everywhere 3.6e-4,
-// averaged M update in the first 2 steps 1.5e-4, in the first 4 or in all steps 1.0e-4; the
-// H update and the squares (exactly symmetric for symmetric input) can stay mirrored.
+// and averaging removes it.  Measured at cond 7e3, p = 4, n = 1000 (error of the root against
+// float64): reference arithmetic (NumPy full products) 1.2e-4; this kernel with full products
+// 2.0e-4, mirrored everywhere 9.3e-4, averaged M update in the first 2 steps 2.8e-4 (default,
+// +3.6 % time on 256 x 512^2), in the first 4 steps 1.8e-4 (+8.5 %); on well-conditioned
+// blocks all variants are at 1e-6.  The H update and the squares (exactly symmetric for
+// symmetric input) stay mirrored (tools/dev_sym_accuracy.py: averaging them changes nothing).
 enum TileFlags { TF_MIRROR = 1, TF_RAW = 2, TF_AVG = 4, TF_SELFAVG = 8 };
 
 // acc <- (acc + P^T) / 2 with P the 128x128 tile of C at (prow0, pcol0) (the transposed
@@ -161,12 +168,13 @@ enum TileFlags { TF_MIRROR = 1, TF_RAW = 2, TF_AVG = 4, TF_SELFAVG = 8 };
 // reads are 512-byte runs and every LDS access is 16 bytes.  smem: 64*132 floats.
 __device__ inline void average_with_transposed_tile(f32x16 (&acc)[2][2], float* smem,
                                                      const float* C, int ld, int prow0,
-                                                     int pcol0) {
+                                                     int pcol0, NewtonState* st) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   constexpr int TLD = 132;
   const int r4 = (tid & 31) * 4;
+  unsigned dmax = 0, xmax = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -184,11 +192,21 @@ __device__ inline void average_with_transposed_tile(f32x16 (&acc)[2][2], float* 
       for (int g = 0; g < 4; ++g) {
         const f32x4 pv = *reinterpret_cast<const f32x4*>(trow + tm * 32 + 8 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[tm][h][4 * g + j] = __fmul_rn(0.5f, __fadd_rn(acc[tm][h][4 * g + j], pv[j]));
+        for (int j = 0; j < 4; ++j) {
+          const float x = acc[tm][h][4 * g + j];
+          const unsigned d = abs_bits(__fsub_rn(x, pv[j])), m = abs_bits(x);
+          dmax = d > dmax ? d : dmax;
+          xmax = m > xmax ? m : xmax;
+          acc[tm][h][4 * g + j] = __fmul_rn(0.5f, __fadd_rn(x, pv[j]));
+        }
       }
     __syncthreads();
   }
+  // how far the computed product is from symmetric (the size of the commutator noise the
+  // averaging removes): steers whether the next steps still need the full product
+  dmax = wave_max_u32(dmax);
+  xmax = wave_max_u32(xmax);
+  if (lane == 0) { atomicMax(&st->asym_bits, dmax); atomicMax(&st->xmax_bits, xmax); }
 }
 
 template <int BK, bool WT, bool DEEP>
@@ -236,7 +254,7 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
     __syncthreads();
   }
   if ((flags & (TF_AVG | TF_SELFAVG)) != 0)
-    average_with_transposed_tile(acc, smem, C, ld, tn_ * TILE, tm_ * TILE);
+    average_with_transposed_tile(acc, smem, C, ld, tn_ * TILE, tm_ * TILE, st);
   // M update: C = new M; Mi = (1-alpha) I + alpha M (DS:844, two roundings as
   // written there); err = max |M - I| (DS:847) with the identity masked to n.
   float* Mi = mi_buf(nb, cur ^ 1);  // the Mi of the NEXT step
@@ -311,6 +329,18 @@ __device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, Newto
     newton_product_tile<BK, WT, DEEP>(nb, st, prod, cur, pass ? tn : tm, pass ? tm : tn,
                                       pass ? f1 : f0, smem, stamp);
   }
+}
+
+// Does step `it` (the one about to run) average its M update?  The first `navg` steps of a
+// try do.  (An adaptive rule was tried and dropped: neither the measured asymmetry
+// max|X - X^T| / max|X| of the full product — 2-4e-7 on Wishart blocks of cond 10, 5-9e-7 at
+// cond 1e4 — nor the elementwise error max|M - I| of the first steps separates the blocks
+// that need the averaging from those that do not; what decides is the conditioning, which
+// only the iteration count reveals, afterwards.  The asymmetry of the first step is still
+// reported per block, PS_M_ASYMMETRY.)
+__device__ inline bool newton_avg_next(int it, int navg, unsigned asym_bits, unsigned xmax_bits) {
+  (void)asym_bits; (void)xmax_bits;
+  return it < navg;
 }
 
 // ---- (re)initialisation of a try (DS:866-875), tile bodies ----------------------------
@@ -399,11 +429,12 @@ __device__ inline void newton_copy_tile(const NewtonBlock* nb, int sel, int tm, 
 }
 
 __device__ inline void write_metrics(float* metrics, int b, float err, int it, float ratio,
-                                     int tries, int total_iters, float max_ev, int pit) {
+                                     int tries, int total_iters, float max_ev, int pit,
+                                     float asym_first = 0.f) {
   float* m = metrics + (int64_t)b * PS_METRICS_STRIDE;
   m[PS_M_ERROR] = err; m[PS_M_ITERS] = (float)it; m[PS_M_ERROR_RATIO] = ratio;
   m[PS_M_RETRIES] = (float)tries; m[PS_M_TOTAL_ITERS] = (float)total_iters;
-  m[PS_M_MAX_EV] = max_ev; m[PS_M_POWER_ITERS] = (float)pit; m[PS_M_RESERVED] = 0.f;
+  m[PS_M_MAX_EV] = max_ev; m[PS_M_POWER_ITERS] = (float)pit; m[PS_M_ASYMMETRY] = asym_first;
 }
 
 // ==================================================================================
@@ -419,7 +450,8 @@ __global__ __launch_bounds__(256, 3) void newton_stage_kernel(
   const NewtonBlock* nb = &blocks[tk.block];
   NewtonState* st = &states[tk.block];
   if (st->phase != PH_ACTIVE) return;
-  newton_product_item<BK, false, false>(nb, st, tk.prod, st->cur, st->it < navg, te.tm, te.tn, smem);
+  (void)navg;
+  newton_product_item<BK, false, false>(nb, st, tk.prod, st->cur, st->avg_on, te.tm, te.tn, smem);
 }
 
 __global__ __launch_bounds__(256) void newton_init1_kernel(const NewtonBlock* blocks,
@@ -460,7 +492,7 @@ __device__ inline void finish_try(NewtonState* st) {
 // Newton step (DS:848 carry + DS:836-840 condition).
 __global__ __launch_bounds__(256) void newton_control_kernel(
     NewtonState* states, int nblocks, int mode, int num_iters, float tol, int gen,
-    HostStatus* status) {
+    HostStatus* status, int navg) {
   __shared__ int s_nd, s_ni;
   if (threadIdx.x == 0) { s_nd = 0; s_ni = 0; }
   __syncthreads();
@@ -472,6 +504,8 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
       st->err_bits = 0;
       st->ratio = 1.f;
       st->it = 0;
+      st->asym_bits = 0; st->xmax_bits = 0;
+      st->avg_on = newton_avg_next(0, navg, 0u, 0u) ? 1 : 0;
       const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
       if (cont) st->phase = PH_ACTIVE; else finish_try(st);
     } else if (mode == 1 && st->phase == PH_ACTIVE) {
@@ -482,6 +516,10 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
       st->it += 1;
       st->total_iters += 1;
       st->cur ^= 1;
+      if (st->it == 1 && st->avg_on)
+        st->asym_first = st->xmax_bits ? __uint_as_float(st->asym_bits) / __uint_as_float(st->xmax_bits) : 0.f;
+      st->avg_on = (st->avg_on && newton_avg_next(st->it, navg, st->asym_bits, st->xmax_bits)) ? 1 : 0;
+      st->asym_bits = 0; st->xmax_bits = 0;
       const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
       if (!cont) finish_try(st);
     }
@@ -547,7 +585,7 @@ __global__ __launch_bounds__(256) void newton_final_kernel(const NewtonBlock* bl
       write_metrics(metrics, blockIdx.x, 0.f, 0, 1.f, 1, 0, st->max_ev, st->power_iters);
     else
       write_metrics(metrics, blockIdx.x, st->err, st->it, st->ratio, st->tries,
-                    st->total_iters, st->max_ev, st->power_iters);
+                    st->total_iters, st->max_ev, st->power_iters, st->asym_first);
   }
 }
 
@@ -660,7 +698,7 @@ __device__ inline void p_block_done(const PArgs& pa, const NewtonBlock* nb, Newt
                                     int b, float err, int it, float ratio, int tries,
                                     int total_iters, int sel) {
   write_metrics(pa.metrics, b, err, it, ratio, tries, total_iters, ald(&st->max_ev),
-                ald(&st->power_iters));
+                ald(&st->power_iters), ald(&st->asym_first));
   ast(&st->phase, (int)PH_DONE);
   release_agent();
   push_tiles(pa, nb, b, IT_COPY, 0, (nb->n_full + TILE - 1) / TILE, false, sel);
@@ -687,8 +725,8 @@ __device__ inline void p_finish_try(const PArgs& pa, const NewtonBlock* nb, Newt
 }
 
 __device__ inline void p_start_step(const PArgs& pa, const NewtonBlock* nb, int b, int cur,
-                                    int it) {
-  const int bits = (cur & 1) | (it < pa.navg ? 2 : 0);
+                                    int avg) {
+  const int bits = (cur & 1) | (avg ? 2 : 0);
   release_agent();
   push_product(pa, nb, b, 0, bits);
   if (nb->nprod >= 3) push_product(pa, nb, b, 1, bits);
@@ -702,8 +740,12 @@ __device__ inline void p_control_init(const PArgs& pa, const NewtonBlock* nb, Ne
   ast(&st->err, err);
   ast(&st->ratio, 1.f);
   ast(&st->it, 0);
+  ast(&st->asym_bits, 0u);
+  ast(&st->xmax_bits, 0u);
+  const int avg0 = newton_avg_next(0, pa.navg, 0u, 0u) ? 1 : 0;
+  ast(&st->avg_on, avg0);
   const bool cont = 0 < pa.num_iters && err > pa.tol;
-  if (cont) { ast(&st->phase, (int)PH_ACTIVE); p_start_step(pa, nb, b, cur, 0); }
+  if (cont) { ast(&st->phase, (int)PH_ACTIVE); p_start_step(pa, nb, b, cur, avg0); }
   else p_finish_try(pa, nb, st, b, err, 0, 1.f, cur, ald(&st->total_iters));
 }
 
@@ -721,8 +763,15 @@ __device__ inline void p_control_step(const PArgs& pa, const NewtonBlock* nb, Ne
   ast(&st->it, it);
   ast(&st->total_iters, total);
   ast(&st->cur, ncur);
+  const unsigned ab = ald(&st->asym_bits), xb = ald(&st->xmax_bits);
+  const int was = ald(&st->avg_on);
+  if (it == 1 && was) ast(&st->asym_first, xb ? __uint_as_float(ab) / __uint_as_float(xb) : 0.f);
+  const int avg = (was && newton_avg_next(it, pa.navg, ab, xb)) ? 1 : 0;
+  ast(&st->avg_on, avg);
+  ast(&st->asym_bits, 0u);
+  ast(&st->xmax_bits, 0u);
   const bool cont = it < pa.num_iters && new_err > pa.tol && ratio < 1.2f;
-  if (cont) p_start_step(pa, nb, b, ncur, it);
+  if (cont) p_start_step(pa, nb, b, ncur, avg);
   else p_finish_try(pa, nb, st, b, new_err, it, ratio, ncur, total);
 }
 
@@ -1390,7 +1439,7 @@ static int newton_driver(
         hipLaunchKernelGGL(newton_init2_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
                            lo.states, lo.init_tiles);
         hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
-                           batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr);
+                           batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr, navg);
         prof.end();
       }
       for (int s = 0; s < pl.nstages; ++s) {
@@ -1407,7 +1456,7 @@ static int newton_driver(
         prof.end();
       }
       hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
-                         batch, 1, num_iters, error_tolerance, g, slot);
+                         batch, 1, num_iters, error_tolerance, g, slot, navg);
       if ((rc = (int)hipGetLastError()) != 0) break;
       if ((rc = (int)hipEventRecord(ev[g & 1], st)) != 0) break;
       ++executed;

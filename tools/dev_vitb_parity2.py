@@ -20,7 +20,7 @@ for i in (0, 23, 393, 28):
     ridge = 1e-6 * float(m[0, 3])
     h64 = (v * (np.maximum(w, 0) + ridge) ** (-1.0 / p)) @ v.T
     h = r[0].cpu().numpy()
-    out.append("%s/avg%s: vs-f64 %.2e asym %.1e iters %d err %.1e" % (sym, navg, f(h, h64), np.abs(h - h.T).max() / np.abs(h).max(), m[0, 1], m[0, 0]))
+    out.append("%s/avg%s: vs-f64 %.2e asym0 %.1e asym %.1e iters %d err %.1e" % (sym, navg, f(h, h64), m[0, 7], np.abs(h - h.T).max() / np.abs(h).max(), m[0, 1], m[0, 0]))
   h_ref, m_ref = orc.matrix_inverse_pth_root(a, p)
   out.append("oracle: vs-f64 %.2e asym %.1e" % (f(h_ref, h64), np.abs(h_ref - h_ref.T).max() / np.abs(h_ref).max()))
   hs = 0.5 * (h_ref + h_ref.T)
