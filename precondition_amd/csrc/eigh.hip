@@ -300,6 +300,100 @@ __device__ inline float row16_sum(float x) {
   return row16_add_ror<1>(x);
 }
 
+// All sweeps of the one-sided Jacobi on the LDS images G (= A V) and V, m (even) players,
+// 1024 threads.  Returns the number of sweeps run (the last one without a rotation).
+__device__ inline int onesided_jacobi_lds(float* G, float* V, int* s_rot, int m, bool tall,
+                                          int max_sweeps) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane >> 4, l = lane & 15;     // 16 lanes per pair, 4 pairs per wavefront
+  const int k = 4 * wave + sub;                 // pair index within the round
+  const bool has_pair = k < (m >> 1);
+  int sweeps_total = 0;
+  for (int sweeps = 0; sweeps < max_sweeps; ++sweeps, ++sweeps_total) {
+    int rotated = 0;
+    for (int round = 0; round < m - 1; ++round) {
+      if (has_pair) {
+        int p, q;
+        rr_pair_raw(m, round, k, p, q);
+        float* gp = G + p * SE_LD + 4 * l;
+        float* gq = G + q * SE_LD + 4 * l;
+        float* vp = V + p * SE_LD + 4 * l;
+        float* vq = V + q * SE_LD + 4 * l;
+        // elements 4l..4l+3 and 64+4l..64+4l+3 of each column (16 lanes x 16 B contiguous);
+        // all eight reads are issued before anything waits on them
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 a0 = *reinterpret_cast<f32x4*>(gp), b0 = *reinterpret_cast<f32x4*>(gq);
+        f32x4 w0 = *reinterpret_cast<f32x4*>(vp), x0 = *reinterpret_cast<f32x4*>(vq);
+        f32x4 a1 = zero4, b1 = zero4, w1 = zero4, x1 = zero4;
+        if (tall) {
+          a1 = *reinterpret_cast<f32x4*>(gp + 64); b1 = *reinterpret_cast<f32x4*>(gq + 64);
+          w1 = *reinterpret_cast<f32x4*>(vp + 64); x1 = *reinterpret_cast<f32x4*>(vq + 64);
+        }
+        float aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          aa += a0[j] * a0[j] + a1[j] * a1[j];
+          bb += b0[j] * b0[j] + b1[j] * b1[j];
+          ab += a0[j] * b0[j] + a1[j] * b1[j];
+        }
+        aa = row16_sum(aa); bb = row16_sum(bb); ab = row16_sum(ab);
+        // rotate unless the columns are already orthogonal to working precision
+        if (fabsf(ab) > 3e-7f * __builtin_amdgcn_sqrtf(aa * bb)) {
+          const float zeta = (bb - aa) * __builtin_amdgcn_rcpf(2.f * ab);
+          const float t = copysignf(1.f, zeta) *
+                          __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta));
+          const float c = __builtin_amdgcn_rsqf(1.f + t * t), sn = c * t;
+          if (c == c && sn == sn) {
+            f32x4 na0, nb0, nw0, nx0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              na0[j] = c * a0[j] - sn * b0[j]; nb0[j] = sn * a0[j] + c * b0[j];
+              nw0[j] = c * w0[j] - sn * x0[j]; nx0[j] = sn * w0[j] + c * x0[j];
+            }
+            *reinterpret_cast<f32x4*>(gp) = na0; *reinterpret_cast<f32x4*>(gq) = nb0;
+            *reinterpret_cast<f32x4*>(vp) = nw0; *reinterpret_cast<f32x4*>(vq) = nx0;
+            if (tall) {
+              f32x4 na1, nb1, nw1, nx1;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                na1[j] = c * a1[j] - sn * b1[j]; nb1[j] = sn * a1[j] + c * b1[j];
+                nw1[j] = c * w1[j] - sn * x1[j]; nx1[j] = sn * w1[j] + c * x1[j];
+              }
+              *reinterpret_cast<f32x4*>(gp + 64) = na1; *reinterpret_cast<f32x4*>(gq + 64) = nb1;
+              *reinterpret_cast<f32x4*>(vp + 64) = nw1; *reinterpret_cast<f32x4*>(vq + 64) = nx1;
+            }
+            rotated = 1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // a sweep without a single rotation: converged (s_rot is double buffered by parity)
+    if (rotated && l == 0) s_rot[sweeps & 1] = 1;
+    __syncthreads();
+    const int any = s_rot[sweeps & 1];
+    __syncthreads();
+    if (tid == 0) s_rot[sweeps & 1] = 0;   // re-armed for sweep + 2 (after the next barriers)
+    if (!any) { ++sweeps_total; break; }
+  }
+  __syncthreads();
+  return sweeps_total;
+}
+
+// Renormalises the columns of V (the approximate rcp / rsq of the rotation parameters scale a
+// rotation by 1 + O(eps)) and of G with them (G = A V).  1024 threads; ends with a barrier.
+__device__ inline void onesided_renormalize(float* G, float* V, int m) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = wave; j < m; j += SE_T / 64) {
+    const float v0 = V[j * SE_LD + lane], v1 = V[j * SE_LD + 64 + lane];
+    const float nn = wave_sum_f32(v0 * v0 + v1 * v1);
+    const float inv = nn > 0.f ? 1.f / sqrtf(nn) : 0.f;
+    V[j * SE_LD + lane] = v0 * inv; V[j * SE_LD + 64 + lane] = v1 * inv;
+    G[j * SE_LD + lane] *= inv; G[j * SE_LD + 64 + lane] *= inv;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, const int* ids) {
   extern __shared__ __align__(16) float sem[];
   float* G = sem;                       // [128][132] column-major: G[col * SE_LD + row]
@@ -313,9 +407,6 @@ __global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, con
   const bool tall = n > 64;             // rows 64.. exist (else that half of every column is zero)
   const float* A = eb->A;               // regularised input D (eigh_init_kernel), stride npad
   const int lane = tid & 63, wave = tid >> 6;
-  const int sub = lane >> 4, l = lane & 15;     // 16 lanes per pair, 4 pairs per wavefront
-  const int k = 4 * wave + sub;                 // pair index within the round
-  const bool has_pair = k < (m >> 1);
   float shift = 0.f;
   int sweeps_total = 0;
   // One-sided Jacobi yields the SVD: for an indefinite matrix with eigenvalues +x and -x of
@@ -336,74 +427,7 @@ __global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, con
     if (tid < 2) s_rot[tid] = 0;
     __syncthreads();
 
-    for (int sweeps = 0; sweeps < SE_MAX_SWEEPS; ++sweeps, ++sweeps_total) {
-      int rotated = 0;
-      for (int round = 0; round < m - 1; ++round) {
-        if (has_pair) {
-          int p, q;
-          rr_pair_raw(m, round, k, p, q);
-          float* gp = G + p * SE_LD + 4 * l;
-          float* gq = G + q * SE_LD + 4 * l;
-          float* vp = V + p * SE_LD + 4 * l;
-          float* vq = V + q * SE_LD + 4 * l;
-          // elements 4l..4l+3 and 64+4l..64+4l+3 of each column (16 lanes x 16 B contiguous);
-          // all eight reads are issued before anything waits on them
-          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-          f32x4 a0 = *reinterpret_cast<f32x4*>(gp), b0 = *reinterpret_cast<f32x4*>(gq);
-          f32x4 w0 = *reinterpret_cast<f32x4*>(vp), x0 = *reinterpret_cast<f32x4*>(vq);
-          f32x4 a1 = zero4, b1 = zero4, w1 = zero4, x1 = zero4;
-          if (tall) {
-            a1 = *reinterpret_cast<f32x4*>(gp + 64); b1 = *reinterpret_cast<f32x4*>(gq + 64);
-            w1 = *reinterpret_cast<f32x4*>(vp + 64); x1 = *reinterpret_cast<f32x4*>(vq + 64);
-          }
-          float aa = 0.f, bb = 0.f, ab = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            aa += a0[j] * a0[j] + a1[j] * a1[j];
-            bb += b0[j] * b0[j] + b1[j] * b1[j];
-            ab += a0[j] * b0[j] + a1[j] * b1[j];
-          }
-          aa = row16_sum(aa); bb = row16_sum(bb); ab = row16_sum(ab);
-          // rotate unless the columns are already orthogonal to working precision
-          if (fabsf(ab) > 3e-7f * __builtin_amdgcn_sqrtf(aa * bb)) {
-            const float zeta = (bb - aa) * __builtin_amdgcn_rcpf(2.f * ab);
-            const float t = copysignf(1.f, zeta) *
-                            __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta));
-            const float c = __builtin_amdgcn_rsqf(1.f + t * t), sn = c * t;
-            if (c == c && sn == sn) {
-              f32x4 na0, nb0, nw0, nx0;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                na0[j] = c * a0[j] - sn * b0[j]; nb0[j] = sn * a0[j] + c * b0[j];
-                nw0[j] = c * w0[j] - sn * x0[j]; nx0[j] = sn * w0[j] + c * x0[j];
-              }
-              *reinterpret_cast<f32x4*>(gp) = na0; *reinterpret_cast<f32x4*>(gq) = nb0;
-              *reinterpret_cast<f32x4*>(vp) = nw0; *reinterpret_cast<f32x4*>(vq) = nx0;
-              if (tall) {
-                f32x4 na1, nb1, nw1, nx1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  na1[j] = c * a1[j] - sn * b1[j]; nb1[j] = sn * a1[j] + c * b1[j];
-                  nw1[j] = c * w1[j] - sn * x1[j]; nx1[j] = sn * w1[j] + c * x1[j];
-                }
-                *reinterpret_cast<f32x4*>(gp + 64) = na1; *reinterpret_cast<f32x4*>(gq + 64) = nb1;
-                *reinterpret_cast<f32x4*>(vp + 64) = nw1; *reinterpret_cast<f32x4*>(vq + 64) = nx1;
-              }
-              rotated = 1;
-            }
-          }
-        }
-        __syncthreads();
-      }
-      // a sweep without a single rotation: converged (s_rot is double buffered by parity)
-      if (rotated && l == 0) s_rot[sweeps & 1] = 1;
-      __syncthreads();
-      const int any = s_rot[sweeps & 1];
-      __syncthreads();
-      if (tid == 0) s_rot[sweeps & 1] = 0;   // re-armed for sweep + 2 (after the next barriers)
-      if (!any) { ++sweeps_total; break; }
-    }
-    __syncthreads();
+    sweeps_total += onesided_jacobi_lds(G, V, s_rot, m, tall, SE_MAX_SWEEPS);
     // The approximate rcp / rsq of the rotation parameters scale a rotation by 1 + O(eps):
     // renormalise the eigenvectors (and g_j with them, G = A V), then the Rayleigh quotients.
     float lo_ev = 0.f, hi_abs = 0.f;
@@ -438,8 +462,7 @@ __global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, con
   if (eb->evals_out != nullptr) {
     // plain eigenpairs (ps_eigh_batched_f32): straight to the caller's arrays in LAPACK's
     // ASCENDING order.  rank_j = #{i : lambda_i < lambda_j or (equal and i < j)}; the
-    // eigenvalue of column j sits in s_ev[j], its rank in s_rank[j] (both alias G's padding
-    // rows... no: they live behind V, G is still needed for the quotients).
+    // eigenvalue of column j sits in s_ev[j], its rank in s_rank[j] (behind V in the LDS).
     float* s_ev = s_red + 32;                           // [128]
     int* s_rank = reinterpret_cast<int*>(s_ev + 128);   // [128]
     for (int j = wave; j < n; j += SE_T / 64) {
@@ -454,7 +477,7 @@ __global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, con
       int rank = 0;
       for (int i = 0; i < n; ++i) {
         const float o = s_ev[i];
-        rank += (o < mine || (o == mine && i < tid) || (o != o && mine == mine)) ? 1 : 0;
+        rank += (o < mine || (o == mine && i < tid)) ? 1 : 0;
       }
       if (mine != mine) {   // NaNs last, in index order
         rank = 0;
