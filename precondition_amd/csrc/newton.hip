@@ -440,8 +440,9 @@ __device__ inline void write_metrics(float* metrics, int b, float err, int it, f
 // ==================================================================================
 // staged execution (PS_NEWTON_PERSISTENT=0)
 // ==================================================================================
-template <int BK>
-__global__ __launch_bounds__(256, 3) void newton_stage_kernel(
+// DEEP = false: 3 workgroups per CU.  DEEP = true: two-K-tile-deep register prefetch, 2 per CU.
+template <int BK, bool DEEP>
+__global__ __launch_bounds__(256, DEEP ? 2 : 3) void newton_stage_kernel(
     const NewtonBlock* blocks, NewtonState* states, const NewtonTask* tasks,
     const TileEntry* tiles, int ntiles, int navg) {
   extern __shared__ __align__(16) float smem[];  // SmemCfg<BK>::TOTAL floats
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256, 3) void newton_stage_kernel(
   NewtonState* st = &states[tk.block];
   if (st->phase != PH_ACTIVE) return;
   (void)navg;
-  newton_product_item<BK, false, false>(nb, st, tk.prod, st->cur, st->avg_on, te.tm, te.tn, smem);
+  newton_product_item<BK, false, DEEP>(nb, st, tk.prod, st->cur, st->avg_on, te.tm, te.tn, smem);
 }
 
 __global__ __launch_bounds__(256) void newton_init1_kernel(const NewtonBlock* blocks,
@@ -1213,9 +1214,14 @@ HostStatus* pinned_status() {
 // CUs).  Correctness does not depend on residency (no workgroup ever waits for a specific
 // other workgroup: waits are for queue items, which only running workgroups produce),
 // so the query is for speed only.
-bool deep_mode() {  // dev A/B: PS_NEWTON_DEEP=1 selects the deep-prefetch / 2-per-CU variant
+// Deep-prefetch / 2-per-CU variant of the product kernels.  Staged execution: on by default
+// with BK = 32 (measured, 256 x 512^2 / 64 x 1024^2 product launches: BK16 13.75 / 22.69 ms,
+// BK16+deep 13.73 / 22.39, BK32 14.51 / 22.76, BK32+deep 13.57 / 21.70).  Persistent execution:
+// off by default (3 workgroups per CU cover each other's dequeue / epilogue phases better).
+// PS_NEWTON_DEEP = 0 | 1 and PS_NEWTON_BK = 16 | 32 override.
+bool deep_mode(bool dflt) {
   const char* e = getenv("PS_NEWTON_DEEP");
-  return e && atoi(e) != 0;
+  return e ? atoi(e) != 0 : dflt;
 }
 
 int persistent_grid(size_t lds_bytes, bool deep) {
@@ -1352,7 +1358,7 @@ static int newton_driver(
     pa.metrics = metrics; pa.qcap = (unsigned)pl.qcap; pa.nblocks = batch;
     pa.nlive = pl.nlive; pa.num_iters = num_iters; pa.tol = error_tolerance;
     const size_t lds = (PSMEM<NBK> + 16) * sizeof(float);
-    const bool deep = deep_mode();
+    const bool deep = deep_mode(false);
     const int grid = std::min(persistent_grid(lds, deep), 4096);
     const bool dev_prof = getenv("PS_NEWTON_PROF") != nullptr;
     pa.prof = dev_prof ? lo.prof : nullptr;
@@ -1408,14 +1414,18 @@ static int newton_driver(
   if (!status) return PS_EINTERNAL;
   // K-tile depth of the product kernel: 32 (73.7 KB LDS => exactly 2 workgroups per
   // CU, half the barriers) or 16 (40 KB, 3 per CU).  PS_NEWTON_BK overrides.
-  static int stage_bk = 0;
+  // Variant of the product kernel (dev A/B): PS_NEWTON_BK = 16 | 32, PS_NEWTON_DEEP = 0 | 1.
+  static int stage_bk = 0, stage_deep = 0;
   if (stage_bk == 0) {
     const char* e = getenv("PS_NEWTON_BK");
-    stage_bk = (e && atoi(e) == 16) ? 16 : ((e && atoi(e) == 32) ? 32 : NBK);
-    if (hipFuncSetAttribute((const void*)newton_stage_kernel<32>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(SmemCfg<32>::TOTAL * sizeof(float))) != hipSuccess)
-      stage_bk = 16;
+    stage_bk = (e && atoi(e) == 16) ? 16 : 32;
+    stage_deep = deep_mode(true) ? 1 : 0;
+    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
+    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
   }
   const int ninit = (int)pl.init_tiles.size();
   int executed = 0;
@@ -1445,14 +1455,15 @@ static int newton_driver(
       for (int s = 0; s < pl.nstages; ++s) {
         const int nt = (int)pl.stage_tiles[s].size();
         prof.begin(0);
-        if (stage_bk == 32)
-          hipLaunchKernelGGL(newton_stage_kernel<32>, dim3(nt), dim3(256),
-                             SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tasks[s], lo.tiles[s], nt, navg);
-        else
-          hipLaunchKernelGGL(newton_stage_kernel<16>, dim3(nt), dim3(256),
-                             SmemCfg<16>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tasks[s], lo.tiles[s], nt, navg);
+#define PS_STAGE(BKV, DEEPV)                                                              \
+  hipLaunchKernelGGL((newton_stage_kernel<BKV, DEEPV>), dim3(nt), dim3(256),                \
+                     SmemCfg<BKV>::TOTAL * sizeof(float), st, lo.blocks, lo.states,         \
+                     lo.tasks[s], lo.tiles[s], nt, navg)
+        if (stage_bk == 32 && stage_deep) PS_STAGE(32, true);
+        else if (stage_bk == 32) PS_STAGE(32, false);
+        else if (stage_deep) PS_STAGE(16, true);
+        else PS_STAGE(16, false);
+#undef PS_STAGE
         prof.end();
       }
       hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
