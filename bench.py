@@ -416,6 +416,7 @@ def pmc_traffic(workload, kernel):
     for k in summ["kernels"]:
       if k["kernel"].startswith(kernel):
         return k["hbm_bytes_per_launch_corrected"]
+    return None
   except (OSError, ValueError, KeyError):
     pass
   return None
