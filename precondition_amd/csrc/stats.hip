@@ -15,6 +15,7 @@
 // the reference).  This removes (T-1)/(2T) of the MFMA work, T = tiles per side.
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -22,7 +23,8 @@
 
 namespace psk {
 
-constexpr int SBK = 16;
+constexpr int SBK = 32;  // K-tile; two register sets of prefetch (gemm_core DEEP), 2 WG/CU
+constexpr int STATS_LDS_BYTES = SmemCfg<SBK>::TOTAL * (int)sizeof(float);
 
 struct StatsTask {
   const float* g;
@@ -30,6 +32,9 @@ struct StatsTask {
   float* sout;
   int64_t seg_stride;
   int d, k, ld, lds, nseg, vec;
+  int fast;    // interior tiles may take the unguarded K loop (aligned g, k % SBK == 0)
+  int svec;    // the statistic allows 16-byte accesses (aligned pointers, lds % 4 == 0)
+  int layout;  // KC / MC
 };
 
 struct StatsTile {
@@ -37,8 +42,13 @@ struct StatsTile {
   short tm, tn;
 };
 
+__device__ __forceinline__ float stats_blend(float w1, float old, float w2, float g) {
+  return __fadd_rn(__fmul_rn(w1, old), __fmul_rn(w2, g));  // DS:1470's rounding sequence
+}
+
 // out[tn-tile rows, tm-tile cols] = w1*old + w2*acc^T, in two 64-row halves through LDS
 // (stride 129: conflict-free both ways) so that the global accesses are 256-byte runs.
+// Bounds-checked: edge tiles and unaligned statistics.
 __device__ inline void stats_store_mirror(const f32x16 (&acc)[2][2], float* smem,
                                           const StatsTask& tk, int tm, int tn, float w1,
                                           float w2) {
@@ -66,27 +76,103 @@ __device__ inline void stats_store_mirror(const f32x16 (&acc)[2][2], float* smem
       const int row = row0 + c, col = col0 + h * 64 + lr;
       if (row < tk.d && col < tk.d) {
         const int64_t o = (int64_t)row * tk.lds + col;
-        gstore1(tk.sout + o, __fadd_rn(__fmul_rn(w1, gload1(tk.sin + o)),
-                                       __fmul_rn(w2, smem[lr * TLD + c])));
+        gstore1(tk.sout + o, stats_blend(w1, gload1(tk.sin + o), w2, smem[lr * TLD + c]));
       }
     }
     __syncthreads();
   }
 }
 
-template <int LAYOUT>
-__device__ inline void stats_tile(const StatsTask& tk, int tm, int tn, float w1, float w2,
-                                  float* smem) {
+// The same for an interior tile of a 16-byte aligned statistic: the transposed image T[c][r]
+// (gemm_core store_tile_transposed_v4's layout: stride 132, ds_write/read_b128) and 16-byte
+// global loads of `old` / stores of the result, 512-byte runs per 32 lanes.
+__device__ inline void stats_store_mirror_v4(const f32x16 (&acc)[2][2], float* smem,
+                                             const StatsTask& tk, int tm_, int tn_, float w1,
+                                             float w2) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int TLD = 132;
+  const int row0 = tn_ * TILE, col0 = tm_ * TILE;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float* trow = smem + (wn * 32 + (lane & 31)) * TLD + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {acc[tm][h][4 * g + 0], acc[tm][h][4 * g + 1], acc[tm][h][4 * g + 2],
+                   acc[tm][h][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(trow + tm * 32 + 8 * g) = v;
+      }
+    __syncthreads();
+    const int r4 = (tid & 31) * 4;
+    f32x4 old[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ci = (tid >> 5) + 8 * k;
+      const int c = (ci >> 5) * 64 + h * 32 + (ci & 31);
+      old[k] = gload4(tk.sin + (int64_t)(row0 + c) * tk.lds + col0 + r4);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ci = (tid >> 5) + 8 * k;
+      const int c = (ci >> 5) * 64 + h * 32 + (ci & 31);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(smem + ci * TLD + r4);
+      f32x4 o = {stats_blend(w1, old[k][0], w2, v[0]), stats_blend(w1, old[k][1], w2, v[1]),
+                 stats_blend(w1, old[k][2], w2, v[2]), stats_blend(w1, old[k][3], w2, v[3])};
+      *(f32x4 PS_GLOBAL*)(tk.sout + (int64_t)(row0 + c) * tk.lds + col0 + r4) = o;
+    }
+    __syncthreads();
+  }
+}
+
+template <int LAYOUT, bool FAST>
+__device__ __forceinline__ void stats_tile(const StatsTask& tk, int tm, int tn, float w1,
+                                           float w2, float* smem) {
   f32x16 acc[2][2];
   zero_acc(acc);
-  for (int s = 0; s < tk.nseg; ++s) {
-    const float* base = tk.g + (int64_t)s * tk.seg_stride;
-    Operand A{base, tk.ld, tm * TILE, tk.d, tk.k, tk.vec != 0};
-    Operand B{base, tk.ld, tn * TILE, tk.d, tk.k, tk.vec != 0};
-    gemm_tile_accum<LAYOUT, LAYOUT, SBK, true>(A, B, tk.k, smem, acc);
+  // nseg == 1 (every matrix-shaped block) outside the segment loop: the loop around the
+  // two-register-set pipeline costs ~100 spilled VGPRs, which only rank>2 blocks then pay
+  if (tk.nseg == 1) {
+    Operand A{tk.g, tk.ld, tm * TILE, tk.d, tk.k, tk.vec != 0};
+    Operand B{tk.g, tk.ld, tn * TILE, tk.d, tk.k, tk.vec != 0};
+    gemm_tile_accum<LAYOUT, LAYOUT, SBK, !FAST, FAST>(A, B, tk.k, smem, acc);
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < tk.nseg; ++s) {
+      const float* base = tk.g + (int64_t)s * tk.seg_stride;
+      Operand A{base, tk.ld, tm * TILE, tk.d, tk.k, tk.vec != 0};
+      Operand B{base, tk.ld, tn * TILE, tk.d, tk.k, tk.vec != 0};
+      gemm_tile_accum<LAYOUT, LAYOUT, SBK, !FAST, false>(A, B, tk.k, smem, acc);
+    }
   }
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  if (FAST) {
+    // wave-uniform block bases + one per-lane offset (newton.hip's epilogue addressing)
+    const int lane_off = 4 * (lane >> 5) * tk.lds + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t b = (int64_t)(tm * TILE + wm * 64 + i * 32) * tk.lds + tn * TILE +
+                          wn * 64 + j * 32;
+        const float* oblk = tk.sin + b;
+        float* nblk = tk.sout + b;
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          old[r] = gload1(oblk + (int64_t)((r & 3) + 8 * (r >> 2)) * tk.lds + lane_off);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          gstore1(nblk + (int64_t)((r & 3) + 8 * (r >> 2)) * tk.lds + lane_off,
+                  stats_blend(w1, old[r], w2, acc[i][j][r]));
+      }
+    if (tm != tn) stats_store_mirror_v4(acc, smem, tk, tm, tn, w1, w2);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -97,31 +183,118 @@ __device__ inline void stats_tile(const StatsTask& tk, int tm, int tn, float w1,
         const int col = tn * TILE + acc_col(wn, j, lane);
         if (row < tk.d && col < tk.d) {
           const int64_t o = (int64_t)row * tk.lds + col;
-          gstore1(tk.sout + o, __fadd_rn(__fmul_rn(w1, gload1(tk.sin + o)),
-                                         __fmul_rn(w2, acc[i][j][r])));
+          gstore1(tk.sout + o, stats_blend(w1, gload1(tk.sin + o), w2, acc[i][j][r]));
         }
       }
   if (tm != tn) stats_store_mirror(acc, smem, tk, tm, tn, w1, w2);
 }
 
+// A tile takes the fast path when it is interior, the contraction length is a whole number
+// of K-tiles and the host found every pointer / leading dimension 16-byte aligned.
+__device__ __forceinline__ bool stats_tile_is_fast(const StatsTask& tk, int tm, int tn) {
+  return tk.fast != 0 && tk.svec != 0 && (tn + 1) * TILE <= tk.d && (tm + 1) * TILE <= tk.d;
+}
+
 template <int LAYOUT>
+__device__ __forceinline__ void stats_tile_any(const StatsTask& tk, int tm, int tn, float w1,
+                                               float w2, float* smem) {
+  if (stats_tile_is_fast(tk, tm, tn))
+    stats_tile<LAYOUT, true>(tk, tm, tn, w1, w2, smem);
+  else
+    stats_tile<LAYOUT, false>(tk, tm, tn, w1, w2, smem);
+}
+
+// Statistic of a vector block (k = 1: biases, scales): S = w1*S + w2 * g g^T is one product per
+// element, fl(g_i * g_j) -- exactly what the MFMA path returns for a single k -- so the tile is
+// streamed by the VALU (16-byte accesses where the statistic allows them) without the LDS
+// pipeline.  Writes the 128x128 tile at (rt, ct); the caller passes both orders of an
+// off-diagonal pair.  A ViT-B tree holds 149 such statistics, 0.85 GB of read + write.
+__device__ inline void stats_vector_tile(const StatsTask& tk, int rt, int ct, float w1,
+                                         float w2) {
+  const int tid = threadIdx.x;
+  const int c = ct * TILE + (tid & 31) * 4;
+  const int estride = tk.layout == KC ? tk.ld : 1;  // element i of the vector
+  float gc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    gc[e] = c + e < tk.d ? gload1(tk.g + (int64_t)(c + e) * estride) : 0.f;
+  const bool v4 = tk.svec != 0 && c + 3 < tk.d;
+  if (v4 && (rt + 1) * TILE <= tk.d) {
+    // whole rows in range: 8 loads in flight per lane (the workgroup count per CU is set by
+    // the LDS of the matrix path, so the memory parallelism has to come from the lane)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 old[8];
+      float gr[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int r = rt * TILE + (half * 8 + p) * 8 + (tid >> 5);
+        gr[p] = gload1(tk.g + (int64_t)r * estride);
+        old[p] = gload4(tk.sin + (int64_t)r * tk.lds + c);
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int r = rt * TILE + (half * 8 + p) * 8 + (tid >> 5);
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          out[e] = stats_blend(w1, old[p][e], w2, __fmul_rn(gr[p], gc[e]));
+        *(f32x4 PS_GLOBAL*)(tk.sout + (int64_t)r * tk.lds + c) = out;
+      }
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int p = 0; p < 16; ++p) {
+    const int r = rt * TILE + p * 8 + (tid >> 5);
+    if (r >= tk.d) break;
+    const float gr = gload1(tk.g + (int64_t)r * estride);
+    const int64_t o = (int64_t)r * tk.lds + c;
+    if (v4) {
+      const f32x4 old = gload4(tk.sin + o);
+      f32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = stats_blend(w1, old[e], w2, __fmul_rn(gr, gc[e]));
+      *(f32x4 PS_GLOBAL*)(tk.sout + o) = out;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < tk.d)
+          gstore1(tk.sout + o + e,
+                  stats_blend(w1, gload1(tk.sin + o + e), w2, __fmul_rn(gr, gc[e])));
+    }
+  }
+}
+
+// One launch per parameter tree: every tile of every statistic, both operand layouts and the
+// vector statistics (the branch is uniform per workgroup).  The tile list arrives in hardware
+// dispatch order: workgroup b runs on XCD b % 8, and the host has dealt the statistics over
+// the 8 XCDs by cost (make_tile_list), padding the shorter lists with task = -1.
 __global__ __launch_bounds__(256, 2) void stats_grouped_kernel(const StatsTask* tasks,
                                                                const StatsTile* tiles,
                                                                int ntiles, float w1,
                                                                float w2) {
-  __shared__ __align__(16) float smem[SmemCfg<SBK>::TOTAL];
-  const StatsTile te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  extern __shared__ __align__(16) float smem[];
+  const StatsTile te = tiles[blockIdx.x];
+  if (te.task < 0) return;
   const StatsTask tk = tasks[te.task];
-  stats_tile<LAYOUT>(tk, te.tm, te.tn, w1, w2, smem);
+  if (tk.k == 1 && tk.nseg == 1) {
+    stats_vector_tile(tk, te.tm, te.tn, w1, w2);
+    if (te.tm != te.tn) stats_vector_tile(tk, te.tn, te.tm, w1, w2);
+  } else if (tk.layout == KC) {
+    stats_tile_any<KC>(tk, te.tm, te.tn, w1, w2, smem);
+  } else {
+    stats_tile_any<MC>(tk, te.tm, te.tn, w1, w2, smem);
+  }
 }
 
 template <int LAYOUT>
 __global__ __launch_bounds__(256, 2) void stats_single_kernel(StatsTask tk, int tiles_n,
                                                               float w1, float w2) {
-  __shared__ __align__(16) float smem[SmemCfg<SBK>::TOTAL];
+  extern __shared__ __align__(16) float smem[];
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   if (t / tiles_n > t % tiles_n) return;  // lower tiles are written by their mirrors
-  stats_tile<LAYOUT>(tk, t / tiles_n, t % tiles_n, w1, w2, smem);
+  stats_tile_any<LAYOUT>(tk, t / tiles_n, t % tiles_n, w1, w2, smem);
 }
 
 }  // namespace psk
@@ -129,6 +302,8 @@ __global__ __launch_bounds__(256, 2) void stats_single_kernel(StatsTask tk, int 
 using namespace psk;
 
 namespace {
+
+constexpr int NXCD = 8;
 
 bool to_task(const ps_stats_desc& d, StatsTask& t) {
   if (!d.g || !d.stat_in || !d.stat_out || d.d < 1 || d.k < 1 || d.nseg < 1 ||
@@ -141,6 +316,9 @@ bool to_task(const ps_stats_desc& d, StatsTask& t) {
   t.seg_stride = d.seg_stride;
   t.d = d.d; t.k = d.k; t.ld = (int)d.ld; t.lds = (int)d.lds; t.nseg = d.nseg;
   t.vec = ((uintptr_t)d.g % 16 == 0) && (d.ld % 4 == 0) && (d.seg_stride % 4 == 0);
+  t.fast = t.vec && d.k % SBK == 0;
+  t.svec = (uintptr_t)d.stat_in % 16 == 0 && (uintptr_t)d.stat_out % 16 == 0 && d.lds % 4 == 0;
+  t.layout = d.layout;
   return true;
 }
 
@@ -150,8 +328,90 @@ size_t grouped_bytes(const ps_stats_desc* desc, int count) {
     const size_t t = (desc[i].d + TILE - 1) / TILE;
     tiles += t * t;
   }
+  // the dealt list is padded to 8 x the longest per-XCD list (<= 8 x tiles)
   return psh::align_up(sizeof(StatsTask) * count, 256) +
-         psh::align_up(sizeof(StatsTile) * tiles, 256) + 1024;
+         psh::align_up(sizeof(StatsTile) * tiles * NXCD, 256) + 1024;
+}
+
+// Tile list in dispatch order.  Workgroups are dealt round-robin over the 8 XCDs (each with
+// its own L2), so entry b of the list runs on XCD b % 8.  Units of work -- a whole statistic,
+// or a run of its tiles when the launch is too small to give every XCD a few statistics --
+// are assigned to the XCDs by longest-processing-time-first on a per-tile cost (K-tiles of the
+// contraction + an epilogue term; a vector statistic's tile is a short stream), which keeps a
+// statistic's tiles on one L2 and the 8 XCDs equally loaded.  Inside an XCD the expensive
+// tiles go first so that the cheap ones fill the tail.
+struct TileUnit {
+  int task, first, count;  // tiles [first, first + count) of the task's upper triangle
+  int64_t tile_cost;
+};
+
+void make_tile_list(const std::vector<StatsTask>& tasks, std::vector<StatsTile>& out) {
+  int64_t total = 0;
+  std::vector<int> ntile(tasks.size());
+  for (size_t i = 0; i < tasks.size(); ++i) {
+    const int nt = (tasks[i].d + TILE - 1) / TILE;
+    ntile[i] = nt * (nt + 1) / 2;
+    total += ntile[i];
+  }
+  const int unit_max = (int)std::max<int64_t>(1, total / (NXCD * 8));
+  std::vector<TileUnit> units;
+  for (size_t i = 0; i < tasks.size(); ++i) {
+    const StatsTask& t = tasks[i];
+    const bool vec = t.k == 1 && t.nseg == 1;
+    const int64_t kt = ((int64_t)t.k + SBK - 1) / SBK * t.nseg;
+    const int64_t cost = vec ? 3 : kt + 6;
+    for (int f = 0; f < ntile[i]; f += unit_max)
+      units.push_back({(int)i, f, std::min(unit_max, ntile[i] - f), cost});
+  }
+  std::vector<int> order(units.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return units[a].tile_cost * units[a].count > units[b].tile_cost * units[b].count;
+  });
+  std::vector<int> bins[NXCD];
+  int64_t load[NXCD] = {0};
+  for (int u : order) {
+    int best = 0;
+    for (int x = 1; x < NXCD; ++x)
+      if (load[x] < load[best]) best = x;
+    bins[best].push_back(u);
+    load[best] += units[u].tile_cost * units[u].count;
+  }
+  std::vector<StatsTile> lists[NXCD];
+  size_t longest = 0;
+  for (int x = 0; x < NXCD; ++x) {
+    std::stable_sort(bins[x].begin(), bins[x].end(),
+                     [&](int a, int b) { return units[a].tile_cost > units[b].tile_cost; });
+    for (int u : bins[x]) {
+      const TileUnit& un = units[u];
+      const int nt = (tasks[un.task].d + TILE - 1) / TILE;
+      int idx = 0;
+      for (int tm = 0; tm < nt; ++tm)
+        for (int tn = tm; tn < nt; ++tn, ++idx)
+          if (idx >= un.first && idx < un.first + un.count)
+            lists[x].push_back({un.task, (short)tm, (short)tn});
+    }
+    longest = std::max(longest, lists[x].size());
+  }
+  out.assign(longest * NXCD, StatsTile{-1, 0, 0});
+  for (int x = 0; x < NXCD; ++x)
+    for (size_t j = 0; j < lists[x].size(); ++j) out[j * NXCD + x] = lists[x][j];
+}
+
+template <typename K>
+void allow_lds(K kernel) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            STATS_LDS_BYTES);
+}
+
+void stats_lds_once() {
+  static const bool done = [] {
+    allow_lds(stats_grouped_kernel);
+    allow_lds(stats_single_kernel<KC>);
+    allow_lds(stats_single_kernel<MC>);
+    return true;
+  }();
+  (void)done;
 }
 
 }  // namespace
@@ -169,41 +429,26 @@ extern "C" int ps_stats_update_grouped_f32(void* stream, const ps_stats_desc* de
   if (!desc || count <= 0 || !workspace) return PS_EINVAL;
   if (workspace_bytes < grouped_bytes(desc, count)) return PS_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  std::vector<StatsTask> tasks[2];
-  std::vector<StatsTile> tiles[2];
-  for (int i = 0; i < count; ++i) {
-    StatsTask t;
-    if (!to_task(desc[i], t)) return PS_EINVAL;
-    const int L = desc[i].layout;
-    const int id = (int)tasks[L].size();
-    tasks[L].push_back(t);
-    const int nt = (t.d + TILE - 1) / TILE;
-    for (int tm = 0; tm < nt; ++tm)
-      for (int tn = tm; tn < nt; ++tn) tiles[L].push_back({id, (short)tm, (short)tn});
-  }
+  stats_lds_once();
+  std::vector<StatsTask> tasks(count);
+  for (int i = 0; i < count; ++i)
+    if (!to_task(desc[i], tasks[i])) return PS_EINVAL;
+  std::vector<StatsTile> tiles;
+  make_tile_list(tasks, tiles);
+  // one staging buffer, one H2D copy: [tasks][tiles]
+  const size_t task_bytes = psh::align_up(sizeof(StatsTask) * tasks.size(), 256);
+  const size_t tile_bytes = sizeof(StatsTile) * tiles.size();
   psh::Arena ar(workspace, workspace_bytes);
-  StatsTask* d_tasks[2];
-  StatsTile* d_tiles[2];
-  for (int L = 0; L < 2; ++L) {
-    d_tasks[L] = ar.take<StatsTask>(tasks[L].size());
-    d_tiles[L] = ar.take<StatsTile>(tiles[L].size());
-  }
+  char* d_plan = ar.take<char>(task_bytes + tile_bytes);
   if (ar.overflow) return PS_EWORKSPACE;
-  for (int L = 0; L < 2; ++L) {
-    if (tasks[L].empty()) continue;
-    PS_RC(psh::upload_async(st, d_tasks[L], tasks[L].data(), sizeof(StatsTask) * tasks[L].size()));
-    PS_RC(psh::upload_async(st, d_tiles[L], tiles[L].data(), sizeof(StatsTile) * tiles[L].size()));
-  }
-  if (!tasks[0].empty()) {
-    const int nt = (int)tiles[0].size();
-    hipLaunchKernelGGL(stats_grouped_kernel<KC>, dim3(nt), dim3(256), 0, st, d_tasks[0],
-                       d_tiles[0], nt, w1, w2);
-  }
-  if (!tasks[1].empty()) {
-    const int nt = (int)tiles[1].size();
-    hipLaunchKernelGGL(stats_grouped_kernel<MC>, dim3(nt), dim3(256), 0, st, d_tasks[1],
-                       d_tiles[1], nt, w1, w2);
-  }
+  std::vector<char> plan(task_bytes + tile_bytes);
+  memcpy(plan.data(), tasks.data(), sizeof(StatsTask) * tasks.size());
+  memcpy(plan.data() + task_bytes, tiles.data(), tile_bytes);
+  PS_RC(psh::upload_async(st, d_plan, plan.data(), plan.size()));
+  const int nt = (int)tiles.size();
+  hipLaunchKernelGGL(stats_grouped_kernel, dim3(nt), dim3(256), STATS_LDS_BYTES, st,
+                     (const StatsTask*)d_plan, (const StatsTile*)(d_plan + task_bytes), nt, w1,
+                     w2);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -223,12 +468,13 @@ extern "C" int ps_stats_update_f32(void* stream, const float* g, int64_t rows,
   d.stat_in = stat_in; d.stat_out = stat_out; d.lds = lds;
   StatsTask t;
   if (!to_task(d, t)) return PS_EINVAL;
+  stats_lds_once();
   const int nt = (t.d + TILE - 1) / TILE;
   if (axis == 0)
-    hipLaunchKernelGGL(stats_single_kernel<KC>, dim3(nt * nt), dim3(256), 0,
+    hipLaunchKernelGGL(stats_single_kernel<KC>, dim3(nt * nt), dim3(256), STATS_LDS_BYTES,
                        (hipStream_t)stream, t, nt, w1, w2);
   else
-    hipLaunchKernelGGL(stats_single_kernel<MC>, dim3(nt * nt), dim3(256), 0,
+    hipLaunchKernelGGL(stats_single_kernel<MC>, dim3(nt * nt), dim3(256), STATS_LDS_BYTES,
                        (hipStream_t)stream, t, nt, w1, w2);
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -548,9 +548,9 @@ _SDESC_DT = np.dtype([("g", "u8"), ("layout", "i4"), ("d", "i4"), ("k", "i4"), (
 
 @_device_guarded
 def stats_update_grouped(items, w1: float, w2: float):
-  """items: list of (g_block, axis, stat_in, stat_out). One launch per layout.  Row-
-  contiguous 2-D blocks (the common case) are described column-wise with NumPy; other
-  ranks / strides go through gram_desc one by one."""
+  """items: list of (g_block, axis, stat_in, stat_out). One launch for all of them.  Row-
+  contiguous 2-D blocks and contiguous vectors (the common cases) are described column-wise
+  with NumPy; other ranks / strides go through gram_desc one by one."""
   if not items:
     return
   n_items = len(items)
@@ -560,7 +560,8 @@ def stats_update_grouped(items, w1: float, w2: float):
   tbl = np.zeros(n_items, _SDESC_DT)
   keep = []
   fast = [i for i, it in enumerate(items)
-          if it[0].dim() == 2 and (it[0].stride(1) == 1 or it[0].shape[1] == 1)]
+          if (it[0].dim() == 2 and (it[0].stride(1) == 1 or it[0].shape[1] == 1)) or
+          (it[0].dim() == 1 and it[0].stride(0) == 1)]
   fast_set = set(fast)
   for i, (g, axis, sin, sout) in enumerate(items):
     if not g.is_cuda or g.dtype != torch.float32 or not sin.is_cuda:
@@ -576,11 +577,16 @@ def stats_update_grouped(items, w1: float, w2: float):
     G = [items[i][0] for i in fast]
     SI = [items[i][2] for i in fast]
     SO = [items[i][3] for i in fast]
-    axis = np.array([items[i][1] for i in fast], np.int64)
+    # a contiguous vector block [d] is the row matrix [1, d] contracted over axis 0
+    # (gram_desc: layout 1, k = 1, ld = d)
+    if any(t.dim() == 1 and items[i][1] != 0 for i, t in zip(fast, G)):
+      raise ValueError("axis out of range for a 1-D block")
+    axis = np.array([items[i][1] if t.dim() == 2 else 1 for i, t in zip(fast, G)], np.int64)
     if np.any((axis != 0) & (axis != 1)):
       raise ValueError("axis out of range for a 2-D block")
-    sg = np.array([t.shape for t in G], np.int64)
-    ld = _ld_2d(sg, np.array([t.stride() for t in G], np.int64))
+    sg = np.array([t.shape if t.dim() == 2 else (1, t.shape[0]) for t in G], np.int64)
+    ld = _ld_2d(sg, np.array([t.stride() if t.dim() == 2 else (t.shape[0], 1) for t in G],
+                             np.int64))
     so = np.array([t.shape for t in SO], np.int64)
     lds = _ld_2d(so, np.array([t.stride() for t in SO], np.int64))
     lds_in = _ld_2d(np.array([t.shape for t in SI], np.int64),

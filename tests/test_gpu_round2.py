@@ -355,3 +355,70 @@ def test_sharded_optimizer_state_api_hip_matches_plain_optimizer(device):
     for a, b in zip(up, us):
       assert torch.equal(a, b)
   assert int(st_s.count) == len(grads)
+
+
+def test_stats_vector_blocks_stream_path(device):
+  """Statistics of vector blocks (k = 1) take the streaming path of the grouped launch:
+  fl(fl(w1*old) + fl(w2*fl(g_i*g_j))) bit for bit (what the MFMA path returns for one k),
+  for aligned and unaligned statistics, ragged sizes, both operand layouts, in place."""
+  from precondition_amd import kernels as K
+  rng = np.random.default_rng(21)
+  w1, w2 = np.float32(0.999), np.float32(0.001)
+  items, wants = [], []
+  for d, pad, as_column in ((768, 0, False), (260, 0, False), (131, 1, False), (1024, 0, True),
+                            (129, 3, True), (5, 0, False)):
+    gv = rng.standard_normal(d).astype(np.float32)
+    if as_column:   # [d, 1] block, axis 0: element stride = leading dimension
+      g, axis = torch.tensor(gv.reshape(d, 1), device=device), 0
+    else:           # [d] block: contiguous elements
+      g, axis = torch.tensor(gv, device=device), 0
+    old = rng.standard_normal((d, d)).astype(np.float32)  # asymmetric on purpose
+    buf = torch.zeros((d, d + pad), device=device)
+    stat = buf[:, :d]
+    stat.copy_(torch.tensor(old))
+    items.append((g, axis, stat, stat))
+    wants.append((w1 * old) + (w2 * np.outer(gv, gv).astype(np.float32)))
+  K.stats_update_grouped(items, float(w1), float(w2))
+  for (g, axis, stat, _), want in zip(items, wants):
+    assert np.array_equal(stat.cpu().numpy(), want), tuple(g.shape)
+  # the single-statistic entry point (MFMA path) agrees bit for bit
+  d = 260
+  gv = torch.tensor(rng.standard_normal(d).astype(np.float32), device=device)
+  old = torch.tensor(rng.standard_normal((d, d)).astype(np.float32), device=device)
+  one = K.gram_weighted_update(old, gv, 0, 0.9, 0.1)
+  grp = old.clone()
+  K.stats_update_grouped([(gv, 0, grp, grp)], 0.9, 0.1)
+  assert torch.equal(one, grp)
+
+
+def test_stats_interior_and_edge_tiles_agree(device):
+  """Interior tiles of aligned statistics run the unguarded K loop and 16-byte epilogues, edge
+  tiles / unaligned statistics the guarded ones: same products in the same order, so a block
+  and the same block embedded in a ragged or unaligned problem agree bit for bit."""
+  from precondition_amd import kernels as K
+  rng = np.random.default_rng(22)
+  for axis in (0, 1):
+    d, k = 384, 256
+    shape = (d, k) if axis == 0 else (k, d)
+    g = torch.tensor(rng.standard_normal(shape).astype(np.float32), device=device)
+    old = torch.tensor(rng.standard_normal((d, d)).astype(np.float32), device=device)
+    fast = torch.empty_like(old)
+    K.stats_update_grouped([(g, axis, old, fast)], 0.9, 0.1)
+    # unaligned statistic (leading dimension d + 1): guarded path throughout
+    buf_in = torch.zeros((d, d + 1), device=device); buf_in[:, :d] = old
+    buf_out = torch.zeros((d, d + 1), device=device)
+    K.stats_update_grouped([(g, axis, buf_in[:, :d], buf_out[:, :d])], 0.9, 0.1)
+    assert torch.equal(buf_out[:, :d], fast)
+    # gram part exactly symmetric, and the oracle within float32 accumulation noise
+    gram = torch.empty_like(old)
+    K.stats_update_grouped([(g, axis, torch.zeros_like(old), gram)], 0.0, 1.0)
+    assert torch.equal(gram, gram.T)
+    ref = orc.gram_weighted_update(old.cpu().numpy(), g.cpu().numpy(), axis, 0.9, 0.1)
+    assert np.allclose(fast.cpu().numpy(), ref, rtol=1e-5, atol=1e-4)
+    # a contraction length that is not a whole number of K-tiles: guarded K loop
+    k2 = 250
+    g2 = g[:, :k2] if axis == 0 else g[:k2, :]
+    out2 = torch.empty_like(old)
+    K.stats_update_grouped([(g2, axis, old, out2)], 0.9, 0.1)
+    ref2 = orc.gram_weighted_update(old.cpu().numpy(), g2.cpu().numpy(), axis, 0.9, 0.1)
+    assert np.allclose(out2.cpu().numpy(), ref2, rtol=1e-5, atol=1e-4)
