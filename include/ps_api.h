@@ -105,7 +105,7 @@ int ps_power_iteration_v0(int n, float* out_host);
  * nseg=1}; the middle axis of a [b0,b1,b2] view with strides (s0,s1,1) is
  * {layout 0, d=b1, k=b2, ld=s1, nseg=b0, seg_stride=s0}.
  * stat_out may alias stat_in (in-place).  desc is a HOST array; all pointers
- * inside are device pointers.  One launch per layout covers the whole
+ * inside are device pointers.  One launch covers the whole
  * Python-unrolled loop of DS:1582-1590. */
 typedef struct {
   const float* g;
@@ -164,13 +164,18 @@ int ps_mat_power_f32(void* stream, const float* m, int n, int ldm, int p,
  * (as it does in the reference whenever it is padded to max_size, DS:2841-2843;
  * the reference's unpadded matrix_size == 1 branch raises, DS:850-855/907).
  * symmetry: PS_SYMMETRY_* above.
- * The call only enqueues work (no host synchronisation): the whole iteration — init,
- * products, loop control, retries, copy-out — runs in ONE persistent kernel whose
- * workgroups pull (block, product, tile) items from device-side queues; a block's next
- * product is released by the last tile of the products it depends on (DS:844-846), the
- * loop condition of DS:836-848 is evaluated on the device by the last tile of a step.
- * iters_executed_host (may be NULL) is set to -1 (the host no longer knows; per-block
- * counts are in the metrics table). */
+ * Two executions of the same tile code, bit-identical results (tests/test_gpu_round2.py):
+ *   staged (default): one launch per product stage for the whole batch + one control launch
+ *     per step; the loop condition of DS:836-848 is evaluated on the device, the host only
+ *     reads "blocks still running" from pinned memory one iteration behind the GPU (one
+ *     event wait per Newton step).  iters_executed_host (may be NULL) receives the number
+ *     of step rounds the host issued.
+ *   persistent (PS_NEWTON_PERSISTENT=1): the call only enqueues work; init, products, loop
+ *     control, retries and copy-out run in ONE persistent kernel whose workgroups pull
+ *     (block, product, tile) items from device-side queues; a block's next product is
+ *     released by the last tile of the products it depends on (DS:844-846).
+ *     iters_executed_host is set to -1 (per-block counts are in the metrics table).
+ *   The staged execution is the faster one on MI355X today. */
 size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
                                       const int32_t* p,
                                       const int32_t* padding_start);
