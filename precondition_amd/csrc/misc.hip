@@ -133,10 +133,69 @@ struct GTask {
 };
 struct GTile { int task; short tm, tn; int ks; };
 
+// One-row products (m = 1: the preconditioner applied to a vector block, g^T P) are a
+// matrix-vector pass: a 128-column strip of B is streamed once by the VALU (16-byte loads,
+// 8 in flight per lane, rows dealt to 8 lane groups and combined through LDS in a fixed
+// order) instead of running 128 x 128 MFMA tiles with one useful row.  The ViT-B tree has 149
+// such blocks: ~1000 of the 6300 tiles of an application stage.
+__device__ inline void gemv_row_tile(const float* a, int64_t astride, const float* b, int ldb,
+                                     float* c, int n, int k, int col0, bool vecb, float* smem) {
+  const int tid = threadIdx.x;
+  const int cg = tid & 31, rg = tid >> 5;
+  const int col = col0 + cg * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vecb && col + 3 < n) {
+    int kk = rg;
+    for (; kk + 56 < k; kk += 64) {
+      f32x4 v[8];
+      float av[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = gload4(b + (int64_t)(kk + 8 * u) * ldb + col);
+        av[u] = gload1(a + (int64_t)(kk + 8 * u) * astride);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = __fmaf_rn(av[u], v[u][e], s[e]);
+    }
+    for (; kk < k; kk += 8) {
+      const f32x4 v = gload4(b + (int64_t)kk * ldb + col);
+      const float av = gload1(a + (int64_t)kk * astride);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = __fmaf_rn(av, v[e], s[e]);
+    }
+  } else {
+    for (int kk = rg; kk < k; kk += 8) {
+      const float av = gload1(a + (int64_t)kk * astride);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < n) s[e] = __fmaf_rn(av, gload1(b + (int64_t)kk * ldb + col + e), s[e]);
+    }
+  }
+  float* red = smem;  // [8][128]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rg * 128 + cg * 4 + e] = s[e];
+  __syncthreads();
+  if (tid < 128 && col0 + tid < n) {
+    float t = red[tid];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) t = __fadd_rn(t, red[r * 128 + tid]);
+    gstore1(c + col0 + tid, t);
+  }
+}
+
+constexpr int GBK_FAST = 32;  // interior tiles: unguarded loads, two register sets in flight
+constexpr int GEMM_GROUPED_LDS_BYTES = SmemCfg<GBK_FAST>::TOTAL * (int)sizeof(float);
+
+// Interior tiles of 16-byte aligned operands whose k range is a whole number of 32-deep
+// K-tiles run the unguarded, two-register-set K loop of the Newton / statistics kernels and
+// an epilogue with wave-uniform addressing; edge tiles and unaligned operands the guarded
+// BK = 16 loop.  Same products in the same k order: bit-identical results.
 template <int LA, int LB>
 __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GTask* tasks,
                                                               const GTile* tiles, int ntiles) {
-  __shared__ __align__(16) float smem[SmemCfg<GBK>::TOTAL];
+  extern __shared__ __align__(16) float smem[];
   const GTile te = tiles[xcd_remap(blockIdx.x, ntiles)];
   const GTask tk = tasks[te.task];
   const int k0 = te.ks * tk.kchunk;
@@ -147,11 +206,34 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GTask* tasks
   Operand A{ap, tk.lda, te.tm * TILE, tk.m, kext, tk.veca != 0};
   Operand B{bp, tk.ldb, te.tn * TILE, tk.n, kext, tk.vecb != 0};
   f32x16 acc[2][2];
-  gemm_tile<LA, LB, GBK, true>(A, B, kext, smem, acc);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
   float* out = tk.ksplit > 1 ? tk.partial + (int64_t)te.ks * tk.m * tk.n : tk.c;
   const int ldo = tk.ksplit > 1 ? tk.n : tk.ldc;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  if (LB == MC && tk.m == 1 && tk.ksplit == 1) {
+    gemv_row_tile(tk.a, LA == KC ? 1 : tk.lda, tk.b, tk.ldb, tk.c, tk.n, tk.k, te.tn * TILE,
+                  tk.vecb != 0, smem);
+    return;
+  }
+  const bool fast = tk.veca != 0 && tk.vecb != 0 && kext % GBK_FAST == 0 &&
+                    (te.tm + 1) * TILE <= tk.m && (te.tn + 1) * TILE <= tk.n;
+  if (fast) {
+    gemm_tile<LA, LB, GBK_FAST, false, true>(A, B, kext, smem, acc);
+    const int lane_off = 4 * (lane >> 5) * ldo + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float* blk = out + (int64_t)(te.tm * TILE + wm * 64 + i * 32) * ldo + te.tn * TILE +
+                     wn * 64 + j * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          gstore1(blk + (int64_t)((r & 3) + 8 * (r >> 2)) * ldo + lane_off, acc[i][j][r]);
+      }
+    return;
+  }
+  gemm_tile<LA, LB, GBK, true>(A, B, kext, smem, acc);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -266,10 +348,19 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
     PS_RC(psh::upload_async(st, di[g], split_ids[g].data(), sizeof(int) * split_ids[g].size()));
   }
   const dim3 blk(256);
+  static const bool lds_ok = [] {
+    const void* ks[4] = {(const void*)gemm_grouped_kernel<KC, MC>, (const void*)gemm_grouped_kernel<KC, KC>,
+                         (const void*)gemm_grouped_kernel<MC, MC>, (const void*)gemm_grouped_kernel<MC, KC>};
+    for (const void* k : ks)
+      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GEMM_GROUPED_LDS_BYTES);
+    return true;
+  }();
+  (void)lds_ok;
 #define PS_GG(G, LA, LB)                                                                   \
   if (!tasks[G].empty()) {                                                                 \
     hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB>), dim3((unsigned)tiles[G].size()), blk, \
-                       0, st, dt[G], dl[G], (int)tiles[G].size());                         \
+                       GEMM_GROUPED_LDS_BYTES, st, dt[G], dl[G], (int)tiles[G].size());    \
     if (!split_ids[G].empty())                                                             \
       hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)split_ids[G].size(), 16), \
                          blk, 0, st, dt[G], di[G]);                                        \

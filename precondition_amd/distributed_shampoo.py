@@ -22,7 +22,10 @@ steps raise without libprecondition_amd.so and an MI355X.
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import logging
+import os
 from typing import Any, Callable, List, Optional
 
 import numpy as np
@@ -66,6 +69,25 @@ def preconditioning_compute_steps_schedule(lr_fn, start_preconditioning_compute_
   t = (start_preconditioning_compute_steps +
        (1 - decay_factor) * end_preconditioning_compute_steps)
   return max((t // 10) * 10, 1)
+
+
+@contextlib.contextmanager
+def _collector_paused():
+  """update() of a few-hundred-leaf tree allocates ~10^4 short-lived containers (block views,
+  descriptor rows, state tuples) and creates NO reference cycles (tools/dev_find_cycles.py).
+  At CPython's thresholds that churn alone triggers ~14 young, ~1.4 middle and ~0.14 FULL
+  collections per call; the full ones walk every object of the process (torch, numpy, the
+  optimizer state) and cost ~3 ms per update() on the ViT-B tree, amortised.  The collector is
+  therefore paused for the duration of the call and restored on exit: what it would have found
+  is still found, by one young-generation pass after the call.  PS_UPDATE_KEEP_GC=1 opts out."""
+  paused = gc.isenabled() and os.environ.get("PS_UPDATE_KEEP_GC", "0") != "1"
+  if paused:
+    gc.disable()
+  try:
+    yield
+  finally:
+    if paused:
+      gc.enable()
 
 
 def distributed_shampoo(
@@ -285,6 +307,25 @@ def distributed_shampoo(
     return len(param.shape) < skip_preconditioning_rank_lt or any(
         s > skip_preconditioning_dim_size_gt for s in param.shape)
 
+  _plan_cache = {}
+
+  def _tree_plan(params_flat):
+    """plan.TreePlan of this tree (shapes only), or None when the tree or the options need
+    the general per-block path: FD / compression, quantized second moments, owner-only
+    statistics, blocks of merged rank > 2, the host-logic test backend."""
+    if (not hasattr(backend, "transform_grads_fused") or frequent_directions or
+        compression_rank or quantize_second_moment or shard_stats or
+        os.environ.get("PS_UPDATE_PLAN", "1") == "0"):
+      return None
+    key = tuple(tuple(p.shape) for p in params_flat)
+    if key not in _plan_cache:
+      from .plan import TreePlan
+      skipped = [_skip_preconditioning(p) for p in params_flat]
+      pcs = [None if sk else preconditioner_from_params(p)
+             for p, sk in zip(params_flat, skipped)]
+      _plan_cache[key] = TreePlan.build(key, pcs, skipped)
+    return _plan_cache[key]
+
   def _placeholder_like(x):
     """A statistic this rank does not own: no storage."""
     if isinstance(x, QuantizedValue):
@@ -343,6 +384,20 @@ def distributed_shampoo(
     w1 = beta2
     w2 = beta2 if beta2 == 1.0 else 1.0 - beta2  # DS:2635-2636
     perform = statistics_compute_steps <= 1 or step % statistics_compute_steps == 0
+    plan = _tree_plan(params_flat) if perform else None
+    if plan is not None and all(g.is_contiguous() for g in grads_flat):
+      # every (block, axis) addressed as `gradient pointer + planned offset`: no block views
+      olds = [s for st in stats_flat for s in st.statistics]
+      if len(olds) == len(plan.stat_dims) and all(s.is_contiguous() for s in olds):
+        news = [torch.empty_like(s) for s in olds]
+        plan.stats_update(grads_flat, olds, news, w1, w2)
+        out, k = [], 0
+        for st, cnt in zip(stats_flat, plan.n_stats_of):
+          out.append(ParameterStats(st.diagonal_statistics, news[k:k + cnt], st.preconditioners,
+                                    st.diagonal_momentum, st.momentum, MaskedNode(),
+                                    st.training_metrics))
+          k += cnt
+        return out
     new_lists, items, fd_items, new_avg = [], [], [], []
     owned = _owned_mask(params_flat) if shard_stats else None
     float_old = None
@@ -623,6 +678,16 @@ def distributed_shampoo(
     transpose and a concatenation per block.  Everything else takes the per-block
     path of blocking.Preconditioner."""
     out = [None] * len(grads_flat)
+    plan = _tree_plan(params_flat)
+    if plan is not None and all(g.is_contiguous() for g in grads_flat):
+      precs_flat = [p for st in states for p in st.preconditioners]
+      if len(precs_flat) == len(plan.stat_dims) and all(
+          p.is_contiguous() and p.dtype == torch.float32 for p in precs_flat):
+        for i, (g, sk) in enumerate(zip(grads_flat, plan.skipped)):
+          if not sk:
+            out[i] = torch.empty_like(g)
+        plan.apply_preconditioners(grads_flat, precs_flat, out)
+        return out
     stage_a, stage_b, keep = [], [], []
     precs = [st.preconditioners for st in states]
     if quantize_second_moment:  # _maybe_dequantize_preconditioners, DS:2097-2106
@@ -776,6 +841,10 @@ def distributed_shampoo(
   # ---------------------------------------------------------------------------
   def update_fn(grads, state, params):
     """DS:3627-3659."""
+    with _collector_paused():
+      return _update_impl(grads, state, params)
+
+  def _update_impl(grads, state, params):
     params_flat, treedef = pytree.tree_flatten(params)
     stats_flat = treedef.flatten_up_to(state.stats)
     grads_flat = treedef.flatten_up_to(grads)
@@ -942,6 +1011,10 @@ def distributed_shampoo(
 
   def sharded_update_fn(grads, state, params):
     """DS:2420-2583."""
+    with _collector_paused():
+      return _sharded_update_impl(grads, state, params)
+
+  def _sharded_update_impl(grads, state, params):
     params_flat, treedef = pytree.tree_flatten(params)
     grads_flat = treedef.flatten_up_to(grads)
     grad_dtypes = [g.dtype for g in grads_flat]

@@ -647,48 +647,68 @@ def fd_update_root_batched(calls):
 # ---------------------------------------------------------------------------
 # fused _transform_grad for a whole tree (DS:3496-3625)
 # ---------------------------------------------------------------------------
+_TDESC_DT = np.dtype([(n, "u8") for n in ("grad", "pgrad", "param", "diag_in", "diag_out",
+                                          "mom_in", "mom_out", "dmom_in", "dmom_out",
+                                          "upd_out")] + [("numel", "i8")], align=True)
+
+
 @_device_guarded
 def transform_grads_fused(items, cfg: dict):
   """items: list of dicts with contiguous float32 device tensors
   {grad, pgrad|None, param|None, diag_in|None, mom_in, dmom_in}; returns per item
-  (update, new_diag|None, new_mom, new_dmom).  cfg: fields of ps_transform_config."""
+  (update, new_diag|None, new_mom, new_dmom).  cfg: fields of ps_transform_config.
+  The descriptor table is filled column-wise with NumPy."""
   if not items:
     return []
+  n = len(items)
   dev = items[0]["grad"].device
-  descs = (TransformDesc * len(items))()
-  outs, keep = [], []
-  for i, it in enumerate(items):
-    g = it["grad"].contiguous()
-    _require_gpu(g, "_transform_grad")
-    upd = torch.empty_like(g)
-    mom = torch.empty_like(g)
-    dmom = torch.empty_like(g)
-    nd = torch.empty_like(g) if it.get("diag_in") is not None else None
-    d = descs[i]
-    d.grad = g.data_ptr()
-    keep.append(g)
-    for name in ("pgrad", "param", "diag_in", "mom_in", "dmom_in"):
+  assert _TDESC_DT.itemsize == C.sizeof(TransformDesc)
+  tbl = np.zeros(n, _TDESC_DT)
+  keep = []
+
+  def column(name, required=False):
+    ptrs = np.zeros(n, np.uint64)
+    col = []
+    for i, it in enumerate(items):
       t = it.get(name)
-      if t is not None:
+      if t is None:
+        if required:
+          raise ValueError(f"_transform_grad: item {i} has no {name}")
+        col.append(None)
+        continue
+      if not t.is_contiguous():
         t = t.contiguous()
-        keep.append(t)
-        setattr(d, name, t.data_ptr())
-      else:
-        setattr(d, name, None)
-    d.diag_out = nd.data_ptr() if nd is not None else None
-    d.mom_out, d.dmom_out, d.upd_out = mom.data_ptr(), dmom.data_ptr(), upd.data_ptr()
-    d.numel = g.numel()
-    outs.append((upd, nd, mom, dmom))
+      if not t.is_cuda or t.dtype != torch.float32:
+        _require_gpu(t, "_transform_grad")
+      col.append(t)
+      ptrs[i] = t.data_ptr()
+    keep.append(col)
+    return ptrs, col
+
+  tbl["grad"], grads = column("grad", required=True)
+  _same_device(grads, "_transform_grad")
+  for name in ("pgrad", "param", "diag_in", "mom_in", "dmom_in"):
+    tbl[name], _ = column(name)
+  has_diag = [it.get("diag_in") is not None for it in items]
+  upd = [torch.empty_like(g) for g in grads]
+  mom = [torch.empty_like(g) for g in grads]
+  dmom = [torch.empty_like(g) for g in grads]
+  nd = [torch.empty_like(g) if h else None for g, h in zip(grads, has_diag)]
+  tbl["upd_out"] = [t.data_ptr() for t in upd]
+  tbl["mom_out"] = [t.data_ptr() for t in mom]
+  tbl["dmom_out"] = [t.data_ptr() for t in dmom]
+  tbl["diag_out"] = [0 if t is None else t.data_ptr() for t in nd]
+  tbl["numel"] = [g.numel() for g in grads]
   c = TransformConfig()
   for k, v in cfg.items():
     setattr(c, k, v)
+  descs = C.cast(tbl.ctypes.data, C.POINTER(TransformDesc))
   L = lib()
-  ws = _workspace(L.ps_transform_grads_workspace_bytes(descs, len(items)), dev)
-  rc = L.ps_transform_grads_f32(_stream(), descs, len(items), C.byref(c), ws.data_ptr(),
-                                ws.numel())
+  ws = _workspace(L.ps_transform_grads_workspace_bytes(descs, n), dev)
+  rc = L.ps_transform_grads_f32(_stream(), descs, n, C.byref(c), ws.data_ptr(), ws.numel())
   check(rc, "ps_transform_grads_f32")
   del keep
-  return outs
+  return list(zip(upd, nd, mom, dmom))
 
 
 # ---------------------------------------------------------------------------

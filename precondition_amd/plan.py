@@ -1,0 +1,212 @@
+"""Per-tree plan of the every-step calls of update() (DS:3627-3659).
+
+Everything about a parameter tree that depends on its SHAPES only — which blocks a parameter
+is cut into, where a block starts inside the (merged, contiguous) gradient, the dimensions and
+leading dimensions of every Gram update and of every product of the preconditioner
+application — is resolved once, into NumPy descriptor-table templates.  A step then only
+fills the pointer columns (`base pointer of the parameter's gradient + byte offset of the
+block`, statistics / preconditioner / output pointers) with a few vector operations and hands
+the tables to the C-ABI: no block views, no per-block Python objects.  The reference gets the
+same effect from tracing its Python-unrolled loops (DS:1582-1590, 1689-1708) once under jit.
+
+Covers blocks of merged rank 1 and 2 with every axis preconditioned and no compression (the
+dense mode of a transformer tree); anything else makes `TreePlan.build` return None and the
+optimizer keeps its general per-block path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import kernels
+from ._lib import GemmDesc, StatsDesc, check, lib
+
+
+class TreePlan:
+
+  def __init__(self):
+    self.n_params = 0
+    self.skipped: List[bool] = []
+    self.numel: List[int] = []
+    self.tshapes: List[tuple] = []
+    self.n_stats_of: List[int] = []       # statistics per parameter
+    self.stat_dims = np.zeros(0, np.int64)  # d of every statistic, plan order
+    # statistics table
+    self.stats_tbl = None
+    self.st_param = None
+    self.st_goff = None
+    # application tables
+    self.a_tbl = self.b_tbl = None
+    self.a_param = self.a_goff = self.a_stat = self.a_coff = self.a_c_is_res = None
+    self.b_param = self.b_stat = self.b_xoff = self.b_coff = None
+    self.x_elems = 0
+
+  @staticmethod
+  def build(shapes: Sequence[tuple], pcs, skipped: Sequence[bool]) -> Optional["TreePlan"]:
+    """pcs[i]: blocking.Preconditioner of parameter i (None when skipped)."""
+    pl = TreePlan()
+    pl.n_params = len(shapes)
+    pl.skipped = list(skipped)
+    st_rows, a_rows, b_rows = [], [], []
+    stat_base = 0
+    x_off = 0
+    for i, (shape, pc) in enumerate(zip(shapes, pcs)):
+      ne = 1
+      for d in shape:
+        ne *= int(d)
+      pl.numel.append(ne)
+      if pl.skipped[i]:
+        pl.tshapes.append(tuple(shape))
+        pl.n_stats_of.append(0)
+        continue
+      tshape = pc._transformed_shape
+      nd = len(tshape)
+      if nd not in (1, 2) or not all(pc.should_precondition_dims()) or pc._compression_rank:
+        return None
+      if ne == 0:
+        return None
+      pl.tshapes.append(tshape)
+      meta = torch.empty(tshape, dtype=torch.float32, device="meta")
+      row_ld = int(tshape[1]) if nd == 2 else 1
+      k = 0
+      for blk in pc._partitioner.partition(meta):
+        off = int(blk.storage_offset()) * 4
+        if nd == 1:
+          d = int(blk.shape[0])
+          # gram_desc: [d] -> layout 1, k = 1, ld = d
+          st_rows.append((i, off, 1, d, 1, d))
+          # g^T P as a one-row product: a = [d, 1] (transa), c = [1, d] inside the result
+          a_rows.append((i, off, stat_base + k, d * 0 + 1, d, d, 1, d, d, True, off))
+          k += 1
+        else:
+          m, n = int(blk.shape[0]), int(blk.shape[1])
+          if blk.stride(1) != 1 or blk.stride(0) != row_ld:
+            return None
+          st_rows.append((i, off, 0, m, n, row_ld))   # axis 0: layout 0, d = m, k = n
+          st_rows.append((i, off, 1, n, m, row_ld))   # axis 1: layout 1, d = n, k = m
+          # stage A: X [n, m] = g^T P_L (transa);  stage B: Y [m, n] = X^T P_R into the result
+          a_rows.append((i, off, stat_base + k, n, m, m, row_ld, m, m, False, x_off * 4))
+          b_rows.append((i, stat_base + k + 1, x_off * 4, off, m, n, n, m, n, row_ld))
+          x_off += m * n
+          k += 2
+      pl.n_stats_of.append(k)
+      stat_base += k
+    pl.x_elems = x_off
+    # ---- statistics template -------------------------------------------------
+    S = len(st_rows)
+    tbl = np.zeros(S, kernels._SDESC_DT)
+    if S:
+      arr = np.array(st_rows, np.int64)
+      pl.st_param, pl.st_goff = arr[:, 0].copy(), arr[:, 1].astype(np.uint64)
+      tbl["layout"], tbl["d"], tbl["k"], tbl["ld"] = arr[:, 2], arr[:, 3], arr[:, 4], arr[:, 5]
+      tbl["nseg"] = 1
+      tbl["lds"] = arr[:, 3]
+      pl.stat_dims = arr[:, 3].copy()
+    pl.stats_tbl = tbl
+    # ---- application templates -------------------------------------------------
+    def gemm_tbl(rows):
+      t = np.zeros(len(rows), kernels._GDESC_DT)
+      return t
+    pl.a_tbl = gemm_tbl(a_rows)
+    if a_rows:
+      # (param, goff, stat, m, n, k, lda, ldb, ldc, c_is_res, coff)
+      pl.a_param = np.array([r[0] for r in a_rows], np.int64)
+      pl.a_goff = np.array([r[1] for r in a_rows], np.uint64)
+      pl.a_stat = np.array([r[2] for r in a_rows], np.int64)
+      pl.a_c_is_res = np.array([r[9] for r in a_rows], bool)
+      pl.a_coff = np.array([r[10] for r in a_rows], np.uint64)
+      t = pl.a_tbl
+      t["m"] = [r[3] for r in a_rows]
+      t["n"] = [r[4] for r in a_rows]
+      t["k"] = [r[5] for r in a_rows]
+      t["lda"] = [r[6] for r in a_rows]
+      t["ldb"] = [r[7] for r in a_rows]
+      t["ldc"] = [r[8] for r in a_rows]
+      t["transa"], t["transb"] = 1, 0
+    pl.b_tbl = gemm_tbl(b_rows)
+    if b_rows:
+      # (param, stat, xoff, coff, m, n, k, lda, ldb, ldc)
+      pl.b_param = np.array([r[0] for r in b_rows], np.int64)
+      pl.b_stat = np.array([r[1] for r in b_rows], np.int64)
+      pl.b_xoff = np.array([r[2] for r in b_rows], np.uint64)
+      pl.b_coff = np.array([r[3] for r in b_rows], np.uint64)
+      t = pl.b_tbl
+      t["m"] = [r[4] for r in b_rows]
+      t["n"] = [r[5] for r in b_rows]
+      t["k"] = [r[6] for r in b_rows]
+      t["lda"] = [r[7] for r in b_rows]
+      t["ldb"] = [r[8] for r in b_rows]
+      t["ldc"] = [r[9] for r in b_rows]
+      t["transa"], t["transb"] = 1, 0
+    return pl
+
+  # ---------------------------------------------------------------------------
+  @staticmethod
+  def _ptrs(tensors) -> np.ndarray:
+    return np.fromiter((t.data_ptr() for t in tensors), np.uint64, len(tensors))
+
+  def check_dense(self, tensors, what: str):
+    """Contiguous float32 tensors on one device (the plan addresses them by pointer)."""
+    dev = tensors[0].device
+    for t in tensors:
+      if t.dtype != torch.float32 or not t.is_cuda or t.device != dev or not t.is_contiguous():
+        kernels._require_gpu(t, what)
+        raise ValueError(f"{what}: the tree plan needs contiguous float32 tensors on one device")
+    return dev
+
+  def stats_update(self, grads_flat, stats_in, stats_out, w1: float, w2: float):
+    """gram_weighted_update of every (block, axis) of the tree (DS:1582-1590) in one launch.
+    stats_in / stats_out: flat lists in plan order (contiguous [d, d] tensors)."""
+    S = len(self.stats_tbl)
+    if S == 0:
+      return
+    dev = self.check_dense(grads_flat, "gram_weighted_update")
+    tbl = self.stats_tbl.copy()
+    gp = self._ptrs(grads_flat)
+    tbl["g"] = gp[self.st_param] + self.st_goff
+    tbl["stat_in"] = self._ptrs(stats_in)
+    tbl["stat_out"] = self._ptrs(stats_out)
+    with torch.cuda.device(dev):
+      descs = C.cast(tbl.ctypes.data, C.POINTER(StatsDesc))
+      L = lib()
+      ws = kernels._workspace(L.ps_stats_update_grouped_workspace_bytes(descs, S), dev)
+      rc = L.ps_stats_update_grouped_f32(kernels._stream(), descs, S, float(w1), float(w2),
+                                         ws.data_ptr(), ws.numel())
+    check(rc, "ps_stats_update_grouped_f32")
+
+  def apply_preconditioners(self, grads_flat, precs_flat, results):
+    """Preconditioner.preconditioned_grad (DS:1645-1708) for every planned parameter:
+    two grouped launches.  precs_flat: preconditioners in plan order; results[i]: contiguous
+    output of parameter i (None for skipped parameters)."""
+    if len(self.a_tbl) == 0:
+      return
+    dev = grads_flat[0].device
+    x = torch.empty(max(self.x_elems, 1), dtype=torch.float32, device=dev)
+    xp = np.uint64(x.data_ptr())
+    gp = self._ptrs(grads_flat)
+    pp = self._ptrs(precs_flat)
+    rp = np.fromiter((0 if r is None else r.data_ptr() for r in results), np.uint64,
+                     len(results))
+    ta = self.a_tbl.copy()
+    ta["a"] = gp[self.a_param] + self.a_goff
+    ta["b"] = pp[self.a_stat]
+    ta["c"] = np.where(self.a_c_is_res, rp[self.a_param], xp) + self.a_coff
+    L = lib()
+    with torch.cuda.device(dev):
+      for tbl in (ta, None):
+        if tbl is None:
+          if len(self.b_tbl) == 0:
+            break
+          tbl = self.b_tbl.copy()
+          tbl["a"] = xp + self.b_xoff
+          tbl["b"] = pp[self.b_stat]
+          tbl["c"] = rp[self.b_param] + self.b_coff
+        n = len(tbl)
+        descs = C.cast(tbl.ctypes.data, C.POINTER(GemmDesc))
+        ws = kernels._workspace(L.ps_gemm_grouped_workspace_bytes(descs, n), dev)
+        rc = L.ps_gemm_grouped_f32(kernels._stream(), descs, n, ws.data_ptr(), ws.numel())
+        check(rc, "ps_gemm_grouped_f32")
+    del x  # the caching allocator keeps it alive until the stream has consumed it

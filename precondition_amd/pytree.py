@@ -52,6 +52,41 @@ def _node(x):
   return None
 
 
+# The recursive walkers are module-level functions on purpose: a nested `def rec` that calls
+# itself forms a reference cycle (function -> closure cell -> function) that also holds the
+# accumulated leaf list, i.e. every tensor of the flattened optimizer state, until the cyclic
+# garbage collector runs — gigabytes of device memory per update() pinned behind the GC.
+def _flatten_up_to(sk, t, out):
+  if sk is LEAF:
+    out.append(t)
+    return
+  a = _node(sk)[0]
+  nt = _node(t)
+  if nt is None or len(nt[0]) != len(a):
+    raise ValueError(f"tree structure mismatch: {sk!r} vs {t!r}")
+  for s, c in zip(a, nt[0]):
+    _flatten_up_to(s, c, out)
+
+
+def _unflatten(sk, it):
+  if sk is LEAF:
+    return next(it)
+  ch, rebuild = _node(sk)
+  return rebuild([_unflatten(c, it) for c in ch])
+
+
+def _flatten(t, leaves, is_leaf):
+  if is_leaf is not None and is_leaf(t):
+    leaves.append(t)
+    return LEAF
+  nd = _node(t)
+  if nd is None:
+    leaves.append(t)
+    return LEAF
+  ch, rebuild = nd
+  return rebuild([_flatten(c, leaves, is_leaf) for c in ch])
+
+
 class TreeDef:
   """Structure of a pytree: the tree itself with every leaf replaced by LEAF."""
 
@@ -61,48 +96,17 @@ class TreeDef:
   def flatten_up_to(self, tree) -> List[Any]:
     """Flattens `tree` only as deep as this structure goes (DS:3640-3641)."""
     out = []
-
-    def rec(sk, t):
-      if sk is LEAF:
-        out.append(t)
-        return
-      a = _node(sk)[0]
-      nt = _node(t)
-      if nt is None or len(nt[0]) != len(a):
-        raise ValueError(f"tree structure mismatch: {sk!r} vs {t!r}")
-      for s, c in zip(a, nt[0]):
-        rec(s, c)
-
-    rec(self.skeleton, tree)
+    _flatten_up_to(self.skeleton, tree, out)
     return out
 
   def unflatten(self, leaves):
-    it = iter(leaves)
-
-    def rec(sk):
-      if sk is LEAF:
-        return next(it)
-      ch, rebuild = _node(sk)
-      return rebuild([rec(c) for c in ch])
-
-    return rec(self.skeleton)
+    return _unflatten(self.skeleton, iter(leaves))
 
 
 def tree_flatten(tree, is_leaf: Callable[[Any], bool] = None) -> Tuple[List[Any], TreeDef]:
   leaves = []
-
-  def rec(t):
-    if is_leaf is not None and is_leaf(t):
-      leaves.append(t)
-      return LEAF
-    nd = _node(t)
-    if nd is None:
-      leaves.append(t)
-      return LEAF
-    ch, rebuild = nd
-    return rebuild([rec(c) for c in ch])
-
-  return leaves, TreeDef(rec(tree))
+  skeleton = _flatten(tree, leaves, is_leaf)
+  return leaves, TreeDef(skeleton)
 
 
 def tree_unflatten(treedef: TreeDef, leaves):

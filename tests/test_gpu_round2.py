@@ -422,3 +422,77 @@ def test_stats_interior_and_edge_tiles_agree(device):
     K.stats_update_grouped([(g2, axis, old, out2)], 0.9, 0.1)
     ref2 = orc.gram_weighted_update(old.cpu().numpy(), g2.cpu().numpy(), axis, 0.9, 0.1)
     assert np.allclose(out2.cpu().numpy(), ref2, rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_grouped_one_row_products_stream_path(device):
+  """m = 1 products (preconditioner applied to a vector block, DS:1707 with a [d] gradient)
+  take the matrix-vector path of the grouped launch; checked against float64 for aligned,
+  ragged and unaligned operands, both storages of the row vector, next to ordinary tiles."""
+  from precondition_amd import kernels as K
+  rng = np.random.default_rng(23)
+  items, refs = [], []
+  for d, n, pad, col_vec in ((768, 768, 0, True), (1024, 1024, 0, False), (300, 517, 0, True),
+                             (129, 131, 1, False), (64, 40, 3, True), (2000, 128, 0, False)):
+    a = rng.standard_normal(d).astype(np.float32)
+    b = rng.standard_normal((d, n)).astype(np.float32)
+    bt = torch.zeros((d, n + pad), device=device)[:, :n]
+    bt.copy_(torch.tensor(b))
+    if col_vec:   # stored [d, 1], transa: op(a) = [1, d]
+      at, ta = torch.tensor(a.reshape(d, 1), device=device), True
+    else:         # stored [1, d]
+      at, ta = torch.tensor(a.reshape(1, d), device=device), False
+    c = torch.full((1, n), float("nan"), device=device)
+    items.append((at, bt, c, ta, False))
+    refs.append(a.astype(np.float64) @ b.astype(np.float64))
+  # an ordinary product in the same launch group
+  a2 = rng.standard_normal((256, 384)).astype(np.float32)
+  b2 = rng.standard_normal((256, 200)).astype(np.float32)
+  c2 = torch.empty((384, 200), device=device)
+  items.append((torch.tensor(a2, device=device), torch.tensor(b2, device=device), c2, True, False))
+  K.gemm_grouped(items)
+  for (at, bt, c, _, _), ref in zip(items[:-1], refs):
+    got = c.cpu().numpy()[0].astype(np.float64)
+    scale = np.sqrt(at.numel())
+    assert np.all(np.isfinite(got))
+    assert np.max(np.abs(got - ref)) < 2e-5 * scale, (at.shape, bt.shape)
+  ref2 = a2.astype(np.float64).T @ b2.astype(np.float64)
+  assert np.max(np.abs(c2.cpu().numpy() - ref2)) < 2e-4
+
+
+def test_update_tree_plan_bit_identical_to_per_block_path(device, monkeypatch):
+  """The per-tree plan (descriptor tables from shapes, block pointers = gradient pointer +
+  offset) issues the same kernels on the same operands as the per-block path: updates and
+  state are bit-identical over several steps incl. a preconditioner recompute, on a tree with
+  vector, matrix, blocked (ragged) and skipped parameters."""
+  import precondition_amd as pa
+  rng = np.random.default_rng(31)
+  shapes = [(96,), (64, 48), (200, 72), (3, 4, 40), (130,), ()]
+  params = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=device) for s in shapes]
+
+  def run(plan):
+    monkeypatch.setenv("PS_UPDATE_PLAN", "1" if plan else "0")
+    opt = pa.distributed_shampoo(0.1, 64, preconditioning_compute_steps=2,
+                                 start_preconditioning_step=2,
+                                 graft_type=pa.GraftingType.RMSPROP_NORMALIZED,
+                                 skip_preconditioning_rank_lt=1)
+    st = opt.init(params)
+    g_rng = np.random.default_rng(5)
+    ups = []
+    for _ in range(5):
+      grads = [torch.tensor(g_rng.standard_normal(s).astype(np.float32), device=device)
+               for s in shapes]
+      u, st = opt.update(grads, st, params)
+      ups.append(u)
+    return ups, st
+
+  ups_a, st_a = run(True)
+  ups_b, st_b = run(False)
+  for ua, ub in zip(ups_a, ups_b):
+    for x, y in zip(ua, ub):
+      assert torch.equal(x, y)
+  for sa, sb in zip(st_a.stats, st_b.stats):
+    for x, y in zip(sa.statistics, sb.statistics):
+      assert torch.equal(x, y)
+    for x, y in zip(sa.preconditioners, sb.preconditioners):
+      assert torch.equal(x, y)
+    assert torch.equal(sa.momentum.to_float(), sb.momentum.to_float())

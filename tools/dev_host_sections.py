@@ -1,5 +1,6 @@
 """Dev: wall-clock split of update() on the ViT-B tree (needs the temporary section timers)."""
-import os, sys, time
+import os, sys, time, gc
+if os.environ.get("NOGC"): gc.disable()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import precondition_amd as pa
