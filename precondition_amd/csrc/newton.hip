@@ -446,13 +446,30 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void newton_stage_kernel(
     const NewtonBlock* blocks, NewtonState* states, const NewtonTask* tasks,
     const TileEntry* tiles, int ntiles, int navg) {
   extern __shared__ __align__(16) float smem[];  // SmemCfg<BK>::TOTAL floats
-  const TileEntry te = tiles[xcd_remap(blockIdx.x, ntiles)];
-  const NewtonTask tk = tasks[te.task];
-  const NewtonBlock* nb = &blocks[tk.block];
-  NewtonState* st = &states[tk.block];
-  if (st->phase != PH_ACTIVE) return;
   (void)navg;
-  newton_product_item<BK, false, DEEP>(nb, st, tk.prod, st->cur, st->avg_on, te.tm, te.tn, smem);
+  // gridDim.x == ntiles: one tile per workgroup (hardware dispatch).  A smaller grid
+  // (PS_NEWTON_GRID) walks the list with stride gridDim.x; the next tile's descriptors are
+  // loaded while the current tile computes.
+  const int stride = gridDim.x;
+  int i = blockIdx.x;
+  TileEntry te = tiles[xcd_remap(i, ntiles)];
+  NewtonTask tk = tasks[te.task];
+  while (true) {
+    const int inext = i + stride;
+    const bool more = inext < ntiles;
+    TileEntry te_n = te;
+    if (more) te_n = tiles[xcd_remap(inext, ntiles)];
+    const NewtonBlock* nb = &blocks[tk.block];
+    NewtonState* st = &states[tk.block];
+    if (st->phase == PH_ACTIVE)
+      newton_product_item<BK, false, DEEP>(nb, st, tk.prod, st->cur, st->avg_on, te.tm, te.tn,
+                                           smem);
+    if (!more) break;
+    tk = tasks[te_n.task];
+    te = te_n;
+    i = inext;
+    __syncthreads();  // smem (reduction scratch of the epilogue) is reused by the next tile
+  }
 }
 
 __global__ __launch_bounds__(256) void newton_init1_kernel(const NewtonBlock* blocks,
@@ -1111,6 +1128,16 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
   }
 }
 
+// dev A/B: PS_NEWTON_GRID=g caps the stage launches at g workgroups that loop over the tile
+// list (0 / unset: one workgroup per tile).
+static int stage_grid(int ntiles) {
+  static const int cap = [] {
+    const char* e = getenv("PS_NEWTON_GRID");
+    return e ? atoi(e) : 0;
+  }();
+  return cap > 0 ? std::min(cap, ntiles) : ntiles;
+}
+
 struct WsLayout {
   NewtonBlock* blocks;
   NewtonState* states;
@@ -1456,7 +1483,7 @@ static int newton_driver(
         const int nt = (int)pl.stage_tiles[s].size();
         prof.begin(0);
 #define PS_STAGE(BKV, DEEPV)                                                              \
-  hipLaunchKernelGGL((newton_stage_kernel<BKV, DEEPV>), dim3(nt), dim3(256),                \
+  hipLaunchKernelGGL((newton_stage_kernel<BKV, DEEPV>), dim3(stage_grid(nt)), dim3(256),    \
                      SmemCfg<BKV>::TOTAL * sizeof(float), st, lo.blocks, lo.states,         \
                      lo.tasks[s], lo.tiles[s], nt, navg)
         if (stage_bk == 32 && stage_deep) PS_STAGE(32, true);

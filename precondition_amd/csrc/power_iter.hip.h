@@ -50,6 +50,7 @@ struct PiBlock {
   float lambda;   // s_out
   int iters;      // steps executed
   const int* asym;  // *asym != 0: the block is not exactly symmetric (full mat-vec)
+  int team;         // resident execution: workgroups in the block's team
 };
 
 struct PiTile {
@@ -109,6 +110,30 @@ static __global__ void sym_fill_kernel(int* asym, int count, int value) {
   if (i < count) asym[i] = value;
 }
 
+// ---- shared tile arithmetic (streaming and resident kernels: identical, term for term) ----
+// Dot product of a lane's 4 matrix columns with its 4 vector elements (fused multiply-adds).
+__device__ __forceinline__ float pi_dot4(const f32x4& x, const f32x4& v) {
+  return __fmaf_rn(x[3], v[3], __fmaf_rn(x[2], v[2], __fmaf_rn(x[1], v[1], __fmul_rn(x[0], v[0]))));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float pi_dpp_add(float x) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWMASK, 0xf, false);
+  return x + __int_as_float(r);
+}
+// Sum over the 32 lanes of a half-wavefront with DPP adds only: rotations by 8, 4, 2, 1
+// inside each row of 16 lanes (every lane of the row then holds the row's sum: each step
+// adds a commuting pair), then lane 15 of the lower row broadcast into the upper row
+// (row_bcast15).  The total is valid in the UPPER row of each half: lanes 16-31 / 48-63.
+__device__ __forceinline__ float pi_half_sum(float x) {
+  x = pi_dpp_add<0x128, 0xf>(x);  // row_ror:8
+  x = pi_dpp_add<0x124, 0xf>(x);  // row_ror:4
+  x = pi_dpp_add<0x122, 0xf>(x);  // row_ror:2
+  x = pi_dpp_add<0x121, 0xf>(x);  // row_ror:1
+  x = pi_dpp_add<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+  return x;
+}
+constexpr int PI_SUM_LANE = 16;   // (lane & 31) of the lanes that hold pi_half_sum's total
+
 // Row dot products of one 128x128 tile with a 128-vector: u[r] = sum_c A[r0+r][c0+c] v[c],
 // written to P_out[r].  Register streaming: lane = (row parity rh, float4 column group c4),
 // a wavefront walks 32 rows two at a time with all 16 loads in flight.
@@ -137,13 +162,8 @@ __device__ inline void pi_tile_rowdot(const float* a, int lda, int n, int r0, in
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int r = 32 * wave + 2 * it + rh;
-    float u = x[it][0] * vc[0];
-    u += x[it][1] * vc[1];
-    u += x[it][2] * vc[2];
-    u += x[it][3] * vc[3];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) u += __shfl_xor(u, off, 64);  // within the half
-    if (c4 == 0) P_out[r] = u;
+    const float u = pi_half_sum(pi_dot4(x[it], vc));
+    if (c4 == PI_SUM_LANE) P_out[r] = u;
   }
 }
 
@@ -197,15 +217,11 @@ static __global__ __launch_bounds__(256) void pi_mv_kernel(PiBlock* blocks,
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int r = 32 * wave + 2 * it + rh;
-    float u = x[it][0] * vj[0];
-    u += x[it][1] * vj[1];
-    u += x[it][2] * vj[2];
-    u += x[it][3] * vj[3];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) u += __shfl_xor(u, off, 64);  // within the half
-    if (c4 == 0) P[((int64_t)te.I * t + te.J) * PT + r] = u;
+    const float u = pi_half_sum(pi_dot4(x[it], vj));
+    if (c4 == PI_SUM_LANE) P[((int64_t)te.I * t + te.J) * PT + r] = u;
     const float vi = vI[r];
-    w[0] += x[it][0] * vi; w[1] += x[it][1] * vi; w[2] += x[it][2] * vi; w[3] += x[it][3] * vi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = __fmaf_rn(x[it][e], vi, w[e]);
   }
   if (offdiag && *pb->asym != 0) {
     // not symmetric: the contribution of v_I to y_J needs the tile (J, I) itself
@@ -293,6 +309,308 @@ static __global__ void pi_output_kernel(const PiBlock* blocks, int nblocks, floa
     for (int j = threadIdx.x; j < pb->n; j += blockDim.x) out_v[(int64_t)b * ldv + j] = pb->vn[j];
 }
 
+// ==================================================================================
+// Resident execution: the whole iteration in ONE launch, matrices held in registers.
+// ==================================================================================
+// The streaming execution above re-reads every matrix from HBM in each of the <= 100 steps
+// (173 MB per step for 256 x 512^2: 29 us at the HBM ceiling) and pays two launches per step.
+// But the upper block triangles of a whole batch fit the register files of the chip
+// (256 CUs x 512 KB): here every workgroup keeps up to PI_RNT 128x128 tiles (64 VGPRs per
+// tile) in registers for the entire iteration, and the workgroups of a block -- its "team" --
+// exchange only 128-float vectors through the memory-side cache:
+//   step:  tile mat-vecs from registers -> partial products P[X][Y]      (hop 1)
+//          the owner of block row X (the workgroup holding tile (X,X)) sums its row in
+//          pi_red_kernel's order and publishes y_X                        (hop 2)
+//          every workgroup gathers y and redoes the block's scalar reduction (s = v.y,
+//          ||y||, stop decision) and keeps the next iterate in LDS.
+// A step costs two hand-off latencies instead of a pass over HBM.  The arithmetic is the
+// streaming kernels' own (same per-tile code; the 512-thread reduction of pi_red_kernel is
+// emulated by 256 threads x 2 virtual threads): results are bit-identical.
+//
+// Hand-off = 8-byte granules {value, tag} written and polled with agent-coherent (sc1)
+// accesses (MI355X_MICROARCH.md, handoff-1to1): the tag is the step number + 1, the slabs are
+// zeroed by the host before the launch, so a granule validates itself -- no counters, no
+// cache-wide release / acquire fences (an agent-scope fence writes back / invalidates a whole
+// L2 on this multi-XCD part: 40 us per step measured with the fence protocol, 19 us with
+// counter + sc1 loads).  Slabs are double buffered by step parity: a workgroup can run at most
+// one step ahead of its slowest team mate (it needs every team mate's step-k data to finish
+// step k), so the slot of step k+2 is free when it is written.
+// Teams spin, so they must be co-resident: the host launches at most the resident capacity
+// of the chip per pass; blocks whose team exceeds it use the streaming execution.  Every
+// spin is bounded: on expiry the block's result is NaN (reported as a failed root).
+typedef unsigned long long pi_granule;
+
+__device__ __forceinline__ void pi_publish(pi_granule* p, float v, unsigned tag) {
+  const pi_granule g = ((pi_granule)tag << 32) | (pi_granule)__float_as_uint(v);
+  __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ pi_granule pi_peek(const pi_granule* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Polls until the granule carries `tag`; *dead is set when the bound expires.
+__device__ __forceinline__ float pi_await(const pi_granule* p, pi_granule g, unsigned tag,
+                                          bool* dead) {
+  int spins = 0;
+  unsigned long long t0 = 0;
+  while ((unsigned)(g >> 32) != tag) {
+    if ((++spins & 1023) == 0) {   // bound: 5 s of the 100 MHz constant clock
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > 500000000ull) { *dead = true; break; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+    g = pi_peek(p);
+  }
+  return __uint_as_float((unsigned)g);
+}
+
+#ifndef PI_RNT
+#define PI_RNT 3
+#endif
+#ifndef PI_ONE_HOP_T
+#define PI_ONE_HOP_T 4   // blocks of up to this many tiles per side exchange in one hop
+#endif
+struct PiTeamWG {
+  int block;
+  short ntile;   // tiles held by this workgroup (1..PI_RNT); 0: all-padding block
+  short lead;    // 1: writes the block's results
+  short I[4], J[4];
+};
+
+__device__ inline void pi_load_tile(const PiBlock* pb, int r0, int c0, int wave, int c4, int rh,
+                                    f32x4 (&x)[16]) {
+  const int n = pb->n, lda = pb->lda;
+  const float* a = pb->a;
+  const bool fast = pb->vec_ok && c0 + PT <= n && r0 + PT <= n;
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int r = 32 * wave + 2 * it + rh;
+      x[it] = gload4(a + (int64_t)(r0 + r) * lda + c0 + 4 * c4);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int r = 32 * wave + 2 * it + rh;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + 4 * c4 + e < n) t[e] = gload1(a + (int64_t)(r0 + r) * lda + c0 + 4 * c4 + e);
+      }
+      x[it] = t;
+    }
+  }
+}
+
+// One tile's contributions from registers: the arithmetic of pi_mv_kernel, term for term.
+// P: granule slab of this step, [t][t][128].  The 128 row sums u (produced two lanes at a
+// time) and the column sums are staged in LDS and published by 128 consecutive lanes, so a
+// vector leaves the CU as whole 128-byte lines (scattered 16-byte sc1 stores made the steps
+// transaction-bound).  stage: [2][128] floats of LDS owned by this tile slot.
+__device__ inline void pi_tile_from_regs(const PiBlock* pb, const f32x4 (&x)[16], int I, int J,
+                                         const float* vn, pi_granule* P, unsigned tag,
+                                         float (*wpart)[PT], float (*stage)[PT], bool asym,
+                                         int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int c4 = lane & 31, rh = lane >> 5;
+  const int r0 = I * PT, c0 = J * PT, t = pb->t;
+  const bool offdiag = I != J;
+  const float* vI = vn + r0;
+  const f32x4 vj = *reinterpret_cast<const f32x4*>(vn + c0 + 4 * c4);
+  f32x4 w = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int r = 32 * wave + 2 * it + rh;
+    const float u = pi_half_sum(pi_dot4(x[it], vj));
+    if (c4 == PI_SUM_LANE) stage[0][r] = u;
+    const float vi = vI[r];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = __fmaf_rn(x[it][e], vi, w[e]);
+  }
+  if (offdiag && asym) {
+    // the mirrored tile is streamed from memory, a few rows at a time (rare path: the tiles
+    // held in registers leave no room for pi_tile_rowdot's 16 loads in flight); the per-row
+    // arithmetic is pi_tile_rowdot's
+    const f32x4 vi4 = *reinterpret_cast<const f32x4*>(vI + 4 * c4);
+    const bool fast = pb->vec_ok && c0 + PT <= pb->n && r0 + PT <= pb->n;
+    const float* a = pb->a;
+    const int lda = pb->lda, n = pb->n;
+#pragma unroll 2
+    for (int it = 0; it < 16; ++it) {
+      const int r = 32 * wave + 2 * it + rh;
+      f32x4 xx = {0.f, 0.f, 0.f, 0.f};
+      if (fast) {
+        xx = gload4(a + (int64_t)(c0 + r) * lda + r0 + 4 * c4);
+      } else if (c0 + r < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (r0 + 4 * c4 + e < n) xx[e] = gload1(a + (int64_t)(c0 + r) * lda + r0 + 4 * c4 + e);
+      }
+      const float u = pi_half_sum(pi_dot4(xx, vi4));
+      if (c4 == PI_SUM_LANE) stage[1][r] = u;
+    }
+  } else if (offdiag) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] += __shfl_xor(w[e], 32, 64);
+    if (rh == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wpart[wave][4 * c4 + e] = w[e];
+    }
+  }
+  __syncthreads();
+  if (tid < PT) {
+    pi_publish(P + ((int64_t)I * t + J) * PT + tid, stage[0][tid], tag);
+    if (offdiag)
+      pi_publish(P + ((int64_t)J * t + I) * PT + tid,
+                 asym ? stage[1][tid]
+                      : ((wpart[0][tid] + wpart[1][tid]) + wpart[2][tid]) + wpart[3][tid],
+                 tag);
+  }
+}
+
+template <int NT>
+static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void pi_resident_kernel(
+    PiBlock* blocks, const PiTeamWG* wgs, int num_iters, float tol) {
+  extern __shared__ __align__(16) float pi_lds[];  // vn[tp] | y[tp], tp = t*128 of the largest block
+  __shared__ float wpart[NT][4][PT];
+  __shared__ float stage[NT][2][PT];
+  __shared__ float red[16];
+  __shared__ int s_dead;
+  const PiTeamWG te = wgs[blockIdx.x];
+  if (te.block < 0) return;
+  PiBlock* pb = &blocks[te.block];
+  const int n = pb->n, t = pb->t, tp = t * PT, tid = threadIdx.x;
+  if (n == 0) {  // all padding: v0 masked to zero, 0/0 (DS:634)
+    if (te.lead && tid == 0) {
+      pb->lambda = __uint_as_float(0x7fc00000u);
+      pb->iters = 1;
+      pb->stop_iter = 0;
+    }
+    return;
+  }
+  float* vn = pi_lds;
+  float* ysm = pi_lds + tp;
+  for (int j = tid; j < tp; j += 256) vn[j] = pb->vn[j];
+  if (tid == 0) s_dead = 0;
+  const int wave = tid >> 6, lane = tid & 63;
+  f32x4 x[NT][16];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    if (k < te.ntile) {
+      pi_load_tile(pb, te.I[k] * PT, te.J[k] * PT, wave, lane & 31, lane >> 5, x[k]);
+    } else {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) x[k][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  const bool asym = *pb->asym != 0;
+  pi_granule* Pbase = reinterpret_cast<pi_granule*>(pb->P);
+  const int64_t slab = (int64_t)t * t * PT;            // P granules per parity
+  pi_granule* Ybase = Pbase + 2 * slab;                // y granules: [2][tp]
+  float s_prev = 0.f;
+  bool dead = false;
+  for (int iter = 0; iter < num_iters; ++iter) {
+    const unsigned tag = (unsigned)iter + 1u;
+    pi_granule* P = Pbase + (int64_t)(iter & 1) * slab;
+    pi_granule* Yg = Ybase + (int64_t)(iter & 1) * tp;
+    // ---- hop 1: partial products of this workgroup's tiles ----
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+      if (k < te.ntile)
+        pi_tile_from_regs(pb, x[k], te.I[k], te.J[k], vn, P, tag, wpart[k], stage[k], asym, tid);
+    float sv[2] = {0.f, 0.f}, ssv[2] = {0.f, 0.f};
+    if (t <= PI_ONE_HOP_T) {
+      // small blocks: every workgroup sums the whole slab itself (one hand-off latency per
+      // step; t*t*128 granules = 16 KB at t = 4)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        for (int j = tid + 256 * v; j < tp; j += 512) {
+          const int X = j >> 7, r = j & 127;
+          const pi_granule* p = P + (int64_t)X * t * PT + r;
+          float y = 0.f;
+          int Y = 0;
+          for (; Y + 4 <= t; Y += 4) {  // independent loads, pi_red_kernel's summation order
+            const pi_granule g0 = pi_peek(p + (Y + 0) * PT), g1 = pi_peek(p + (Y + 1) * PT),
+                             g2 = pi_peek(p + (Y + 2) * PT), g3 = pi_peek(p + (Y + 3) * PT);
+            const float p0 = pi_await(p + (Y + 0) * PT, g0, tag, &dead);
+            const float p1 = pi_await(p + (Y + 1) * PT, g1, tag, &dead);
+            const float p2 = pi_await(p + (Y + 2) * PT, g2, tag, &dead);
+            const float p3 = pi_await(p + (Y + 3) * PT, g3, tag, &dead);
+            y = (((y + p0) + p1) + p2) + p3;
+          }
+          for (; Y < t; ++Y) y += pi_await(p + Y * PT, pi_peek(p + Y * PT), tag, &dead);
+          ysm[j] = y;
+          sv[v] += vn[j] * y;   // DS:637
+          ssv[v] += y * y;
+        }
+      }
+    } else {
+      // ---- hop 2: rows owned by this workgroup (it holds their diagonal tile) ----
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        if (k < te.ntile && te.I[k] == te.J[k] && tid < PT) {
+          const int X = te.I[k];
+          const pi_granule* p = P + (int64_t)X * t * PT + tid;
+          float y = 0.f;
+          int Y = 0;
+          for (; Y + 4 <= t; Y += 4) {
+            const pi_granule g0 = pi_peek(p + (Y + 0) * PT), g1 = pi_peek(p + (Y + 1) * PT),
+                             g2 = pi_peek(p + (Y + 2) * PT), g3 = pi_peek(p + (Y + 3) * PT);
+            const float p0 = pi_await(p + (Y + 0) * PT, g0, tag, &dead);
+            const float p1 = pi_await(p + (Y + 1) * PT, g1, tag, &dead);
+            const float p2 = pi_await(p + (Y + 2) * PT, g2, tag, &dead);
+            const float p3 = pi_await(p + (Y + 3) * PT, g3, tag, &dead);
+            y = (((y + p0) + p1) + p2) + p3;
+          }
+          for (; Y < t; ++Y) y += pi_await(p + Y * PT, pi_peek(p + Y * PT), tag, &dead);
+          pi_publish(Yg + X * PT + tid, y, tag);
+        }
+      }
+      // ---- gather y; pi_red_kernel's reduction, its 512 threads as 2 virtual threads each ----
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        for (int j = tid + 256 * v; j < tp; j += 512) {
+          const float y = pi_await(Yg + j, pi_peek(Yg + j), tag, &dead);
+          ysm[j] = y;
+          sv[v] += vn[j] * y;   // DS:637
+          ssv[v] += y * y;
+        }
+      }
+    }
+    if (dead) s_dead = 1;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const float a = wave_sum_f32(sv[v]), b = wave_sum_f32(ssv[v]);
+      if (lane == 0) { red[4 * v + wave] = a; red[8 + 4 * v + wave] = b; }
+    }
+    __syncthreads();
+    float s_new = 0.f, n2 = 0.f;
+    for (int w = 0; w < 8; ++w) { s_new += red[w]; n2 += red[8 + w]; }
+    const bool expired = s_dead != 0;
+    if (expired) s_new = __uint_as_float(0x7fc00000u);
+    const float nrm = sqrtf(n2);
+    const bool run = fabsf(s_new - s_prev) > tol;  // DS:639 (false for NaN: the loop ends)
+    const bool last = iter + 1 >= num_iters;
+    for (int j = tid; j < tp; j += 256) vn[j] = j < n ? ysm[j] / nrm : 0.f;
+    __syncthreads();
+    s_prev = s_new;
+    if (!run || last || expired) {
+      if (te.lead) {
+        for (int j = tid; j < tp; j += 256) pb->vn[j] = vn[j];
+        if (tid == 0) {
+          pb->s_prev = s_new;
+          pb->lambda = s_new;
+          pb->iters = iter + 1;
+          pb->stop_iter = iter;
+        }
+      }
+      break;
+    }
+  }
+}
+
 // ---- host side --------------------------------------------------------------------
 struct PiPlan {
   int batch = 0, max_n = 0;
@@ -303,6 +621,13 @@ struct PiPlan {
   float* d_v0 = nullptr;
   int* d_asym = nullptr;   // [batch] 1 = not exactly symmetric
   std::vector<float*> d_vn, d_P;
+  // resident execution (pi_resident_kernel): team workgroups, split into co-resident passes
+  static constexpr int RNT = PI_RNT;     // tiles per workgroup
+  std::vector<PiTeamWG> wgs;
+  std::vector<int> team;                 // workgroups per block
+  PiTeamWG* d_wgs = nullptr;
+  char* d_region = nullptr;              // per-block iterates + slabs (zeroed per resident call)
+  size_t region_bytes = 0;
 
   void build(int b, const std::vector<int>& ne) {
     batch = b;
@@ -315,6 +640,26 @@ struct PiPlan {
       for (int I = 0; I < t; ++I)
         for (int J = I; J < t; ++J) tiles.push_back({i, (short)I, (short)J});
     }
+    // teams: consecutive tiles of a block, RNT per workgroup; an all-padding block gets one
+    // workgroup that only writes its NaN result
+    wgs.clear();
+    team.assign(b, 0);
+    size_t k = 0;
+    for (int i = 0; i < b; ++i) {
+      const int t = (ne[i] + PT - 1) / PT, nt = t * (t + 1) / 2;
+      if (nt == 0) {
+        wgs.push_back({i, 0, 1, {0, 0, 0, 0}, {0, 0, 0, 0}});
+        team[i] = 1;
+        continue;
+      }
+      for (int f = 0; f < nt; f += RNT) {
+        PiTeamWG w{i, (short)std::min(RNT, nt - f), (short)(f == 0 ? 1 : 0), {0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int e = 0; e < w.ntile; ++e) { w.I[e] = tiles[k + f + e].I; w.J[e] = tiles[k + f + e].J; }
+        wgs.push_back(w);
+        ++team[i];
+      }
+      k += nt;
+    }
   }
 
   void carve(psh::Arena& ar, bool assign) {
@@ -322,13 +667,20 @@ struct PiPlan {
     PiTile* tl = ar.take<PiTile>(std::max<size_t>(tiles.size(), 1));
     float* v0 = ar.take<float>(std::max(max_n, 1));
     int* asym = ar.take<int>(std::max(batch, 1));
-    if (assign) { d_blocks = blk; d_tiles = tl; d_v0 = v0; d_asym = asym; d_vn.clear(); d_P.clear(); }
+    PiTeamWG* wg = ar.take<PiTeamWG>(std::max<size_t>(wgs.size(), 1));
+    if (assign) {
+      d_blocks = blk; d_tiles = tl; d_v0 = v0; d_asym = asym; d_wgs = wg;
+      d_vn.clear(); d_P.clear();
+    }
+    char* region0 = ar.base ? ar.base + psh::align_up(ar.off, 256) : nullptr;
     for (int i = 0; i < batch; ++i) {
       const int t = (n_eff[i] + PT - 1) / PT;
       float* vn = ar.take<float>(std::max(t * PT, 1));
-      float* P = ar.take<float>(std::max(t * t * PT, 1));
+      // resident execution: 8-byte granules, two step parities of the partial slab + of y
+      float* P = ar.take<float>(std::max(4 * (t * t + t) * PT, 1));
       if (assign) { d_vn.push_back(vn); d_P.push_back(P); }
     }
+    if (assign) { d_region = region0; region_bytes = ar.base ? (size_t)(ar.base + ar.off - region0) : 0; }
   }
 
   // Uploads the descriptors through the pinned staging ring (no stream synchronisation).
@@ -346,6 +698,7 @@ struct PiPlan {
       pb.P = d_P[i];
       pb.stop_iter = -1;
       pb.asym = d_asym + i;
+      pb.team = team[i];
     }
     std::vector<float> v0(std::max(max_n, 1));
     ps_power_iteration_v0(max_n, v0.data());
@@ -353,6 +706,8 @@ struct PiPlan {
     PS_RC(psh::upload_async(st, d_v0, v0.data(), sizeof(float) * v0.size()));
     if (!tiles.empty())
       PS_RC(psh::upload_async(st, d_tiles, tiles.data(), sizeof(PiTile) * tiles.size()));
+    if (!wgs.empty())
+      PS_RC(psh::upload_async(st, d_wgs, wgs.data(), sizeof(PiTeamWG) * wgs.size()));
     return 0;
   }
 
@@ -371,13 +726,93 @@ struct PiPlan {
     return 0;
   }
 
-  // Enqueues the whole iteration: 2 launches per step, fixed count (data-dependent
-  // stops are taken on the device; stopped blocks' workgroups exit at once).
+  // Co-resident capacity of the resident kernel on this device (workgroups), 0 = unusable.
+  static int resident_capacity(size_t dyn_lds) {
+    static int cus = -1;
+    if (cus < 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        cus = 0;
+      else
+        cus = prop.multiProcessorCount;
+      (void)hipFuncSetAttribute((const void*)pi_resident_kernel<RNT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    }
+    int per_cu = 0;
+    if (cus <= 0 || hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                        &per_cu, pi_resident_kernel<RNT>, 256, dyn_lds) != hipSuccess)
+      return 0;
+    // the occupancy API can answer one block per CU too high for kernels with ~100 SGPRs
+    // (MI355X_MICROARCH.md, correctness boundaries): never exceed the launch bound
+    const int bound = RNT >= 3 ? 2 : (RNT == 2 ? 3 : 4);
+    return std::min(per_cu, bound) * cus;
+  }
+
+  static bool resident_enabled() {  // read per call: tests switch executions in one process
+    const char* e = getenv("PS_PI_RESIDENT");
+    return !(e && e[0] == '0');
+  }
+
+  // Two resident launches on DIFFERENT streams could each hold part of the chip while their
+  // teams wait for slots: the resident execution is used only when the previous resident
+  // launch of this process went to the same stream or has completed.
+  static bool resident_exclusive(hipStream_t st, bool record) {
+    static std::mutex mu;
+    static hipStream_t last_stream = nullptr;
+    static hipEvent_t last_ev = nullptr;
+    static bool any = false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!record) {
+      if (!any || last_stream == st) return true;
+      return hipEventQuery(last_ev) == hipSuccess;
+    }
+    if (!last_ev && hipEventCreateWithFlags(&last_ev, hipEventDisableTiming) != hipSuccess)
+      return false;
+    (void)hipEventRecord(last_ev, st);
+    last_stream = st;
+    any = true;
+    return true;
+  }
+
+  // Enqueues the whole iteration.  Resident execution (default): one launch per co-resident
+  // pass, matrices in registers.  Streaming execution (PS_PI_RESIDENT=0, teams larger than the
+  // chip, or a resident launch in flight on another stream): 2 launches per step, fixed
+  // count (data-dependent stops are taken on the device; stopped blocks' workgroups exit at
+  // once).  Same arithmetic, bit-identical results.
   int enqueue(hipStream_t st, int num_iters, float tol) {
     const size_t shm = 0;
     const size_t red_shm = (size_t)((max_n + PT - 1) / PT) * PT * sizeof(float);  // <= 64 KB
     if (batch == 0) return 0;
+    const size_t res_lds = 2 * red_shm;
+    const int cap = (resident_enabled() && num_iters > 0 && res_lds <= 48 * 1024)
+                        ? resident_capacity(res_lds) : 0;
+    int biggest = 0;
+    for (int i = 0; i < batch; ++i) biggest = std::max(biggest, team[i]);
+    const bool resident = cap > 0 && biggest <= cap && resident_exclusive(st, false);
+    // granule tags must not match leftovers of an earlier call in the same workspace
+    if (resident && region_bytes) PS_HIP(hipMemsetAsync(d_region, 0, region_bytes, st));
     hipLaunchKernelGGL(pi_init_kernel, dim3(batch), dim3(256), 0, st, d_blocks, d_v0);
+    if (resident) {
+      // passes of whole teams, in block order, at most `cap` workgroups each
+      size_t first = 0;
+      while (first < wgs.size()) {
+        size_t end = first;
+        int used = 0;
+        while (end < wgs.size()) {
+          const int tm = team[wgs[end].block];
+          if (used + tm > cap) break;
+          used += tm;
+          end += tm;
+        }
+        hipLaunchKernelGGL(pi_resident_kernel<RNT>, dim3((unsigned)(end - first)), dim3(256),
+                           res_lds, st, d_blocks, d_wgs + first, num_iters, tol);
+        first = end;
+      }
+      PS_LAUNCH_CHECK();
+      resident_exclusive(st, true);
+      return 0;
+    }
     const int nt = (int)tiles.size();
     for (int i = 0; i < num_iters; ++i) {
       if (nt > 0)
