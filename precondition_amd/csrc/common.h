@@ -5,7 +5,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
+#include <vector>
 
 #include "../../include/ps_api.h"
 
@@ -100,6 +102,62 @@ inline int upload_async(hipStream_t st, void* dst, const void* src, size_t bytes
   PS_HIP(hipEventRecord(s.ev, st));
   s.used = true;
   return 0;
+}
+
+// ---- tile lists in hardware dispatch order --------------------------------------------
+// Workgroups of a launch are dealt round-robin over the 8 XCDs (each with its own L2), so
+// entry b of a tile list that the kernel indexes with blockIdx.x runs on XCD b % 8.
+// deal_to_xcds splits the tasks of a grouped launch (task i = ntile[i] tiles of cost[i]
+// each) into units -- a whole task, or a run of its tiles when the launch is too small to
+// give every XCD a few tasks -- assigns the units to the XCDs by longest-processing-time-
+// first, and orders every XCD's units by descending per-tile cost (cheap tiles fill the
+// tail).  A task's tiles stay on one L2 and the 8 XCDs finish together; a contiguous-chunk
+// remap of a cost-sorted or heterogeneous list leaves one XCD with all the expensive tiles.
+// The caller expands the units into tiles, pads the shorter lists with no-op entries and
+// interleaves them: list[j * 8 + x] = j-th tile of XCD x.
+constexpr int NXCD = 8;
+struct DealUnit {
+  int task, first, count;  // tiles [first, first + count) of the task, in the task's own order
+  int64_t tile_cost;
+};
+
+inline void deal_to_xcds(const std::vector<int>& ntile, const std::vector<int64_t>& cost,
+                         std::vector<DealUnit> (&lists)[NXCD]) {
+  int64_t total = 0;
+  for (int n : ntile) total += n;
+  const int unit_max = (int)std::max<int64_t>(1, total / (NXCD * 8));
+  std::vector<DealUnit> units;
+  for (size_t i = 0; i < ntile.size(); ++i)
+    for (int f = 0; f < ntile[i]; f += unit_max)
+      units.push_back({(int)i, f, std::min(unit_max, ntile[i] - f), cost[i]});
+  std::vector<int> order(units.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return units[a].tile_cost * units[a].count > units[b].tile_cost * units[b].count;
+  });
+  int64_t load[NXCD] = {0};
+  for (int x = 0; x < NXCD; ++x) lists[x].clear();
+  for (int u : order) {
+    int best = 0;
+    for (int x = 1; x < NXCD; ++x)
+      if (load[x] < load[best]) best = x;
+    lists[best].push_back(units[u]);
+    load[best] += units[u].tile_cost * units[u].count;
+  }
+  for (int x = 0; x < NXCD; ++x)
+    std::stable_sort(lists[x].begin(), lists[x].end(),
+                     [](const DealUnit& a, const DealUnit& b) { return a.tile_cost > b.tile_cost; });
+}
+
+// Interleaves per-XCD tile lists into dispatch order, padding with `noop`.
+template <typename Tile>
+inline void interleave_xcd_lists(std::vector<Tile> (&lists)[NXCD], const Tile& noop,
+                                 std::vector<Tile>& out) {
+  size_t longest = 0;
+  for (int x = 0; x < NXCD; ++x) longest = std::max(longest, lists[x].size());
+  out.assign(longest * NXCD, noop);
+  for (int x = 0; x < NXCD; ++x)
+    for (size_t j = 0; j < lists[x].size(); ++j) out[j * NXCD + x] = lists[x][j];
 }
 
 }  // namespace psh

@@ -196,7 +196,8 @@ template <int LA, int LB>
 __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GTask* tasks,
                                                               const GTile* tiles, int ntiles) {
   extern __shared__ __align__(16) float smem[];
-  const GTile te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  const GTile te = tiles[blockIdx.x];   // dispatch order (common.h deal_to_xcds)
+  if (te.task < 0) return;
   const GTask tk = tasks[te.task];
   const int k0 = te.ks * tk.kchunk;
   const int kext = min(tk.kchunk, tk.k - k0);
@@ -287,7 +288,7 @@ static size_t grouped_gemm_bytes(const ps_gemm_desc* d, int count) {
     if (s > 1) partial += psh::align_up((size_t)s * d[i].m * d[i].n * sizeof(float), 256) + 256;
   }
   return 4 * (psh::align_up(sizeof(GTask) * count, 256) + 256) +
-         4 * (psh::align_up(sizeof(GTile) * split_tiles, 256) + 256) +
+         4 * (psh::align_up(sizeof(GTile) * split_tiles * psh::NXCD, 256) + 256) +
          psh::align_up(sizeof(int) * count, 256) + 256 + partial + 1024;
 }
 
@@ -327,10 +328,33 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
     const int id = (int)tasks[g].size();
     tasks[g].push_back(t);
     if (t.ksplit > 1) split_ids[g].push_back(id);
-    const int tm = (d.m + TILE - 1) / TILE, tn = (d.n + TILE - 1) / TILE;
-    for (int a = 0; a < tm; ++a)
-      for (int b = 0; b < tn; ++b)
-        for (int ks = 0; ks < t.ksplit; ++ks) tiles[g].push_back({id, (short)a, (short)b, ks});
+  }
+  // tile lists in dispatch order: tasks dealt to the XCDs by cost (K-tiles per tile + an
+  // epilogue term; the mat-vec tiles of one-row products are short streams)
+  for (int g = 0; g < 4; ++g) {
+    if (tasks[g].empty()) continue;
+    std::vector<int> ntile(tasks[g].size());
+    std::vector<int64_t> cost(tasks[g].size());
+    for (size_t i = 0; i < tasks[g].size(); ++i) {
+      const GTask& t = tasks[g][i];
+      const int tm = (t.m + TILE - 1) / TILE, tn = (t.n + TILE - 1) / TILE;
+      ntile[i] = tm * tn * t.ksplit;
+      const bool gemv = (g == 0 || g == 2) && t.m == 1 && t.ksplit == 1;
+      cost[i] = gemv ? 2 : (t.kchunk + 31) / 32 + 4;
+    }
+    std::vector<psh::DealUnit> units[psh::NXCD];
+    psh::deal_to_xcds(ntile, cost, units);
+    std::vector<GTile> lists[psh::NXCD];
+    for (int x = 0; x < psh::NXCD; ++x)
+      for (const psh::DealUnit& un : units[x]) {
+        const GTask& t = tasks[g][un.task];
+        const int tn = (t.n + TILE - 1) / TILE;
+        for (int idx = un.first; idx < un.first + un.count; ++idx) {
+          const int ks = idx % t.ksplit, ab = idx / t.ksplit;
+          lists[x].push_back({un.task, (short)(ab / tn), (short)(ab % tn), ks});
+        }
+      }
+    psh::interleave_xcd_lists(lists, GTile{-1, 0, 0, 0}, tiles[g]);
   }
   GTask* dt[4];
   GTile* dl[4];

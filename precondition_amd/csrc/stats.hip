@@ -303,7 +303,7 @@ using namespace psk;
 
 namespace {
 
-constexpr int NXCD = 8;
+using psh::NXCD;
 
 bool to_task(const ps_stats_desc& d, StatsTask& t) {
   if (!d.g || !d.stat_in || !d.stat_out || d.d < 1 || d.k < 1 || d.nseg < 1 ||
@@ -333,57 +333,23 @@ size_t grouped_bytes(const ps_stats_desc* desc, int count) {
          psh::align_up(sizeof(StatsTile) * tiles * NXCD, 256) + 1024;
 }
 
-// Tile list in dispatch order.  Workgroups are dealt round-robin over the 8 XCDs (each with
-// its own L2), so entry b of the list runs on XCD b % 8.  Units of work -- a whole statistic,
-// or a run of its tiles when the launch is too small to give every XCD a few statistics --
-// are assigned to the XCDs by longest-processing-time-first on a per-tile cost (K-tiles of the
-// contraction + an epilogue term; a vector statistic's tile is a short stream), which keeps a
-// statistic's tiles on one L2 and the 8 XCDs equally loaded.  Inside an XCD the expensive
-// tiles go first so that the cheap ones fill the tail.
-struct TileUnit {
-  int task, first, count;  // tiles [first, first + count) of the task's upper triangle
-  int64_t tile_cost;
-};
-
+// Tile list in dispatch order (common.h deal_to_xcds): per-tile cost = K-tiles of the
+// contraction + an epilogue term; a vector statistic's tile is a short stream.
 void make_tile_list(const std::vector<StatsTask>& tasks, std::vector<StatsTile>& out) {
-  int64_t total = 0;
   std::vector<int> ntile(tasks.size());
-  for (size_t i = 0; i < tasks.size(); ++i) {
-    const int nt = (tasks[i].d + TILE - 1) / TILE;
-    ntile[i] = nt * (nt + 1) / 2;
-    total += ntile[i];
-  }
-  const int unit_max = (int)std::max<int64_t>(1, total / (NXCD * 8));
-  std::vector<TileUnit> units;
+  std::vector<int64_t> cost(tasks.size());
   for (size_t i = 0; i < tasks.size(); ++i) {
     const StatsTask& t = tasks[i];
+    const int nt = (t.d + TILE - 1) / TILE;
+    ntile[i] = nt * (nt + 1) / 2;
     const bool vec = t.k == 1 && t.nseg == 1;
-    const int64_t kt = ((int64_t)t.k + SBK - 1) / SBK * t.nseg;
-    const int64_t cost = vec ? 3 : kt + 6;
-    for (int f = 0; f < ntile[i]; f += unit_max)
-      units.push_back({(int)i, f, std::min(unit_max, ntile[i] - f), cost});
+    cost[i] = vec ? 3 : ((int64_t)t.k + SBK - 1) / SBK * t.nseg + 6;
   }
-  std::vector<int> order(units.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    return units[a].tile_cost * units[a].count > units[b].tile_cost * units[b].count;
-  });
-  std::vector<int> bins[NXCD];
-  int64_t load[NXCD] = {0};
-  for (int u : order) {
-    int best = 0;
-    for (int x = 1; x < NXCD; ++x)
-      if (load[x] < load[best]) best = x;
-    bins[best].push_back(u);
-    load[best] += units[u].tile_cost * units[u].count;
-  }
-  std::vector<StatsTile> lists[NXCD];
-  size_t longest = 0;
-  for (int x = 0; x < NXCD; ++x) {
-    std::stable_sort(bins[x].begin(), bins[x].end(),
-                     [&](int a, int b) { return units[a].tile_cost > units[b].tile_cost; });
-    for (int u : bins[x]) {
-      const TileUnit& un = units[u];
+  std::vector<psh::DealUnit> units[psh::NXCD];
+  psh::deal_to_xcds(ntile, cost, units);
+  std::vector<StatsTile> lists[psh::NXCD];
+  for (int x = 0; x < psh::NXCD; ++x)
+    for (const psh::DealUnit& un : units[x]) {
       const int nt = (tasks[un.task].d + TILE - 1) / TILE;
       int idx = 0;
       for (int tm = 0; tm < nt; ++tm)
@@ -391,11 +357,7 @@ void make_tile_list(const std::vector<StatsTask>& tasks, std::vector<StatsTile>&
           if (idx >= un.first && idx < un.first + un.count)
             lists[x].push_back({un.task, (short)tm, (short)tn});
     }
-    longest = std::max(longest, lists[x].size());
-  }
-  out.assign(longest * NXCD, StatsTile{-1, 0, 0});
-  for (int x = 0; x < NXCD; ++x)
-    for (size_t j = 0; j < lists[x].size(); ++j) out[j * NXCD + x] = lists[x][j];
+  psh::interleave_xcd_lists(lists, StatsTile{-1, 0, 0}, out);
 }
 
 template <typename K>
