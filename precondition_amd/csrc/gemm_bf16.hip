@@ -161,8 +161,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_splitk_reduce_kernel(const HTas
   if (tk.ksplit <= 1) return;
   const int64_t mn = (int64_t)tk.m * tk.n;
   for (int64_t e = blockIdx.y * 256 + threadIdx.x; e < mn; e += (int64_t)gridDim.y * 256) {
+    // all partials of the element in flight, then summed in split order (deterministic)
     float v = 0.f;
-    for (int s = 0; s < tk.ksplit; ++s) v += tk.partial[s * mn + e];
+    int s = 0;
+    for (; s + 4 <= tk.ksplit; s += 4) {
+      const float p0 = tk.partial[(s + 0) * mn + e], p1 = tk.partial[(s + 1) * mn + e],
+                  p2 = tk.partial[(s + 2) * mn + e], p3 = tk.partial[(s + 3) * mn + e];
+      v = (((v + p0) + p1) + p2) + p3;
+    }
+    for (; s < tk.ksplit; ++s) v += tk.partial[s * mn + e];
     tk.c[(e / tk.n) * tk.ldc + e % tk.n] = v;
   }
 }
@@ -316,7 +323,7 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
     bool any_split = false;
     for (auto& t : tasks[g]) any_split |= t.ksplit > 1;
     if (any_split)
-      hipLaunchKernelGGL(gemm_bf16_splitk_reduce_kernel, dim3((unsigned)tasks[g].size(), 16),
+      hipLaunchKernelGGL(gemm_bf16_splitk_reduce_kernel, dim3((unsigned)tasks[g].size(), 256),
                          dim3(256), 0, st, dt);
     PS_LAUNCH_CHECK();
   }

@@ -253,8 +253,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GTask* ta
   const GTask tk = tasks[task_ids[blockIdx.x]];
   const int64_t mn = (int64_t)tk.m * tk.n;
   for (int64_t e = blockIdx.y * 256 + threadIdx.x; e < mn; e += (int64_t)gridDim.y * 256) {
+    // all partials of the element in flight, then summed in split order (deterministic)
     float v = 0.f;
-    for (int s = 0; s < tk.ksplit; ++s) v += tk.partial[s * mn + e];
+    int s = 0;
+    for (; s + 4 <= tk.ksplit; s += 4) {
+      const float p0 = tk.partial[(s + 0) * mn + e], p1 = tk.partial[(s + 1) * mn + e],
+                  p2 = tk.partial[(s + 2) * mn + e], p3 = tk.partial[(s + 3) * mn + e];
+      v = (((v + p0) + p1) + p2) + p3;
+    }
+    for (; s < tk.ksplit; ++s) v += tk.partial[s * mn + e];
     tk.c[(e / tk.n) * tk.ldc + e % tk.n] = v;
   }
 }
@@ -386,7 +393,7 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
     hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB>), dim3((unsigned)tiles[G].size()), blk, \
                        GEMM_GROUPED_LDS_BYTES, st, dt[G], dl[G], (int)tiles[G].size());    \
     if (!split_ids[G].empty())                                                             \
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)split_ids[G].size(), 16), \
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)split_ids[G].size(), 256), \
                          blk, 0, st, dt[G], di[G]);                                        \
   }
   PS_GG(0, KC, MC);

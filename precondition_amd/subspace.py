@@ -162,7 +162,7 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
     spread = (_acosh((top - ctr[:, :, 0]) / e[:, :, 0]) -
               _acosh((xk - ctr[:, :, 0]) / e[:, :, 0])).clamp_min(1e-6)
     deg = torch.clamp(torch.floor(4.6 / spread), 1, degree)[:, :, None]   # [B, 1, 1]
-    max_deg = int(deg.max())
+    max_deg, min_deg = (int(v) for v in torch.stack((deg.max(), deg.min())).tolist())
     # z = C x is current from the Rayleigh-Ritz step
     y_prev = x.clone()
     y = (z - ctr * x) * (sigma1 / e)
@@ -173,6 +173,9 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
       gemms += 1
       sigma_new = 1.0 / (2.0 / sigma1 - sigma)
       y_next = (z - ctr * y) * (2.0 * sigma_new / e) - (sigma * sigma_new) * y_prev
+      if step <= min_deg:  # every matrix still filters: no masked selects over [B, n, b]
+        y_prev, y, sigma = y, y_next, sigma_new
+        continue
       active = deg >= step
       y_prev = torch.where(active, y, y_prev)
       y = torch.where(active, y_next, y)
