@@ -302,8 +302,12 @@ __device__ inline float row16_sum(float x) {
 
 // All sweeps of the one-sided Jacobi on the LDS images G (= A V) and V, m (even) players,
 // 1024 threads.  Returns the number of sweeps run (the last one without a rotation).
-__device__ inline int onesided_jacobi_lds(float* G, float* V, int* s_rot, int m, bool tall,
-                                          int max_sweeps) {
+// EXTRA = elements per lane beyond the first 64 rows: 0 (m <= 64), 2 (m <= 96: rows 64 + 2l,
+// 64 + 2l + 1), 4 (m <= 128: rows 64 + 4l ...).  Rows that do not exist are never touched: a
+// 96 x 96 problem (the block size of the subspace iteration) does 3/4 of the 128-row work.
+template <int EXTRA>
+__device__ inline int onesided_jacobi_lds_t(float* G, float* V, int* s_rot, int m,
+                                            int max_sweeps) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane >> 4, l = lane & 15;     // 16 lanes per pair, 4 pairs per wavefront
   const int k = 4 * wave + sub;                 // pair index within the round
@@ -325,16 +329,24 @@ __device__ inline int onesided_jacobi_lds(float* G, float* V, int* s_rot, int m,
         f32x4 a0 = *reinterpret_cast<f32x4*>(gp), b0 = *reinterpret_cast<f32x4*>(gq);
         f32x4 w0 = *reinterpret_cast<f32x4*>(vp), x0 = *reinterpret_cast<f32x4*>(vq);
         f32x4 a1 = zero4, b1 = zero4, w1 = zero4, x1 = zero4;
-        if (tall) {
+        if (EXTRA == 4) {
           a1 = *reinterpret_cast<f32x4*>(gp + 64); b1 = *reinterpret_cast<f32x4*>(gq + 64);
           w1 = *reinterpret_cast<f32x4*>(vp + 64); x1 = *reinterpret_cast<f32x4*>(vq + 64);
+        } else if (EXTRA == 2) {
+          // rows 64 + 2l, 64 + 2l + 1: column base + 64 + 2l = (base + 4l) + 64 - 2l
+          const f32x2 ta = *reinterpret_cast<f32x2*>(gp + 64 - 2 * l), tb = *reinterpret_cast<f32x2*>(gq + 64 - 2 * l);
+          const f32x2 tw = *reinterpret_cast<f32x2*>(vp + 64 - 2 * l), tx = *reinterpret_cast<f32x2*>(vq + 64 - 2 * l);
+          a1[0] = ta[0]; a1[1] = ta[1]; b1[0] = tb[0]; b1[1] = tb[1];
+          w1[0] = tw[0]; w1[1] = tw[1]; x1[0] = tx[0]; x1[1] = tx[1];
         }
         float aa = 0.f, bb = 0.f, ab = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          aa += a0[j] * a0[j] + a1[j] * a1[j];
-          bb += b0[j] * b0[j] + b1[j] * b1[j];
-          ab += a0[j] * b0[j] + a1[j] * b1[j];
+          aa += a0[j] * a0[j]; bb += b0[j] * b0[j]; ab += a0[j] * b0[j];
+        }
+#pragma unroll
+        for (int j = 0; j < EXTRA; ++j) {
+          aa += a1[j] * a1[j]; bb += b1[j] * b1[j]; ab += a1[j] * b1[j];
         }
         aa = row16_sum(aa); bb = row16_sum(bb); ab = row16_sum(ab);
         // rotate unless the columns are already orthogonal to working precision
@@ -352,15 +364,22 @@ __device__ inline int onesided_jacobi_lds(float* G, float* V, int* s_rot, int m,
             }
             *reinterpret_cast<f32x4*>(gp) = na0; *reinterpret_cast<f32x4*>(gq) = nb0;
             *reinterpret_cast<f32x4*>(vp) = nw0; *reinterpret_cast<f32x4*>(vq) = nx0;
-            if (tall) {
-              f32x4 na1, nb1, nw1, nx1;
+            if (EXTRA > 0) {
+              f32x4 na1 = zero4, nb1 = zero4, nw1 = zero4, nx1 = zero4;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
+              for (int j = 0; j < EXTRA; ++j) {
                 na1[j] = c * a1[j] - sn * b1[j]; nb1[j] = sn * a1[j] + c * b1[j];
                 nw1[j] = c * w1[j] - sn * x1[j]; nx1[j] = sn * w1[j] + c * x1[j];
               }
-              *reinterpret_cast<f32x4*>(gp + 64) = na1; *reinterpret_cast<f32x4*>(gq + 64) = nb1;
-              *reinterpret_cast<f32x4*>(vp + 64) = nw1; *reinterpret_cast<f32x4*>(vq + 64) = nx1;
+              if (EXTRA == 4) {
+                *reinterpret_cast<f32x4*>(gp + 64) = na1; *reinterpret_cast<f32x4*>(gq + 64) = nb1;
+                *reinterpret_cast<f32x4*>(vp + 64) = nw1; *reinterpret_cast<f32x4*>(vq + 64) = nx1;
+              } else {
+                *reinterpret_cast<f32x2*>(gp + 64 - 2 * l) = f32x2{na1[0], na1[1]};
+                *reinterpret_cast<f32x2*>(gq + 64 - 2 * l) = f32x2{nb1[0], nb1[1]};
+                *reinterpret_cast<f32x2*>(vp + 64 - 2 * l) = f32x2{nw1[0], nw1[1]};
+                *reinterpret_cast<f32x2*>(vq + 64 - 2 * l) = f32x2{nx1[0], nx1[1]};
+              }
             }
             rotated = 1;
           }
@@ -378,6 +397,13 @@ __device__ inline int onesided_jacobi_lds(float* G, float* V, int* s_rot, int m,
   }
   __syncthreads();
   return sweeps_total;
+}
+
+__device__ inline int onesided_jacobi_lds(float* G, float* V, int* s_rot, int m, int extra,
+                                          int max_sweeps) {
+  if (extra == 0) return onesided_jacobi_lds_t<0>(G, V, s_rot, m, max_sweeps);
+  if (extra == 2) return onesided_jacobi_lds_t<2>(G, V, s_rot, m, max_sweeps);
+  return onesided_jacobi_lds_t<4>(G, V, s_rot, m, max_sweeps);
 }
 
 // Renormalises the columns of V (the approximate rcp / rsq of the rotation parameters scale a
@@ -404,7 +430,8 @@ __global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, con
   const int n = eb->n, ld = eb->npad, tid = threadIdx.x;
   if (n == 0) return;
   const int m = (n + 1) & ~1;           // players of the tournament (a dummy column if n is odd)
-  const bool tall = n > 64;             // rows 64.. exist (else that half of every column is zero)
+  // elements per lane beyond row 63: rows 64.. do not exist / exist up to 95 / up to 127
+  const int extra = n <= 64 ? 0 : (n <= 96 ? 2 : 4);
   const float* A = eb->A;               // regularised input D (eigh_init_kernel), stride npad
   const int lane = tid & 63, wave = tid >> 6;
   float shift = 0.f;
@@ -427,7 +454,7 @@ __global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, con
     if (tid < 2) s_rot[tid] = 0;
     __syncthreads();
 
-    sweeps_total += onesided_jacobi_lds(G, V, s_rot, m, tall, SE_MAX_SWEEPS);
+    sweeps_total += onesided_jacobi_lds(G, V, s_rot, m, extra, SE_MAX_SWEEPS);
     // The approximate rcp / rsq of the rotation parameters scale a rotation by 1 + O(eps):
     // renormalise the eigenvectors (and g_j with them, G = A V), then the Rayleigh quotients.
     float lo_ev = 0.f, hi_abs = 0.f;

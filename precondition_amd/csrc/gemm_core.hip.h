@@ -28,6 +28,7 @@ namespace psk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TILE = 128;      // BM = BN
 constexpr int NTHREADS = 256;  // 4 wavefronts
