@@ -393,15 +393,19 @@ def executed_fraction(n, p=4, iters=8.0):
   issues on the MFMA pipe.  Symmetric mode (the default): every product runs only the
   tiles with tm <= tn of its T x T tile grid ((T+1)/(2T) of the work) except the M update
   of the first `ps_newton_averaged_steps()` steps, which is computed in full (and averaged
-  with its transpose, csrc/newton.hip TileFlags).  `iters` = Newton steps per block."""
+  with its transpose, csrc/newton.hip TileFlags).  The H update of step 0 (H0 = h0 I times
+  Mi) is not a product at all: newton_init2_tile writes fl(h0 * mi).  `iters` = Newton
+  steps per block (one try assumed)."""
+  it = max(float(iters), 1.0)
+  c = c_of_p(p)
   if os.environ.get("PS_NEWTON_SYMMETRIC", "1") == "0":
-    return 1.0
+    return (c * it - 1.0) / (c * it)
   from precondition_amd import _lib
   navg = min(float(_lib.lib().ps_newton_averaged_steps()), float(iters))
   t = (n + 127) // 128
   half = (t + 1) / (2.0 * t)
-  c = c_of_p(p)
-  return ((c - 1) * half + (navg / max(iters, 1.0)) * 1.0 + (1 - navg / max(iters, 1.0)) * half) / c
+  per_step = (c - 1) * half + (navg / it) * 1.0 + (1 - navg / it) * half
+  return (per_step * it - half) / (c * it)
 
 
 def pmc_traffic(workload, kernel):

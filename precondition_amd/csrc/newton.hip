@@ -386,7 +386,7 @@ __device__ inline void newton_init2_tile(const NewtonBlock* nb, NewtonState* st,
   unsigned emax = 0;
   for (int e = tid; e < TILE * TILE; e += 256) {
     const int row = tm * TILE + e / TILE, col = tn * TILE + e % TILE;
-    float m = 0.f, mi = 0.f, h = 0.f;
+    float m = 0.f, mi = 0.f, h = 0.f, h1 = 0.f;
     if (row < n && col < n) {
       float d = gload1(nb->a + (int64_t)row * nb->lda + col);
       const float ident = row == col ? 1.f : 0.f;
@@ -394,6 +394,10 @@ __device__ inline void newton_init2_tile(const NewtonBlock* nb, NewtonState* st,
       m = __fmul_rn(d, z);                                   // DS:871
       mi = __fadd_rn(__fmul_rn(oma, ident), __fmul_rn(alpha, m));
       h = __fmul_rn(ident, h0);
+      // The first H update of a try, H0 Mi with H0 = h0 I (DS:845), is one product per
+      // element: fl(h0 * mi) -- what the MFMA returns for a single non-zero term -- so it is
+      // written here and the step-0 tiles of product P0 are skipped (stage kernel / queue).
+      h1 = __fmul_rn(h0, mi);
       const unsigned eb = abs_bits(__fsub_rn(m, ident));     // DS:872
       emax = eb > emax ? eb : emax;
     }
@@ -401,7 +405,7 @@ __device__ inline void newton_init2_tile(const NewtonBlock* nb, NewtonState* st,
     tstore1<WT>(M + o, m);
     tstore1<WT>(Mi + o, mi);
     tstore1<WT>(H0 + o, h);
-    tstore1<WT>(H1 + o, h);
+    tstore1<WT>(H1 + o, h1);
   }
   emax = wave_max_u32(emax);
   if ((tid & 63) == 0) red[tid >> 6] = emax;
@@ -461,7 +465,8 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void newton_stage_kernel(
     if (more) te_n = tiles[xcd_remap(inext, ntiles)];
     const NewtonBlock* nb = &blocks[tk.block];
     NewtonState* st = &states[tk.block];
-    if (st->phase == PH_ACTIVE)
+    // P0 of step 0 (H0 Mi, H0 a scaled identity) was written by newton_init2_tile
+    if (st->phase == PH_ACTIVE && !(tk.prod == 0 && st->it == 0))
       newton_product_item<BK, false, DEEP>(nb, st, tk.prod, st->cur, st->avg_on, te.tm, te.tn,
                                            smem);
     if (!more) break;
@@ -910,8 +915,9 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void newton_persistent_kernel(PA
     const NewtonBlock* nb = &pa.blocks[b];
     NewtonState* st = &pa.states[b];
     if (kind == IT_PROD) {
-      newton_product_item<BK, PERSIST_WT, DEEP>(nb, st, prod, bit, avg, tm, tn, smem,
-                                    pa.prof ? s_stamp : nullptr);
+      if (!(prod == 0 && ald(&st->it) == 0))   // step-0 P0: written by newton_init2_tile
+        newton_product_item<BK, PERSIST_WT, DEEP>(nb, st, prod, bit, avg, tm, tn, smem,
+                                      pa.prof ? s_stamp : nullptr);
     } else if (kind == IT_INIT1) {
       newton_init1_tile<PERSIST_WT>(nb, ald(&st->ridge_try), tm, tn, scratch);
     } else if (kind == IT_INIT2) {
