@@ -88,7 +88,7 @@ struct NewtonState {
   float err, ratio, max_ev, ridge, ridge_try;
   unsigned err_bits;
   // averaged M update: max |X - X^T| and max |X| of the step (bit patterns), and whether the
-  // NEXT step still averages (adaptive: see newton_avg_next)
+  // NEXT step still averages (newton_avg_next: a fixed number of leading steps)
   unsigned asym_bits, xmax_bits;
   int avg_on;
   float asym_first;   // relative asymmetry measured in the first step of the last try
