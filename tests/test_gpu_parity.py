@@ -476,7 +476,7 @@ def test_eigh_root_hip_vs_oracle_and_fp64(device):
     assert np.abs(h - h.T).max() <= 1e-6 * np.abs(h).max()
 
 
-@pytest.mark.parametrize("nb,n", [(4, 2048), (16, 512)])
+@pytest.mark.parametrize("nb,n", [(64, 2048), (16, 512)])
 def test_eigh_full_size_properties(nb, n, device):
   """BASELINE config 3 geometry (2048^2, p=2): val^2 (A + eps I) = I, sampled oracle."""
   gen = torch.Generator(device=device).manual_seed(2048)

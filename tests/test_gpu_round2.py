@@ -537,3 +537,29 @@ def test_power_iteration_resident_bit_identical_to_streaming(device, monkeypatch
   for i in (1, 5, 9, 10):
     _, ref, _ = orc.power_iteration(mats[i].cpu().numpy(), 100, 1e-6)
     assert np.isclose(lam[i], ref, rtol=2e-5)
+
+
+def test_fd_cfg5_full_size_vs_oracle(device):
+  """BASELINE configs[4] at its full size: rank-64 Frequent-Directions updates of a 4096-dim
+  factor (bf16x3 products by default), two chained updates, each compared with the oracle's
+  fd_update_root (DS:1123-1290: LAPACK SVD of [sqrt(decay) W | R]) on the same inputs."""
+  from precondition_amd import low_rank
+  from tests.test_optimizer_host_logic import packed_matches
+  d, r, p = 4096, 64, 4
+  rng = np.random.default_rng(4096)
+  prev = np.zeros((d, r + 2), np.float32)
+  for t in range(2):
+    g = rng.standard_normal((d, d)).astype(np.float32) * np.float32(1.0 + 0.3 * t)
+    g[:r + 2] *= np.linspace(6.0, 2.0, r + 2)[:, None].astype(np.float32)
+    ref = orc.fd_update_root(g, p, r, ridge_epsilon=1e-6, error_tolerance=0.0,
+                             relative_matrix_epsilon=True, decay=0.999, padding_start=d,
+                             prev=prev)
+    gram = low_rank.gram_of_block(torch.tensor(g, device=device), 0)
+    new, _ = low_rank._fd_update_root(
+        gram, p, rank=r, ridge_epsilon=1e-6, error_tolerance=0.0, relative_matrix_epsilon=True,
+        decay=0.999, padding_start=d, prev=torch.tensor(prev, device=device),
+        new_grad_is_gram=True)
+    got = new.cpu().numpy()
+    assert packed_matches(got, ref, r, tol=2e-3), t
+    assert np.isclose(got[1, -1], ref[1, -1], rtol=1e-3)
+    prev = ref
