@@ -756,23 +756,29 @@ struct PiPlan {
 
   // Two resident launches on DIFFERENT streams could each hold part of the chip while their
   // teams wait for slots: the resident execution is used only when the previous resident
-  // launch of this process went to the same stream or has completed.
-  static bool resident_exclusive(hipStream_t st, bool record) {
-    static std::mutex mu;
-    static hipStream_t last_stream = nullptr;
-    static hipEvent_t last_ev = nullptr;
-    static bool any = false;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!record) {
-      if (!any || last_stream == st) return true;
-      return hipEventQuery(last_ev) == hipSuccess;
-    }
-    if (!last_ev && hipEventCreateWithFlags(&last_ev, hipEventDisableTiming) != hipSuccess)
-      return false;
-    (void)hipEventRecord(last_ev, st);
-    last_stream = st;
-    any = true;
+  // launch of this process went to the same stream or has completed.  acquire() claims the
+  // chip for `st` (or refuses), release() records the completion event behind the launches.
+  struct ResidentGate {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    bool any = false, pending = false;
+  };
+  static ResidentGate& gate() { static ResidentGate g; return g; }
+  static bool resident_acquire(hipStream_t st) {
+    ResidentGate& g = gate();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ev && hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) return false;
+    if (g.any && g.stream != st && (g.pending || hipEventQuery(g.ev) != hipSuccess)) return false;
+    if (g.any && g.stream == st && g.pending) return false;  // same stream from two threads
+    g.stream = st; g.any = true; g.pending = true;
     return true;
+  }
+  static void resident_release(hipStream_t st) {
+    ResidentGate& g = gate();
+    std::lock_guard<std::mutex> lk(g.mu);
+    (void)hipEventRecord(g.ev, st);
+    g.pending = false;
   }
 
   // Enqueues the whole iteration.  Resident execution (default): one launch per co-resident
@@ -789,9 +795,12 @@ struct PiPlan {
                         ? resident_capacity(res_lds) : 0;
     int biggest = 0;
     for (int i = 0; i < batch; ++i) biggest = std::max(biggest, team[i]);
-    const bool resident = cap > 0 && biggest <= cap && resident_exclusive(st, false);
+    const bool resident = cap > 0 && biggest <= cap && resident_acquire(st);
     // granule tags must not match leftovers of an earlier call in the same workspace
-    if (resident && region_bytes) PS_HIP(hipMemsetAsync(d_region, 0, region_bytes, st));
+    if (resident && region_bytes) {
+      const hipError_t e = hipMemsetAsync(d_region, 0, region_bytes, st);
+      if (e != hipSuccess) { resident_release(st); return (int)e; }
+    }
     hipLaunchKernelGGL(pi_init_kernel, dim3(batch), dim3(256), 0, st, d_blocks, d_v0);
     if (resident) {
       // passes of whole teams, in block order, at most `cap` workgroups each
@@ -809,8 +818,8 @@ struct PiPlan {
                            res_lds, st, d_blocks, d_wgs + first, num_iters, tol);
         first = end;
       }
+      resident_release(st);
       PS_LAUNCH_CHECK();
-      resident_exclusive(st, true);
       return 0;
     }
     const int nt = (int)tiles.size();
