@@ -563,3 +563,40 @@ def test_fd_cfg5_full_size_vs_oracle(device):
     assert packed_matches(got, ref, r, tol=2e-3), t
     assert np.isclose(got[1, -1], ref[1, -1], rtol=1e-3)
     prev = ref
+
+
+def test_power_iteration_concurrent_streams(device):
+  """Two host threads on two streams: at most one resident launch is in flight at a time (the
+  other call takes the streaming execution), results stay bit-identical to a serial call."""
+  import threading
+  from precondition_amd import kernels as K
+  gen = torch.Generator(device=device).manual_seed(11)
+  mats = []
+  for s in [512] * 24 + [300, 129, 64]:
+    g = torch.randn((s, 2 * s), generator=gen, device=device)
+    mats.append((g @ g.T).contiguous())
+  ref_lam, ref_its = K.power_iteration_batched(mats)
+  torch.cuda.synchronize()
+  ref_lam, ref_its = ref_lam.cpu().numpy(), ref_its.cpu().numpy()
+  out, errs = {}, []
+
+  def worker(k):
+    try:
+      st = torch.cuda.Stream(device=device)
+      with torch.cuda.stream(st):
+        res = []
+        for _ in range(6):
+          lam, its = K.power_iteration_batched(mats)
+          res.append((lam, its))
+        st.synchronize()
+      out[k] = [(l.cpu().numpy(), i.cpu().numpy()) for l, i in res]
+    except Exception as e:  # pragma: no cover
+      errs.append(e)
+
+  ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+  for t in ts: t.start()
+  for t in ts: t.join()
+  assert not errs, errs
+  for k in range(2):
+    for lam, its in out[k]:
+      assert np.array_equal(lam, ref_lam) and np.array_equal(its, ref_its)
