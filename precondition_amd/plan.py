@@ -164,6 +164,8 @@ class TreePlan:
     if S == 0:
       return
     dev = self.check_dense(grads_flat, "gram_weighted_update")
+    if self.check_dense(list(stats_in) + list(stats_out), "gram_weighted_update") != dev:
+      raise ValueError("gram_weighted_update: gradients and statistics live on different devices")
     tbl = self.stats_tbl.copy()
     gp = self._ptrs(grads_flat)
     tbl["g"] = gp[self.st_param] + self.st_goff
@@ -183,7 +185,9 @@ class TreePlan:
     output of parameter i (None for skipped parameters)."""
     if len(self.a_tbl) == 0:
       return
-    dev = grads_flat[0].device
+    dev = self.check_dense(grads_flat, "preconditioned_grad")
+    self.check_dense([p for p in precs_flat] + [r for r in results if r is not None],
+                     "preconditioned_grad")
     x = torch.empty(max(self.x_elems, 1), dtype=torch.float32, device=dev)
     xp = np.uint64(x.data_ptr())
     gp = self._ptrs(grads_flat)
