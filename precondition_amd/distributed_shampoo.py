@@ -525,6 +525,7 @@ def distributed_shampoo(
               out=[outs[k] for k in dense])
           rows[dense, :comm.METRICS_STRIDE] = m
         fd_calls, fd_slots = [], []
+        lr_calls, lr_slots = [], []
         for k, i in enumerate(indices):
           if k in dense:
             continue
@@ -552,10 +553,17 @@ def distributed_shampoo(
                 generate_fd_metrics=generate_fd_metrics))
             fd_slots.append((k, n_i))
           else:
-            val, tm = backend.low_rank_root(
-                statistics[i], exponents[i], compression_rank=compression_rank,
+            lr_calls.append(dict(
+                matrix=statistics[i], p=exponents[i], compression_rank=compression_rank,
                 ridge_epsilon=matrix_epsilon,
-                relative_matrix_epsilon=relative_matrix_epsilon, padding_start=sizes[i])
+                relative_matrix_epsilon=relative_matrix_epsilon, padding_start=sizes[i]))
+            lr_slots.append(k)
+        if lr_calls:  # all low-rank roots of this rank in one batched call
+          if hasattr(backend, "low_rank_root_batched"):
+            results = backend.low_rank_root_batched(lr_calls)
+          else:
+            results = [backend.low_rank_root(c.pop("matrix"), c.pop("p"), **c) for c in lr_calls]
+          for k, (val, tm) in zip(lr_slots, results):
             outs[k].copy_(val)
             rows[k, 0] = tm.inverse_pth_root_errors
         if fd_calls:  # the eigen-step of all sketch updates of this rank runs batched

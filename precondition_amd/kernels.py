@@ -633,6 +633,13 @@ def low_rank_root(*args, **kwargs):
   return low_rank._low_rank_root(*args, **kwargs)
 
 
+def low_rank_root_batched(calls):
+  """_low_rank_root for a list of keyword dicts (power iteration, eigh and the error metric
+  batched; no host synchronisation)."""
+  from . import low_rank
+  return low_rank._low_rank_root_batched(calls)
+
+
 def fd_update_root(*args, **kwargs):
   from . import low_rank
   return low_rank._fd_update_root(*args, **kwargs)

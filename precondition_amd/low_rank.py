@@ -19,7 +19,7 @@ reconstructed covariance, as the reference's own tests do (DST:770-885).
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -89,44 +89,86 @@ def _low_rank_root(matrix: torch.Tensor, p: int, compression_rank: int = 0,
   """Top- (rank > 0) or bottom- (rank < 0) |rank| eigenpairs of the inverse p-th
   root plus the mean of the remaining inverted eigenvalues, packed [d, |rank|+2]."""
   del prev
-  assert compression_rank != 0
-  d = matrix.shape[0]
-  assert matrix.shape[0] == matrix.shape[1] and d > abs(compression_rank) + 2
-  r = abs(compression_rank)
-  dev = matrix.device
-  real_dim = d if padding_start is None else int(padding_start)
-  if real_dim == 0:  # DS:1114-1118
-    return (torch.zeros((d, r + 2), dtype=torch.float32, device=dev), _metrics(0.0))
-  a = matrix[:real_dim, :real_dim].contiguous()
-  if relative_matrix_epsilon:
-    _, max_ev = kernels.power_iteration(a, 100, error_tolerance)
-    max_ev = float(max_ev)
-  else:
-    max_ev = 1.0
-  ridge = ridge_epsilon * max(max_ev, error_tolerance)
-  reg = a + ridge * torch.eye(real_dim, dtype=torch.float32, device=dev)
-  (e,), (u,) = kernels.eigh_batched([reg])  # ascending, like LAPACK
-  recovered = kernels.matmul(u, kernels.matmul(reg, u), transa=True)
-  error = (recovered - torch.diag(e)).abs().max()
-  alpha = -1.0 / p
-  inv_e = torch.where(e == 0.0, torch.zeros_like(e),
-                      torch.clamp(e, min=ridge) ** alpha)
-  # The reference's padded problem has (d - real_dim) zero eigenvalues in front
-  # (inv_e = 0 there); after its flip/roll the kept pairs come first (DS:1085-1097).
-  if compression_rank < 0:
-    order = torch.arange(real_dim, device=dev)            # [low .. hi]
-  else:
-    order = torch.arange(real_dim - 1, -1, -1, device=dev)  # [hi .. low]
-  inv_sorted, u_sorted = inv_e[order], u[:, order]
-  k = min(r, real_dim)
-  keep_e = torch.zeros((r,), dtype=torch.float32, device=dev)
-  u_keep = torch.zeros((d, r), dtype=torch.float32, device=dev)
-  keep_e[:k] = inv_sorted[:k]
-  u_keep[:real_dim, :k] = u_sorted[:, :k]
-  num_avg = real_dim - r
-  const = inv_sorted[k:].sum() / (num_avg if num_avg > 0 else 1.0)
-  val = _low_rank_pack(u_keep, keep_e, const, compression_rank)
-  return val, _metrics(error)
+  return _low_rank_root_batched([dict(
+      matrix=matrix, p=p, compression_rank=compression_rank, ridge_epsilon=ridge_epsilon,
+      error_tolerance=error_tolerance, relative_matrix_epsilon=relative_matrix_epsilon,
+      padding_start=padding_start)])[0]
+
+
+def _low_rank_root_batched(calls) -> List[Tuple[torch.Tensor, TrainingMetrics]]:
+  """_low_rank_root for a list of keyword dicts: ONE batched power iteration, one batched
+  eigendecomposition and two grouped products (the error metric) for all statistics of a
+  recompute, and no host synchronisation — the largest eigenvalue and the ridge stay on
+  the device (the reference runs this under vmap, DS:2742-2744)."""
+  out: List[Optional[Tuple[torch.Tensor, TrainingMetrics]]] = [None] * len(calls)
+  live = []
+  for idx, c in enumerate(calls):
+    matrix, rank = c["matrix"], c["compression_rank"]
+    assert rank != 0
+    d = matrix.shape[0]
+    assert matrix.shape[0] == matrix.shape[1] and d > abs(rank) + 2
+    ps = c.get("padding_start")
+    real_dim = d if ps is None else int(ps)
+    if real_dim == 0:  # DS:1114-1118
+      out[idx] = (torch.zeros((d, abs(rank) + 2), dtype=torch.float32, device=matrix.device),
+                  _metrics(0.0))
+    else:
+      live.append((idx, matrix[:real_dim, :real_dim].contiguous(), real_dim))
+  if not live:
+    return out
+  dev = live[0][1].device
+  mats = [a for _, a, _ in live]
+  # largest eigenvalues for the relative ridge: all matrices in one call, result on the device
+  rel = [j for j, (idx, _, _) in enumerate(live) if calls[idx].get("relative_matrix_epsilon", True)]
+  max_ev = [None] * len(live)
+  if rel:
+    tols = {float(calls[live[j][0]].get("error_tolerance", 1e-6)) for j in rel}
+    for tol in tols:   # the stop tolerance of the power iteration is per call
+      grp = [j for j in rel if float(calls[live[j][0]].get("error_tolerance", 1e-6)) == tol]
+      lam, _ = kernels.power_iteration_batched([mats[j] for j in grp], 100, tol)
+      for k, j in enumerate(grp):
+        max_ev[j] = lam[k]
+  regs, ridges = [], []
+  for j, (idx, a, real_dim) in enumerate(live):
+    c = calls[idx]
+    tol = float(c.get("error_tolerance", 1e-6))
+    eps = float(c.get("ridge_epsilon", 1e-6))
+    if max_ev[j] is None:
+      ridge = torch.tensor(eps * max(1.0, tol), dtype=torch.float32, device=dev)
+    else:
+      ridge = eps * torch.clamp(max_ev[j], min=tol)
+    ridges.append(ridge)
+    regs.append(a + ridge * torch.eye(real_dim, dtype=torch.float32, device=dev))
+  es, us = kernels.eigh_batched(regs)  # ascending, like LAPACK
+  tmp = [torch.empty_like(r) for r in regs]
+  rec = [torch.empty_like(r) for r in regs]
+  kernels.gemm_grouped([(r, u, t, False, False) for r, u, t in zip(regs, us, tmp)])
+  kernels.gemm_grouped([(u, t, x, True, False) for u, t, x in zip(us, tmp, rec)])
+  for j, (idx, a, real_dim) in enumerate(live):
+    c = calls[idx]
+    rank, p = c["compression_rank"], c["p"]
+    r = abs(rank)
+    d = c["matrix"].shape[0]
+    e, u, ridge = es[j], us[j], ridges[j]
+    error = (rec[j] - torch.diag(e)).abs().max()
+    alpha = -1.0 / p
+    inv_e = torch.where(e == 0.0, torch.zeros_like(e), torch.clamp(e, min=ridge) ** alpha)
+    # The reference's padded problem has (d - real_dim) zero eigenvalues in front
+    # (inv_e = 0 there); after its flip/roll the kept pairs come first (DS:1085-1097).
+    if rank < 0:
+      order = torch.arange(real_dim, device=dev)            # [low .. hi]
+    else:
+      order = torch.arange(real_dim - 1, -1, -1, device=dev)  # [hi .. low]
+    inv_sorted, u_sorted = inv_e[order], u[:, order]
+    k = min(r, real_dim)
+    keep_e = torch.zeros((r,), dtype=torch.float32, device=dev)
+    u_keep = torch.zeros((d, r), dtype=torch.float32, device=dev)
+    keep_e[:k] = inv_sorted[:k]
+    u_keep[:real_dim, :k] = u_sorted[:, :k]
+    num_avg = real_dim - r
+    const = inv_sorted[k:].sum() / (num_avg if num_avg > 0 else 1.0)
+    out[idx] = (_low_rank_pack(u_keep, keep_e, const, rank), _metrics(error))
+  return out
 
 
 # ---- frequent_directions_update (DS:1473-1505) -------------------------------------
