@@ -426,6 +426,22 @@ def pmc_traffic(workload, kernel):
   return None
 
 
+def pmc_field(workload, kernel, field):
+  """A per-kernel figure of the committed PMC summary (None if absent)."""
+  path = os.path.join(ROOT, "profiles", "r02_pmc_cfg2_summary.json")
+  try:
+    with open(path) as f:
+      summ = json.load(f)
+    if summ.get("workload") != workload:
+      return None
+    for k in summ["kernels"]:
+      if k["kernel"].startswith(kernel) and k.get("execution") == "staged":
+        return k.get(field)
+  except (OSError, ValueError, KeyError):
+    pass
+  return None
+
+
 def parity_sample(work, count=8):
   """rel-Fro error of the GPU roots against the oracle (the checker, SURVEY 8d
   'Accuracy') on the first `count` blocks of the workload, same inputs; also iteration
@@ -574,6 +590,10 @@ def main():
                                else "psk::newton_stage_kernel"),
         "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate "
                         "rocprofv3 --pmc passes (profiles/r02_pmc_cfg2_summary.json)",
+        # clock under MFMA load from the committed PMC pass (GRBM_GUI_ACTIVE / duration): the
+        # 157.3 TFLOP/s peak assumes 2.4 GHz
+        "clock_GHz_under_load": pmc_field(args.workload, "psk::newton_", "clock_GHz"),
+        "mfma_busy_frac_pmc": pmc_field(args.workload, "psk::newton_", "mfma_busy_frac"),
         "launches": int(launches),
         "avg_launch_ms": round(stage_ms / max(launches, 1), 4),
         "executed_gflop_per_launch": round(fl1 * ex / max(launches, 1) / 1e9, 3),
