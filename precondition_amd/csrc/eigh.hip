@@ -62,6 +62,7 @@ struct EighBlock {
   float off_rel;
   unsigned err_bits;
   int power_iters;
+  unsigned soff_bits;  // max scaled off-diagonal |a_ij| / sqrt(|a_ii a_jj|) (eigh_scaled_off_kernel)
 };
 
 struct ETile {
@@ -629,6 +630,13 @@ __global__ __launch_bounds__(256) void eigh_control_kernel(EighBlock* blocks, in
       float ss = 0.f;
       for (int i = 0; i < t * t; ++i) ss += eb->sumsq_partial[i];
       eb->normD = sqrtf(ss);
+    } else if (mode == 2) {
+      // after eigh_scaled_off_kernel: blocks whose largest scaled off-diagonal entry is still
+      // above `tol` sweep once more (NaN: stop, everything downstream is NaN anyway)
+      const float so = __uint_as_float(eb->soff_bits);
+      eb->soff_bits = 0;
+      eb->off_rel = so;
+      eb->active = (!eb->small && so > tol) ? 1 : 0;
     } else if (eb->active) {
       const int cnt = eb->npairs * (eb->nb - 1);
       float off = 0.f;
@@ -826,6 +834,123 @@ __global__ __launch_bounds__(256) void eigh_rayleigh_f64_kernel(EighBlock* block
     double e = 0.0;
     for (int r = 0; r < 16; ++r) e += sE[r][tid];
     eb->A[(int64_t)(i0 + tid) * ld + i0 + tid] = (float)e;
+  }
+}
+
+// ---- A <- V^T D V with float64 accumulation (the transition to the finishing sweeps) ----
+// The blocked two-sided sweeps accumulate absolute errors of a few eps32 * ||D|| in A, far
+// above the small eigenvalues of a graded / rank-deficient-plus-ridge statistic (1e-6 ||D||),
+// and the float32 re-projection V^T D V adds the same again.  With the projection accumulated
+// in float64 (products of float32 numbers are exact in float64; T = D V is kept as a float32
+// hi/lo pair in the temporaries X, W) every entry of A is correct to its own float32
+// rounding, so the finishing sweeps work on small entries that are accurate RELATIVE to
+// themselves and the eigenvectors of the small eigenvalues come out as accurately as LAPACK's
+// (tools/dev_eigh_refine_proto2.py: root error on a graded 129 x 129 input 2e-2 -> 1e-4).
+// Tiles: 64 x 64 per workgroup (4 per 128 x 128 entry of the tile list), 4 x 4 per thread,
+// float64 FMAs on the vector pipe (2 * 2n^3 DFMA-flops per matrix: ~80 ms for 64 x 2048^2).
+// STAGE 0: (X, W) = hi / lo of D V.   STAGE 1: A = V^T (X + W).
+template <int STAGE>
+__global__ __launch_bounds__(256) void eigh_reproject_f64_kernel(EighBlock* blocks,
+                                                                 const ETile* tiles) {
+  __shared__ float sL[RK][RQ + 1];
+  __shared__ float sR[RK][RQ + 1];
+  __shared__ float sR2[RK][RQ + 1];
+  const ETile te = tiles[blockIdx.x >> 2];
+  const int sub = blockIdx.x & 3;
+  EighBlock* eb = &blocks[te.block];
+  if (eb->small || eb->n == 0) return;
+  const int ld = eb->npad, tid = threadIdx.x;
+  const int i0 = te.k * TILE + (sub >> 1) * RQ, j0 = te.t * TILE + (sub & 1) * RQ;
+  const float* L = STAGE == 0 ? eb->D : eb->V;
+  const float* R = STAGE == 0 ? eb->V : eb->X;
+  const float* R2 = eb->W;
+  const int tr = tid >> 4, tc = tid & 15;
+  double x[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) x[a][b] = 0.0;
+  for (int k0 = 0; k0 < ld; k0 += RK) {
+    for (int e = tid; e < RK * RQ; e += 256) {
+      if (STAGE == 0) {   // left[k][m] = D[i0 + m][k0 + k]
+        const int m = e / RK, k = e % RK;
+        sL[k][m] = gload1(L + (int64_t)(i0 + m) * ld + k0 + k);
+      } else {            // left[k][m] = V[k0 + k][i0 + m]
+        const int k = e / RQ, m = e % RQ;
+        sL[k][m] = gload1(L + (int64_t)(k0 + k) * ld + i0 + m);
+      }
+      const int k = e / RQ, c = e % RQ;
+      sR[k][c] = gload1(R + (int64_t)(k0 + k) * ld + j0 + c);
+      if (STAGE == 1) sR2[k][c] = gload1(R2 + (int64_t)(k0 + k) * ld + j0 + c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+      double lv[4], rv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) lv[a] = (double)sL[k][4 * tr + a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        rv[b] = STAGE == 0 ? (double)sR[k][4 * tc + b]
+                           : (double)sR[k][4 * tc + b] + (double)sR2[k][4 * tc + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x[a][b] = fma(lv[a], rv[b], x[a][b]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int64_t o = (int64_t)(i0 + 4 * tr + a) * ld + j0 + 4 * tc + b;
+      if (STAGE == 0) {
+        const float hi = (float)x[a][b];
+        eb->X[o] = hi;
+        eb->W[o] = (float)(x[a][b] - (double)hi);
+      } else {
+        eb->A[o] = (float)x[a][b];
+      }
+    }
+}
+
+// Largest scaled off-diagonal entry max_{i != j} |a_ij| / sqrt(|a_ii| |a_jj|) of the working
+// matrix: the convergence measure that is meaningful for EVERY eigenvalue of a positive
+// definite matrix, not only for those near ||A|| (the pivots' absolute off-norm is what the
+// sweep phases stop on).  One workgroup per 128 x 128 tile, bit-pattern atomicMax per block.
+__global__ __launch_bounds__(256) void eigh_scaled_off_kernel(EighBlock* blocks,
+                                                              const ETile* tiles) {
+  __shared__ float dr[TILE], dc[TILE];
+  __shared__ unsigned red[4];
+  const ETile te = tiles[blockIdx.x];
+  EighBlock* eb = &blocks[te.block];
+  if (eb->small || eb->n == 0) return;
+  const int ld = eb->npad, n = eb->n, tid = threadIdx.x;
+  const float* A = eb->A;
+  const int r0 = te.k * TILE, c0 = te.t * TILE;
+  if (tid < TILE) {
+    dr[tid] = fmaxf(fabsf(gload1(A + (int64_t)(r0 + tid) * ld + r0 + tid)), 1e-37f);
+    dc[tid] = fmaxf(fabsf(gload1(A + (int64_t)(c0 + tid) * ld + c0 + tid)), 1e-37f);
+  }
+  __syncthreads();
+  unsigned m = 0;
+  for (int e = tid; e < TILE * TILE; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    const int row = r0 + r, col = c0 + c;
+    if (row < n && col < n && row != col) {
+      const float v = fabsf(gload1(A + (int64_t)row * ld + col)) * rsqrtf(dr[r]) * rsqrtf(dc[c]);
+      const unsigned b = __float_as_uint(v);   // non-negative: bit order = value order; NaN on top
+      m = b > m ? b : m;
+    }
+  }
+  m = wave_max_u32(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned mm = red[0];
+    for (int w = 1; w < 4; ++w) mm = red[w] > mm ? red[w] : mm;
+    atomicMax(&eb->soff_bits, mm);
   }
 }
 
@@ -1119,13 +1244,44 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                        (int)GB_V, (int)GB_X, (int)GB_W, (int)GE_STORE);
     hipLaunchKernelGGL(eigh_set_active_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
                        batch, 1);  // V <-> W
-    hipLaunchKernelGGL((eigh_gemm_kernel<KC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
-                       (int)GB_D, (int)GB_V, (int)GB_X, (int)GE_STORE);
-    hipLaunchKernelGGL((eigh_gemm_kernel<MC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
-                       (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_STORE);
+    static const int f64_reproject = [] {
+      const char* e = getenv("PS_EIGH_F64_REPROJECT"); return e ? atoi(e) : 1; }();
+    if (f64_reproject && any_big) {
+      hipLaunchKernelGGL(eigh_reproject_f64_kernel<0>, dim3(4 * nsq), blk, 0, st, lo.blocks, lo.sq);
+      hipLaunchKernelGGL(eigh_reproject_f64_kernel<1>, dim3(4 * nsq), blk, 0, st, lo.blocks, lo.sq);
+    } else {
+      hipLaunchKernelGGL((eigh_gemm_kernel<KC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
+                         (int)GB_D, (int)GB_V, (int)GB_X, (int)GE_STORE);
+      hipLaunchKernelGGL((eigh_gemm_kernel<MC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
+                         (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_STORE);
+    }
     PS_LAUNCH_CHECK();
     // phase 2: finish (quadratic): stop once a sweep STARTED below 1e-4
     if (any_big && (rc = run_phase(1e-4f, 4))) return rc;
+    // phase 3: the absolute off-norm says nothing about the small eigenvalues of a graded
+    // spectrum: sweep on while the largest SCALED off-diagonal entry is above the float32
+    // floor (well-conditioned inputs are far below it after phase 2 and skip this)
+    static const float scaled_tol = [] {
+      const char* e = getenv("PS_EIGH_SCALED_TOL"); return e ? (float)atof(e) : 1e-5f; }();
+    static const int extra_sweeps = [] {
+      const char* e = getenv("PS_EIGH_EXTRA_SWEEPS"); return e ? atoi(e) : 4; }();
+    for (int extra = 0; any_big && extra <= extra_sweeps; ++extra) {
+      EStatus* slot = &status[gen % 64];
+      slot->gen = -1;
+      hipLaunchKernelGGL(eigh_scaled_off_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      hipLaunchKernelGGL(eigh_control_kernel, dim3(1), blk, 0, st, lo.blocks, batch, 2, scaled_tol,
+                         gen, slot);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return (int)e;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return (int)e;
+      if (slot->gen != gen) return PS_EINTERNAL;
+      if (getenv("PS_EIGH_TRACE"))
+        fprintf(stderr, "eigh scaled off-diagonal max %.3e, %d block(s) above %.1e\n",
+                slot->max_off, slot->active, scaled_tol);
+      ++gen;
+      if (slot->active == 0 || extra == extra_sweeps) break;
+      if ((rc = run_phase(0.f, 1))) return rc;
+    }
     {
       static int refine = -1;
       if (refine < 0) { const char* e = getenv("PS_EIGH_REFINE"); refine = e ? atoi(e) != 0 : 1; }

@@ -600,3 +600,36 @@ def test_power_iteration_concurrent_streams(device):
   for k in range(2):
     for lam, its in out[k]:
       assert np.array_equal(lam, ref_lam) and np.array_equal(its, ref_its)
+
+
+@pytest.mark.parametrize("n,kind,p", [(169, "graded", 4), (512, "graded", 2), (260, "lowrank", 2),
+                                      (1024, "graded", 4)])
+def test_eigh_root_accuracy_on_graded_spectra_near_lapack(n, kind, p, device):
+  """The eigh root (DS:943-1030) on spectra graded over six decades / rank-deficient + ridge:
+  the re-projection A <- V^T D V accumulated in float64 and finishing sweeps driven by the
+  SCALED off-diagonal entries bring the blocked Jacobi path to LAPACK-float32 accuracy (both
+  measured against the float64 closed form; it was 1e-2 ... 4e-2 with the absolute stopping
+  rule alone, LAPACK ~1e-4)."""
+  from precondition_amd import kernels as K
+  rng = np.random.default_rng(n + p)
+  if kind == "lowrank":
+    g = rng.standard_normal((n, n // 4)); a = g @ g.T
+  else:
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    a = (q * 10.0 ** rng.uniform(-4, 2, n)) @ q.T
+  a = ((a + a.T) / 2).astype(np.float32)
+  a64 = a.astype(np.float64)
+  ridge = 1e-6 * np.linalg.eigvalsh(a64).max()
+  w, v = np.linalg.eigh(a64 + ridge * np.eye(n))
+  f = lambda e: np.maximum(e, ridge) ** (-1.0 / p)
+  truth = (v * f(w)) @ v.T
+  d32 = (a + np.float32(ridge) * np.eye(n, dtype=np.float32)).astype(np.float32)
+  wl, vl = np.linalg.eigh(d32)
+  lap = (vl.astype(np.float64) * f(wl.astype(np.float64))) @ vl.T.astype(np.float64)
+  roots, _ = K.matrix_inverse_pth_root_batched([torch.tensor(a, device=device)], [p], [n],
+                                               eigh=True)
+  got = roots[0].cpu().numpy().astype(np.float64)
+  tn = np.linalg.norm(truth)
+  e_hip, e_lap = np.linalg.norm(got - truth) / tn, np.linalg.norm(lap - truth) / tn
+  assert e_hip < 6 * e_lap + 2e-4, (e_hip, e_lap)
+  assert e_hip < 2e-3
