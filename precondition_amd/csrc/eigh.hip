@@ -421,7 +421,8 @@ __device__ inline void onesided_renormalize(float* G, float* V, int m) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, const int* ids) {
+__global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, const int* ids,
+                                                          int refresh) {
   extern __shared__ __align__(16) float sem[];
   float* G = sem;                       // [128][132] column-major: G[col * SE_LD + row]
   float* V = sem + SE_MAXN * SE_LD;
@@ -456,6 +457,67 @@ __global__ __launch_bounds__(SE_T) void eigh_small_kernel(EighBlock* blocks, con
     __syncthreads();
 
     sweeps_total += onesided_jacobi_lds(G, V, s_rot, m, extra, SE_MAX_SWEEPS);
+    // Refresh: the columns g_j = A v_j were carried through every rotation in float32, i.e.
+    // with absolute errors of eps32 * ||A|| -- far above a g_j that belongs to an eigenvalue
+    // 1e-6 ||A|| of a graded spectrum, so the rotations among the small directions were
+    // computed from noise.  G = A V is recomputed from the converged V with float64
+    // accumulation (A staged in G's own LDS image) and the sweeps run on: the dot products
+    // of accurate g_j resolve the small directions (root error on graded 64..128 problems
+    // 5e-4 ... 2e-3 -> LAPACK-float32 level).  Converged well-conditioned problems pay one
+    // rotation-free sweep.  Only spectra graded over more than three decades need it (the
+    // carried error is eps32 * ||A||): min ||g_j|| < 1e-3 max ||g_j|| over the real columns.
+    bool graded = false;
+    if (refresh) {
+      float lo2 = 3.0e38f, hi2 = 0.f;
+      for (int j = wave; j < n; j += SE_T / 64) {
+        const float g0 = G[j * SE_LD + lane], g1 = G[j * SE_LD + 64 + lane];
+        const float nn = wave_sum_f32(g0 * g0 + g1 * g1);
+        lo2 = fminf(lo2, nn); hi2 = fmaxf(hi2, nn);
+      }
+      if (lane == 0) { s_red[wave] = lo2; }
+      __syncthreads();
+      float lo_all = 3.0e38f;
+      for (int w = 0; w < SE_T / 64; ++w) lo_all = fminf(lo_all, s_red[w]);
+      __syncthreads();
+      if (lane == 0) s_red[wave] = hi2;
+      __syncthreads();
+      float hi_all = 0.f;
+      for (int w = 0; w < SE_T / 64; ++w) hi_all = fmaxf(hi_all, s_red[w]);
+      __syncthreads();
+      graded = lo_all < 1e-6f * hi_all;   // squared norms
+    }
+    if (graded) {
+      for (int e = tid; e < SE_MAXN * SE_MAXN; e += SE_T) {
+        const int col = e >> 7, row = e & 127;
+        float g = 0.f;
+        if (row < n && col < n) {
+          g = 0.5f * (gload1(A + (int64_t)col * ld + row) + gload1(A + (int64_t)row * ld + col));
+          if (row == col) g += shift;
+        }
+        G[col * SE_LD + row] = g;    // the (symmetric) matrix itself, column-major
+      }
+      __syncthreads();
+      double ng[SE_MAXN * SE_MAXN / SE_T];
+#pragma unroll
+      for (int i = 0; i < SE_MAXN * SE_MAXN / SE_T; ++i) {
+        const int e = tid + SE_T * i;
+        const int col = e >> 7, row = e & 127;
+        double acc = 0.0;
+        if (col < m && row < n)
+          for (int k = 0; k < n; ++k)   // A[row][k] = A[k][row] (symmetrised above)
+            acc = fma((double)G[k * SE_LD + row], (double)V[col * SE_LD + k], acc);
+        ng[i] = acc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < SE_MAXN * SE_MAXN / SE_T; ++i) {
+        const int e = tid + SE_T * i;
+        G[(e >> 7) * SE_LD + (e & 127)] = (float)ng[i];
+      }
+      if (tid < 2) s_rot[tid] = 0;
+      __syncthreads();
+      sweeps_total += onesided_jacobi_lds(G, V, s_rot, m, extra, SE_MAX_SWEEPS);
+    }
     // The approximate rcp / rsq of the rotation parameters scale a rotation by 1 + O(eps):
     // renormalise the eigenvectors (and g_j with them, G = A V), then the Rayleigh quotients.
     float lo_ev = 0.f, hi_abs = 0.f;
@@ -1230,8 +1292,10 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
         small_attr = true;
       }
+      static const int small_refresh = [] {
+        const char* e = getenv("PS_EIGH_SMALL_REFRESH"); return e ? atoi(e) : 1; }();
       hipLaunchKernelGGL(eigh_small_kernel, dim3((unsigned)pl.small_ids.size()), dim3(SE_T),
-                         small_lds, st, lo.blocks, lo.small_ids);
+                         small_lds, st, lo.blocks, lo.small_ids, small_refresh);
       PS_LAUNCH_CHECK();
     }
     if (mode == 1 && !any_big) return PS_OK;  // the kernel wrote sorted pairs to the outputs

@@ -15,7 +15,7 @@ def make(n, kind):
   else:
     g = rng.standard_normal((n, 2 * n)); a = g @ g.T
   return ((a + a.T) / 2).astype(np.float32)
-for n, kind in ((129, "graded"), (169, "graded"), (260, "lowrank"), (512, "lowrank"), (512, "graded"),
+for n, kind in ((64, "graded"), (96, "graded"), (128, "graded"), (128, "lowrank"), (100, "lowrank"), (129, "graded"), (169, "graded"), (260, "lowrank"), (512, "lowrank"), (512, "graded"),
                 (1024, "graded"), (1024, "lowrank"), (512, "wishart"), (2048, "graded")):
   for p in (2, 4):
     a = make(n, kind); a64 = a.astype(np.float64)
