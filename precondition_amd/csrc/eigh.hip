@@ -911,6 +911,9 @@ __global__ __launch_bounds__(256) void eigh_rayleigh_f64_kernel(EighBlock* block
 // Tiles: 64 x 64 per workgroup (4 per 128 x 128 entry of the tile list), 4 x 4 per thread,
 // float64 FMAs on the vector pipe (2 * 2n^3 DFMA-flops per matrix: ~80 ms for 64 x 2048^2).
 // STAGE 0: (X, W) = hi / lo of D V.   STAGE 1: A = V^T (X + W).
+// STAGE 2: X = 1.5 I - 0.5 V^T V (the Newton-Schulz factor of the final polish: with a float32
+// Gram matrix the off-diagonal entries of V^T V carry sqrt(n) eps32 of noise, as large as the
+// loss of orthogonality they are meant to measure).
 template <int STAGE>
 __global__ __launch_bounds__(256) void eigh_reproject_f64_kernel(EighBlock* blocks,
                                                                  const ETile* tiles) {
@@ -924,7 +927,7 @@ __global__ __launch_bounds__(256) void eigh_reproject_f64_kernel(EighBlock* bloc
   const int ld = eb->npad, tid = threadIdx.x;
   const int i0 = te.k * TILE + (sub >> 1) * RQ, j0 = te.t * TILE + (sub & 1) * RQ;
   const float* L = STAGE == 0 ? eb->D : eb->V;
-  const float* R = STAGE == 0 ? eb->V : eb->X;
+  const float* R = STAGE == 1 ? eb->X : eb->V;
   const float* R2 = eb->W;
   const int tr = tid >> 4, tc = tid & 15;
   double x[4][4];
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(256) void eigh_reproject_f64_kernel(EighBlock* bloc
       for (int a = 0; a < 4; ++a) lv[a] = (double)sL[k][4 * tr + a];
 #pragma unroll
       for (int b = 0; b < 4; ++b)
-        rv[b] = STAGE == 0 ? (double)sR[k][4 * tc + b]
+        rv[b] = STAGE != 1 ? (double)sR[k][4 * tc + b]
                            : (double)sR[k][4 * tc + b] + (double)sR2[k][4 * tc + b];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
@@ -971,8 +974,11 @@ __global__ __launch_bounds__(256) void eigh_reproject_f64_kernel(EighBlock* bloc
         const float hi = (float)x[a][b];
         eb->X[o] = hi;
         eb->W[o] = (float)(x[a][b] - (double)hi);
-      } else {
+      } else if (STAGE == 1) {
         eb->A[o] = (float)x[a][b];
+      } else {
+        const bool diag = i0 + 4 * tr + a == j0 + 4 * tc + b;
+        eb->X[o] = (float)((diag ? 1.5 : 0.0) - 0.5 * x[a][b]);
       }
     }
 }
@@ -1345,6 +1351,24 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       ++gen;
       if (slot->active == 0 || extra == extra_sweeps) break;
       if ((rc = run_phase(0.f, 1))) return rc;
+    }
+    {
+      static const int final_polish = [] {
+        const char* e = getenv("PS_EIGH_FINAL_POLISH"); return e ? atoi(e) : 1; }();
+      // the sweeps after the re-projection let V drift from orthogonality again by a few
+      // eps32 per sweep: one more Newton-Schulz step V <- V (1.5 I - 0.5 V^T V) (two products)
+      // takes most graded / rank-deficient cases to LAPACK-float32's error to three digits
+      if (final_polish && any_big) {
+        if (final_polish >= 2)
+          hipLaunchKernelGGL(eigh_reproject_f64_kernel<2>, dim3(4 * nsq), blk, 0, st, lo.blocks, lo.sq);
+        else
+          hipLaunchKernelGGL((eigh_gemm_kernel<MC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
+                             (int)GB_V, (int)GB_V, (int)GB_X, (int)GE_POLISH);
+        hipLaunchKernelGGL((eigh_gemm_kernel<KC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
+                           (int)GB_V, (int)GB_X, (int)GB_W, (int)GE_STORE);
+        hipLaunchKernelGGL(eigh_set_active_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
+                           batch, 1);  // V <-> W
+      }
     }
     {
       static int refine = -1;
