@@ -1,0 +1,61 @@
+"""Dev: seeded fuzz of the low-rank root (DS:1033-1120) and the Frequent-Directions update
+(DS:1123-1290) against the oracle: random sizes, ranks (top and bottom), spectra, padding."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import shampoo_oracle as orc
+from precondition_amd import low_rank
+from tests.test_optimizer_host_logic import packed_matches
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(77)
+bad = total = 0
+calls, refs, meta = [], [], []
+for case in range(60):
+  n = int(rng.integers(12, 400))
+  kind = int(rng.integers(0, 3))
+  if kind == 0:
+    g = rng.standard_normal((n, 2 * n)); a = g @ g.T
+  elif kind == 1:
+    g = rng.standard_normal((n, max(2, n // 3))); a = g @ g.T
+  else:
+    q, _ = np.linalg.qr(rng.standard_normal((n, n))); a = (q * 10.0 ** rng.uniform(-3, 2, n)) @ q.T
+  a = ((a + a.T) / 2).astype(np.float32)
+  r = int(rng.integers(1, max(2, min(16, n - 3))))
+  rank = r if rng.uniform() < 0.5 else -r
+  p = int(rng.choice([2, 4, 8]))
+  full = n + int(rng.choice([0, 0, 5]))
+  m = np.zeros((full, full), np.float32); m[:n, :n] = a
+  with np.errstate(all="ignore"):
+    ref, err = orc.low_rank_root(m, p, rank, padding_start=n)
+  calls.append(dict(matrix=torch.tensor(m, device=dev), p=p, compression_rank=rank, padding_start=n))
+  refs.append(ref); meta.append((n, full, rank, p, kind))
+res = low_rank._low_rank_root_batched(calls)
+for (val, tm), ref, mt in zip(res, refs, meta):
+  total += 1
+  got = val.cpu().numpy()
+  if not packed_matches(got, ref, abs(mt[2]), tol=5e-3):
+    bad += 1
+    print("LOWRANK MISMATCH", mt, float(np.abs(got - ref).max()))
+print("low-rank fuzz:", total, "cases,", bad, "mismatches")
+# FD chains
+bad = total = 0
+for case in range(16):
+  d = int(rng.integers(24, 300)); r = int(rng.integers(2, max(3, min(12, d // 3))))
+  p = int(rng.choice([2, 4]))
+  prev = np.zeros((d, r + 2), np.float32)
+  for t in range(3):
+    k = int(rng.integers(1, 2 * d))
+    g = (rng.standard_normal((d, k)) * (1 + t)).astype(np.float32)
+    fac = orc.frequent_directions_update(g, 0)   # [d, d] factor, R R^T = g g^T
+    ref = orc.fd_update_root(fac, p, r, decay=0.99, padding_start=d, prev=prev)
+    gram = torch.tensor(g, device=dev); gram = (gram @ gram.T)
+    new, _ = low_rank._fd_update_root(gram, p, rank=r, decay=0.99, padding_start=d,
+                                      prev=torch.tensor(prev, device=dev), new_grad_is_gram=True)
+    total += 1
+    got = new.cpu().numpy()
+    ok = packed_matches(got, ref, r, tol=5e-3) and np.isclose(got[1, -1], ref[1, -1], rtol=2e-3, atol=1e-6)
+    if not ok:
+      bad += 1
+      print("FD MISMATCH d", d, "rank", r, "p", p, "step", t, "k", k, float(np.abs(got - ref).max()))
+    prev = ref
+print("FD fuzz:", total, "cases,", bad, "mismatches")
