@@ -1,0 +1,14 @@
+#!/bin/bash
+# Dev: rocprofv3 kernel stats of the eigh path (cfg3 and smaller sizes; run on the GPU box).
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_eigh
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/dev_eigh_bench.py > $OUT/run.log 2> $OUT/run.err
+cd $GRAFT_REPO_ROOT
+grep -E "eigh" $OUT/run.log
+python - <<PY
+import csv, glob
+for f in glob.glob("gpurun_out/prof_eigh/trace/**/*kernel_stats.csv", recursive=True):
+  for r in list(csv.DictReader(open(f)))[:14]:
+    print(r["Name"][:70], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"])
+PY
