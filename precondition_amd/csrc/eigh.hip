@@ -908,12 +908,14 @@ __global__ __launch_bounds__(256) void eigh_rayleigh_f64_kernel(EighBlock* block
 // rounding, so the finishing sweeps work on small entries that are accurate RELATIVE to
 // themselves and the eigenvectors of the small eigenvalues come out as accurately as LAPACK's
 // (tools/dev_eigh_refine_proto2.py: root error on a graded 129 x 129 input 2e-2 -> 1e-4).
-// Tiles: 64 x 64 per workgroup (4 per 128 x 128 entry of the tile list), 4 x 4 per thread,
-// float64 FMAs on the vector pipe (2 * 2n^3 DFMA-flops per matrix: ~80 ms for 64 x 2048^2).
+// Tiles: 64 x 64 per workgroup (4 per 128 x 128 entry of the tile list), one wavefront per
+// 32 x 32 quadrant on the float64 MFMA (v_mfma_f64_16x16x4_f64; 2 * 2n^3 flops per matrix).
 // STAGE 0: (X, W) = hi / lo of D V.   STAGE 1: A = V^T (X + W).
 // STAGE 2: X = 1.5 I - 0.5 V^T V (the Newton-Schulz factor of the final polish: with a float32
 // Gram matrix the off-diagonal entries of V^T V carry sqrt(n) eps32 of noise, as large as the
 // loss of orthogonality they are meant to measure).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 template <int STAGE>
 __global__ __launch_bounds__(256) void eigh_reproject_f64_kernel(EighBlock* blocks,
                                                                  const ETile* tiles) {
@@ -929,58 +931,74 @@ __global__ __launch_bounds__(256) void eigh_reproject_f64_kernel(EighBlock* bloc
   const float* L = STAGE == 0 ? eb->D : eb->V;
   const float* R = STAGE == 1 ? eb->X : eb->V;
   const float* R2 = eb->W;
-  const int tr = tid >> 4, tc = tid & 15;
-  double x[4][4];
+  // v_mfma_f64_16x16x4_f64: one wavefront per 32 x 32 quadrant = 2 x 2 tiles of 16 x 16;
+  // A fragment: lane -> A[i = lane & 15][k = lane >> 4], B fragment: B[k = lane >> 4][j = lane & 15],
+  // accumulator element v of a lane: D[i = (lane >> 4) + 4 * v][j = lane & 15]
+  const int wave = tid >> 6, lane = tid & 63;
+  const int qr = 32 * (wave >> 1), qc = 32 * (wave & 1);
+  const int fi = lane & 15, fk = lane >> 4;
+  f64x4 acc[2][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) x[a][b] = 0.0;
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < ld; k0 += RK) {
-    for (int e = tid; e < RK * RQ; e += 256) {
-      if (STAGE == 0) {   // left[k][m] = D[i0 + m][k0 + k]
-        const int m = e / RK, k = e % RK;
-        sL[k][m] = gload1(L + (int64_t)(i0 + m) * ld + k0 + k);
+    {  // one 16-byte load per thread and operand (npad is a multiple of 128: always aligned)
+      if (STAGE == 0) {   // left[k][m] = D[i0 + m][k0 + k]: row m holds 16 consecutive k
+        const int m = tid >> 2, k4 = (tid & 3) * 4;
+        const f32x4 v = gload4(L + (int64_t)(i0 + m) * ld + k0 + k4);
+        sL[k4 + 0][m] = v[0]; sL[k4 + 1][m] = v[1]; sL[k4 + 2][m] = v[2]; sL[k4 + 3][m] = v[3];
       } else {            // left[k][m] = V[k0 + k][i0 + m]
-        const int k = e / RQ, m = e % RQ;
-        sL[k][m] = gload1(L + (int64_t)(k0 + k) * ld + i0 + m);
+        const int k = tid >> 4, m4 = (tid & 15) * 4;
+        const f32x4 v = gload4(L + (int64_t)(k0 + k) * ld + i0 + m4);
+        sL[k][m4 + 0] = v[0]; sL[k][m4 + 1] = v[1]; sL[k][m4 + 2] = v[2]; sL[k][m4 + 3] = v[3];
       }
-      const int k = e / RQ, c = e % RQ;
-      sR[k][c] = gload1(R + (int64_t)(k0 + k) * ld + j0 + c);
-      if (STAGE == 1) sR2[k][c] = gload1(R2 + (int64_t)(k0 + k) * ld + j0 + c);
+      const int k = tid >> 4, c4 = (tid & 15) * 4;
+      const f32x4 r = gload4(R + (int64_t)(k0 + k) * ld + j0 + c4);
+      sR[k][c4 + 0] = r[0]; sR[k][c4 + 1] = r[1]; sR[k][c4 + 2] = r[2]; sR[k][c4 + 3] = r[3];
+      if (STAGE == 1) {
+        const f32x4 r2 = gload4(R2 + (int64_t)(k0 + k) * ld + j0 + c4);
+        sR2[k][c4 + 0] = r2[0]; sR2[k][c4 + 1] = r2[1]; sR2[k][c4 + 2] = r2[2]; sR2[k][c4 + 3] = r2[3];
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RK; ++k) {
-      double lv[4], rv[4];
+    for (int kk = 0; kk < RK; kk += 4) {
+      double af[2], bf[2];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) lv[a] = (double)sL[k][4 * tr + a];
+      for (int a = 0; a < 2; ++a) af[a] = (double)sL[kk + fk][qr + 16 * a + fi];
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        rv[b] = STAGE != 1 ? (double)sR[k][4 * tc + b]
-                           : (double)sR[k][4 * tc + b] + (double)sR2[k][4 * tc + b];
+      for (int b = 0; b < 2; ++b)
+        bf[b] = STAGE != 1 ? (double)sR[kk + fk][qc + 16 * b + fi]
+                           : (double)sR[kk + fk][qc + 16 * b + fi] +
+                                 (double)sR2[kk + fk][qc + 16 * b + fi];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) x[a][b] = fma(lv[a], rv[b], x[a][b]);
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int64_t o = (int64_t)(i0 + 4 * tr + a) * ld + j0 + 4 * tc + b;
-      if (STAGE == 0) {
-        const float hi = (float)x[a][b];
-        eb->X[o] = hi;
-        eb->W[o] = (float)(x[a][b] - (double)hi);
-      } else if (STAGE == 1) {
-        eb->A[o] = (float)x[a][b];
-      } else {
-        const bool diag = i0 + 4 * tr + a == j0 + 4 * tc + b;
-        eb->X[o] = (float)((diag ? 1.5 : 0.0) - 0.5 * x[a][b]);
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = i0 + qr + 16 * a + fk + 4 * v, col = j0 + qc + 16 * b + fi;
+        const int64_t o = (int64_t)row * ld + col;
+        const double x = acc[a][b][v];
+        if (STAGE == 0) {
+          const float hi = (float)x;
+          eb->X[o] = hi;
+          eb->W[o] = (float)(x - (double)hi);
+        } else if (STAGE == 1) {
+          eb->A[o] = (float)x;
+        } else {
+          eb->X[o] = (float)((row == col ? 1.5 : 0.0) - 0.5 * x);
+        }
       }
-    }
 }
 
 // Largest scaled off-diagonal entry max_{i != j} |a_ij| / sqrt(|a_ii| |a_jj|) of the working
