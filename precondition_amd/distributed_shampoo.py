@@ -311,10 +311,10 @@ def distributed_shampoo(
 
   def _tree_plan(params_flat):
     """plan.TreePlan of this tree (shapes only), or None when the tree or the options need
-    the general per-block path: FD / compression, quantized second moments, owner-only
-    statistics, blocks of merged rank > 2, the host-logic test backend."""
+    the general per-block path: FD / compression, owner-only statistics, blocks of merged
+    rank > 2, the host-logic test backend."""
     if (not hasattr(backend, "transform_grads_fused") or frequent_directions or
-        compression_rank or quantize_second_moment or shard_stats or
+        compression_rank or shard_stats or
         os.environ.get("PS_UPDATE_PLAN", "1") == "0"):
       return None
     key = tuple(tuple(p.shape) for p in params_flat)
@@ -388,7 +388,21 @@ def distributed_shampoo(
     if plan is not None and all(g.is_contiguous() for g in grads_flat):
       # every (block, axis) addressed as `gradient pointer + planned offset`: no block views
       olds = [s for st in stats_flat for s in st.statistics]
-      if len(olds) == len(plan.stat_dims) and all(s.is_contiguous() for s in olds):
+      if quantize_second_moment and len(olds) == len(plan.stat_dims):
+        # int16 state (DS:2652-2654): dequantize the tree in one launch, update the float
+        # temporaries in place, quantize them back
+        fl = _to_float_many(olds)
+        if all(s.is_contiguous() for s in fl):
+          plan.stats_update(grads_flat, fl, fl, w1, w2)
+          qs = _quantize_many(fl, qdt_second_moment, True)
+          out, k = [], 0
+          for st, cnt in zip(stats_flat, plan.n_stats_of):
+            out.append(ParameterStats(st.diagonal_statistics, qs[k:k + cnt], st.preconditioners,
+                                      st.diagonal_momentum, st.momentum, MaskedNode(),
+                                      st.training_metrics))
+            k += cnt
+          return out
+      elif len(olds) == len(plan.stat_dims) and all(s.is_contiguous() for s in olds):
         news = [torch.empty_like(s) for s in olds]
         plan.stats_update(grads_flat, olds, news, w1, w2)
         out, k = [], 0
@@ -689,6 +703,8 @@ def distributed_shampoo(
     plan = _tree_plan(params_flat)
     if plan is not None and all(g.is_contiguous() for g in grads_flat):
       precs_flat = [p for st in states for p in st.preconditioners]
+      if quantize_second_moment:  # _maybe_dequantize_preconditioners, DS:2097-2106
+        precs_flat = _to_float_many(precs_flat)
       if len(precs_flat) == len(plan.stat_dims) and all(
           p.is_contiguous() and p.dtype == torch.float32 for p in precs_flat):
         for i, (g, sk) in enumerate(zip(grads_flat, plan.skipped)):
