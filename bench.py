@@ -289,11 +289,40 @@ def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
     times.append((time.perf_counter() - t0) / factors)
     del grads
   tails = [float(p[1, -1]) for p in prevs]
+  roof = None
+  if subspace._filter_precision(d) != "f32" and not SELFTEST:
+    # the dominant kernel: one C @ Y product of the filter for all factors (HBM-bound: the
+    # covariance is read once as a bf16 hi/lo pair = 4 bytes per element, for b = 96 columns)
+    from precondition_amd import kernels as K
+    b = 96
+    cs = [torch.randn((d, d), generator=gen, device=dev) for _ in range(factors)]
+    c16 = [K.to_bf16(c, split=True) for c in cs]
+    y = torch.randn((factors * d, b), generator=gen, device=dev)
+    z = torch.empty((factors, d, b), device=dev)
+    yt = K.to_bf16(y, split=True, transpose=True)
+    items = [((c16[j][0], c16[j][1]), (yt[0][:, j * d:(j + 1) * d], yt[1][:, j * d:(j + 1) * d]),
+              z[j]) for j in range(factors)]
+    K.gemm_bf16_grouped(items); _sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+      K.gemm_bf16_grouped(items)
+    e1.record(); _sync()
+    ms = e0.elapsed_time(e1) / 10
+    nbytes = factors * (4.0 * d * d + 4.0 * d * b + 4.0 * d * b)   # C (hi+lo), Y^T (hi+lo), Z
+    roof = {"kernel": "gemm_bf16_grouped_kernel (+ split-K reduce): Z = C @ Y, hi/lo operands",
+            "bound": "hbm", "peak": 8000, "unit": "GB/s",
+            "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "frac": round(nbytes / (ms * 1e-3) / 1e9 / 8000, 4),
+            "ms_per_product_all_factors": round(ms, 4),
+            "equiv_bf16x3_tflops": round(factors * 3 * 2.0 * d * d * b / (ms * 1e-3) / 1e12, 1)}
+    del cs, c16, y, z, yt, items
   return {"workload": f"{factors} factors of dim {d}, rank {rank}, {updates} FD updates from a "
                       "zero sketch, grad blocks ~N(0,1) [4096x4096], fp32",
           "products": subspace._filter_precision(d),
           "ms_per_factor_update": [round(t * 1e3, 1) for t in times],
           "tail_after_updates": round(float(np.mean(tails)), 1),
+          "roofline": roof,
           "note": "Gram + leading rank+1 eigenpairs of the 4096x4096 covariance update by "
                   "Chebyshev-filtered subspace iteration (all factors batched): large products on "
                   "the bf16 MFMA (hi/lo split operands, fp32 accumulation) or the fp32 MFMA, "
