@@ -115,6 +115,24 @@ class Workload:
         eigh=self.name.startswith("eigh"), max_ev=max_ev)
     return m
 
+  def split_point(self):
+    """First-part size of the two-phase step.  A Newton stage launches T(T+1)/2 tiles per block
+    on 512 resident workgroup slots (2 per CU): both parts should be close to a whole number
+    of rounds (half of cfg2's 256 blocks = 1280 tiles = 2.5 rounds would waste a sixth of its
+    last round), and the second part -- whose all-gather is NOT hidden -- should be the smaller
+    one.  Falls back to the middle."""
+    t = (self.n + 127) // 128
+    tpb = t * (t + 1) // 2
+    best, best_cost = self.nb // 2, None
+    for h in range(max(1, (2 * self.nb) // 5), max(2, (3 * self.nb) // 4) + 1):
+      if h >= self.nb:
+        break
+      waste = sum((-(x * tpb)) % 512 for x in (h, self.nb - h)) / 512.0   # idle slot-rounds
+      cost = waste + 0.5 * (self.nb - h) / self.nb                          # + exposed gather share
+      if best_cost is None or cost < best_cost - 1e-9:
+        best, best_cost = h, cost
+    return best
+
   def compute(self):
     """This rank's roots only (no collective)."""
     self.metrics = self._roots(0, self.nb)
@@ -126,14 +144,14 @@ class Workload:
     # N > 1: the batch is rooted in two halves so that the RCCL all-gather of the
     # first half's roots (NCCL-side stream, async) runs under the second half's
     # Newton iterations (measured cost of the split on one GPU: +3 % at 512^2,
-    # +4 % at 1024^2).  `gathered` is laid out [half][rank][block].
+    # +4 % at 1024^2).  `gathered` is laid out [part][rank][block].
     # The power iteration (100 short HBM-bound launches) runs ONCE over the whole batch
     # and both halves take their largest eigenvalue from it: split halves of it would
     # sit on the launch-latency floor (split cost 1.4 -> 0.5 ms at 512^2; results are
     # bit-identical, same kernels).
     import torch.distributed as dist
     from precondition_amd import kernels as K
-    h = self.nb // 2
+    h = self.split_point()
     per = self.n * self.n
     g = self.gathered.view(-1)
     handles = []
@@ -144,7 +162,7 @@ class Workload:
                                          padding_starts=[self.n] * self.nb)
     for k, (lo, hi) in enumerate(((0, h), (h, self.nb))):
       ms.append(self._roots(lo, hi, None if lam is None else lam[lo:hi]))
-      off = k * self.world * h * per
+      off = self.world * lo * per   # parts are laid out one after the other: [part][rank][block]
       out = g[off: off + self.world * (hi - lo) * per]
       inp = self.roots[lo:hi].reshape(-1)
       if dist.get_backend() == "gloo":  # dev only (see main): stage through the host
@@ -162,12 +180,12 @@ class Workload:
     sit in its rank's slots of both halves (DS:2876: all_gather returns rank order)."""
     if self.gathered is None:
       return True
-    h = self.nb // 2
+    h = self.split_point()
     per = self.n * self.n
     g = self.gathered.view(-1)
     ok = True
     for k, (lo, hi) in enumerate(((0, h), (h, self.nb))):
-      off = k * self.world * h * per + rank * (hi - lo) * per
+      off = self.world * lo * per + rank * (hi - lo) * per
       ok &= bool(torch.equal(g[off: off + (hi - lo) * per], self.roots[lo:hi].reshape(-1)))
     return ok
 
