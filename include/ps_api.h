@@ -53,6 +53,7 @@ enum {
   PS_EWORKSPACE = -2, /* workspace too small */
   PS_EUNSUPPORTED = -3,
   PS_EINTERNAL = -4,
+  PS_ECOMM = -6,      /* RCCL not loadable, or an RCCL call failed (ps_comm_last_error) */
   PS_EDEVICE = -5     /* called with a HIP device current that is not the one this
                          process first used the library on (one process per GPU) */
 };
@@ -372,6 +373,27 @@ int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int count, void* wo
 size_t ps_dequantize_workspace_bytes(const ps_quant_desc* desc, int count);
 int ps_dequantize_f32(void* stream, const ps_quant_desc* desc, int count, void* workspace,
                       size_t workspace_bytes);
+
+/* ---- seam (iii): the exchange of DS:2876-2877 (jax.lax.all_gather of the roots and of the
+ * metrics) as plain RCCL calls, one communicator per process (one process per GPU).  The
+ * library does not link RCCL: the entry points resolve ncclGetUniqueId / ncclCommInitRank /
+ * ncclAllGather / ncclCommDestroy from the librccl.so already loaded in the process (torch's
+ * own, when the host is PyTorch) or from the default library path, and return PS_ECOMM when
+ * there is none.  The Python host of this repository performs the same exchange through
+ * torch.distributed (backend "nccl" = RCCL); these entry points are what a non-torch host
+ * binds instead.
+ *   ps_comm_unique_id : rank 0 fills PS_COMM_ID_BYTES bytes, the host ships them to all ranks
+ *   ps_comm_init      : collective over `world` ranks; *comm receives an opaque handle
+ *   ps_comm_allgather : recv[r * bytes_per_rank ...] = rank r's send buffer, enqueued on
+ *                       `stream` (device pointers; send may alias its own slot of recv)
+ *   ps_comm_destroy   : releases the communicator */
+#define PS_COMM_ID_BYTES 128
+int ps_comm_unique_id(void* id_out);
+int ps_comm_init(void** comm, int rank, int world, const void* unique_id);
+int ps_comm_allgather(void* stream, void* comm, const void* send, void* recv,
+                      size_t bytes_per_rank);
+int ps_comm_destroy(void* comm);
+const char* ps_comm_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -149,6 +149,11 @@ _SIGNATURES = {
     "ps_transform_grads_f32":
         (C.c_int, [C.c_void_p, C.POINTER(TransformDesc), C.c_int, C.POINTER(TransformConfig),
                    C.c_void_p, C.c_size_t]),
+    "ps_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ps_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    "ps_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ps_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ps_comm_last_error": (C.c_char_p, []),
     "ps_quantize_workspace_bytes": (C.c_size_t, [C.POINTER(QuantDesc), C.c_int]),
     "ps_quantize_f32":
         (C.c_int, [C.c_void_p, C.POINTER(QuantDesc), C.c_int, C.c_void_p, C.c_size_t]),

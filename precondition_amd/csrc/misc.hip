@@ -19,6 +19,7 @@ extern "C" const char* ps_error_string(int code) {
     case PS_EUNSUPPORTED: return "unsupported size or exponent";
     case PS_EINTERNAL: return "internal error";
     case PS_EDEVICE: return "wrong HIP device current (the library serves one device per process)";
+    case PS_ECOMM: return "RCCL unavailable or an RCCL call failed (ps_comm_last_error)";
     default:
       return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }

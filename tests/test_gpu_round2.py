@@ -635,3 +635,28 @@ def test_eigh_root_accuracy_on_graded_spectra_near_lapack(n, kind, p, device):
   e_hip, e_lap = np.linalg.norm(got - truth) / tn, np.linalg.norm(lap - truth) / tn
   assert e_hip < 6 * e_lap + 2e-4, (e_hip, e_lap)
   assert e_hip < 2e-3
+
+
+def test_comm_entry_points_one_rank_rccl(device):
+  """Seam (iii) at the C-ABI (DS:2876-2877): ps_comm_* resolve RCCL at run time; a one-rank
+  communicator gathers a buffer into itself (N > 1 needs more GPUs than a test box has; the
+  same calls with world > 1 are what a non-torch host issues)."""
+  import ctypes as C
+  from precondition_amd import _lib
+  L = _lib.lib()
+  uid = (C.c_char * 128)()
+  rc = L.ps_comm_unique_id(uid)
+  assert rc == 0, L.ps_comm_last_error()
+  comm = C.c_void_p()
+  with torch.cuda.device(device):
+    rc = L.ps_comm_init(C.byref(comm), 0, 1, uid)
+    assert rc == 0, L.ps_comm_last_error()
+    send = torch.arange(4096, dtype=torch.float32, device=device)
+    recv = torch.zeros_like(send)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = L.ps_comm_allgather(st, comm, send.data_ptr(), recv.data_ptr(), send.numel() * 4)
+    assert rc == 0, L.ps_comm_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    assert L.ps_comm_destroy(comm) == 0
+  assert L.ps_comm_allgather(st, None, send.data_ptr(), recv.data_ptr(), 16) == -1
