@@ -182,9 +182,10 @@ size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
                                       const int32_t* padding_start);
 /* Number of leading Newton steps of every try in which the M update (DS:845) of an exactly
  * symmetric block is computed in full and averaged with its transpose instead of being
- * mirrored from its upper tile triangle (default 2; PS_NEWTON_AVG_STEPS overrides; see
- * csrc/newton.hip TileFlags: at cond ~1e4 mirroring everywhere is 5x less accurate than
- * full products, 2 averaged steps bring it to 1.4x, 4 steps to parity).  For FLOP accounting. */
+ * mirrored from its upper tile triangle (default 4; PS_NEWTON_AVG_STEPS overrides; see
+ * csrc/newton.hip TileFlags: at cond ~7e3, p = 4 the error against the float64 root is
+ * 9.3e-4 mirrored everywhere, 1.76e-4 with 4 averaged steps, 1.96e-4 with full products
+ * in this library's summation order and 1.26e-4 in NumPy's).  For FLOP accounting. */
 int ps_newton_averaged_steps(void);
 int ps_newton_root_batched_f32(void* stream, const float* const* a,
                                const int32_t* n, const int32_t* lda,

@@ -63,6 +63,11 @@ struct EighBlock {
   unsigned err_bits;
   int power_iters;
   unsigned soff_bits;  // max scaled off-diagonal |a_ij| / sqrt(|a_ii a_jj|) (eigh_scaled_off_kernel)
+  // one-sided block Jacobi on the Cholesky factor (eigh_cj.hip.h)
+  int cj;          // this block takes that path
+  int cj_active;   // ... and is still sweeping
+  int chol_fail;   // the factorisation met a non-positive pivot: two-sided fallback
+  int cj_group;    // which of the two interleaved streams sweeps this block
 };
 
 struct ETile {
@@ -306,16 +311,20 @@ __device__ inline float row16_sum(float x) {
 // EXTRA = elements per lane beyond the first 64 rows: 0 (m <= 64), 2 (m <= 96: rows 64 + 2l,
 // 64 + 2l + 1), 4 (m <= 128: rows 64 + 4l ...).  Rows that do not exist are never touched: a
 // 96 x 96 problem (the block size of the subspace iteration) does 3/4 of the 128-row work.
+// done_cos2: the iteration also stops after a sweep whose largest rotated pair had a squared
+// cosine below it (the NEXT sweep would be the quadratically converged, rotation-free one): 0
+// keeps the strict rule.  Used by the pivots of eigh_cj.hip.h, whose outer iteration re-checks
+// every pair against the true Gram matrix anyway.
 template <int EXTRA>
 __device__ inline int onesided_jacobi_lds_t(float* G, float* V, int* s_rot, int m,
-                                            int max_sweeps) {
+                                            int max_sweeps, float done_cos2 = 0.f) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane >> 4, l = lane & 15;     // 16 lanes per pair, 4 pairs per wavefront
   const int k = 4 * wave + sub;                 // pair index within the round
   const bool has_pair = k < (m >> 1);
   int sweeps_total = 0;
   for (int sweeps = 0; sweeps < max_sweeps; ++sweeps, ++sweeps_total) {
-    int rotated = 0;
+    float rotated = 0.f;   // largest squared cosine of a rotated pair in this sweep
     for (int round = 0; round < m - 1; ++round) {
       if (has_pair) {
         int p, q;
@@ -382,19 +391,19 @@ __device__ inline int onesided_jacobi_lds_t(float* G, float* V, int* s_rot, int 
                 *reinterpret_cast<f32x2*>(vq + 64 - 2 * l) = f32x2{nx1[0], nx1[1]};
               }
             }
-            rotated = 1;
+            rotated = fmaxf(rotated, ab * ab * __builtin_amdgcn_rcpf(aa * bb));
           }
         }
       }
       __syncthreads();
     }
     // a sweep without a single rotation: converged (s_rot is double buffered by parity)
-    if (rotated && l == 0) s_rot[sweeps & 1] = 1;
+    if (rotated > 0.f && l == 0) atomicMax(&s_rot[sweeps & 1], __float_as_int(rotated));
     __syncthreads();
     const int any = s_rot[sweeps & 1];
     __syncthreads();
     if (tid == 0) s_rot[sweeps & 1] = 0;   // re-armed for sweep + 2 (after the next barriers)
-    if (!any) { ++sweeps_total; break; }
+    if (!any || __int_as_float(any) < done_cos2) { ++sweeps_total; break; }
   }
   __syncthreads();
   return sweeps_total;
@@ -727,7 +736,7 @@ __global__ void eigh_set_active_kernel(EighBlock* blocks, int nblocks, int swap_
   if (b >= nblocks) return;
   EighBlock* eb = &blocks[b];
   if (eb->n == 0) return;
-  eb->active = eb->small ? 0 : 1;
+  eb->active = (eb->small || eb->cj) ? 0 : 1;
   if (swap_vw) { float* t = eb->V; eb->V = eb->W; eb->W = t; }
 }
 
@@ -1040,6 +1049,8 @@ __global__ __launch_bounds__(256) void eigh_scaled_off_kernel(EighBlock* blocks,
   }
 }
 
+#include "eigh_cj.hip.h"
+
 // mode 1: eigenvalues = diag(A), eigenvectors = V[:, :n] (cropped to n x n).
 __global__ __launch_bounds__(256) void eigh_copy_pairs_kernel(EighBlock* blocks,
                                                               const ETile* tiles) {
@@ -1098,6 +1109,9 @@ struct EPlan {
   std::vector<ETile> row_tiles;   // (block, k, coltile)
   std::vector<ETile> col_tiles;   // (block, k, rowtile, which)
   std::vector<ETile> rq_tiles;    // (block, chunk of 64 eigenvectors) for the refinement
+  std::vector<ETile> chol_tiles;  // (block, 64-row tile) of the blocks swept by eigh_cj.hip.h
+  std::vector<int> big_ids;       // those blocks
+  std::vector<ETile> cj_pair[2], cj_row[2];  // pair / row-tile lists of the two stream groups
   PiPlan pip;
 };
 
@@ -1122,9 +1136,14 @@ void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_s
       continue;
     }
     pl.max_nb = std::max(pl.max_nb, nb);
+    const int grp = (int)(pl.big_ids.size() & 1);
+    pl.big_ids.push_back(b);
+    for (int i = 0; i < nb; ++i) pl.chol_tiles.push_back({b, (short)i, 0, 0, 0});
     for (int k = 0; k < np; ++k) {
       pl.pair_tiles.push_back({b, (short)k, 0, 0, 0});
+      pl.cj_pair[grp].push_back({b, (short)k, 0, 0, 0});
       for (int c = 0; c < t; ++c) {
+        pl.cj_row[grp].push_back({b, (short)k, (short)c, 0, 0});
         pl.row_tiles.push_back({b, (short)k, (short)c, 0, 0});
         pl.col_tiles.push_back({b, (short)k, (short)c, 0, 0});
         pl.col_tiles.push_back({b, (short)k, (short)c, 1, 0});
@@ -1136,7 +1155,8 @@ void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_s
 struct ELayout {
   EighBlock* blocks;
   int* small_ids;
-  ETile *sq, *pair, *row, *col, *rq;
+  ETile *sq, *pair, *row, *col, *rq, *chol, *cj_pair[2], *cj_row[2];
+  int* big_ids;
   std::vector<float*> mat[5], Q, offp, ssq, evals;
 };
 
@@ -1150,8 +1170,16 @@ size_t ecarve(EPlan& pl, Arena& ar, ELayout* lo) {
   ETile* cl = ar.take<ETile>(pl.col_tiles.size());
   ETile* rq = ar.take<ETile>(std::max<size_t>(pl.rq_tiles.size(), 1));
   int* sid = ar.take<int>(std::max<size_t>(pl.small_ids.size(), 1));
+  ETile* ch = ar.take<ETile>(std::max<size_t>(pl.chol_tiles.size(), 1));
+  int* bid = ar.take<int>(std::max<size_t>(pl.big_ids.size(), 1));
+  ETile* cjp[2]; ETile* cjr[2];
+  for (int g = 0; g < 2; ++g) {
+    cjp[g] = ar.take<ETile>(std::max<size_t>(pl.cj_pair[g].size(), 1));
+    cjr[g] = ar.take<ETile>(std::max<size_t>(pl.cj_row[g].size(), 1));
+  }
   if (lo) { lo->blocks = blocks; lo->sq = sq; lo->pair = pr; lo->row = rw; lo->col = cl;
-            lo->rq = rq; lo->small_ids = sid; }
+            lo->rq = rq; lo->small_ids = sid; lo->chol = ch; lo->big_ids = bid;
+            for (int g = 0; g < 2; ++g) { lo->cj_pair[g] = cjp[g]; lo->cj_row[g] = cjr[g]; } }
   for (int b = 0; b < B; ++b) {
     const size_t sq_e = (size_t)pl.npad[b] * pl.npad[b];
     for (int k = 0; k < 5; ++k) { float* m = ar.take<float>(sq_e); if (lo) lo->mat[k].push_back(m); }
@@ -1239,6 +1267,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     eb.off_rel = 1.f;
   }
   for (int b : pl.small_ids) hb[b].small = 1;
+  for (size_t i = 0; i < pl.big_ids.size(); ++i) hb[pl.big_ids[i]].cj_group = (int)(i & 1);
   auto up = [&](void* d, const void* h, size_t bytes) -> int {
     return psh::upload_async(st, d, h, bytes);  // pinned staging ring: no stream synchronisation
   };
@@ -1254,6 +1283,20 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   if (!pl.small_ids.empty() &&
       (rc = up(lo.small_ids, pl.small_ids.data(), sizeof(int) * pl.small_ids.size())))
     return rc;
+  if (!pl.chol_tiles.empty() &&
+      (rc = up(lo.chol, pl.chol_tiles.data(), sizeof(ETile) * pl.chol_tiles.size())))
+    return rc;
+  if (!pl.big_ids.empty() &&
+      (rc = up(lo.big_ids, pl.big_ids.data(), sizeof(int) * pl.big_ids.size())))
+    return rc;
+  for (int g = 0; g < 2; ++g) {
+    if (!pl.cj_pair[g].empty() &&
+        (rc = up(lo.cj_pair[g], pl.cj_pair[g].data(), sizeof(ETile) * pl.cj_pair[g].size())))
+      return rc;
+    if (!pl.cj_row[g].empty() &&
+        (rc = up(lo.cj_row[g], pl.cj_row[g].data(), sizeof(ETile) * pl.cj_row[g].size())))
+      return rc;
+  }
   if (relative_matrix_epsilon) {
     if ((rc = pl.pip.upload(st, a, lda))) return rc;
     // the reference's power iteration is a plain mat-vec loop on the raw input (DS:996-1001)
@@ -1323,6 +1366,125 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       PS_LAUNCH_CHECK();
     }
     if (mode == 1 && !any_big) return PS_OK;  // the kernel wrote sorted pairs to the outputs
+    // Root mode, blocks of more than 128 rows: one-sided block Jacobi on the Cholesky factor
+    // (eigh_cj.hip.h).  PS_EIGH_CJ=0 restores the blocked two-sided solver for everything.
+    const int cj_on = [] { const char* e = getenv("PS_EIGH_CJ"); return e ? atoi(e) : 1; }();
+    bool run_two_sided = any_big;
+    if (cj_on && mode == 0 && any_big) {
+      const float cj_tol = [] {
+        const char* e = getenv("PS_EIGH_CJ_TOL"); return e ? (float)atof(e) : 2e-6f; }();
+      const int cj_inner = [] {
+        const char* e = getenv("PS_EIGH_CJ_INNER"); return e ? atoi(e) : 3; }();
+      const float cj_done = [] {   // inner iteration: stop after a sweep below this cosine
+        const char* e = getenv("PS_EIGH_CJ_DONE"); return e ? (float)atof(e) : 1e-3f; }();
+      const int cj_max_sweeps = [] {
+        const char* e = getenv("PS_EIGH_CJ_MAX_SWEEPS"); return e ? atoi(e) : 24; }();
+      const int cj_sort = [] { const char* e = getenv("PS_EIGH_CJ_SORT"); return e ? atoi(e) : 1; }();
+      const size_t piv_lds = (size_t)(2 * SE_MAXN * SE_LD + 32 + 3 * SE_MAXN) * sizeof(float);
+      static bool piv_attr = false;
+      if (!piv_attr) {
+        PS_HIP(hipFuncSetAttribute((const void*)cj_pivot_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)piv_lds));
+        piv_attr = true;
+      }
+      static thread_local hipEvent_t cj_ev[2] = {nullptr, nullptr};
+      for (int i = 0; i < 2; ++i)
+        if (!cj_ev[i]) PS_HIP(hipEventCreateWithFlags(&cj_ev[i], hipEventDisableTiming));
+      const int nchol = (int)pl.chol_tiles.size(), nbig = (int)pl.big_ids.size();
+      hipLaunchKernelGGL(cj_select_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks, batch);
+      hipLaunchKernelGGL(cj_zero_upper_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      for (int j = 0; j < pl.max_nb; ++j) {
+        hipLaunchKernelGGL(cj_chol_schur_kernel, dim3(nchol), blk, 0, st, lo.blocks, lo.chol, j);
+        hipLaunchKernelGGL(cj_chol_potrf_kernel, dim3(nbig), blk, 0, st, lo.blocks, lo.big_ids, j);
+        hipLaunchKernelGGL(cj_chol_trsm_kernel, dim3(nchol), blk, 0, st, lo.blocks, lo.chol, j);
+      }
+      int gen = 0;
+      {
+        EStatus* slot = &status[gen % 64];
+        slot->gen = -1;
+        hipLaunchKernelGGL(cj_control_kernel, dim3(1), blk, 0, st, lo.blocks, batch, 0, 0.f, gen,
+                           slot, -1);
+        PS_LAUNCH_CHECK();
+        PS_HIP(hipStreamSynchronize(st));   // the only stall of the path: fallback blocks known
+        if (slot->gen != gen) return PS_EINTERNAL;
+        run_two_sided = slot->pad_ > 0;
+        if (getenv("PS_EIGH_TRACE"))
+          fprintf(stderr, "eigh cj: Cholesky done, %d block(s) fall back to the two-sided solver\n",
+                  slot->pad_);
+        ++gen;
+      }
+      // Sweeps.  The blocks are dealt to two groups that sweep on two streams (the caller's and
+      // a side stream of this thread): the pivot kernel is LDS / VALU work with one workgroup
+      // per CU, the Gram and update kernels are MFMA work with small LDS footprints, so one
+      // group's pivots run beside the other group's products on the same CUs (PS_EIGH_CJ_STREAMS=1:
+      // everything on the caller's stream).  The host stays one sweep ahead of the GPU (it waits
+      // for the status of sweep s - 1 only after sweep s is queued), so the streams never
+      // drain; converged blocks' workgroups exit at once.
+      const int nstreams = [] { const char* e = getenv("PS_EIGH_CJ_STREAMS"); return e ? atoi(e) : 2; }();
+      static thread_local hipStream_t side = nullptr;
+      static thread_local hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
+      if (!side) PS_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      for (int i = 0; i < 3; ++i)
+        if (!side_ev[i]) PS_HIP(hipEventCreateWithFlags(&side_ev[i], hipEventDisableTiming));
+      // K-tile depth of the update products: 8 = 20 KB of LDS, which fits beside a pivot workgroup
+      const int cj_ubk = [] { const char* e = getenv("PS_EIGH_CJ_UBK"); return e ? atoi(e) : 8; }();
+      const bool two = nstreams >= 2 && !pl.cj_pair[1].empty();
+      hipStream_t gs[2] = {st, two ? side : st};
+      if (two) {   // everything queued so far on the caller's stream happens before the side stream starts
+        PS_HIP(hipEventRecord(side_ev[2], st));
+        PS_HIP(hipStreamWaitEvent(side, side_ev[2], 0));
+      }
+      const int first_gen = gen;
+      bool done[2] = {false, pl.cj_pair[1].empty()};
+      for (int s = 0; s < cj_max_sweeps; ++s) {
+        for (int r = 0; r < pl.max_nb - 1; ++r)
+          for (int g = 0; g < 2; ++g) {
+            if (done[g]) continue;
+            const int np_g = (int)pl.cj_pair[g].size(), nr_g = (int)pl.cj_row[g].size();
+            hipLaunchKernelGGL(cj_gram_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks, lo.cj_pair[g],
+                               np_g, r);
+            hipLaunchKernelGGL(cj_pivot_kernel, dim3(np_g), dim3(SE_T), piv_lds, gs[g], lo.blocks,
+                               lo.cj_pair[g], r, cj_tol, cj_inner, cj_done * cj_done, cj_sort);
+            if (cj_ubk == 8)
+              hipLaunchKernelGGL(cj_update_kernel_t<8>, dim3(nr_g), blk, 0, gs[g], lo.blocks,
+                                 lo.cj_row[g], nr_g, r);
+            else
+              hipLaunchKernelGGL(cj_update_kernel_t<16>, dim3(nr_g), blk, 0, gs[g], lo.blocks,
+                                 lo.cj_row[g], nr_g, r);
+          }
+        for (int g = 0; g < 2; ++g) {
+          if (done[g]) continue;
+          EStatus* slot = &status[(2 * gen + g) % 64];
+          slot->gen = -1;
+          hipLaunchKernelGGL(cj_control_kernel, dim3(1), blk, 0, gs[g], lo.blocks, batch, 1, cj_tol,
+                             gen, slot, g);
+          PS_HIP(hipEventRecord(g == 0 ? cj_ev[s & 1] : side_ev[s & 1], gs[g]));
+        }
+        PS_LAUNCH_CHECK();
+        ++gen;
+        if (s >= 1) {
+          for (int g = 0; g < 2; ++g) {
+            if (done[g]) continue;
+            PS_HIP(hipEventSynchronize(g == 0 ? cj_ev[(s - 1) & 1] : side_ev[(s - 1) & 1]));
+            EStatus* prev = &status[(2 * (gen - 2) + g) % 64];
+            if (prev->gen != gen - 2) return PS_EINTERNAL;
+            if (getenv("PS_EIGH_TRACE"))
+              fprintf(stderr, "eigh cj sweep %d group %d: max scaled Gram entry %.3e, %d block(s) still sweeping\n",
+                      gen - 2 - first_gen, g, prev->max_off, prev->active);
+            if (prev->active == 0) done[g] = true;
+          }
+          if (done[0] && done[1]) break;
+        }
+      }
+      if (two) {
+        PS_HIP(hipEventRecord(side_ev[2], side));
+        PS_HIP(hipStreamWaitEvent(st, side_ev[2], 0));
+      }
+      hipLaunchKernelGGL(cj_norms_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      hipLaunchKernelGGL(cj_finalize_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      PS_LAUNCH_CHECK();
+    }
+    if (run_two_sided) {
     // phase 1: sweep until the pivot off-norm at the start of a sweep < 1e-3 ||D||
     if (any_big && (rc = run_phase(1e-3f, 30))) return rc;
     // polish: V <- V (1.5 I - 0.5 V^T V);  A <- V^T D V
@@ -1369,6 +1531,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       ++gen;
       if (slot->active == 0 || extra == extra_sweeps) break;
       if ((rc = run_phase(0.f, 1))) return rc;
+    }
     }
     {
       static const int final_polish = [] {

@@ -1,0 +1,471 @@
+// eigh_cj.hip.h — round-3 eigensolver of the eigh root path (included by eigh.hip inside
+// namespace psk): one-sided (Hestenes) block Jacobi on the Cholesky factor.
+//
+//   D = A + ridge I (DS:1005-1006)  =  L L^T      float64-accumulated blocked Cholesky, L stored
+//                                                 as float32 in G
+//   sweeps over round-robin pairs (I, J) of 64-wide block columns of G:
+//       P = [G_I G_J]^T [G_I G_J]        128 x 128 Gram matrix        (cj_gram_kernel, MFMA f32)
+//       Q = eigenvectors of P            one-sided Jacobi in LDS      (cj_pivot_kernel)
+//       [G_I G_J] <- [G_I G_J] Q         128-row tiles, K = 128       (cj_update_kernel, MFMA f32)
+//   until every scaled Gram entry |g_i . g_j| / (|g_i| |g_j|) seen in a sweep is below `tol`.
+//   Then D = G G^T = U diag(|g_j|^2) U^T with U = the normalised columns of G: the eigenvectors
+//   need no accumulation and there is no left-side update, 6 n^3 flops per sweep instead of the
+//   12 n^3 of the two-sided method (A <- J^T A, A <- A J, V <- V J), and the rotations act on a
+//   factor whose condition number is the square root of D's (Demmel-Veselic: the small
+//   eigenvalues of a graded / rank-deficient-plus-ridge statistic keep their relative accuracy).
+//   Prototype with sweep counts and accuracy: tools/proto_onesided_chol.py.
+//
+// Replaces jnp.linalg.eigh at DS:1007 (LAPACK ssyevd on the reference's CPU path) for blocks
+// of more than 128 rows in root mode; the blocked two-sided solver stays as the fallback for a
+// block whose Cholesky factorisation breaks down (an input that is not positive definite after
+// the ridge) and for plain eigenpairs of possibly indefinite matrices (ps_eigh_batched_f32).
+//
+// Workspace aliases (no extra memory): G = eb->X, the Gram matrices P of a round = eb->V
+// (unused until the eigenvectors are written there at the end), the float64 Cholesky panel and
+// the inverse of its diagonal block = eb->W, the per-(round, pair) skip flags = eb->offpart.
+#pragma once
+
+constexpr int CB = 64;   // Cholesky tile
+
+// ---- Cholesky, step j: S_ij = D_ij - sum_{k < j} L_ik L_jk^T for the tiles i >= j of the
+// panel, accumulated in float64 on v_mfma_f64_16x16x4_f64 (operands are float32: their products
+// are exact in float64), written as float64 to the panel buffer Sp[npad][64].
+__global__ __launch_bounds__(256) void cj_chol_schur_kernel(EighBlock* blocks, const ETile* tiles,
+                                                            int j) {
+  __shared__ float sL[RK][RQ + 1];
+  __shared__ float sR[RK][RQ + 1];
+  const ETile te = tiles[blockIdx.x];
+  EighBlock* eb = &blocks[te.block];
+  const int i = te.k;
+  if (!eb->cj_active || i < j || j >= eb->npad / CB) return;
+  const int ld = eb->npad, tid = threadIdx.x;
+  const int i0 = i * CB, j0 = j * CB;
+  const float* G = eb->X;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int qr = 32 * (wave >> 1), qc = 32 * (wave & 1);
+  const int fi = lane & 15, fk = lane >> 4;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < j0; k0 += RK) {
+    const int m = tid >> 2, k4 = (tid & 3) * 4;
+    const f32x4 v = gload4(G + (int64_t)(i0 + m) * ld + k0 + k4);
+    const f32x4 w = gload4(G + (int64_t)(j0 + m) * ld + k0 + k4);
+    sL[k4 + 0][m] = v[0]; sL[k4 + 1][m] = v[1]; sL[k4 + 2][m] = v[2]; sL[k4 + 3][m] = v[3];
+    sR[k4 + 0][m] = w[0]; sR[k4 + 1][m] = w[1]; sR[k4 + 2][m] = w[2]; sR[k4 + 3][m] = w[3];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < RK; kk += 4) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = (double)sL[kk + fk][qr + 16 * a + fi];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bf[b] = (double)sR[kk + fk][qc + 16 * b + fi];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  double* Sp = reinterpret_cast<double*>(eb->W);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = qr + 16 * a + fk + 4 * v, c = qc + 16 * b + fi;
+        const double d = (double)gload1(eb->D + (int64_t)(i0 + r) * ld + j0 + c);
+        Sp[(int64_t)(i0 + r) * CB + c] = d - acc[a][b][v];
+      }
+}
+
+// ---- Cholesky, step j: L_jj = chol(S_jj) in float64 in LDS, rounded to float32 into G (upper
+// part zero); the inverse of the ROUNDED factor (float64) goes to the scratch behind the panel.
+// Rows beyond the block's true size are an identity for the arithmetic and zero in G.  A
+// non-positive or non-finite pivot marks the block (chol_fail): it is solved by the two-sided
+// fallback.  One workgroup per block.
+__global__ __launch_bounds__(256) void cj_chol_potrf_kernel(EighBlock* blocks, const int* ids,
+                                                            int j) {
+  __shared__ double S[CB][CB + 1];
+  __shared__ double Xi[CB][CB + 1];
+  __shared__ double s_d;
+  EighBlock* eb = &blocks[ids[blockIdx.x]];
+  if (!eb->cj_active || j >= eb->npad / CB) return;
+  const int ld = eb->npad, n = eb->n, tid = threadIdx.x, j0 = j * CB;
+  double* Sp = reinterpret_cast<double*>(eb->W);
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    double v = Sp[(int64_t)(j0 + r) * CB + c];
+    if (j0 + r >= n || j0 + c >= n) v = r == c ? 1.0 : 0.0;
+    S[r][c] = v;
+  }
+  __syncthreads();
+  bool fail = false;
+  for (int c = 0; c < CB; ++c) {
+    if (tid == 0) {
+      const double d = S[c][c];
+      const bool ok = d > 0.0 && d < 1.0e300;
+      s_d = ok ? sqrt(d) : 1.0;
+      if (!ok) eb->chol_fail = 1;
+    }
+    __syncthreads();
+    const double d = s_d;
+    if (tid > c && tid < CB) S[tid][c] = S[tid][c] / d;
+    if (tid == 0) S[c][c] = d;
+    __syncthreads();
+    const int w = CB - 1 - c;
+    for (int e = tid; e < w * w; e += 256) {
+      const int r = c + 1 + e / w, cc = c + 1 + e % w;
+      if (cc <= r) S[r][cc] = fma(-S[r][c], S[cc][c], S[r][cc]);
+    }
+    __syncthreads();
+  }
+  (void)fail;
+  float* G = eb->X;
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    float v = 0.f;
+    if (c <= r && j0 + r < n) v = (float)S[r][c];
+    gstore1(G + (int64_t)(j0 + r) * ld + j0 + c, v);
+    if (c <= r) S[r][c] = (j0 + r < n) ? (double)v : (r == c ? 1.0 : 0.0);   // the rounded factor
+    else S[r][c] = 0.0;
+  }
+  __syncthreads();
+  // X = L^-1 (lower triangular), one column per thread
+  if (tid < CB) {
+    const int c = tid;
+    for (int r = 0; r < c; ++r) Xi[r][c] = 0.0;
+    Xi[c][c] = 1.0 / S[c][c];
+    for (int r = c + 1; r < CB; ++r) {
+      double s = 0.0;
+      for (int k = c; k < r; ++k) s = fma(S[r][k], Xi[k][c], s);
+      Xi[r][c] = -s / S[r][r];
+    }
+  }
+  __syncthreads();
+  double* Linv = Sp + (int64_t)ld * CB;
+  for (int e = tid; e < CB * CB; e += 256) Linv[e] = Xi[e >> 6][e & 63];
+}
+
+// ---- Cholesky, step j: L_ij = S_ij L_jj^-T for the tiles i > j, float64, rounded into G.
+__global__ __launch_bounds__(256) void cj_chol_trsm_kernel(EighBlock* blocks, const ETile* tiles,
+                                                           int j) {
+  __shared__ double S[CB][CB + 1];
+  __shared__ double Xi[CB][CB + 1];
+  const ETile te = tiles[blockIdx.x];
+  EighBlock* eb = &blocks[te.block];
+  const int i = te.k;
+  if (!eb->cj_active || i <= j || j >= eb->npad / CB) return;
+  const int ld = eb->npad, tid = threadIdx.x, i0 = i * CB, j0 = j * CB;
+  const double* Sp = reinterpret_cast<const double*>(eb->W);
+  const double* Linv = Sp + (int64_t)ld * CB;
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    S[r][c] = Sp[(int64_t)(i0 + r) * CB + c];
+    Xi[r][c] = Linv[e];
+  }
+  __syncthreads();
+  float* G = eb->X;
+  const int m = tid >> 2;
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int c = (tid & 3) + 4 * q;
+    double s = 0.0;
+    for (int k = 0; k <= c; ++k) s = fma(S[m][k], Xi[c][k], s);
+    gstore1(G + (int64_t)(i0 + m) * ld + j0 + c, (float)s);
+  }
+}
+
+// zero the part of G above the diagonal that the factorisation never writes (the workspace is
+// not cleared by the caller): whole 128-tiles with k < t, and the upper-right 64 x 64 quadrant
+// of the diagonal 128-tiles (cj_chol_potrf_kernel writes the 64 x 64 diagonal tiles in full).
+__global__ __launch_bounds__(256) void cj_zero_upper_kernel(EighBlock* blocks, const ETile* tiles) {
+  const ETile te = tiles[blockIdx.x];
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj_active || te.k > te.t) return;
+  const int ld = eb->npad, tid = threadIdx.x;
+  float* G = eb->X;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const bool diag = te.k == te.t;
+  for (int e = tid; e < TILE * TILE / 4; e += 256) {
+    const int r = e >> 5, c4 = (e & 31) * 4;
+    if (diag && !(r < CB && c4 >= CB)) continue;
+    *(f32x4 PS_GLOBAL*)(G + (int64_t)(te.k * TILE + r) * ld + te.t * TILE + c4) = z;
+  }
+}
+
+// which blocks take this path; the two-sided solver skips them (active = 0)
+__global__ void cj_select_kernel(EighBlock* blocks, int nblocks) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  EighBlock* eb = &blocks[b];
+  const int on = (eb->n > 0 && !eb->small && eb->npad >= 2 * TILE) ? 1 : 0;
+  eb->cj = on;
+  eb->cj_active = on;
+  eb->chol_fail = 0;
+  if (on) eb->active = 0;
+}
+
+// ---- P = [G_I G_J]^T [G_I G_J]: one workgroup per (block, pair); the K-tile of the panel
+// (16 rows x the 128 gathered columns) is staged ONCE and serves as both MFMA operands.
+__global__ __launch_bounds__(256, 2) void cj_gram_kernel(EighBlock* blocks, const ETile* tiles,
+                                                         int ntiles, int round) {
+  constexpr int BK = 16, LD = SmemCfg<BK>::MC_LD;   // [16][132]
+  __shared__ __align__(16) float smem[2 * BK * LD];
+  const ETile te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj_active || round >= eb->nb - 1) return;
+  int I, J;
+  rr_pair(eb->nb, round, te.k, I, J);
+  const int ld = eb->npad, tid = threadIdx.x;
+  const float* G = eb->X;
+  const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+  // thread -> two float4 of a K-tile: rows k = f >> 5, columns 4 * (f & 31) of the gathered panel
+  int goff[2], soff[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int f = tid + 256 * v, k = f >> 5, c4 = (f & 31) * 4;
+    const int gc = c4 < JB ? I * JB + c4 : J * JB + (c4 - JB);
+    goff[v] = k * ld + gc;
+    soff[v] = k * LD + c4;
+  }
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  const int nk = ld / BK;
+  f32x4 r[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) r[v] = gload4(G + goff[v]);
+#pragma unroll
+  for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(smem + soff[v]) = r[v];
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    float* cur = smem + (kt & 1) * BK * LD;
+    float* nxt = smem + ((kt + 1) & 1) * BK * LD;
+    const bool more = kt + 1 < nk;
+    if (more) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) r[v] = gload4(G + (int64_t)(kt + 1) * BK * ld + goff[v]);
+    }
+    compute_ktile<MC, MC, BK>(cur, cur, acc, wm, wn, lane);
+    if (more) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(nxt + soff[v]) = r[v];
+    }
+    __syncthreads();
+  }
+  float* P = eb->V + (int64_t)te.k * JP * JP;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        gstore1(P + acc_row(wm, i, q, lane) * JP + acc_col(wn, j, lane), acc[i][j][q]);
+}
+
+// ---- Q = eigenvectors of the Gram matrix of the pair: one-sided Jacobi on (P, I) in LDS (the
+// solver of eigh_small_kernel), all inner sweeps in the launch.  Pairs whose largest scaled
+// off-diagonal entry is already below `tol` are skipped (flag for the update kernel); the
+// maximum over the sweep is what the outer iteration stops on.
+__global__ __launch_bounds__(SE_T) void cj_pivot_kernel(EighBlock* blocks, const ETile* tiles,
+                                                        int round, float tol, int max_inner,
+                                                        float done_cos2, int sort) {
+  extern __shared__ __align__(16) float sem[];
+  float* Gs = sem;                      // [128][132] column-major
+  float* Vs = sem + SE_MAXN * SE_LD;
+  float* s_red = sem + 2 * SE_MAXN * SE_LD;                // [16]
+  int* s_rot = reinterpret_cast<int*>(s_red + 16);         // [2]
+  float* s_dinv = s_red + 32;                              // [128]
+  const ETile te = tiles[blockIdx.x];
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj_active || round >= eb->nb - 1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* P = eb->V + (int64_t)te.k * JP * JP;
+  int* flags = reinterpret_cast<int*>(eb->offpart);
+  if (tid < JP) s_dinv[tid] = rsqrtf(fmaxf(gload1(P + tid * JP + tid), 1e-37f));
+  if (tid < 2) s_rot[tid] = 0;
+  __syncthreads();
+  unsigned so = 0;
+  for (int e = tid; e < JP * JP; e += SE_T) {
+    const int row = e >> 7, col = e & 127;
+    const float p = gload1(P + e);
+    Gs[col * SE_LD + row] = p;
+    Vs[col * SE_LD + row] = row == col ? 1.f : 0.f;
+    if (row != col) {
+      const unsigned b = __float_as_uint(fabsf(p) * s_dinv[row] * s_dinv[col]);
+      so = b > so ? b : so;
+    }
+  }
+  so = wave_max_u32(so);
+  if (lane == 0) reinterpret_cast<unsigned*>(s_red)[wave] = so;
+  __syncthreads();
+  unsigned som = 0;
+  for (int w = 0; w < SE_T / 64; ++w) {
+    const unsigned o = reinterpret_cast<unsigned*>(s_red)[w];
+    som = o > som ? o : som;
+  }
+  const float sof = __uint_as_float(som);
+  const bool rotate = sof > tol;   // NaN: no rotation, the NaN ends the iteration
+  if (tid == 0) {
+    atomicMax(&eb->soff_bits, som);
+    flags[round * eb->npairs + te.k] = rotate ? 1 : 0;
+  }
+  if (!rotate) return;
+  __syncthreads();
+  onesided_jacobi_lds_t<4>(Gs, Vs, s_rot, JP, max_inner, done_cos2);
+  // the approximate rcp / rsq of the rotation parameters scale a rotation by 1 + O(eps):
+  // renormalise; |g_j| = |P v_j| = the eigenvalue of column j
+  float* s_ev = s_dinv + JP;                              // [128]
+  int* s_rank = reinterpret_cast<int*>(s_ev + JP);        // [128]
+  for (int j = wave; j < JP; j += SE_T / 64) {
+    const float v0 = Vs[j * SE_LD + lane], v1 = Vs[j * SE_LD + 64 + lane];
+    const float g0 = Gs[j * SE_LD + lane], g1 = Gs[j * SE_LD + 64 + lane];
+    const float nn = wave_sum_f32(v0 * v0 + v1 * v1);
+    const float gg = wave_sum_f32(g0 * g0 + g1 * g1);
+    const float inv = nn > 0.f ? 1.f / sqrtf(nn) : 0.f;
+    Vs[j * SE_LD + lane] = v0 * inv; Vs[j * SE_LD + 64 + lane] = v1 * inv;
+    if (lane == 0) s_ev[j] = gg;
+  }
+  __syncthreads();
+  // Columns leave the pivot sorted by descending norm (de Rijk's ordering: without it the
+  // block iteration needs 11 instead of 8 sweeps at n = 1024, and with a random order it does
+  // not converge in 24: tools/proto_onesided_chol.py)
+  if (tid < JP) {
+    const float mine = s_ev[tid];
+    int rank = 0;
+    for (int i = 0; i < JP; ++i) {
+      const float o = s_ev[i];
+      rank += (o > mine || (o == mine && i < tid)) ? 1 : 0;
+    }
+    if (mine != mine) rank = tid;
+    s_rank[tid] = sort ? rank : tid;
+  }
+  __syncthreads();
+  float* Qg = eb->Q + (int64_t)te.k * JP * JP;
+  for (int e = tid; e < JP * JP; e += SE_T) {
+    const int k = e >> 7, jc = e & 127;          // Q[k][rank_j] = component k of eigenvector j
+    gstore1(Qg + k * JP + s_rank[jc], Vs[jc * SE_LD + k]);
+  }
+}
+
+// ---- [G_I G_J] <- [G_I G_J] Q on 128-row tiles (K = 128 gathered from the two block columns)
+template <int UBK>
+__global__ __launch_bounds__(256, 2) void cj_update_kernel_t(EighBlock* blocks, const ETile* tiles,
+                                                             int ntiles, int round) {
+  __shared__ __align__(16) float smem[SmemCfg<UBK>::total(KC, MC)];
+  const ETile te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj_active || round >= eb->nb - 1) return;
+  if (reinterpret_cast<const int*>(eb->offpart)[round * eb->npairs + te.k] == 0) return;
+  int I, J;
+  rr_pair(eb->nb, round, te.k, I, J);
+  const int ld = eb->npad;
+  const float* Qg = eb->Q + (int64_t)te.k * JP * JP;
+  float* X = eb->X;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  for (int seg = 0; seg < 2; ++seg) {
+    const int cb = (seg == 0 ? I : J) * JB;
+    Operand a{X + cb, ld, te.t * TILE, ld, JB, true};         // (m,k) = X[rt+m][cb+k]
+    Operand b{Qg + seg * JB * JP, JP, 0, JP, JB, true};       // (j,k) = Q[seg*64+k][j]
+    gemm_tile_accum<KC, MC, UBK, false>(a, b, JB, smem, acc);
+  }
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = te.t * TILE + acc_row(wm, i, r, lane);
+        const int c = acc_col(wn, j, lane);
+        const int col = c < JB ? I * JB + c : J * JB + (c - JB);
+        gstore1(X + (int64_t)row * ld + col, acc[i][j][r]);
+      }
+}
+
+// ---- per-sweep control: blocks whose largest scaled Gram entry of the sweep is under `tol`
+// are done.  mode 0 = after the Cholesky factorisation (failed blocks go to the fallback).
+__global__ __launch_bounds__(256) void cj_control_kernel(EighBlock* blocks, int nblocks, int mode,
+                                                         float tol, int gen, EStatus* status,
+                                                         int group) {
+  __shared__ int s_act, s_fail;
+  __shared__ float s_max;
+  if (threadIdx.x == 0) { s_act = 0; s_fail = 0; s_max = 0.f; }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    EighBlock* eb = &blocks[b];
+    if (!eb->cj || (group >= 0 && eb->cj_group != group)) continue;
+    if (mode == 0) {
+      if (eb->chol_fail) { eb->cj = 0; eb->cj_active = 0; eb->active = 1; atomicAdd(&s_fail, 1); }
+    } else if (eb->cj_active) {
+      const float so = __uint_as_float(eb->soff_bits);
+      eb->soff_bits = 0;
+      eb->off_rel = so;
+      eb->sweeps += 1;
+      if (!(so > tol)) eb->cj_active = 0;
+    }
+    if (eb->cj_active) {
+      atomicAdd(&s_act, 1);
+      atomicMax(reinterpret_cast<int*>(&s_max), __float_as_int(fmaxf(eb->off_rel, 0.f)));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && status) {
+    status->active = s_act;
+    status->max_off = s_max;
+    status->pad_ = s_fail;
+    __threadfence_system();
+    status->gen = gen;
+  }
+}
+
+// ---- eigenvalues |g_j|^2 (float64 accumulation) of a chunk of 128 columns
+__global__ __launch_bounds__(256) void cj_norms_kernel(EighBlock* blocks, const ETile* tiles) {
+  __shared__ double part[2][TILE];
+  const ETile te = tiles[blockIdx.x];    // sq tile list: only te.k == 0 tiles work, te.t = chunk
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj || te.k != 0) return;
+  const int ld = eb->npad, tid = threadIdx.x;
+  const float* G = eb->X;
+  const int c = te.t * TILE + (tid & 127), half = tid >> 7;
+  double s = 0.0;
+  for (int r = half; r < ld; r += 2) {
+    const double g = (double)gload1(G + (int64_t)r * ld + c);
+    s = fma(g, g, s);
+  }
+  part[half][tid & 127] = s;
+  __syncthreads();
+  if (tid < TILE) eb->evals[te.t * TILE + tid] = (float)(part[0][tid] + part[1][tid]);
+}
+
+// ---- V = G diag(1 / |g_j|), diag(A) = |g_j|^2
+__global__ __launch_bounds__(256) void cj_finalize_kernel(EighBlock* blocks, const ETile* tiles) {
+  __shared__ float inv[TILE];
+  const ETile te = tiles[blockIdx.x];
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj) return;
+  const int ld = eb->npad, n = eb->n, tid = threadIdx.x;
+  if (tid < TILE) {
+    const int c = te.t * TILE + tid;
+    const float e = eb->evals[c];
+    inv[tid] = (c < n && e > 0.f) ? (float)(1.0 / sqrt((double)e)) : (e == e ? 0.f : e);
+  }
+  __syncthreads();
+  const float* G = eb->X;
+  for (int e = tid; e < TILE * TILE; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    const int row = te.k * TILE + r, col = te.t * TILE + c;
+    const int64_t o = (int64_t)row * ld + col;
+    float v = gload1(G + o) * inv[c];
+    if (row >= n || col >= n) v = row == col ? 1.f : 0.f;
+    eb->V[o] = v;
+    eb->A[o] = row == col ? (col < n ? eb->evals[col] : 0.f) : 0.f;
+  }
+}

@@ -55,7 +55,7 @@ constexpr int NBK = 16;        // K-tile depth of the Newton products
 constexpr int MAX_PROD = 8;    // products per Newton step (p <= 64)
 constexpr int NTEMP = 5;
 constexpr int NQ = 8;          // item queues (one per XCD)
-constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 2;
+constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 4;
 
 
 enum Phase { PH_INIT = 0, PH_ACTIVE = 1, PH_DONE = 2 };
@@ -155,10 +155,12 @@ __device__ inline float* resolve(const NewtonBlock* nb, int id, int cur) {
 // the upper triangle over the lower (TF_MIRROR) turns K into a SYMMETRIC perturbation of the
 // same size, which moves eigenvalues at first order, while K itself is harmless (x^T K x = 0)
 // and averaging removes it.  Measured at cond 7e3, p = 4, n = 1000 (error of the root against
-// float64): reference arithmetic (NumPy full products) 1.2e-4; this kernel with full products
-// 2.0e-4, mirrored everywhere 9.3e-4, averaged M update in the first 2 steps 2.8e-4 (default,
-// +3.6 % time on 256 x 512^2), in the first 4 steps 1.8e-4 (+8.5 %); on well-conditioned
-// blocks all variants are at 1e-6.  The H update and the squares (exactly symmetric for
+// float64): reference arithmetic (NumPy full products) 1.26e-4; this kernel with full products
+// (PS_SYMMETRY_GENERAL) 1.96e-4, mirrored everywhere 9.3e-4, averaged M update in the first 2
+// steps 2.8e-4, in the first 4 steps 1.76e-4 (the default since round 3: inside the spread of
+// the two full-product float32 evaluations; +3.9 % time on 256 x 512^2 and 64 x 1024^2 over 2
+// steps), first 6 steps 1.66e-4, every step 1.65e-4 (+10...14 %); on well-conditioned blocks
+// all variants are at 1e-6.  The H update and the squares (exactly symmetric for
 // symmetric input) stay mirrored (tools/dev_sym_accuracy.py: averaging them changes nothing).
 enum TileFlags { TF_MIRROR = 1, TF_RAW = 2, TF_AVG = 4, TF_SELFAVG = 8 };
 
