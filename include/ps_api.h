@@ -15,8 +15,11 @@
  *         (with power_iteration DS:595-652 -> ps_power_iteration_batched_f32 and
  *          mat_power DS:655-678 -> ps_mat_power_f32 also exposed, since the
  *          reference's tests call them directly)
- *   (iii) jax.lax.all_gather DS:2876-2877 -> done by the host with RCCL through
- *         torch.distributed (plumbing); no entry point here.
+ *   (iii) jax.lax.all_gather DS:2876-2877 -> ps_comm_unique_id / ps_comm_init /
+ *         ps_comm_allgather / ps_comm_destroy (RCCL resolved at run time).  These are the
+ *         binding for a host WITHOUT torch; the Python host of this repository issues the same
+ *         collective through torch.distributed (backend "nccl" = RCCL), which owns its
+ *         communicator, and brackets asynchronous gathers with ps_collective_in_flight.
  *
  * Conventions
  *   - Plain C, no torch/HIP types in signatures: streams are passed as void*
@@ -28,10 +31,23 @@
  *     the *_workspace_bytes functions.  No hidden device allocation happens inside
  *     a compute call (a few KB of pinned host memory are allocated once per
  *     process for convergence flags).
- *   - Calls are stream-ordered and only enqueue work.  Data-dependent iteration counts
- *     (DS:836-848, 862-864) are resolved on the device; the only entry points that wait
- *     for the GPU are ps_eigh_* (one wait per Jacobi sweep) and any call made while
- *     ps_profile_enable(1) is in force.
+ *   - Calls are stream-ordered.  Data-dependent iteration counts (DS:836-848, 862-864) are
+ *     resolved on the device, but the host has to know when to stop queueing steps, so the
+ *     iterative entry points WAIT on the GPU while they run -- always one step behind it, so
+ *     that the stream never drains:
+ *       ps_newton_root_batched*_f32 (staged execution, the default): one event wait per Newton
+ *         step, on the step before the one just queued; returns when the last step is queued.
+ *       ps_eigh_root_batched_f32 (blocks of more than 128 rows): one stream synchronisation
+ *         after the Cholesky factorisation (fallback blocks must be known), then one event wait
+ *         per Jacobi sweep, one sweep behind the GPU.  ps_eigh_batched_f32 on matrices of more
+ *         than 128 rows: one stream synchronisation per sweep.
+ *       ps_diag_mfma_clock and any call made while ps_profile_enable(1) is in force
+ *         synchronise the stream.
+ *     Everything else (statistics, products, power iteration, quantisation, transform,
+ *     eigendecompositions of <= 128 rows, ps_comm_allgather) only enqueues.
+ *   - ps_eigh_root_batched_f32 sweeps its blocks on the caller's stream AND on one internal
+ *     side stream per host thread (forked from and joined back into the caller's stream with
+ *     events, so the call is stream-ordered as a whole).
  *   - Numerical failure is data, not an error (DS:2936-2950): it is reported in
  *     the metrics table and the function still returns 0.
  */
@@ -71,7 +87,6 @@ enum {
   PS_M_ASYMMETRY = 7,    /* max|X - X^T| / max|X| of the full M update X of the first step of
                             the last try (0 if that step did not average): the commutator
                             noise of the iterates, ~1e-7 well conditioned, ~1e-5 at cond 1e4 */
-  PS_M_RESERVED = 7,
   PS_METRICS_STRIDE = 8
 };
 
@@ -395,6 +410,30 @@ int ps_comm_allgather(void* stream, void* comm, const void* send, void* recv,
                       size_t bytes_per_rank);
 int ps_comm_destroy(void* comm);
 const char* ps_comm_last_error(void);
+
+/* ---- health of the resident power iteration; diagnostics --------------------------------
+ * The resident execution of the power iteration (one launch, matrices in registers) spin-waits
+ * on the workgroups of a block's team and is launched at the co-resident capacity of an
+ * otherwise IDLE chip.  Kernels that hold CUs on other streams (an RCCL gather) delay team
+ * mates; every wait is bounded by one deadline per launch (PS_PI_TIMEOUT_MS, default 5000) and
+ * an expired wait is counted in pinned host memory.  The root entry points re-run their call on
+ * the streaming kernels when they see the count move at their first host wait, and the process
+ * uses the streaming execution from then on (until ps_power_iteration_reset_health).
+ *   ps_collective_in_flight(+1 / -1): the host brackets asynchronous collectives with these;
+ *       while the count is positive the streaming execution is used.  Returns the new count.
+ *   ps_power_iteration_health: expired waits so far, collectives in flight, and whether the
+ *       next call would use the resident execution (any pointer may be NULL).
+ *   ps_diag_spin: filler kernel (tests): `workgroups` x `threads` with `lds_bytes` of dynamic
+ *       LDS each spin for `ms` milliseconds on `stream`.
+ *   ps_diag_mfma_clock: shader clock (GHz) held under fp32-MFMA load on non-trivial operands
+ *       and the fp32 MFMA TFLOP/s of that loop, after `warm_ms` of back-to-back launches;
+ *       synchronises the stream and allocates two small device buffers. */
+int ps_collective_in_flight(int delta);
+int ps_power_iteration_health(unsigned* expired_waits, int* collectives_in_flight,
+                              int* resident_enabled);
+int ps_power_iteration_reset_health(void);
+int ps_diag_spin(void* stream, int workgroups, int threads, int lds_bytes, double ms);
+int ps_diag_mfma_clock(void* stream, double warm_ms, double* clock_ghz, double* mfma_f32_tflops);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ def symmetry_code(symmetry) -> int:
       raise ValueError(f"symmetry must be one of {sorted(_SYMMETRY)}, got {symmetry!r}")
   return int(symmetry)
 (PS_M_ERROR, PS_M_ITERS, PS_M_ERROR_RATIO, PS_M_MAX_EV, PS_M_RETRIES,
- PS_M_TOTAL_ITERS, PS_M_POWER_ITERS, PS_M_RESERVED) = range(8)
+ PS_M_TOTAL_ITERS, PS_M_POWER_ITERS, PS_M_ASYMMETRY) = range(8)
 
 
 class PsError(RuntimeError):
@@ -164,6 +164,11 @@ _SIGNATURES = {
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ps_eigh_sorted_max_n": (C.c_int, []),
+    "ps_collective_in_flight": (C.c_int, [C.c_int]),
+    "ps_power_iteration_health": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ps_power_iteration_reset_health": (C.c_int, []),
+    "ps_diag_spin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "ps_diag_mfma_clock": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "ps_profile_enable": (C.c_int, [C.c_int]),
     "ps_profile_reset": (C.c_int, []),
     "ps_profile_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -82,6 +82,17 @@ def ownership_table(sizes: Sequence[int], exponents: Sequence[int], world: int,
   raise ValueError(f"unknown ownership {ownership!r}")
 
 
+def _collective_in_flight(delta: int) -> int:
+  """Tells the library that an asynchronous RCCL collective was launched (+1) / has been waited
+  for (-1): its kernels hold CUs on RCCL's stream, so the register-resident power iteration --
+  whose workgroups spin on team mates and are launched at the capacity of an idle chip -- is not
+  used while one is in flight (include/ps_api.h: ps_collective_in_flight).  Returns 1 if the
+  count was changed."""
+  from . import _lib
+  _lib.lib().ps_collective_in_flight(int(delta))
+  return 1
+
+
 def sharded_inverse_pth_roots(
     statistics: Sequence[torch.Tensor],
     exponents: Sequence[int],
@@ -97,7 +108,7 @@ def sharded_inverse_pth_roots(
     overlap_min_bytes: int = 32 << 20,
     payload_elems: Optional[Sequence[int]] = None,
     sizes: Optional[Sequence[int]] = None,
-    pi_first: bool = False,
+    pi_first: Optional[bool] = None,
     metrics_cols: int = METRICS_STRIDE,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
@@ -114,10 +125,14 @@ def sharded_inverse_pth_roots(
   bucket sizes, DS:3102-3127); `outs` and the returned roots are then flat views.
   `sizes[i]` (default statistics[i].shape[0]): with owner-only statistics
   (`shard_statistics`) the entries this rank does not own are placeholders.
-  `pi_first` (HIP Newton root only): in the two-phase layout the power iteration runs
-  once over all of this rank's statistics and each phase's root call gets its largest
-  eigenvalues from it (`max_ev=`): halves of the 100 short launches would sit on the
-  launch-latency floor.  Same kernels, bit-identical results.
+  `pi_first` (HIP Newton root only; default: on whenever two phases are used): in the
+  two-phase layout the power iteration runs once over all of this rank's statistics, BEFORE
+  the first all-gather is in flight, and each phase's root call gets its largest eigenvalues
+  from it (`max_ev=`): halves of the 100 short launches would sit on the launch-latency floor,
+  and the register-resident power iteration must not start under a collective that holds CUs
+  on another stream (the library is told about asynchronous gathers through
+  `ps_collective_in_flight` and uses its streaming kernels meanwhile).  Same kernels,
+  bit-identical results.
   `metrics_cols` (needs `compute_fn`): width of the gathered metrics rows when the
   per-statistic diagnostics are wider than the 8 PS_M_* columns (FDDiagnostics).
   """
@@ -125,6 +140,7 @@ def sharded_inverse_pth_roots(
   world, rank = world_and_rank(group)
   sizes = [int(s) for s in sizes] if sizes is not None else [int(s.shape[0]) for s in statistics]
   owner = ownership_table(sizes, exponents, world, ownership)
+  hip_root = root_fn is None
   if root_fn is None:
     from . import kernels
     root_fn = kernels.matrix_inverse_pth_root_batched
@@ -166,6 +182,8 @@ def sharded_inverse_pth_roots(
     count[ph][r] += 1
 
   lam_of = None
+  if pi_first is None:
+    pi_first = n_phases == 2 and hip_root
   if (pi_first and n_phases == 2 and compute_fn is None and not eigh and
       relative_matrix_epsilon):
     from . import kernels
@@ -175,6 +193,7 @@ def sharded_inverse_pth_roots(
                                                padding_starts=[sizes[i] for i in all_mine])
       lam_of = {i: k for k, i in enumerate(all_mine)}
   gathered, gathered_metrics, handles = [], [], []
+  in_flight = 0
   for ph in range(n_phases):
     buf_elems = max(max(fill[ph]), 1)
     max_count = max(max(count[ph]), 1)
@@ -214,6 +233,7 @@ def sharded_inverse_pth_roots(
       g.copy_(g_h)
       gm.copy_(m_h)
     elif n_phases == 2 and send.is_cuda:
+      in_flight += _collective_in_flight(+1)
       handles.append(dist.all_gather_into_tensor(g, send, group=group, async_op=True))
       handles.append(dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group,
                                                  async_op=True))
@@ -226,6 +246,9 @@ def sharded_inverse_pth_roots(
   for h in handles:
     if hasattr(h, "wait"):
       h.wait()
+  while in_flight > 0:
+    _collective_in_flight(-1)
+    in_flight -= 1
 
   roots = [
       gathered[phase_of[i]][owner[i], offsets[i]:offsets[i] + elems[i]] for i in range(n_stats)

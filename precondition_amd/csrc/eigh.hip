@@ -1297,30 +1297,38 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
         (rc = up(lo.cj_row[g], pl.cj_row[g].data(), sizeof(ETile) * pl.cj_row[g].size())))
       return rc;
   }
-  if (relative_matrix_epsilon) {
-    if ((rc = pl.pip.upload(st, a, lda))) return rc;
-    // the reference's power iteration is a plain mat-vec loop on the raw input (DS:996-1001)
-    if ((rc = pl.pip.enqueue_symmetry(st, PS_SYMMETRY_VERIFY))) return rc;
-  }
-
   const int nsq = (int)pl.sq_tiles.size();
   const int npair = (int)pl.pair_tiles.size();
   const int nrow = (int)pl.row_tiles.size(), ncol = (int)pl.col_tiles.size();
   const dim3 blk(256);
 
-  // power iteration with tol = error_tolerance (DS:996-1001)
-  if (relative_matrix_epsilon && (rc = pl.pip.enqueue(st, 100, error_tolerance))) return rc;
-  hipLaunchKernelGGL(eigh_setup_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
-                     pl.pip.d_blocks, batch, mode == 0 ? ridge_epsilon : 0.f, error_tolerance,
-                     relative_matrix_epsilon);
-  PS_LAUNCH_CHECK();
+  // Power iteration (tol = error_tolerance, DS:996-1001) -> ridge -> D = A + ridge I.  Queued
+  // again (on the streaming power iteration) if the resident one reports an expired wait at the
+  // first host wait of the call (PiPlan::health).
+  const unsigned pi_expired_before = PiPlan::expired_total();
+  auto enqueue_front = [&]() -> int {
+    int rc2;
+    if ((rc2 = up(lo.blocks, hb.data(), sizeof(EighBlock) * batch))) return rc2;
+    if (relative_matrix_epsilon) {
+      if ((rc2 = pl.pip.upload(st, a, lda))) return rc2;
+      // the reference's power iteration is a plain mat-vec loop on the raw input (DS:996-1001)
+      if ((rc2 = pl.pip.enqueue_symmetry(st, PS_SYMMETRY_VERIFY))) return rc2;
+      if ((rc2 = pl.pip.enqueue(st, 100, error_tolerance))) return rc2;
+    }
+    hipLaunchKernelGGL(eigh_setup_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
+                       pl.pip.d_blocks, batch, mode == 0 ? ridge_epsilon : 0.f, error_tolerance,
+                       relative_matrix_epsilon);
+    if (nsq > 0) {
+      hipLaunchKernelGGL(eigh_init_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      hipLaunchKernelGGL(eigh_control_kernel, dim3(1), blk, 0, st, lo.blocks, batch, 0, 0.f, 0,
+                         (EStatus*)nullptr);
+    }
+    PS_LAUNCH_CHECK();
+    return 0;
+  };
+  if ((rc = enqueue_front())) return rc;
 
   if (nsq > 0) {
-    hipLaunchKernelGGL(eigh_init_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
-    hipLaunchKernelGGL(eigh_control_kernel, dim3(1), blk, 0, st, lo.blocks, batch, 0, 0.f, 0,
-                       (EStatus*)nullptr);
-    PS_LAUNCH_CHECK();
-
     auto sweep = [&]() {
       for (int r = 0; r < pl.max_nb - 1; ++r) {
         hipLaunchKernelGGL(jacobi_pair_kernel, dim3(npair), dim3(JT), pair_lds, st, lo.blocks,
@@ -1351,20 +1359,24 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       return 0;
     };
     const bool any_big = npair > 0;
+    auto enqueue_small = [&]() -> int {
     if (!pl.small_ids.empty()) {  // n <= 128: whole decomposition in one launch, no host wait
-      const size_t small_lds = (size_t)(2 * SE_MAXN * SE_LD + 32 + 256) * sizeof(float);
-      static bool small_attr = false;
-      if (!small_attr) {
-        PS_HIP(hipFuncSetAttribute((const void*)eigh_small_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-        small_attr = true;
+        const size_t small_lds = (size_t)(2 * SE_MAXN * SE_LD + 32 + 256) * sizeof(float);
+        static bool small_attr = false;
+        if (!small_attr) {
+          PS_HIP(hipFuncSetAttribute((const void*)eigh_small_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+          small_attr = true;
+        }
+        static const int small_refresh = [] {
+          const char* e = getenv("PS_EIGH_SMALL_REFRESH"); return e ? atoi(e) : 1; }();
+        hipLaunchKernelGGL(eigh_small_kernel, dim3((unsigned)pl.small_ids.size()), dim3(SE_T),
+                           small_lds, st, lo.blocks, lo.small_ids, small_refresh);
+        PS_LAUNCH_CHECK();
       }
-      static const int small_refresh = [] {
-        const char* e = getenv("PS_EIGH_SMALL_REFRESH"); return e ? atoi(e) : 1; }();
-      hipLaunchKernelGGL(eigh_small_kernel, dim3((unsigned)pl.small_ids.size()), dim3(SE_T),
-                         small_lds, st, lo.blocks, lo.small_ids, small_refresh);
-      PS_LAUNCH_CHECK();
-    }
+      return 0;
+    };
+    if ((rc = enqueue_small())) return rc;
     if (mode == 1 && !any_big) return PS_OK;  // the kernel wrote sorted pairs to the outputs
     // Root mode, blocks of more than 128 rows: one-sided block Jacobi on the Cholesky factor
     // (eigh_cj.hip.h).  PS_EIGH_CJ=0 restores the blocked two-sided solver for everything.
@@ -1399,27 +1411,35 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       for (int i = 0; i < 2; ++i)
         if (!cj_ev[i]) PS_HIP(hipEventCreateWithFlags(&cj_ev[i], hipEventDisableTiming));
       const int nchol = (int)pl.chol_tiles.size(), nbig = (int)pl.big_ids.size();
-      hipLaunchKernelGGL(cj_select_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks, batch);
-      hipLaunchKernelGGL(cj_zero_upper_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
-      for (int j = 0; j < pl.max_nb; ++j) {
-        hipLaunchKernelGGL(cj_chol_schur_kernel, dim3(nchol), blk, 0, st, lo.blocks, lo.chol, j);
-        hipLaunchKernelGGL(cj_chol_potrf_kernel, dim3(nbig), blk, 0, st, lo.blocks, lo.big_ids, j);
-        hipLaunchKernelGGL(cj_chol_trsm_kernel, dim3(nchol), blk, 0, st, lo.blocks, lo.chol, j);
-      }
       int gen = 0;
-      {
-        EStatus* slot = &status[gen % 64];
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        hipLaunchKernelGGL(cj_select_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks, batch);
+        hipLaunchKernelGGL(cj_zero_upper_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+        for (int j = 0; j < pl.max_nb; ++j) {
+          hipLaunchKernelGGL(cj_chol_schur_kernel, dim3(nchol), blk, 0, st, lo.blocks, lo.chol, j);
+          hipLaunchKernelGGL(cj_chol_potrf_kernel, dim3(nbig), blk, 0, st, lo.blocks, lo.big_ids, j);
+          hipLaunchKernelGGL(cj_chol_trsm_kernel, dim3(nchol), blk, 0, st, lo.blocks, lo.chol, j);
+        }
+        EStatus* slot = &status[(2 * gen) % 64];
         slot->gen = -1;
         hipLaunchKernelGGL(cj_control_kernel, dim3(1), blk, 0, st, lo.blocks, batch, 0, 0.f, gen,
                            slot, -1);
         PS_LAUNCH_CHECK();
         PS_HIP(hipStreamSynchronize(st));   // the only stall of the path: fallback blocks known
         if (slot->gen != gen) return PS_EINTERNAL;
+        ++gen;
+        if (attempt == 0 && PiPlan::expired_total() != pi_expired_before) {
+          // the resident power iteration gave up (see PiPlan::health): the ridge of its blocks
+          // is NaN.  The process is on the streaming execution now: queue the front again.
+          if ((rc = enqueue_front())) return rc;
+          if ((rc = enqueue_small())) return rc;
+          continue;
+        }
         run_two_sided = slot->pad_ > 0;
         if (getenv("PS_EIGH_TRACE"))
           fprintf(stderr, "eigh cj: Cholesky done, %d block(s) fall back to the two-sided solver\n",
                   slot->pad_);
-        ++gen;
+        break;
       }
       // Sweeps.  The blocks are dealt to two groups that sweep on two streams (the caller's and
       // a side stream of this thread): the pivot kernel is LDS / VALU work with one workgroup

@@ -1357,10 +1357,29 @@ static int newton_driver(
     ns.phase = pl.n_eff[b] >= 1 ? PH_INIT : PH_DONE;
     ns.ratio = 1.f;
   }
-  PS_RC(pl.pip.upload(st, a, lda));  // also fixes pl.pip.d_asym
-  for (int b = 0; b < batch; ++b) hb[b].asym = pl.pip.d_asym + b;
-  PS_RC(psh::upload_async(st, lo.blocks, hb.data(), sizeof(NewtonBlock) * batch));
-  PS_RC(psh::upload_async(st, lo.states, hs.data(), sizeof(NewtonState) * batch));
+  ProfRun prof(st);
+  // Everything from the descriptor upload to the seeded loop state; run again (on the streaming
+  // power iteration) if the resident power iteration reports an expired wait.
+  const unsigned pi_expired_before = PiPlan::expired_total();
+  auto enqueue_front = [&]() -> int {
+    PS_RC(pl.pip.upload(st, a, lda));  // also fixes pl.pip.d_asym
+    for (int b = 0; b < batch; ++b) hb[b].asym = pl.pip.d_asym + b;
+    PS_RC(psh::upload_async(st, lo.blocks, hb.data(), sizeof(NewtonBlock) * batch));
+    PS_RC(psh::upload_async(st, lo.states, hs.data(), sizeof(NewtonState) * batch));
+    PS_RC(pl.pip.enqueue_symmetry(st, symmetry));
+    // ---- power iteration -> ridge epsilon --------------------------------------
+    prof.begin(1);
+    if (relative_matrix_epsilon && !max_ev_given) {
+      int rc = pl.pip.enqueue(st, 100, 1e-6f);  // DS:820-825
+      if (rc) return rc;
+    }
+    prof.end();
+    hipLaunchKernelGGL(newton_setup_kernel, dim3((batch + 255) / 256), dim3(256), 0, st,
+                       lo.states, pl.pip.d_blocks, batch, ridge_epsilon,
+                       relative_matrix_epsilon, max_ev_given);
+    PS_LAUNCH_CHECK();
+    return 0;
+  };
   if (staged) {
     for (int s = 0; s < pl.nstages; ++s) {
       PS_RC(psh::upload_async(st, lo.tasks[s], pl.stage_tasks[s].data(),
@@ -1371,20 +1390,7 @@ static int newton_driver(
     PS_RC(psh::upload_async(st, lo.init_tiles, pl.init_tiles.data(),
                             sizeof(TileEntry) * pl.init_tiles.size()));
   }
-  PS_RC(pl.pip.enqueue_symmetry(st, symmetry));
-
-  ProfRun prof(st);
-  // ---- power iteration -> ridge epsilon --------------------------------------
-  prof.begin(1);
-  if (relative_matrix_epsilon && !max_ev_given) {
-    int rc = pl.pip.enqueue(st, 100, 1e-6f);  // DS:820-825
-    if (rc) return rc;
-  }
-  prof.end();
-  hipLaunchKernelGGL(newton_setup_kernel, dim3((batch + 255) / 256), dim3(256), 0, st,
-                     lo.states, pl.pip.d_blocks, batch, ridge_epsilon,
-                     relative_matrix_epsilon, max_ev_given);
-  PS_LAUNCH_CHECK();
+  PS_RC(enqueue_front());
 
   if (!staged) {
     // ---- persistent dataflow execution: one launch, no host round trip ------------
@@ -1472,7 +1478,7 @@ static int newton_driver(
       if (e1 != hipSuccess) { (void)hipEventDestroy(ev[0]); return (int)e1; }
     }
     const int cap = 6 * (num_iters + 2) + 4;
-    bool need_init = true;
+    bool need_init = true, pi_retried = false;
     int rc = 0;
     for (int g = 0; g < cap; ++g) {
       HostStatus* slot = &status[g % 64];
@@ -1510,6 +1516,18 @@ static int newton_driver(
         if ((rc = (int)hipEventSynchronize(ev[(g - 1) & 1])) != 0) break;
         const HostStatus seen = status[(g - 1) % 64];
         if (seen.gen != g - 1) { rc = PS_EINTERNAL; break; }
+        if (g == 1 && !pi_retried && PiPlan::expired_total() != pi_expired_before) {
+          pi_retried = true;
+          // The resident power iteration gave up on a team mate that never became resident
+          // (CUs held by another stream's kernels): its blocks carry a NaN eigenvalue.  The
+          // process is on the streaming execution from now on (PiPlan::resident_enabled);
+          // queue the whole call again behind what is already queued and start over.
+          if ((rc = enqueue_front()) != 0) break;
+          need_init = true;
+          g = -1;
+          executed = 0;
+          continue;
+        }
         if (seen.not_done == 0) break;
         need_init = seen.need_init > 0;
       } else {

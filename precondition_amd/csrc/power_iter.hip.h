@@ -27,6 +27,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -51,6 +53,7 @@ struct PiBlock {
   int iters;      // steps executed
   const int* asym;  // *asym != 0: the block is not exactly symmetric (full mat-vec)
   int team;         // resident execution: workgroups in the block's team
+  int expired;      // resident execution: a bounded wait ran out (result NaN, see PiHealth)
 };
 
 struct PiTile {
@@ -337,7 +340,11 @@ static __global__ void pi_output_kernel(const PiBlock* blocks, int nblocks, floa
 // step k), so the slot of step k+2 is free when it is written.
 // Teams spin, so they must be co-resident: the host launches at most the resident capacity
 // of the chip per pass; blocks whose team exceeds it use the streaming execution.  Every
-// spin is bounded: on expiry the block's result is NaN (reported as a failed root).
+// spin is bounded by ONE deadline per launch (PS_PI_TIMEOUT_MS, default 5 s) and by the team's
+// abort granule; on expiry the block's result is NaN, the event is counted in pinned host
+// memory (PiPlan::health), the root drivers re-run the call on the streaming kernels when they
+// see the count move at their first host wait, and the process stays on the streaming
+// execution from then on.
 typedef unsigned long long pi_granule;
 
 __device__ __forceinline__ void pi_publish(pi_granule* p, float v, unsigned tag) {
@@ -347,16 +354,26 @@ __device__ __forceinline__ void pi_publish(pi_granule* p, float v, unsigned tag)
 __device__ __forceinline__ pi_granule pi_peek(const pi_granule* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Polls until the granule carries `tag`; *dead is set when the bound expires.
+// Everything a bounded wait needs: ONE deadline for the whole kernel (constant 100 MHz clock),
+// the team's abort granule (the first member whose wait expires publishes it, the others poll
+// it, so a team leaves together instead of each member spinning out its own bound), and the
+// thread's own flag: once it is set every later wait returns at once.
+struct PiWait {
+  unsigned long long deadline;
+  const pi_granule* abort;
+  bool dead;
+};
+// Polls until the granule carries `tag`.
 __device__ __forceinline__ float pi_await(const pi_granule* p, pi_granule g, unsigned tag,
-                                          bool* dead) {
+                                          PiWait* w) {
+  if (w->dead) return __uint_as_float((unsigned)g);
   int spins = 0;
-  unsigned long long t0 = 0;
   while ((unsigned)(g >> 32) != tag) {
-    if ((++spins & 1023) == 0) {   // bound: 5 s of the 100 MHz constant clock
-      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now;
-      else if (now - t0 > 500000000ull) { *dead = true; break; }
+    if ((++spins & 255) == 0) {
+      if (__builtin_amdgcn_s_memrealtime() > w->deadline || pi_peek(w->abort) != 0) {
+        w->dead = true;
+        break;
+      }
     }
     __builtin_amdgcn_s_sleep(1);
     g = pi_peek(p);
@@ -471,7 +488,8 @@ __device__ inline void pi_tile_from_regs(const PiBlock* pb, const f32x4 (&x)[16]
 
 template <int NT>
 static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void pi_resident_kernel(
-    PiBlock* blocks, const PiTeamWG* wgs, int num_iters, float tol) {
+    PiBlock* blocks, const PiTeamWG* wgs, int num_iters, float tol,
+    unsigned long long timeout_ticks, unsigned* expired_total) {
   extern __shared__ __align__(16) float pi_lds[];  // vn[tp] | y[tp], tp = t*128 of the largest block
   __shared__ float wpart[NT][4][PT];
   __shared__ float stage[NT][2][PT];
@@ -509,8 +527,9 @@ static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void p
   pi_granule* Pbase = reinterpret_cast<pi_granule*>(pb->P);
   const int64_t slab = (int64_t)t * t * PT;            // P granules per parity
   pi_granule* Ybase = Pbase + 2 * slab;                // y granules: [2][tp]
+  pi_granule* abort_g = Ybase + 2 * tp;                // one granule behind them (zeroed per call)
   float s_prev = 0.f;
-  bool dead = false;
+  PiWait wt{__builtin_amdgcn_s_memrealtime() + timeout_ticks, abort_g, timeout_ticks == 0};
   for (int iter = 0; iter < num_iters; ++iter) {
     const unsigned tag = (unsigned)iter + 1u;
     pi_granule* P = Pbase + (int64_t)(iter & 1) * slab;
@@ -534,13 +553,13 @@ static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void p
           for (; Y + 4 <= t; Y += 4) {  // independent loads, pi_red_kernel's summation order
             const pi_granule g0 = pi_peek(p + (Y + 0) * PT), g1 = pi_peek(p + (Y + 1) * PT),
                              g2 = pi_peek(p + (Y + 2) * PT), g3 = pi_peek(p + (Y + 3) * PT);
-            const float p0 = pi_await(p + (Y + 0) * PT, g0, tag, &dead);
-            const float p1 = pi_await(p + (Y + 1) * PT, g1, tag, &dead);
-            const float p2 = pi_await(p + (Y + 2) * PT, g2, tag, &dead);
-            const float p3 = pi_await(p + (Y + 3) * PT, g3, tag, &dead);
+            const float p0 = pi_await(p + (Y + 0) * PT, g0, tag, &wt);
+            const float p1 = pi_await(p + (Y + 1) * PT, g1, tag, &wt);
+            const float p2 = pi_await(p + (Y + 2) * PT, g2, tag, &wt);
+            const float p3 = pi_await(p + (Y + 3) * PT, g3, tag, &wt);
             y = (((y + p0) + p1) + p2) + p3;
           }
-          for (; Y < t; ++Y) y += pi_await(p + Y * PT, pi_peek(p + Y * PT), tag, &dead);
+          for (; Y < t; ++Y) y += pi_await(p + Y * PT, pi_peek(p + Y * PT), tag, &wt);
           ysm[j] = y;
           sv[v] += vn[j] * y;   // DS:637
           ssv[v] += y * y;
@@ -558,13 +577,13 @@ static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void p
           for (; Y + 4 <= t; Y += 4) {
             const pi_granule g0 = pi_peek(p + (Y + 0) * PT), g1 = pi_peek(p + (Y + 1) * PT),
                              g2 = pi_peek(p + (Y + 2) * PT), g3 = pi_peek(p + (Y + 3) * PT);
-            const float p0 = pi_await(p + (Y + 0) * PT, g0, tag, &dead);
-            const float p1 = pi_await(p + (Y + 1) * PT, g1, tag, &dead);
-            const float p2 = pi_await(p + (Y + 2) * PT, g2, tag, &dead);
-            const float p3 = pi_await(p + (Y + 3) * PT, g3, tag, &dead);
+            const float p0 = pi_await(p + (Y + 0) * PT, g0, tag, &wt);
+            const float p1 = pi_await(p + (Y + 1) * PT, g1, tag, &wt);
+            const float p2 = pi_await(p + (Y + 2) * PT, g2, tag, &wt);
+            const float p3 = pi_await(p + (Y + 3) * PT, g3, tag, &wt);
             y = (((y + p0) + p1) + p2) + p3;
           }
-          for (; Y < t; ++Y) y += pi_await(p + Y * PT, pi_peek(p + Y * PT), tag, &dead);
+          for (; Y < t; ++Y) y += pi_await(p + Y * PT, pi_peek(p + Y * PT), tag, &wt);
           pi_publish(Yg + X * PT + tid, y, tag);
         }
       }
@@ -572,14 +591,17 @@ static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void p
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         for (int j = tid + 256 * v; j < tp; j += 512) {
-          const float y = pi_await(Yg + j, pi_peek(Yg + j), tag, &dead);
+          const float y = pi_await(Yg + j, pi_peek(Yg + j), tag, &wt);
           ysm[j] = y;
           sv[v] += vn[j] * y;   // DS:637
           ssv[v] += y * y;
         }
       }
     }
-    if (dead) s_dead = 1;
+    if (wt.dead) {
+      s_dead = 1;
+      pi_publish(abort_g, 0.f, 1u);   // the whole team leaves with this step
+    }
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
       const float a = wave_sum_f32(sv[v]), b = wave_sum_f32(ssv[v]);
@@ -604,6 +626,11 @@ static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void p
           pb->lambda = s_new;
           pb->iters = iter + 1;
           pb->stop_iter = iter;
+          if (expired) {   // host-visible (pinned) count: the drivers re-run on the streaming kernels
+            pb->expired = 1;
+            atomicAdd_system(expired_total, 1u);
+            __threadfence_system();
+          }
         }
       }
       break;
@@ -677,7 +704,7 @@ struct PiPlan {
       const int t = (n_eff[i] + PT - 1) / PT;
       float* vn = ar.take<float>(std::max(t * PT, 1));
       // resident execution: 8-byte granules, two step parities of the partial slab + of y
-      float* P = ar.take<float>(std::max(4 * (t * t + t) * PT, 1));
+      float* P = ar.take<float>(std::max(4 * (t * t + t) * PT + 2, 1));   // + the abort granule
       if (assign) { d_vn.push_back(vn); d_P.push_back(P); }
     }
     if (assign) { d_region = region0; region_bytes = ar.base ? (size_t)(ar.base + ar.off - region0) : 0; }
@@ -749,9 +776,43 @@ struct PiPlan {
     return std::min(per_cu, bound) * cus;
   }
 
+  // Process-wide health of the resident execution.  `expired` is pinned host memory that the
+  // kernel counts into when a bounded wait runs out (a team mate that never became resident:
+  // the launch size assumes an otherwise idle chip); after the first such event the process
+  // stays on the streaming execution.  `collectives` is raised by the host around asynchronous
+  // RCCL gathers (ps_collective_in_flight): their kernels hold CUs on another stream, so the
+  // resident execution is not used while one is in flight.
+  struct PiHealth {
+    unsigned* expired = nullptr;
+    std::atomic<int> collectives{0};
+  };
+  static PiHealth& health() {
+    static PiHealth h;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      void* p = nullptr;
+      if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess) {
+        h.expired = static_cast<unsigned*>(p);
+        *h.expired = 0;
+      }
+    });
+    return h;
+  }
+  static unsigned expired_total() {
+    PiHealth& h = health();
+    return h.expired ? *reinterpret_cast<volatile unsigned*>(h.expired) : 0u;
+  }
+  static unsigned long long timeout_ticks() {   // of the 100 MHz constant clock; read per call
+    const char* e = getenv("PS_PI_TIMEOUT_MS");
+    const double ms = e ? atof(e) : 5000.0;
+    return (unsigned long long)(std::max(ms, 0.0) * 1.0e5);   // 0: every wait counts as expired (tests)
+  }
+
   static bool resident_enabled() {  // read per call: tests switch executions in one process
     const char* e = getenv("PS_PI_RESIDENT");
-    return !(e && e[0] == '0');
+    if (e && e[0] == '0') return false;
+    PiHealth& h = health();
+    return h.expired != nullptr && *h.expired == 0 && h.collectives.load() == 0;
   }
 
   // Two resident launches on DIFFERENT streams could each hold part of the chip while their
@@ -815,7 +876,8 @@ struct PiPlan {
           end += tm;
         }
         hipLaunchKernelGGL(pi_resident_kernel<RNT>, dim3((unsigned)(end - first)), dim3(256),
-                           res_lds, st, d_blocks, d_wgs + first, num_iters, tol);
+                           res_lds, st, d_blocks, d_wgs + first, num_iters, tol, timeout_ticks(),
+                           health().expired);
         first = end;
       }
       resident_release(st);

@@ -338,18 +338,19 @@ def test_sharded_optimizer_state_api_two_ranks():
 # ---------------------------------------------------------------------------
 def test_bench_multi_rank_control_flow_over_gloo(tmp_path):
   """bench.py's N > 1 path end to end, launched exactly as the driver launches it
-  (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2), in its
-  tests-only CPU mode (oracle kernels, shrunk sizes, gloo): rank set-up, the two-phase
+  (python -m torch.distributed.run --nproc-per-node 2 ... --gpus 2) through
+  tests/bench_selftest_launcher.py, which swaps the kernels for the oracle and shrinks the sizes
+  from the TEST side (bench.py has no such hook) and runs over gloo: rank set-up, the two-phase
   all-gather step, barriers, max-over-ranks timing, the ViT-B strong-scaling leg with LPT
   ownership, ONE JSON line from rank 0 with the multi-GPU self-diagnosis."""
   import json
   import subprocess
   env = dict(os.environ)
-  env["PS_BENCH_SELFTEST_CPU"] = "1"
   env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+         os.path.join(ROOT, "tests", "bench_selftest_launcher.py"), "--gpus", "2", "--steps", "2",
+         "--warmup", "1"]
   r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
   assert r.returncode == 0, r.stderr[-3000:]
   lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,0 +1,205 @@
+"""Round-3 GPU tests (through the C-ABI):
+
+* the register-resident power iteration (DS:595-652) next to a kernel that holds half of the
+  CUs on another stream: correct (bit-identical to the streaming execution) when the team mates
+  become resident late, and -- with a short deadline -- the bounded waits expire, the Newton
+  root re-runs the call on the streaming kernels and still matches the oracle, and the process
+  stays on the streaming execution until the health record is reset;
+* ps_collective_in_flight switches the resident execution off while an asynchronous gather is
+  in flight (what comm.sharded_inverse_pth_roots brackets its RCCL calls with);
+* the eigh root path of blocks of more than 128 rows (DS:943-1030): one-sided block Jacobi on the
+  Cholesky factor against the oracle's LAPACK root, the fallback for inputs that are not
+  positive definite, mixed batches, and both executions of the sweep loop;
+* ps_diag_mfma_clock returns a plausible clock.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shampoo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def K():
+  from precondition_amd import kernels
+  return kernels
+
+
+def L():
+  from precondition_amd import _lib
+  return _lib.lib()
+
+
+def wishart(n, k, seed):
+  g = np.random.default_rng(seed).standard_normal((n, k)).astype(np.float32)
+  return (g @ g.T).astype(np.float32)
+
+
+def health():
+  e, c, r = C.c_uint(), C.c_int(), C.c_int()
+  assert L().ps_power_iteration_health(C.addressof(e), C.addressof(c), C.addressof(r)) == 0
+  return e.value, c.value, r.value
+
+
+def hold_half_of_the_cus(stream, ms, cus=128):   # or most of them
+  """`cus` workgroups of 1024 threads with 150 KB of LDS each: one per CU, and nothing of the
+  resident power iteration (13 KB of LDS per workgroup) fits beside one."""
+  assert L().ps_diag_spin(stream.cuda_stream, cus, 1024, 150 * 1024, float(ms)) == 0
+
+
+# ---------------------------------------------------------------------------
+def test_collective_in_flight_switches_resident_execution_off(device):
+  L().ps_power_iteration_reset_health()
+  assert health() == (0, 0, 1)
+  assert L().ps_collective_in_flight(1) == 1
+  assert health() == (0, 1, 0)
+  a = torch.tensor(wishart(256, 1024, 5), device=device)
+  lam_stream, _ = K().power_iteration_batched([a])     # streaming kernels
+  assert L().ps_collective_in_flight(-1) == 0
+  assert health() == (0, 0, 1)
+  lam_res, _ = K().power_iteration_batched([a])        # resident kernel
+  assert torch.equal(lam_stream, lam_res)              # same arithmetic, bit for bit
+
+
+def test_resident_power_iteration_beside_a_kernel_holding_most_cus(device, monkeypatch):
+  """A kernel on another stream holds 250 of the 256 CUs for 150 ms.  Workgroups are dealt to
+  the XCDs round-robin and an XCD without a free CU dispatches nothing, so teams of the resident
+  launch are split until the filler ends: the team mates that did become resident wait (bounded:
+  5 s by default), the iteration is delayed, and nothing else happens -- eigenvalues equal the
+  streaming execution's bit for bit, no wait expires.  (Next to a filler on HALF of the CUs the
+  launch is not even delayed: the free slots hold a prefix of the teams.)"""
+  L().ps_power_iteration_reset_health()
+  mats = [torch.tensor(wishart(512, 2048, 100 + i), device=device) for i in range(160)]
+  monkeypatch.setenv("PS_PI_RESIDENT", "0")
+  lam_ref, it_ref = K().power_iteration_batched(mats)
+  monkeypatch.setenv("PS_PI_RESIDENT", "1")
+  torch.cuda.synchronize()
+  side = torch.cuda.Stream(device=device)
+  hold_half_of_the_cus(side, 150.0, cus=250)
+  time.sleep(0.01)
+  t0 = time.perf_counter()
+  lam, it = K().power_iteration_batched(mats)
+  torch.cuda.current_stream().synchronize()
+  assert time.perf_counter() - t0 > 0.05, "the filler did not delay the resident launch"
+  torch.cuda.synchronize()
+  assert torch.equal(lam, lam_ref) and torch.equal(it, it_ref)
+  assert health()[0] == 0
+  # half of the CUs held: no delay at all
+  hold_half_of_the_cus(side, 150.0, cus=128)
+  time.sleep(0.01)
+  t0 = time.perf_counter()
+  lam, it = K().power_iteration_batched(mats)
+  torch.cuda.current_stream().synchronize()
+  assert time.perf_counter() - t0 < 0.05
+  torch.cuda.synchronize()
+  assert torch.equal(lam, lam_ref) and health()[0] == 0
+
+
+def test_expired_resident_wait_falls_back_to_streaming_in_the_same_call(device, monkeypatch):
+  """The recovery path of an expired wait.  (On this hardware a filler kernel could not be made
+  to split a team for longer than a deadline: workgroups start in launch order, and with most
+  CUs held the whole launch simply starts late -- previous test; tools/dev_pi_expiry*.py.  The
+  expiry is therefore forced: PS_PI_TIMEOUT_MS=0 makes every wait count as expired.)  The
+  resident launch gives up at once (counted in pinned host memory, eigenvalues NaN), the Newton
+  root driver sees the count move at its first host wait and runs the call again on the
+  streaming kernels: roots and iteration counts match the oracle, nothing is NaN, and the
+  process stays on the streaming execution until the record is reset."""
+  L().ps_power_iteration_reset_health()
+  arrs = [wishart(512, 2048, 300 + i) for i in range(24)]
+  mats = [torch.tensor(a, device=device) for a in arrs]
+  monkeypatch.setenv("PS_PI_TIMEOUT_MS", "0")
+  roots, met = K().matrix_inverse_pth_root_batched(mats, [4] * len(mats))
+  torch.cuda.synchronize()
+  met = met.cpu().numpy()
+  expired, _, resident = health()
+  assert expired > 0 and resident == 0, (expired, resident)
+  assert np.isfinite(met[:, :5]).all()
+  for i in (0, 23):
+    h_ref, m_ref = orc.matrix_inverse_pth_root(arrs[i], 4)
+    h = roots[i].cpu().numpy()
+    assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 5e-5
+    assert met[i, 1] == m_ref["inverse_pth_root_iters"] and met[i, 4] == m_ref["total_retries"]
+    assert np.isclose(met[i, 3], m_ref["max_eigen_value"], rtol=2e-5)
+  # the eigh root driver recovers the same way (its first host wait is behind the Cholesky
+  # factorisation); the process is already on the streaming execution here, so force a new expiry
+  L().ps_power_iteration_reset_health()
+  big = [torch.tensor(wishart(256, 1024, 7), device=device)]
+  r_e, m_e = K().matrix_inverse_pth_root_batched(big, [2], eigh=True)
+  assert health()[0] > 0
+  h_ref, _ = orc.matrix_inverse_pth_root_eigh(big[0].cpu().numpy(), 2)
+  assert np.linalg.norm(r_e[0].cpu().numpy() - h_ref) / np.linalg.norm(h_ref) < 1e-4
+  # a standalone call has no host wait to recover at: with a real expiry its result would be NaN,
+  # which is why the process stays on the streaming execution after the first one
+  monkeypatch.delenv("PS_PI_TIMEOUT_MS")
+  lam, _ = K().power_iteration_batched(mats)
+  assert np.array_equal(lam.cpu().numpy(), met[:, 3])
+  L().ps_power_iteration_reset_health()
+  assert health() == (0, 0, 1)
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,k,p", [(256, 1024, 2), (384, 768, 4), (1000, 2000, 2), (200, 800, 2)])
+def test_eigh_root_cholesky_jacobi_vs_oracle(n, k, p, device):
+  """matrix_inverse_pth_root_eigh (DS:943-1030) through the one-sided block Jacobi on the
+  Cholesky factor (csrc/eigh_cj.hip.h; n = 200 pads to 256) against the oracle's LAPACK root:
+  1e-4 on the root (north_star's bar), error metric of the same size as LAPACK's."""
+  a = wishart(n, k, n + p)
+  h_ref, m_ref = orc.matrix_inverse_pth_root_eigh(a, p)
+  roots, met = K().matrix_inverse_pth_root_batched([torch.tensor(a, device=device)], [p], eigh=True)
+  h = roots[0].cpu().numpy()
+  met = met.cpu().numpy()
+  assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 1e-4
+  assert np.abs(h - h.T).max() <= 1e-5 * np.abs(h).max()
+  lam = float(np.linalg.eigvalsh(a.astype(np.float64)).max())
+  assert met[0, 0] < 1e-5 * lam and met[0, 0] < 0.1, met[0]
+  assert 3 <= met[0, 5] <= 24   # sweeps
+
+
+def test_eigh_root_two_sided_fallback_for_indefinite_input(device, monkeypatch):
+  """An input that is not positive definite after the ridge (eigenvalues -0.5 ... 2) cannot be
+  Cholesky-factored: the block is handed to the blocked two-sided solver inside the same call,
+  next to a positive definite block that stays on the one-sided path; both match the oracle."""
+  rng = np.random.default_rng(9)
+  q, _ = np.linalg.qr(rng.standard_normal((256, 256)))
+  bad = ((q * np.linspace(-0.5, 2.0, 256)) @ q.T)
+  bad = ((bad + bad.T) / 2).astype(np.float32)
+  good = wishart(256, 1024, 3)
+  mats = [torch.tensor(good, device=device), torch.tensor(bad, device=device),
+          torch.tensor(wishart(300, 900, 4), device=device)]
+  roots, met = K().matrix_inverse_pth_root_batched(mats, [2, 2, 2], eigh=True)
+  for m, h in zip(mats, roots):
+    h_ref, _ = orc.matrix_inverse_pth_root_eigh(m.cpu().numpy(), 2)
+    rel = np.linalg.norm(h.cpu().numpy() - h_ref) / np.linalg.norm(h_ref)
+    assert rel < 2e-4, rel
+  # the same batch on the two-sided solver alone
+  monkeypatch.setenv("PS_EIGH_CJ", "0")
+  roots2, _ = K().matrix_inverse_pth_root_batched(mats, [2, 2, 2], eigh=True)
+  assert torch.allclose(roots[1], roots2[1], rtol=0, atol=2e-4 * float(roots2[1].abs().max()))
+
+
+def test_eigh_root_one_stream_and_two_streams_agree(device, monkeypatch):
+  """The two stream groups sweep disjoint blocks: results do not depend on the interleaving."""
+  mats = [torch.tensor(wishart(256 + 128 * (i % 2), 1024, 40 + i), device=device) for i in range(5)]
+  monkeypatch.setenv("PS_EIGH_CJ_STREAMS", "1")
+  r1, m1 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True)
+  monkeypatch.setenv("PS_EIGH_CJ_STREAMS", "2")
+  r2, m2 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True)
+  for a, b in zip(r1, r2):
+    assert torch.equal(a, b)
+  assert torch.equal(m1, m2)
+
+
+def test_diag_mfma_clock(device):
+  ghz, tf = C.c_double(), C.c_double()
+  rc = L().ps_diag_mfma_clock(torch.cuda.current_stream().cuda_stream, 200.0,
+                              C.addressof(ghz), C.addressof(tf))
+  assert rc == 0
+  assert 1.0 < ghz.value < 2.6, ghz.value
+  # an MFMA-only loop reaches most of the fp32 MFMA peak at the clock it runs at
+  cus = torch.cuda.get_device_properties(device).multi_processor_count
+  assert tf.value > 0.8 * cus * 4 * 64 * ghz.value / 1e3, (tf.value, ghz.value)
