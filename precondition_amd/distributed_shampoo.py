@@ -171,8 +171,6 @@ def distributed_shampoo(
                      "to equal != preconditioning_compute_steps "
                      f"({preconditioning_compute_steps})")
   # ---- scope of this build
-  if shard_optimizer_states and best_effort_memory_usage_reduction:
-    raise NotImplementedError("shard_optimizer_states with quantized state is not built")
   if shard_optimizer_states and block_ownership != "reference":
     raise ValueError("shard_optimizer_states keeps the reference's batch() ownership")
   if lobpcg_topk_precondition and (eigh or compression_rank != 0):
@@ -192,6 +190,11 @@ def distributed_shampoo(
           f"{comm.world_and_rank(group)[0]} rank(s): one process per GPU")
   if shard_stats and (frequent_directions or compression_rank != 0):
     raise NotImplementedError("shard_statistics supports the dense preconditioner mode")
+
+  def _zeros_f32_like(param):
+    """State buffers are float32 whatever the parameter dtype (the kernels take float32 only;
+    bf16 / fp16 parameters and gradients are promoted at the door of update())."""
+    return torch.zeros_like(param, dtype=torch.float32)
 
   def _owned_mask(params_flat):
     """mask[p][j]: does this rank own statistic j of parameter p (list order = the
@@ -231,9 +234,11 @@ def distributed_shampoo(
     return torch.int8 if (best_effort_memory_usage_reduction and
                           len(var.shape) > 1) else torch.float32
 
+  # pjit mode (shard_optimizer_states): the stacked statistics / preconditioners are float32
+  # arrays (DS:2250-2252, quantized=False at DS:2557); only the momentum buffers are int8
   quantize_second_moment = bool(best_effort_memory_usage_reduction and
                                 not compression_rank and not frequent_directions and
-                                batch_axis_name)
+                                batch_axis_name and not shard_optimizer_states)
   qdt_second_moment = torch.int16 if quantize_second_moment else torch.float32
 
   def _quantize_many(tensors, dtype, extract_diagonal):
@@ -353,16 +358,16 @@ def distributed_shampoo(
         ]
       diagonal_statistics = []
       if _graft_type_has_diagonal_statistics():
-        diagonal_statistics = torch.zeros_like(param)
+        diagonal_statistics = _zeros_f32_like(param)
       if quantize_second_moment:  # DS:2613-2614
         statistics = _quantize_many(statistics, qdt_second_moment, True)
         preconditioners = _quantize_many(preconditioners, qdt_second_moment, True)
-      zeros_q = _quantize_momentum_many([torch.zeros_like(param), torch.zeros_like(param)],
+      zeros_q = _quantize_momentum_many([_zeros_f32_like(param), _zeros_f32_like(param)],
                                         [param, param])  # DS:2608-2609
       return ParameterStats(
           _quantize(diagonal_statistics), statistics, preconditioners,
           zeros_q[0], zeros_q[1],
-          torch.zeros_like(param) if (frequent_directions and average_grad) else MaskedNode(),
+          _zeros_f32_like(param) if (frequent_directions and average_grad) else MaskedNode(),
           init_training_metrics(len(statistics), generate_training_metrics,
                                 generate_fd_metrics, device=dev))
 
@@ -954,12 +959,12 @@ def distributed_shampoo(
     pd = _precond_dim(compression_rank, max_size)
     local_flat, index = [], 0
     for param, sizes in zip(params_flat, sizes_per_param):
-      zeros_q = _quantize_momentum_many([torch.zeros_like(param), torch.zeros_like(param)],
+      zeros_q = _quantize_momentum_many([_zeros_f32_like(param), _zeros_f32_like(param)],
                                         [param, param])
-      diag = torch.zeros_like(param) if _graft_type_has_diagonal_statistics() else []
+      diag = _zeros_f32_like(param)   # DS:2211: always allocated in this mode, whatever the graft type
       local_flat.append(LocalShardedParameterStats(
           _quantize(diag), zeros_q[0], zeros_q[1],
-          torch.zeros_like(param) if (frequent_directions and average_grad) else MaskedNode(),
+          _zeros_f32_like(param) if (frequent_directions and average_grad) else MaskedNode(),
           init_training_metrics(len(sizes), generate_training_metrics, generate_fd_metrics,
                                 device=dev),
           index, tuple(sizes)))
@@ -1043,6 +1048,8 @@ def distributed_shampoo(
     grads_flat = treedef.flatten_up_to(grads)
     grad_dtypes = [g.dtype for g in grads_flat]
     grads_flat = [g if g.dtype == torch.float32 else g.to(torch.float32) for g in grads_flat]
+    if any(p.dtype != torch.float32 for p in params_flat):
+      params_flat = [p if p.dtype == torch.float32 else p.to(torch.float32) for p in params_flat]
     step = int(state.count)
     gstats = state.stats.global_stats
     local_flat = treedef.flatten_up_to(state.stats.local_stats)
@@ -1062,15 +1069,31 @@ def distributed_shampoo(
       stats_flat.append(ParameterStats(loc.diagonal_statistics, st, pcs, loc.diagonal_momentum,
                                        loc.momentum, loc.avg_grad, loc.training_metrics))
     new_stats = _compute_stats_all(grads_flat, stats_flat, params_flat, step)
-    new_stats = _compute_preconditioners(new_stats, params_flat, step)
+    # Order of DS:2443-2452: the gradient is transformed with the preconditioners the state
+    # CAME IN with (the roots computed below reach the update of the NEXT step), unlike the
+    # pmap path, which roots first (DS:3648-3650).  Pinned by tests/golden/e2e_sharded.npz.
     pgs = _preconditioned_grads_all(grads_flat, new_stats, params_flat)
+    if best_effort_memory_usage_reduction:
+      # int8 momentum (DS:3581-3586 to_float): dequantize the whole tree in one launch
+      n_p = len(new_stats)
+      fl = _to_float_many([s_.momentum for s_ in new_stats] +
+                          [s_.diagonal_momentum for s_ in new_stats])
+      new_stats = [s_._replace(momentum=_quantize(fl[i]), diagonal_momentum=_quantize(fl[n_p + i]))
+                   for i, s_ in enumerate(new_stats)]
     if hasattr(backend, "transform_grads_fused"):
       outs = _transform_grads_fused(grads_flat, new_stats, params_flat, pgs, step)
     else:
       outs = [_transform_grad(g, s, p, step, pg)
               for g, s, p, pg in zip(grads_flat, new_stats, params_flat, pgs)]
     updates_flat = [o[0] if o[0].dtype == dt else o[0].to(dt) for o, dt in zip(outs, grad_dtypes)]
-    new_stats = [o[1] for o in outs]
+    stats_flat = [o[1] for o in outs]
+    if best_effort_memory_usage_reduction:
+      mq = _quantize_momentum_many(
+          [s_.momentum.to_float() for s_ in stats_flat] +
+          [s_.diagonal_momentum.to_float() for s_ in stats_flat], params_flat + params_flat)
+      stats_flat = [s_._replace(momentum=mq[i], diagonal_momentum=mq[len(stats_flat) + i])
+                    for i, s_ in enumerate(stats_flat)]
+    new_stats = _compute_preconditioners(stats_flat, params_flat, step)
     # back into the stacked arrays (pad_square_matrix semantics: the padding of a slot is
     # the identity for statistics, DS:2461-2465, and zero for the roots, DST:367-398)
     new_statistics = gstats.statistics.clone()

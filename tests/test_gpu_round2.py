@@ -347,26 +347,21 @@ def test_fd_diagnostics_vs_reference_golden(device):
 
 
 # ---------------------------------------------------------------------------
-def test_sharded_optimizer_state_api_hip_matches_plain_optimizer(device):
-  """shard_optimizer_states (the reference's pjit-mode API, DS:2162-2583) on the HIP path:
-  the stacked padded state must walk the plain optimizer's trajectory bit for bit."""
-  import precondition_amd as pa
-  from tests.test_distributed_gloo import _quant_problem
-  params, grads, kw = _quant_problem()
-  kw = dict(kw)
-  kw["best_effort_memory_usage_reduction"] = False
-  params = tuple(p.to(device) for p in params)
-  grads = [tuple(g.to(device) for g in gs) for gs in grads]
-  plain = pa.distributed_shampoo(0.1, 8, batch_axis_name=None, **kw)
-  shard = pa.distributed_shampoo(0.1, 8, batch_axis_name=None, shard_optimizer_states=True, **kw)
-  st_p = plain.init(params)
-  st_s = shard.init(params).init_fn(params)
-  for g in grads:
-    up, st_p = plain.update(g, st_p, params)
-    us, st_s = shard.update(g, st_s, params)
-    for a, b in zip(up, us):
-      assert torch.equal(a, b)
-  assert int(st_s.count) == len(grads)
+@pytest.mark.parametrize("name", ["shard_a_default_d1", "shard_a_rmsprop_wd_d1",
+                                  "shard_a_int8_momentum_d1"])
+def test_sharded_optimizer_state_api_hip_vs_reference_golden(name, device):
+  """shard_optimizer_states (the reference's pjit-mode API, DS:2162-2583) on the HIP path
+  against goldens generated from the reference's own sharded_init_fn / sharded_update_fn
+  (tools/gen_golden.py gen_e2e_sharded): every update of every step, the final stacked padded
+  statistics / preconditioners / exponents and the per-parameter local state."""
+  from tests.test_optimizer_host_logic import (_sharded_index, check_sharded_final_state,
+                                               run_sharded_case)
+  gold = os.path.join(os.path.dirname(__file__), "golden")
+  z = np.load(os.path.join(gold, "e2e_sharded.npz"))
+  case = [c for c in _sharded_index(gold, 1) if c["name"] == name][0]
+  st, worst = run_sharded_case(case, z, device, None)   # None => HIP kernels
+  assert worst < 1e-3, worst
+  check_sharded_final_state(case, z, st)
 
 
 def test_stats_vector_blocks_stream_path(device):

@@ -748,9 +748,93 @@ def gen_lowrank_big():
     json.dump(index, f, indent=1)
 
 
+def gen_e2e_sharded():
+  """The reference's pjit mode (shard_optimizer_states=True, DS:2162-2583): InitFnState ->
+  sharded_init_fn -> sharded_update_fn over the shim (XLA's sharding constraints are identity
+  on one process).  Fixtures: per-step updates, the final stacked / padded global statistics,
+  preconditioners and exponents (GlobalShardedParameterStats), per-parameter index_start /
+  sizes, diagonal statistics and momenta (LocalShardedParameterStats), for 1 and 2 devices
+  (the 2-device runs exercise the identity / p = 1 padding rows of DS:2476-2486)."""
+  import jax
+  P = jax.sharding.PartitionSpec
+  out, index = {}, []
+
+  def tree(shapes, seed):
+    r = np.random.default_rng(seed)
+    return tuple(r.standard_normal(s).astype(F32) for s in shapes)
+
+  shapes_a = ([40, 24], [24], [6, 10, 8], [70, 33])
+  configs = [
+      ("shard_a_default_d1", tree(shapes_a, 21), dict(
+          block_size=32, preconditioning_compute_steps=2, start_preconditioning_step=2), 6, 1),
+      ("shard_a_default_d2", tree(shapes_a, 21), dict(
+          block_size=32, preconditioning_compute_steps=2, start_preconditioning_step=2), 6, 2),
+      ("shard_a_rmsprop_wd_d1", tree(shapes_a, 22), dict(
+          block_size=16, beta2=0.9, graft_type=ds.GraftingType.RMSPROP_NORMALIZED,
+          preconditioning_compute_steps=1, start_preconditioning_step=1, weight_decay=0.01,
+          nesterov=False), 5, 1),
+      ("shard_a_adagrad_stats2_d2", tree(shapes_a, 23), dict(
+          block_size=64, graft_type=ds.GraftingType.ADAGRAD, statistics_compute_steps=2,
+          preconditioning_compute_steps=2, start_preconditioning_step=3,
+          moving_average_for_momentum=True), 6, 2),
+      # best_effort_memory_usage_reduction in pjit mode: int8 momentum buffers of the rank > 1
+      # parameters (DS:2047-2049, 2212-2213); the stacked statistics stay float32
+      ("shard_a_int8_momentum_d1", tree(shapes_a, 24), dict(
+          block_size=32, preconditioning_compute_steps=2, start_preconditioning_step=2,
+          best_effort_memory_usage_reduction=True, graft_type=ds.GraftingType.RMSPROP), 6, 1),
+  ]
+  for name, params, kw, steps, ndev in configs:
+    lr = 0.1
+    kw = dict(kw)
+    opt = ds.distributed_shampoo(
+        lr, batch_axis_name=None, shard_optimizer_states=True, num_devices_for_pjit=ndev,
+        statistics_partition_spec=P("x", None, None),
+        preconditioner_partition_spec=P("x", None, None), **kw)
+    p_j = tuple(jnp.array(p) for p in params)
+    st = opt.init(p_j).init_fn(p_j)
+    gr_rng = np.random.default_rng(zlib.crc32(name.encode()))
+    for t in range(steps):
+      g = tuple((gr_rng.standard_normal(p.shape) * (1 + 0.1 * t)).astype(F32) for p in params)
+      with np.errstate(all="ignore"):
+        upd, st = opt.update(tuple(jnp.array(x) for x in g), st, p_j)
+      for i in range(len(params)):
+        out[f"{name}__grad{i}_t{t}"] = g[i]
+        out[f"{name}__upd{i}_t{t}"] = npy(upd[i])
+        assert np.asarray(upd[i]).dtype == F32
+    gs = st.stats.global_stats
+    out[f"{name}__global_statistics"] = npy(gs.statistics)
+    out[f"{name}__global_preconditioners"] = npy(gs.preconditioners)
+    out[f"{name}__global_exponents"] = np.asarray(gs.exponents).astype(np.int32)
+    assert npy(gs.statistics).dtype == F32
+    for i, (p, ls) in enumerate(zip(params, st.stats.local_stats)):
+      out[f"{name}__param{i}"] = p
+      out[f"{name}__index_start{i}"] = np.asarray(ls.index_start).astype(np.int32)
+      out[f"{name}__sizes{i}"] = np.asarray([int(x) for x in ls.sizes], np.int32)
+      out[f"{name}__momentum{i}"] = npy(ls.momentum.to_float())
+      out[f"{name}__diag_momentum{i}"] = npy(ls.diagonal_momentum.to_float())
+      if np.asarray(ls.momentum.quantized).dtype == np.int8:
+        out[f"{name}__momentum{i}_codes"] = npy(ls.momentum.quantized)
+        out[f"{name}__momentum{i}_bucket"] = npy(ls.momentum.bucket_size)
+      dsf = ls.diagonal_statistics.to_float()
+      if not (isinstance(dsf, list) and not dsf):
+        out[f"{name}__diag_stats{i}"] = npy(dsf)
+      tm = ls.training_metrics
+      if hasattr(tm, "inverse_pth_root_errors"):
+        out[f"{name}__errors{i}"] = npy(tm.inverse_pth_root_errors)
+    kw_json = {k: (int(v) if isinstance(v, (ds.GraftingType, ds.PreconditionerType)) else v)
+               for k, v in kw.items()}
+    index.append(dict(name=name, n_params=len(params), steps=steps, lr=lr, kwargs=kw_json,
+                      count=int(np.asarray(st.count)), num_devices=ndev))
+    print(f"e2e sharded {name}: {steps} steps on {ndev} device(s), stack "
+          f"{npy(gs.statistics).shape}, last upd[0][:3]={npy(upd[0]).ravel()[:3]}")
+  np.savez_compressed(os.path.join(OUT, "e2e_sharded.npz"), **out)
+  with open(os.path.join(OUT, "e2e_sharded_index.json"), "w") as f:
+    json.dump(index, f, indent=1)
+
+
 if __name__ == "__main__":
   which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e", "lowrank", "quant",
-                           "e2e_quant", "e2e_more", "lowrank_big", "fd_metrics"]
+                           "e2e_quant", "e2e_more", "lowrank_big", "fd_metrics", "e2e_sharded"]
   if "newton" in which:
     gen_newton()
   if "pi" in which:
@@ -775,4 +859,6 @@ if __name__ == "__main__":
     gen_lowrank_big()
   if "fd_metrics" in which:
     gen_fd_metrics()
+  if "e2e_sharded" in which:
+    gen_e2e_sharded()
   print("golden fixtures written to", OUT)
