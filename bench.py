@@ -857,15 +857,17 @@ def main():
         }
 
       def fd_f32():
-        old = os.environ.get("PS_FD_FILTER")
+        old = {k: os.environ.get(k) for k in ("PS_FD_FILTER", "PS_FD_GRAM")}
         os.environ["PS_FD_FILTER"] = "f32"
+        os.environ["PS_FD_GRAM"] = "f32"
         try:
           return fd_cfg5(dev)
         finally:
-          if old is None:
-            os.environ.pop("PS_FD_FILTER", None)
-          else:
-            os.environ["PS_FD_FILTER"] = old
+          for k, v in old.items():
+            if v is None:
+              os.environ.pop(k, None)
+            else:
+              os.environ[k] = v
 
       for key, fn in (("fd_cfg5", lambda: fd_cfg5(dev)), ("fd_cfg5_f32_products", fd_f32),
                       ("quant_f3", lambda: quant_f3(dev)), ("eigh_cfg3", eigh_cfg3)):

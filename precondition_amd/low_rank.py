@@ -172,22 +172,34 @@ def _low_rank_root_batched(calls) -> List[Tuple[torch.Tensor, TrainingMetrics]]:
 
 
 # ---- frequent_directions_update (DS:1473-1505) -------------------------------------
+def _gram_precision(d: int) -> str:
+  """Arithmetic of the covariance update G G^T of a Frequent-Directions step, its own switch
+  (PS_FD_GRAM = f32 | bf16x3): "bf16x3" (the default for aligned 2-D blocks of >= 1024 rows --
+  BASELINE configs[4] names the bf16 MFMA for this branch) multiplies bf16 hi/lo pairs of g
+  with float32 accumulation (2^-17 operand precision) and symmetrises the result; "f32" is the
+  exact-f32 MFMA statistics kernel the dense optimizer always uses (the reference computes this
+  factor at HIGHEST precision, DS:1469)."""
+  import os
+  mode = os.environ.get("PS_FD_GRAM", "bf16x3")
+  if mode not in ("f32", "bf16x3"):
+    raise ValueError(f"PS_FD_GRAM must be f32 or bf16x3, got {mode!r}")
+  return mode
+
+
 def gram_of_block(g: torch.Tensor, axis: int) -> torch.Tensor:
   """tensordot(g, g, all axes but `axis`): the covariance update of one Frequent-Directions
-  step.  Large 2-D blocks take it from the bf16 MFMA on hi/lo pairs of g (bf16x3: 2^-17
-  operand precision, float32 accumulation — BASELINE configs[4] names bf16 MFMA for this
-  branch; PS_FD_FILTER=f32 keeps the exact-f32 statistics kernel); everything else, and
-  the dense statistics of the optimizer, always use the float32 MFMA statistics kernel."""
-  from . import subspace
+  step (see _gram_precision); everything that is not a large aligned 2-D block, and the dense
+  statistics of the optimizer, always use the float32 MFMA statistics kernel."""
   d = g.shape[axis]
   if (g.dim() == 2 and d >= 1024 and d % 32 == 0 and g.shape[1 - axis] % 32 == 0 and
-      subspace._filter_precision(d) != "f32"):
+      _gram_precision(d) != "f32"):
     gt = g if axis == 0 else g.t()
     hi, lo = kernels.to_bf16(gt.contiguous() if not gt.is_contiguous() else gt, split=True)
     out = torch.empty((d, d), dtype=torch.float32, device=g.device)
     kernels.gemm_bf16_grouped([((hi, lo), (hi, lo), out)])
-    # (symmetric up to the order of the two cross terms in the float32 accumulation chain)
-    return out
+    # hi*lo and lo*hi enter the float32 accumulation chain in a fixed order, so out is symmetric
+    # only up to rounding: its consumers (the eigensolvers) want exact symmetry
+    return torch.add(out, out.t()).mul_(0.5)
   zero = torch.zeros((d, d), dtype=torch.float32, device=g.device)
   out = torch.empty_like(zero)
   kernels.stats_update_grouped([(g, axis, zero, out)], 0.0, 1.0)
@@ -246,8 +258,12 @@ def _fd_update_root_batched(calls) -> list:
                                kw.get("generate_training_metrics", True))
     if preps[i]["want_fd"] and preps[i]["ps"] != 0:
       _fd_keep_for_diagnostics(preps[i], kw)
-    if preps[i]["ps"] == 0:  # DS:1284-1288
-      results[i] = (torch.zeros_like(kw["prev"]), _metrics(0.0))
+    if preps[i]["ps"] == 0:  # DS:1284-1288; the reference still returns an FDDiagnostics (zeros)
+      m0 = _metrics(0.0)
+      if preps[i]["want_fd"]:
+        from .state import FDDiagnostics
+        m0 = m0.replace(fd=FDDiagnostics())
+      results[i] = (torch.zeros_like(kw["prev"]), m0)
   todo = [i for i in range(n_calls) if results[i] is None]
   # leading eigenpairs, batched by (size, rank)
   eig = {}
