@@ -1112,6 +1112,8 @@ struct EPlan {
   std::vector<ETile> chol_tiles;  // (block, 64-row tile) of the blocks swept by eigh_cj.hip.h
   std::vector<int> big_ids;       // those blocks
   std::vector<ETile> cj_pair[2], cj_row[2];  // pair / row-tile lists of the two stream groups
+  std::vector<int> cj_group_of;              // per entry of big_ids
+  int cj_swept = 0;
   PiPlan pip;
 };
 
@@ -1136,7 +1138,9 @@ void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_s
       continue;
     }
     pl.max_nb = std::max(pl.max_nb, nb);
-    const int grp = (int)(pl.big_ids.size() & 1);
+    // the two stream groups alternate over the blocks that actually have pairs to sweep
+    const int grp = np > 0 ? (pl.cj_swept++ & 1) : 0;
+    pl.cj_group_of.push_back(grp);
     pl.big_ids.push_back(b);
     for (int i = 0; i < nb; ++i) pl.chol_tiles.push_back({b, (short)i, 0, 0, 0});
     for (int k = 0; k < np; ++k) {
@@ -1267,7 +1271,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     eb.off_rel = 1.f;
   }
   for (int b : pl.small_ids) hb[b].small = 1;
-  for (size_t i = 0; i < pl.big_ids.size(); ++i) hb[pl.big_ids[i]].cj_group = (int)(i & 1);
+  for (size_t i = 0; i < pl.big_ids.size(); ++i) hb[pl.big_ids[i]].cj_group = pl.cj_group_of[i];
   auto up = [&](void* d, const void* h, size_t bytes) -> int {
     return psh::upload_async(st, d, h, bytes);  // pinned staging ring: no stream synchronisation
   };
@@ -1399,6 +1403,8 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
         const char* e = getenv("PS_EIGH_CJ_DONE"); return e ? (float)atof(e) : 1e-3f; }();
       const int cj_max_sweeps = [] {
         const char* e = getenv("PS_EIGH_CJ_MAX_SWEEPS"); return e ? atoi(e) : 24; }();
+      const int cj_stationary = [] { const char* e = getenv("PS_EIGH_CJ_STATIONARY"); return e ? atoi(e) : 1; }();
+      const float cj_one_below = [] { const char* e = getenv("PS_EIGH_CJ_ONE_BELOW"); return e ? (float)atof(e) : 0.1f; }();
       const int cj_sort = [] { const char* e = getenv("PS_EIGH_CJ_SORT"); return e ? atoi(e) : 1; }();
       const size_t piv_lds = (size_t)(2 * SE_MAXN * SE_LD + 32 + 3 * SE_MAXN) * sizeof(float);
       static bool piv_attr = false;
@@ -1463,7 +1469,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
         PS_HIP(hipStreamWaitEvent(side, side_ev[2], 0));
       }
       const int first_gen = gen;
-      bool done[2] = {false, pl.cj_pair[1].empty()};
+      bool done[2] = {pl.cj_pair[0].empty(), pl.cj_pair[1].empty()};
       for (int s = 0; s < cj_max_sweeps; ++s) {
         for (int r = 0; r < pl.max_nb - 1; ++r)
           for (int g = 0; g < 2; ++g) {
@@ -1472,7 +1478,8 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
             hipLaunchKernelGGL(cj_gram_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks, lo.cj_pair[g],
                                np_g, r);
             hipLaunchKernelGGL(cj_pivot_kernel, dim3(np_g), dim3(SE_T), piv_lds, gs[g], lo.blocks,
-                               lo.cj_pair[g], r, cj_tol, cj_inner, cj_done * cj_done, cj_sort);
+                               lo.cj_pair[g], r, cj_tol, cj_inner, cj_done * cj_done, cj_sort,
+                               cj_stationary, cj_one_below);
             if (cj_ubk == 8)
               hipLaunchKernelGGL(cj_update_kernel_t<8>, dim3(nr_g), blk, 0, gs[g], lo.blocks,
                                  lo.cj_row[g], nr_g, r);
@@ -1579,6 +1586,21 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                            batch, 1);  // V <-> W
       }
     }
+    // One-sided path only (no small blocks, no fallback): D U is formed ONCE, float64-accumulated
+    // on the float64 MFMA as a float32 hi/lo pair; the Rayleigh quotients, and the error metric's
+    // product U^T (D U), are taken from it (39 + 8.6 ms of float64 VALU dot products and a float32
+    // D U product become 20 ms).
+    const bool cj_only = cj_on && mode == 0 && any_big && !run_two_sided && pl.small_ids.empty() &&
+                         cj_refine;
+    if (cj_only) {
+      hipLaunchKernelGGL(eigh_reproject_f64_kernel<0>, dim3(4 * nsq), blk, 0, st, lo.blocks, lo.sq);
+      hipLaunchKernelGGL(cj_rayleigh_from_dv_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      hipLaunchKernelGGL(eigh_scale_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      hipLaunchKernelGGL((eigh_gemm_kernel<KC, KC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
+                         (int)GB_W, (int)GB_W, (int)GB_OUT, (int)GE_STORE);
+      hipLaunchKernelGGL((eigh_gemm_kernel<MC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
+                         (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_ERR);
+    } else {
     {
       static int refine = -1;
       if (refine < 0) { const char* e = getenv("PS_EIGH_REFINE"); refine = e ? atoi(e) != 0 : 1; }
@@ -1602,6 +1624,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                        (int)GB_D, (int)GB_V, (int)GB_X, (int)GE_STORE);
     hipLaunchKernelGGL((eigh_gemm_kernel<MC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
                        (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_ERR);
+    }
   }
   if (mode == 1) return PS_OK;
   hipLaunchKernelGGL(eigh_zero_out_kernel, dim3(batch, 16), blk, 0, st, lo.blocks);

@@ -212,7 +212,72 @@ __global__ void cj_select_kernel(EighBlock* blocks, int nblocks) {
 }
 
 // ---- P = [G_I G_J]^T [G_I G_J]: one workgroup per (block, pair); the K-tile of the panel
-// (16 rows x the 128 gathered columns) is staged ONCE and serves as both MFMA operands.
+// (16 rows x the 128 gathered columns) is staged ONCE and serves as both MFMA operands.  P is
+// symmetric: only the 10 upper 32 x 32 tiles (ti <= tj) are computed, dealt 3 + 3 + 2 + 2 to
+// the four wavefronts (the critical wavefront issues 3/4 of the MFMAs of the full product), and
+// only they are stored -- cj_pivot_kernel reads the upper triangle.
+template <int W> struct GramTiles;
+template <> struct GramTiles<0> { static constexpr int N = 3; static constexpr int TI[3] = {0, 0, 0}, TJ[3] = {0, 1, 2}; };
+template <> struct GramTiles<1> { static constexpr int N = 3; static constexpr int TI[3] = {0, 1, 1}, TJ[3] = {3, 1, 2}; };
+template <> struct GramTiles<2> { static constexpr int N = 2; static constexpr int TI[3] = {1, 2, 0}, TJ[3] = {3, 2, 0}; };
+template <> struct GramTiles<3> { static constexpr int N = 2; static constexpr int TI[3] = {2, 3, 0}, TJ[3] = {3, 3, 0}; };
+
+template <int W>
+__device__ __forceinline__ void cj_gram_body(const float* G, int ld, const int (&goff)[2],
+                                             const int (&soff)[2], float* smem, float* P,
+                                             int lane) {
+  using T = GramTiles<W>;
+  constexpr int BK = 16, LD = SmemCfg<BK>::MC_LD;
+  f32x16 acc[T::N];
+#pragma unroll
+  for (int t = 0; t < T::N; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int nk = ld / BK;
+  const int i = lane & 31, h = lane >> 5;
+  f32x4 r[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) r[v] = gload4(G + goff[v]);
+#pragma unroll
+  for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(smem + soff[v]) = r[v];
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* cur = smem + (kt & 1) * BK * LD;
+    float* nxt = smem + ((kt + 1) & 1) * BK * LD;
+    const bool more = kt + 1 < nk;
+    if (more) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) r[v] = gload4(G + (int64_t)(kt + 1) * BK * ld + goff[v]);
+    }
+#pragma unroll
+    for (int c = 0; c < BK / 8; ++c) {
+      float f[4][4];   // fragment of column block b at k = 8c + 4h + s (unused blocks fold away)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) f[b][s2] = cur[(8 * c + 4 * h + s2) * LD + b * 32 + i];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int t = 0; t < T::N; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[T::TI[t]][s2], f[T::TJ[t]][s2], acc[t],
+                                                        0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(nxt + soff[v]) = r[v];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < T::N; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = T::TI[t] * 32 + (q & 3) + 8 * (q >> 2) + 4 * h, col = T::TJ[t] * 32 + i;
+      gstore1(P + row * JP + col, acc[t][q]);
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void cj_gram_kernel(EighBlock* blocks, const ETile* tiles,
                                                          int ntiles, int round) {
   constexpr int BK = 16, LD = SmemCfg<BK>::MC_LD;   // [16][132]
@@ -224,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void cj_gram_kernel(EighBlock* blocks, cons
   rr_pair(eb->nb, round, te.k, I, J);
   const int ld = eb->npad, tid = threadIdx.x;
   const float* G = eb->X;
-  const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // thread -> two float4 of a K-tile: rows k = f >> 5, columns 4 * (f & 31) of the gathered panel
   int goff[2], soff[2];
 #pragma unroll
@@ -234,38 +299,98 @@ __global__ __launch_bounds__(256, 2) void cj_gram_kernel(EighBlock* blocks, cons
     goff[v] = k * ld + gc;
     soff[v] = k * LD + c4;
   }
-  f32x16 acc[2][2];
-  zero_acc(acc);
-  const int nk = ld / BK;
-  f32x4 r[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) r[v] = gload4(G + goff[v]);
-#pragma unroll
-  for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(smem + soff[v]) = r[v];
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    float* cur = smem + (kt & 1) * BK * LD;
-    float* nxt = smem + ((kt + 1) & 1) * BK * LD;
-    const bool more = kt + 1 < nk;
-    if (more) {
-#pragma unroll
-      for (int v = 0; v < 2; ++v) r[v] = gload4(G + (int64_t)(kt + 1) * BK * ld + goff[v]);
-    }
-    compute_ktile<MC, MC, BK>(cur, cur, acc, wm, wn, lane);
-    if (more) {
-#pragma unroll
-      for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(nxt + soff[v]) = r[v];
-    }
-    __syncthreads();
-  }
   float* P = eb->V + (int64_t)te.k * JP * JP;
+  switch (wave) {
+    case 0: cj_gram_body<0>(G, ld, goff, soff, smem, P, lane); break;
+    case 1: cj_gram_body<1>(G, ld, goff, soff, smem, P, lane); break;
+    case 2: cj_gram_body<2>(G, ld, goff, soff, smem, P, lane); break;
+    default: cj_gram_body<3>(G, ld, goff, soff, smem, P, lane); break;
+  }
+}
+
+// ---- all inner sweeps of the one-sided Jacobi on a 128-column problem with ONE column of every
+// pair kept in registers.  A sweep is a recursive-halving tournament: for block sizes s = 128,
+// 64, ..., 2 the first half of every block of s columns stays put ("stationary": its G and V
+// columns live in the registers of its 16-lane group for the s/2 rounds of the level) and meets
+// the columns of the second half one after the other (round r: column i meets s/2 + (i + r) mod
+// s/2); 64 + 32 + ... + 1 = 127 rounds of 64 disjoint pairs, every pair once.  Only the moving
+// column of a pair is read from and written back to LDS in a round: half the LDS traffic of
+// onesided_jacobi_lds_t (whose round-robin tournament moves both columns), which is what bounds
+// that kernel (ds_write_b128 ~79 B/clk).  Same rotation arithmetic.  1024 threads, m = 128.
+__device__ inline int onesided_jacobi_lds_stationary(float* G, float* V, int* s_rot,
+                                                     int max_sweeps, float done_cos2) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane >> 4, l = lane & 15;
+  const int k = 4 * wave + sub;                 // pair index within a round, 0..63
+  int sweeps_total = 0;
+  for (int sweeps = 0; sweeps < max_sweeps; ++sweeps, ++sweeps_total) {
+    float rotated = 0.f;
+    for (int half = 64; half >= 1; half >>= 1) {   // block size s = 2 * half
+      const int blk = k / half, i = k - blk * half;
+      const int p = blk * 2 * half + i;
+      float* gp = G + p * SE_LD + 4 * l;
+      float* vp = V + p * SE_LD + 4 * l;
+      f32x4 a0 = *reinterpret_cast<f32x4*>(gp), a1 = *reinterpret_cast<f32x4*>(gp + 64);
+      f32x4 w0 = *reinterpret_cast<f32x4*>(vp), w1 = *reinterpret_cast<f32x4*>(vp + 64);
+      float aa = 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 4; ++j) aa += a0[j] * a0[j] + a1[j] * a1[j];
+      aa = row16_sum(aa);
+      for (int r = 0; r < half; ++r) {
+        int iq = i + r; if (iq >= half) iq -= half;
+        const int q = blk * 2 * half + half + iq;
+        float* gq = G + q * SE_LD + 4 * l;
+        float* vq = V + q * SE_LD + 4 * l;
+        const f32x4 b0 = *reinterpret_cast<f32x4*>(gq), b1 = *reinterpret_cast<f32x4*>(gq + 64);
+        const f32x4 x0 = *reinterpret_cast<f32x4*>(vq), x1 = *reinterpret_cast<f32x4*>(vq + 64);
+        float bb = 0.f, ab = 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j) {
+          bb += b0[j] * b0[j] + b1[j] * b1[j];
+          ab += a0[j] * b0[j] + a1[j] * b1[j];
+        }
+        bb = row16_sum(bb); ab = row16_sum(ab);
+        if (fabsf(ab) > 3e-7f * __builtin_amdgcn_sqrtf(aa * bb)) {
+          const float zeta = (bb - aa) * __builtin_amdgcn_rcpf(2.f * ab);
+          const float t = copysignf(1.f, zeta) *
+                          __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta));
+          const float c = __builtin_amdgcn_rsqf(1.f + t * t), sn = c * t;
+          if (c == c && sn == sn) {
+            f32x4 nb0, nb1, nx0, nx1;
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        gstore1(P + acc_row(wm, i, q, lane) * JP + acc_col(wn, j, lane), acc[i][j][q]);
+            for (int j = 0; j < 4; ++j) {
+              const float pa0 = a0[j], pa1 = a1[j], pw0 = w0[j], pw1 = w1[j];
+              a0[j] = c * pa0 - sn * b0[j]; nb0[j] = sn * pa0 + c * b0[j];
+              a1[j] = c * pa1 - sn * b1[j]; nb1[j] = sn * pa1 + c * b1[j];
+              w0[j] = c * pw0 - sn * x0[j]; nx0[j] = sn * pw0 + c * x0[j];
+              w1[j] = c * pw1 - sn * x1[j]; nx1[j] = sn * pw1 + c * x1[j];
+            }
+            *reinterpret_cast<f32x4*>(gq) = nb0; *reinterpret_cast<f32x4*>(gq + 64) = nb1;
+            *reinterpret_cast<f32x4*>(vq) = nx0; *reinterpret_cast<f32x4*>(vq + 64) = nx1;
+            rotated = fmaxf(rotated, ab * ab * __builtin_amdgcn_rcpf(aa * bb));
+            // |g_p|^2 after the rotation (exact arithmetic: aa - t * ab); recomputed from the
+            // registers so that it does not drift over the rounds of the level
+            float na = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) na += a0[j] * a0[j] + a1[j] * a1[j];
+            aa = row16_sum(na);
+          }
+        }
+        __syncthreads();
+      }
+      *reinterpret_cast<f32x4*>(gp) = a0; *reinterpret_cast<f32x4*>(gp + 64) = a1;
+      *reinterpret_cast<f32x4*>(vp) = w0; *reinterpret_cast<f32x4*>(vp + 64) = w1;
+      __syncthreads();
+    }
+    if (rotated > 0.f && l == 0) atomicMax(&s_rot[sweeps & 1], __float_as_int(rotated));
+    __syncthreads();
+    const int any = s_rot[sweeps & 1];
+    __syncthreads();
+    if (tid == 0) s_rot[sweeps & 1] = 0;
+    if (!any || __int_as_float(any) < done_cos2) { ++sweeps_total; break; }
+  }
+  __syncthreads();
+  return sweeps_total;
 }
 
 // ---- Q = eigenvectors of the Gram matrix of the pair: one-sided Jacobi on (P, I) in LDS (the
@@ -274,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void cj_gram_kernel(EighBlock* blocks, cons
 // maximum over the sweep is what the outer iteration stops on.
 __global__ __launch_bounds__(SE_T) void cj_pivot_kernel(EighBlock* blocks, const ETile* tiles,
                                                         int round, float tol, int max_inner,
-                                                        float done_cos2, int sort) {
+                                                        float done_cos2, int sort,
+                                                        int stationary, float one_below) {
   extern __shared__ __align__(16) float sem[];
   float* Gs = sem;                      // [128][132] column-major
   float* Vs = sem + SE_MAXN * SE_LD;
@@ -293,7 +419,7 @@ __global__ __launch_bounds__(SE_T) void cj_pivot_kernel(EighBlock* blocks, const
   unsigned so = 0;
   for (int e = tid; e < JP * JP; e += SE_T) {
     const int row = e >> 7, col = e & 127;
-    const float p = gload1(P + e);
+    const float p = gload1(P + (row <= col ? row * JP + col : col * JP + row));   // upper triangle
     Gs[col * SE_LD + row] = p;
     Vs[col * SE_LD + row] = row == col ? 1.f : 0.f;
     if (row != col) {
@@ -317,7 +443,10 @@ __global__ __launch_bounds__(SE_T) void cj_pivot_kernel(EighBlock* blocks, const
   }
   if (!rotate) return;
   __syncthreads();
-  onesided_jacobi_lds_t<4>(Gs, Vs, s_rot, JP, max_inner, done_cos2);
+  // a pair that is already nearly orthogonal (quadratic regime) gets a single inner sweep
+  if (sof < one_below) max_inner = 1;
+  if (stationary) onesided_jacobi_lds_stationary(Gs, Vs, s_rot, max_inner, done_cos2);
+  else onesided_jacobi_lds_t<4>(Gs, Vs, s_rot, JP, max_inner, done_cos2);
   // the approximate rcp / rsq of the rotation parameters scale a rotation by 1 + O(eps):
   // renormalise; |g_j| = |P v_j| = the eigenvalue of column j
   float* s_ev = s_dinv + JP;                              // [128]
@@ -443,6 +572,26 @@ __global__ __launch_bounds__(256) void cj_norms_kernel(EighBlock* blocks, const 
   part[half][tid & 127] = s;
   __syncthreads();
   if (tid < TILE) eb->evals[te.t * TILE + tid] = (float)(part[0][tid] + part[1][tid]);
+}
+
+// ---- Rayleigh quotients e_j = u_j^T (D u_j) from the float64-accumulated product D U kept as a
+// float32 hi/lo pair in (X, W) by eigh_reproject_f64_kernel<0>: diag(A) = e (float64 sum).
+__global__ __launch_bounds__(256) void cj_rayleigh_from_dv_kernel(EighBlock* blocks,
+                                                                  const ETile* tiles) {
+  __shared__ double part[2][TILE];
+  const ETile te = tiles[blockIdx.x];    // sq tile list: only te.k == 0 tiles work, te.t = chunk
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj || te.k != 0) return;
+  const int ld = eb->npad, n = eb->n, tid = threadIdx.x;
+  const int c = te.t * TILE + (tid & 127), half = tid >> 7;
+  double s = 0.0;
+  for (int r = half; r < n; r += 2) {
+    const int64_t o = (int64_t)r * ld + c;
+    s = fma((double)gload1(eb->V + o), (double)gload1(eb->X + o) + (double)gload1(eb->W + o), s);
+  }
+  part[half][tid & 127] = s;
+  __syncthreads();
+  if (tid < TILE && c < n) eb->A[(int64_t)c * ld + c] = (float)(part[0][tid] + part[1][tid]);
 }
 
 // ---- V = G diag(1 / |g_j|), diag(A) = |g_j|^2

@@ -283,7 +283,7 @@ def run_sharded_case(c, z, device, backend, group=None):
   return st, worst
 
 
-def check_sharded_final_state(c, z, st, rank=0, world=1):
+def check_sharded_final_state(c, z, st, rank=0, world=1, tol_p=2e-3):
   """GlobalShardedParameterStats / LocalShardedParameterStats against the reference's: layout
   (stack sizes, index_start, sizes, exponents incl. the p = 1 padding rows) exactly, statistics
   and preconditioners by value; a rank holds rows [rank * b, (rank + 1) * b) of the statistics."""
@@ -300,7 +300,7 @@ def check_sharded_final_state(c, z, st, rank=0, world=1):
   mine_p = gs.preconditioners.cpu().numpy()
   # roots of few-sample statistics (cond ~1e5) move by ~1e-4 with the rounding order of the
   # Gram update, as in the plain-mode goldens
-  assert np.linalg.norm(mine_p - ref_p) <= 2e-3 * np.linalg.norm(ref_p)
+  assert np.linalg.norm(mine_p - ref_p) <= tol_p * np.linalg.norm(ref_p)
   from precondition_amd import pytree
   locs = pytree.tree_flatten(
       st.stats.local_stats,
@@ -317,9 +317,11 @@ def check_sharded_final_state(c, z, st, rank=0, world=1):
       assert np.mean(np.abs(got - ref) > 0.75 * step) < 0.25, (name, i)
     else:
       assert loc.momentum.quantized.dtype == torch.float32
-      assert np.allclose(got, ref, rtol=2e-3, atol=1e-6)
-      assert np.allclose(np_float(loc.diagonal_momentum), z[f"{name}__diag_momentum{i}"],
-                         rtol=2e-3, atol=1e-6)
+      # norm-wise, as check_momentum does: roots of few-sample statistics move by ~1e-4 with the
+      # rounding order of the products, and the momentum accumulates preconditioned gradients
+      assert np.linalg.norm(got - ref) <= max(tol_p, 2e-3) * max(np.linalg.norm(ref), 1e-30), (name, i)
+      dm, dref = np_float(loc.diagonal_momentum), z[f"{name}__diag_momentum{i}"]
+      assert np.linalg.norm(dm - dref) <= max(tol_p, 2e-3) * max(np.linalg.norm(dref), 1e-30), (name, i)
     key = f"{name}__diag_stats{i}"
     if key in z.files:
       assert np.allclose(np_float(loc.diagonal_statistics), z[key], rtol=1e-5, atol=1e-7)
