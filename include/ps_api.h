@@ -411,6 +411,27 @@ int ps_comm_allgather(void* stream, void* comm, const void* send, void* recv,
 int ps_comm_destroy(void* comm);
 const char* ps_comm_last_error(void);
 
+/* ---- Frequent-Directions branch (BASELINE configs[4]): device glue of the subspace iteration
+ * that replaces the SVD of DS:1193 (precondition_amd/subspace.py).
+ *   ps_fd_filter_step_f32: one step of the scaled Chebyshev recurrence for `batch` factors whose
+ *     iterates are stacked [batch][n][b] (float32, contiguous).  params = device [batch][4]
+ *     {ctr, e, sigma1, degree}.  step 1: y' = (z - ctr y) sigma1 / e; step k >= 2:
+ *     y' = (z - ctr y) 2 sigma_k / e - sigma_{k-1} sigma_k y_prev with sigma_1 = sigma1,
+ *     sigma_m = 1 / (2 / sigma1 - sigma_{m-1}); a factor with degree < step keeps y.  When
+ *     yt_hi is given the new iterate is also written transposed as bf16 (hi, and lo = the bf16
+ *     of the remainder when yt_lo is given) at yt[c][j * n + r], leading dimension ldt: the
+ *     operand layout of ps_gemm_bf16_grouped for the next C @ Y product.  y_next must not alias
+ *     z, y or y_prev.
+ *   ps_chol_rinv_batched_f32: out[j] = R^-1 for the Cholesky factor G_j = R^T R of `batch`
+ *     symmetric b x b matrices stacked contiguously (float64 arithmetic, b <= ps_chol_rinv_max_n());
+ *     a pivot <= drop_rel * max diag(G_j) drops its direction (zero row and column of out[j]). */
+int ps_fd_filter_step_f32(void* stream, const float* z, const float* y, const float* y_prev,
+                          float* y_next, void* yt_hi, void* yt_lo, const float* params, int step,
+                          int batch, int64_t n, int64_t b, int64_t ldt);
+int ps_chol_rinv_max_n(void);
+int ps_chol_rinv_batched_f32(void* stream, const float* gram, float* out, int b, int batch,
+                             float drop_rel);
+
 /* ---- health of the resident power iteration; diagnostics --------------------------------
  * The resident execution of the power iteration (one launch, matrices in registers) spin-waits
  * on the workgroups of a block's team and is launched at the co-resident capacity of an

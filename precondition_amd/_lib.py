@@ -164,6 +164,12 @@ _SIGNATURES = {
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ps_eigh_sorted_max_n": (C.c_int, []),
+    "ps_fd_filter_step_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "ps_chol_rinv_max_n": (C.c_int, []),
+    "ps_chol_rinv_batched_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]),
     "ps_collective_in_flight": (C.c_int, [C.c_int]),
     "ps_power_iteration_health": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ps_power_iteration_reset_health": (C.c_int, []),

@@ -1,0 +1,189 @@
+// fd.hip — device kernels of the O(d b) / O(b^3) glue of the Frequent-Directions branch
+// (BASELINE configs[4]; reference: _fd_update_root DS:1123-1290, whose SVD at DS:1193 this build
+// replaces by Chebyshev-filtered subspace iteration, precondition_amd/subspace.py):
+//   ps_fd_filter_step_f32   one step of the scaled Chebyshev recurrence for every factor of a
+//                           call, fused with the bf16 hi/lo split + transposition of the new
+//                           iterate that the next C @ Y product (gemm_bf16.hip) consumes; it
+//                           replaces ~8 elementwise torch kernels and a conversion launch per step;
+//   ps_chol_rinv_batched_f32  R^-1 of the Cholesky factor G = R^T R of the b x b Gram matrices of
+//                           the iterate blocks (float64 in LDS, one workgroup per matrix): the
+//                           orthonormalisation X <- X R^-1 (CholeskyQR) that replaces one of the
+//                           two small eigendecompositions of every outer round.
+// Both are HBM / latency bound byte work; nothing here is reshaped into a GEMM.
+#include <math.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "gemm_core.hip.h"
+
+namespace psk {
+
+// params[j] = {ctr, e, sigma1, deg}.  step 1: y' = (z - ctr y) sigma1 / e.  step k >= 2 with
+// sigma = sigma_{k-1} (sigma_1 = sigma1, sigma_m = 1 / (2 / sigma1 - sigma_{m-1})):
+// sigma' = 1 / (2 / sigma1 - sigma), y' = (z - ctr y) 2 sigma' / e - sigma sigma' y_prev.
+// A factor whose degree is below `step` keeps its iterate (y' = y).
+__global__ __launch_bounds__(256) void fd_filter_step_kernel(
+    const float* z, const float* y, const float* y_prev, float* y_next, uint16_t* hi,
+    uint16_t* lo, const float* params, int step, int n, int b, int64_t ldt, int tiles_r,
+    int tiles_c) {
+  __shared__ float t[64][65];
+  const int per = tiles_r * tiles_c;
+  const int j = blockIdx.x / per, rem = blockIdx.x % per;
+  const int tr = rem / tiles_c, tc = rem % tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64, tid = threadIdx.x;
+  const float ctr = params[4 * j + 0], e = params[4 * j + 1], sigma1 = params[4 * j + 2];
+  const int deg = (int)params[4 * j + 3];
+  float c1, c2 = 0.f;
+  if (step <= 1) {
+    c1 = sigma1 / e;
+  } else {
+    float sigma = sigma1;
+    for (int m = 2; m < step; ++m) sigma = 1.f / (2.f / sigma1 - sigma);
+    const float sn = 1.f / (2.f / sigma1 - sigma);
+    c1 = 2.f * sn / e;
+    c2 = sigma * sn;
+  }
+  const bool active = step <= deg;
+  const int64_t base = (int64_t)j * n * b;
+  for (int el = tid; el < 64 * 64; el += 256) {
+    const int r = el >> 6, c = el & 63;
+    float v = 0.f;
+    if (r0 + r < n && c0 + c < b) {
+      const int64_t o = base + (int64_t)(r0 + r) * b + c0 + c;
+      const float yy = gload1(y + o);
+      v = yy;
+      if (active) {
+        v = (gload1(z + o) - ctr * yy) * c1;
+        if (step > 1) v -= c2 * gload1(y_prev + o);
+      }
+      gstore1(y_next + o, v);
+    }
+    t[r][c] = v;
+  }
+  if (hi == nullptr) return;
+  __syncthreads();
+  for (int el = tid; el < 64 * 64; el += 256) {
+    const int c = el >> 6, r = el & 63;    // output row = column c of the iterate
+    if (r0 + r >= n || c0 + c >= b) continue;
+    const float x = t[r][c];
+    const __bf16 h = (__bf16)x;
+    const int64_t o = (int64_t)(c0 + c) * ldt + (int64_t)j * n + r0 + r;
+    hi[o] = __builtin_bit_cast(uint16_t, h);
+    if (lo != nullptr) lo[o] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+  }
+}
+
+// One workgroup per Gram matrix G (b x b, b <= 96).  L = chol(G) (lower, float64); a pivot at
+// or below drop_rel * max diag(G) drops its direction (row and column of the result zero: the
+// column of X it belongs to becomes zero, like the eigen-based orthonormalisation drops the
+// directions of a rank-deficient block).  out = R^-1 = (L^-1)^T, float32, row-major [b][b].
+constexpr int CQ_MAX = 96;
+__global__ __launch_bounds__(256) void chol_rinv_kernel(const float* gram, float* out, int b,
+                                                        float drop_rel) {
+  extern __shared__ double cq[];
+  double* S = cq;                       // [b][b + 1]
+  double* X = cq + CQ_MAX * (CQ_MAX + 1);
+  __shared__ double s_d, s_max;
+  __shared__ int s_drop[CQ_MAX];
+  const int tid = threadIdx.x, ldS = b + 1;
+  const float* g = gram + (int64_t)blockIdx.x * b * b;
+  for (int e = tid; e < b * b; e += 256) {
+    const int r = e / b, c = e % b;
+    S[r * ldS + c] = 0.5 * ((double)g[r * b + c] + (double)g[c * b + r]);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0.0;
+    for (int i = 0; i < b; ++i) m = fmax(m, S[i * ldS + i]);
+    s_max = m;
+  }
+  __syncthreads();
+  const double thresh = (double)drop_rel * s_max;
+  for (int c = 0; c < b; ++c) {
+    if (tid == 0) {
+      const double d = S[c * ldS + c];
+      const bool ok = d > thresh && d > 0.0 && d < 1.0e300;
+      s_drop[c] = ok ? 0 : 1;
+      s_d = ok ? sqrt(d) : 1.0;
+    }
+    __syncthreads();
+    const double d = s_d;
+    const bool dropped = s_drop[c] != 0;
+    if (tid > c && tid < b) S[tid * ldS + c] = dropped ? 0.0 : S[tid * ldS + c] / d;
+    if (tid == 0) S[c * ldS + c] = d;
+    __syncthreads();
+    if (!dropped) {
+      const int w = b - 1 - c;
+      for (int e = tid; e < w * w; e += 256) {
+        const int r = c + 1 + e / w, cc = c + 1 + e % w;
+        if (cc <= r) S[r * ldS + cc] = fma(-S[r * ldS + c], S[cc * ldS + c], S[r * ldS + cc]);
+      }
+    }
+    __syncthreads();
+  }
+  // X = L^-1 (lower), one column per thread; dropped directions: zero row and column
+  if (tid < b) {
+    const int c = tid;
+    for (int r = 0; r < c; ++r) X[r * ldS + c] = 0.0;
+    if (s_drop[c]) {
+      for (int r = c; r < b; ++r) X[r * ldS + c] = 0.0;
+    } else {
+      X[c * ldS + c] = 1.0 / S[c * ldS + c];
+      for (int r = c + 1; r < b; ++r) {
+        double s = 0.0;
+        if (!s_drop[r]) {
+          for (int k = c; k < r; ++k) s = fma(S[r * ldS + k], X[k * ldS + c], s);
+          s = -s / S[r * ldS + r];
+        }
+        X[r * ldS + c] = s;
+      }
+    }
+  }
+  __syncthreads();
+  float* o = out + (int64_t)blockIdx.x * b * b;
+  for (int e = tid; e < b * b; e += 256) {
+    const int r = e / b, c = e % b;       // out[r][c] = R^-1[r][c] = L^-1[c][r]
+    o[e] = (float)X[c * ldS + r];
+  }
+}
+
+}  // namespace psk
+
+using namespace psk;
+
+extern "C" int ps_fd_filter_step_f32(void* stream, const float* z, const float* y,
+                                     const float* y_prev, float* y_next, void* yt_hi,
+                                     void* yt_lo, const float* params, int step, int batch,
+                                     int64_t n, int64_t b, int64_t ldt) {
+  PS_DEVICE_CHECK();
+  if (!z || !y || !y_next || !params || batch < 1 || n < 1 || b < 1 || step < 1 ||
+      (step > 1 && !y_prev) || (yt_hi && ldt < (int64_t)batch * n) || (!yt_hi && yt_lo))
+    return PS_EINVAL;
+  const int64_t tr = (n + 63) / 64, tc = (b + 63) / 64;
+  if (tr * tc * batch > 0x7fffffff) return PS_EUNSUPPORTED;
+  hipLaunchKernelGGL(fd_filter_step_kernel, dim3((unsigned)(tr * tc * batch)), dim3(256), 0,
+                     (hipStream_t)stream, z, y, y_prev, y_next, (uint16_t*)yt_hi,
+                     (uint16_t*)yt_lo, params, step, (int)n, (int)b, ldt, (int)tr, (int)tc);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_chol_rinv_max_n(void) { return CQ_MAX; }
+
+extern "C" int ps_chol_rinv_batched_f32(void* stream, const float* gram, float* out, int b,
+                                        int batch, float drop_rel) {
+  PS_DEVICE_CHECK();
+  if (!gram || !out || batch < 1 || b < 1 || drop_rel < 0.f) return PS_EINVAL;
+  if (b > CQ_MAX) return PS_EUNSUPPORTED;
+  const size_t lds = 2 * (size_t)CQ_MAX * (CQ_MAX + 1) * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    PS_HIP(hipFuncSetAttribute((const void*)chol_rinv_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL(chol_rinv_kernel, dim3((unsigned)batch), dim3(256), lds,
+                     (hipStream_t)stream, gram, out, b, drop_rel);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}

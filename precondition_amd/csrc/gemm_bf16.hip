@@ -32,7 +32,12 @@ namespace psk {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int HBK = 32;           // k per stage
+// k per stage.  Round 3 tried 64 (whole 128-byte lines per operand row and stage, 64 KB of loads
+// in flight per workgroup, one workgroup per CU, no split-K): 0.168 ms for the cfg5 product
+// (8 x 4096^2 @ 4096 x 96) against 0.155 ms with 32 and two workgroups per CU -- the product is
+// bound by the bytes a CU can take in (A rows from HBM plus the iterate's K-slices from L2,
+// 3.5 MB per workgroup), not by line granularity.
+constexpr int HBK = 32;
 constexpr int HLD = HBK + 8;      // LDS row stride in bf16 elements (80 bytes)
 constexpr int HOP = TILE * HLD;   // bf16 elements of one operand image
 
@@ -49,23 +54,25 @@ struct HTile { int task; short tm, tn; int ks; };
 
 __device__ inline u32x4 gload16(const uint16_t* p) { return *(const u32x4 PS_GLOBAL*)(p); }
 
-// 128 rows x 32 k of one operand array -> registers (2 x 16 bytes per thread)
+// 128 rows x HBK k of one operand array -> registers (HV x 16 bytes per thread)
+constexpr int HV = TILE * HBK / 8 / 256;   // 16-byte chunks per thread
+constexpr int HCPR = HBK / 8;              // chunks per row
 __device__ inline void hload(const uint16_t* base, int64_t ld, int row0, int rows, int k0,
-                             int tid, u32x4 (&r)[2]) {
+                             int tid, u32x4 (&r)[HV]) {
 #pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    const int f = tid + 256 * v;          // 512 chunks of 8 bf16
-    const int row = f >> 2, kc = (f & 3) * 8;
+  for (int v = 0; v < HV; ++v) {
+    const int f = tid + 256 * v;
+    const int row = f / HCPR, kc = (f % HCPR) * 8;
     u32x4 t = {0u, 0u, 0u, 0u};
     if (row0 + row < rows) t = gload16(base + (int64_t)(row0 + row) * ld + k0 + kc);
     r[v] = t;
   }
 }
-__device__ inline void hstore(uint16_t* s, int tid, const u32x4 (&r)[2]) {
+__device__ inline void hstore(uint16_t* s, int tid, const u32x4 (&r)[HV]) {
 #pragma unroll
-  for (int v = 0; v < 2; ++v) {
+  for (int v = 0; v < HV; ++v) {
     const int f = tid + 256 * v;
-    const int row = f >> 2, kc = (f & 3) * 8;
+    const int row = f / HCPR, kc = (f % HCPR) * 8;
     *reinterpret_cast<u32x4*>(s + row * HLD + kc) = r[v];
   }
 }
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
   const int nk = (min(tk.kchunk, tk.k - kbeg) + HBK - 1) / HBK;   // (checked on the host)
   f32x16 acc[2][2];
   zero_acc(acc);
-  u32x4 ra[SA][2], rb[SB][2];
+  u32x4 ra[SA][HV], rb[SB][HV];
   hload(tk.a_hi, tk.lda, row0, tk.m, kbeg, tid, ra[0]);
   if (SA == 2) hload(tk.a_lo, tk.lda, row0, tk.m, kbeg, tid, ra[SA - 1]);
   hload(tk.b_hi, tk.ldb, col0, tk.n, kbeg, tid, rb[0]);
@@ -304,6 +311,8 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
     static bool attr_done = false;
     if (!attr_done) {
       const int big = (int)((size_t)2 * 4 * HOP * sizeof(uint16_t));
+      PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
       PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 2>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, big));
       PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<2, 1>,

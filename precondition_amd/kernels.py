@@ -465,6 +465,49 @@ def gemm_bf16_grouped(items):
         "ps_gemm_bf16_grouped")
 
 
+@_device_guarded
+def fd_filter_step(z, y, y_prev, y_next, params, step, want_bf16=True, split=True):
+  """One step of the scaled Chebyshev recurrence for the stacked iterates [B, n, b] of a
+  subspace-iteration call (include/ps_api.h: ps_fd_filter_step_f32), fused with the bf16
+  hi / lo split + transposition of the new iterate.  `params` = device [B, 4] float32
+  {ctr, e, sigma1, degree}.  Returns (yt_hi, yt_lo) [b, B * n] bfloat16 (None, None without
+  `want_bf16`; yt_lo None without `split`)."""
+  for t in (z, y, y_next, params):
+    _require_gpu(t, "fd_filter_step")
+  bsz, n, b = (int(v) for v in y.shape)
+  for t in (z, y, y_next) + ((y_prev,) if y_prev is not None else ()):
+    if tuple(t.shape) != (bsz, n, b) or not t.is_contiguous() or t.dtype != torch.float32:
+      raise ValueError("fd_filter_step expects contiguous float32 [B, n, b] tensors")
+  if tuple(params.shape) != (bsz, 4) or params.dtype != torch.float32 or not params.is_contiguous():
+    raise ValueError("fd_filter_step: params must be a contiguous float32 [B, 4] tensor")
+  hi = lo = None
+  if want_bf16:
+    hi = torch.empty((b, bsz * n), dtype=torch.bfloat16, device=y.device)
+    lo = torch.empty((b, bsz * n), dtype=torch.bfloat16, device=y.device) if split else None
+  rc = lib().ps_fd_filter_step_f32(
+      _stream(), z.data_ptr(), y.data_ptr(), y_prev.data_ptr() if y_prev is not None else None,
+      y_next.data_ptr(), hi.data_ptr() if hi is not None else None,
+      lo.data_ptr() if lo is not None else None, params.data_ptr(), int(step), bsz, n, b,
+      bsz * n)
+  check(rc, "ps_fd_filter_step_f32")
+  return hi, lo
+
+
+@_device_guarded
+def chol_rinv_batched(gram: torch.Tensor, drop_rel: float = 1e-10) -> torch.Tensor:
+  """R^-1 of the Cholesky factors G_j = R^T R of the stacked symmetric matrices [B, b, b]
+  (float64 arithmetic on the device, b <= ps_chol_rinv_max_n()); directions whose pivot is
+  below drop_rel * max diag(G_j) get a zero row and column."""
+  _require_gpu(gram, "chol_rinv_batched")
+  if gram.dim() != 3 or gram.shape[1] != gram.shape[2] or not gram.is_contiguous():
+    raise ValueError("chol_rinv_batched expects a contiguous [B, b, b] tensor")
+  out = torch.empty_like(gram)
+  check(lib().ps_chol_rinv_batched_f32(_stream(), gram.data_ptr(), out.data_ptr(),
+                                       int(gram.shape[1]), int(gram.shape[0]), float(drop_rel)),
+        "ps_chol_rinv_batched_f32")
+  return out
+
+
 def tensordot_axis0(g: torch.Tensor, pc: torch.Tensor) -> torch.Tensor:
   """tensordot(g, pc, axes=[[0],[0]]) (DS:1707): contracts g's leading axis
   with pc's rows; result shape = g.shape[1:] + (pc.shape[1],)."""

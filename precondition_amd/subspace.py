@@ -41,6 +41,19 @@ def _small_eigh_desc(mats: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
   return e, u
 
 
+def _use_cholqr(b: int) -> bool:
+  """PS_FD_CHOLQR=0 restores the eigen-based orthonormalisation."""
+  import os
+  from . import _lib
+  return os.environ.get("PS_FD_CHOLQR", "1") != "0" and b <= _lib.lib().ps_chol_rinv_max_n()
+
+
+def _fused_filter() -> bool:
+  """PS_FD_FUSED_FILTER=0 restores the torch elementwise recurrence."""
+  import os
+  return os.environ.get("PS_FD_FUSED_FILTER", "1") != "0"
+
+
 def _orthonormalize(x: torch.Tensor, tmp: torch.Tensor) -> torch.Tensor:
   """Columns of every x[j] ([B, n, b]) made orthonormal: x <- x U L^{-1/2} from the
   eigendecomposition of the Gram matrix, then one Newton-Schulz step
@@ -49,10 +62,16 @@ def _orthonormalize(x: torch.Tensor, tmp: torch.Tensor) -> torch.Tensor:
   bsz, n, b = x.shape
   gram = torch.empty((bsz, b, b), dtype=torch.float32, device=x.device)
   _gemm([(x[j], x[j], gram[j], True, False) for j in range(bsz)])
-  lam, u = _small_eigh_desc(gram)
-  keep = lam > 1e-10 * lam[:, :1].clamp_min(1e-30)
-  scale = torch.where(keep, lam.clamp_min(1e-30).rsqrt(), torch.zeros_like(lam))
-  m = u * scale[:, None, :]
+  if _use_cholqr(b):
+    # CholeskyQR: X <- X R^-1 with G = R^T R factored in float64 on the device (one small
+    # launch, no b x b eigendecomposition); a pivot below 1e-10 of the largest diagonal entry
+    # drops its direction like the eigen-based form below does
+    m = _K().chol_rinv_batched(gram, 1e-10)
+  else:
+    lam, u = _small_eigh_desc(gram)
+    keep = lam > 1e-10 * lam[:, :1].clamp_min(1e-30)
+    scale = torch.where(keep, lam.clamp_min(1e-30).rsqrt(), torch.zeros_like(lam))
+    m = u * scale[:, None, :]
   _gemm([(x[j], m[j], tmp[j], False, False) for j in range(bsz)])
   _gemm([(tmp[j], tmp[j], gram[j], True, False) for j in range(bsz)])
   eye = torch.eye(b, dtype=torch.float32, device=x.device)
@@ -163,24 +182,51 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
               _acosh((xk - ctr[:, :, 0]) / e[:, :, 0])).clamp_min(1e-6)
     deg = torch.clamp(torch.floor(4.6 / spread), 1, degree)[:, :, None]   # [B, 1, 1]
     max_deg, min_deg = (int(v) for v in torch.stack((deg.max(), deg.min())).tolist())
-    # z = C x is current from the Rayleigh-Ritz step
-    y_prev = x.clone()
-    y = (z - ctr * x) * (sigma1 / e)
     # plain bf16 operands only while the wanted residuals are far above its 2^-9 floor
     plain = mode == "bf16" and float((res[:, :k] / top).max()) > 2e-2
-    for step in range(2, max_deg + 1):
-      filter_product(y, z, plain)
-      gemms += 1
-      sigma_new = 1.0 / (2.0 / sigma1 - sigma)
-      y_next = (z - ctr * y) * (2.0 * sigma_new / e) - (sigma * sigma_new) * y_prev
-      if step <= min_deg:  # every matrix still filters: no masked selects over [B, n, b]
-        y_prev, y, sigma = y, y_next, sigma_new
-        continue
-      active = deg >= step
-      y_prev = torch.where(active, y, y_prev)
-      y = torch.where(active, y_next, y)
-      sigma = torch.where(active, sigma_new, sigma)
-    x.copy_(y)
+    if _fused_filter():
+      # One fused launch per step (csrc/fd.hip): the recurrence for every factor + the bf16
+      # hi / lo transposed copy of the new iterate that the next C @ Y product reads.
+      params = torch.cat((ctr[:, :, 0], e[:, :, 0], sigma1[:, :, 0], deg[:, :, 0]), dim=1).contiguous()
+      bufs = [x, torch.empty_like(x), torch.empty_like(x)]   # y_prev, y, y_next rotate
+      want16 = c16 is not None
+      # z = C x is current from the Rayleigh-Ritz step
+      yt = _K().fd_filter_step(z, bufs[0], None, bufs[1], params, 1, want_bf16=want16 and max_deg >= 2,
+                               split=not plain)
+      y_prev_b, y_b, y_next_b = bufs[0], bufs[1], bufs[2]
+      for step in range(2, max_deg + 1):
+        if want16:
+          items = []
+          for j in range(bsz):
+            bt = (yt[0][:, j * n:(j + 1) * n], None if plain else yt[1][:, j * n:(j + 1) * n])
+            a = (c16[j][0], None if plain else c16[j][1])
+            items.append((a, bt, z[j]))
+          _K().gemm_bf16_grouped(items)
+        else:
+          _gemm([(c[j], y_b[j], z[j], False, False) for j in range(bsz)])
+        gemms += 1
+        yt = _K().fd_filter_step(z, y_b, y_prev_b, y_next_b, params, step,
+                                 want_bf16=want16 and step < max_deg, split=not plain)
+        y_prev_b, y_b, y_next_b = y_b, y_next_b, y_prev_b
+      if y_b is not x:
+        x.copy_(y_b)
+    else:
+      # z = C x is current from the Rayleigh-Ritz step
+      y_prev = x.clone()
+      y = (z - ctr * x) * (sigma1 / e)
+      for step in range(2, max_deg + 1):
+        filter_product(y, z, plain)
+        gemms += 1
+        sigma_new = 1.0 / (2.0 / sigma1 - sigma)
+        y_next = (z - ctr * y) * (2.0 * sigma_new / e) - (sigma * sigma_new) * y_prev
+        if step <= min_deg:  # every matrix still filters: no masked selects over [B, n, b]
+          y_prev, y, sigma = y, y_next, sigma_new
+          continue
+        active = deg >= step
+        y_prev = torch.where(active, y, y_prev)
+        y = torch.where(active, y_next, y)
+        sigma = torch.where(active, sigma_new, sigma)
+      x.copy_(y)
     x = _orthonormalize(x, tmp)
     theta, res = _rayleigh_ritz(c, x, z, tmp)
     gemms += 1
