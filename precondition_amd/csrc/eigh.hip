@@ -2,7 +2,14 @@
 // (reference: matrix_inverse_pth_root_eigh, DS:943-1030; jnp.linalg.eigh at DS:1007
 // is LAPACK ssyevd on the reference's CPU path).
 //
-// Eigensolver: blocked two-sided Jacobi, built for MFMA + LDS instead of
+// Three eigensolvers share this driver:
+//   n <= 128                     eigh_small_kernel: LDS-resident one-sided Jacobi, one launch;
+//   root mode, n > 128 (round 3) eigh_cj.hip.h: one-sided block Jacobi on the float64-accumulated
+//                                Cholesky factor (no eigenvector accumulation, 6 n^3 per sweep);
+//   its fallback (Cholesky breakdown) and plain eigenpairs of possibly indefinite matrices
+//   (ps_eigh_batched_f32, n > 128): the blocked two-sided Jacobi described next.
+//
+// Blocked two-sided Jacobi, built for MFMA + LDS instead of
 // translating a tridiagonalisation:
 //   * the matrix is cut into 64-wide block columns; a round pairs them up
 //     (round-robin tournament, nb/2 disjoint pairs, nb-1 rounds per sweep);
@@ -916,7 +923,7 @@ __global__ __launch_bounds__(256) void eigh_rayleigh_f64_kernel(EighBlock* block
 // hi/lo pair in the temporaries X, W) every entry of A is correct to its own float32
 // rounding, so the finishing sweeps work on small entries that are accurate RELATIVE to
 // themselves and the eigenvectors of the small eigenvalues come out as accurately as LAPACK's
-// (tools/dev_eigh_refine_proto2.py: root error on a graded 129 x 129 input 2e-2 -> 1e-4).
+// (round-2 NumPy experiment: root error on a graded 129 x 129 input 2e-2 -> 1e-4).
 // Tiles: 64 x 64 per workgroup (4 per 128 x 128 entry of the tile list), one wavefront per
 // 32 x 32 quadrant on the float64 MFMA (v_mfma_f64_16x16x4_f64; 2 * 2n^3 flops per matrix).
 // STAGE 0: (X, W) = hi / lo of D V.   STAGE 1: A = V^T (X + W).
