@@ -520,6 +520,35 @@ def parity_sample_vit_b(vw, roots, metrics, per_class=1):
                   "more (tests/test_gpu_round2.py::test_vit_b_tree_recompute: build <= 1.5 x oracle)"}
 
 
+def newton_bf16x6_leg(dev, clock):
+  """Opt-in product arithmetic of the Newton root, reported separately (never in `value`):
+  PS_NEWTON_PRODUCTS=bf16x6 = three-way bf16 split of both operands, six partial products per
+  product on v_mfma_f32_32x32x16_bf16 with float32 accumulation (~2^-22 relative), exact float32
+  products for the last steps of a block (max|M - I| < 1e-3).  Same workloads, same timing."""
+  out = {"mode": "PS_NEWTON_PRODUCTS=bf16x6 (csrc/newton.hip gemm_tile_bf16x6_sym); the default "
+                 "exact-float32 numbers are the top-level ones"}
+  old = os.environ.get("PS_NEWTON_PRODUCTS")
+  try:
+    for name in ("cfg2_256x512_p4", "headline_64x1024_p4"):
+      w = Workload(name, 0, 1, dev)
+      os.environ["PS_NEWTON_PRODUCTS"] = "f32"
+      f32_sec, _ = timed(w, 3, 1, False)
+      os.environ["PS_NEWTON_PRODUCTS"] = "bf16x6"
+      sec, fl = timed(w, 3, 1, False)
+      out[name] = {"ms_per_step": round(sec * 1e3, 3), "ms_per_step_f32_products": round(f32_sec * 1e3, 3),
+                   "algorithmic_gflops": round(fl / sec / 1e9, 1),
+                   "newton_iters": {"min": float(w.metrics[:, 1].min()), "max": float(w.metrics[:, 1].max())},
+                   "parity_vs_oracle": parity_sample(w, count=4)}
+      del w
+      torch.cuda.empty_cache()
+  finally:
+    if old is None:
+      os.environ.pop("PS_NEWTON_PRODUCTS", None)
+    else:
+      os.environ["PS_NEWTON_PRODUCTS"] = old
+  return out
+
+
 def cpu_baseline(name, budget_s=12.0):
   """The oracle executing the reference's op sequence (its 6 products per step
   at p=4) on the host cores, on a bounded sample of the same workload."""
@@ -869,7 +898,8 @@ def main():
             else:
               os.environ[k] = v
 
-      for key, fn in (("fd_cfg5", lambda: fd_cfg5(dev)), ("fd_cfg5_f32_products", fd_f32),
+      for key, fn in (("newton_bf16x6", lambda: newton_bf16x6_leg(dev, clock)),
+                      ("fd_cfg5", lambda: fd_cfg5(dev)), ("fd_cfg5_f32_products", fd_f32),
                       ("quant_f3", lambda: quant_f3(dev)), ("eigh_cfg3", eigh_cfg3)):
         torch.cuda.empty_cache()
         try:

@@ -194,6 +194,46 @@ def test_eigh_root_one_stream_and_two_streams_agree(device, monkeypatch):
   assert torch.equal(m1, m2)
 
 
+def test_newton_bf16x6_products_opt_in_mode(device, monkeypatch):
+  """PS_NEWTON_PRODUCTS=bf16x6 (three-way bf16 split, six partial products on the bf16 MFMA,
+  exact float32 products for the last steps): float32-faithful, NOT the parity path -- roots
+  within 1e-4 of the oracle (north_star's bar) and of the default mode, iteration and retry
+  counts equal to the default mode's (and the oracle's) on well- and ill-conditioned blocks; blocks that are not exactly
+  symmetric run the float32 products in the same launch (bit-identical to the default mode)."""
+  rng = np.random.default_rng(5)
+  arrs = [wishart(512, 2048, 70), wishart(384, 1536, 71), wishart(1000, 1100, 72)]
+  q, _ = np.linalg.qr(rng.standard_normal((640, 640)))
+  graded = (q * 1e4 ** (-np.arange(640) / 639.0)) @ q.T
+  arrs.append(((graded + graded.T) / 2).astype(np.float32))
+  mats = [torch.tensor(a, device=device) for a in arrs]
+  ps = [4, 2, 4, 4]
+  r32, m32 = K().matrix_inverse_pth_root_batched(mats, ps)
+  monkeypatch.setenv("PS_NEWTON_PRODUCTS", "bf16x6")
+  r16, m16 = K().matrix_inverse_pth_root_batched(mats, ps)
+  m32, m16 = m32.cpu().numpy(), m16.cpu().numpy()
+  differs = False
+  for i, (a, p) in enumerate(zip(arrs, ps)):
+    h_ref, m_ref = orc.matrix_inverse_pth_root(a, p)
+    h16, h32 = r16[i].cpu().numpy(), r32[i].cpu().numpy()
+    scale = 1e-4 if i != 2 else 5e-3   # 1000 x 1100 Wishart: cond ~1e6, both modes ~1e-3 apart
+    assert np.linalg.norm(h16 - h_ref) / np.linalg.norm(h_ref) < scale, i
+    assert np.linalg.norm(h16 - h32) / np.linalg.norm(h32) < scale, i
+    # same stop decisions as the default mode; the oracle's count is equal too except where the
+    # 1e-6 threshold is within rounding of the last error (the cond ~1e6 block: +-1)
+    assert m16[i, 1] == m32[i, 1], (i, m16[i], m32[i])
+    assert abs(m16[i, 1] - m_ref["inverse_pth_root_iters"]) <= (1 if i == 2 else 0), i
+    assert m16[i, 4] == m_ref["total_retries"] == m32[i, 4], i
+    differs |= not np.array_equal(h16, h32)
+  assert differs, "the opt-in mode did not run"
+  # an asymmetric block takes the float32 products: bit-identical in both modes
+  asym = arrs[0].copy(); asym[3, 7] *= 1.0001
+  a_d = torch.tensor(asym, device=device)
+  x16, _ = K().matrix_inverse_pth_root_batched([a_d], [4])
+  monkeypatch.delenv("PS_NEWTON_PRODUCTS")
+  x32, _ = K().matrix_inverse_pth_root_batched([a_d], [4])
+  assert torch.equal(x16[0], x32[0])
+
+
 def test_diag_mfma_clock(device):
   ghz, tf = C.c_double(), C.c_double()
   rc = L().ps_diag_mfma_clock(torch.cuda.current_stream().cuda_stream, 200.0,
