@@ -428,6 +428,14 @@ const char* ps_comm_last_error(void);
 int ps_fd_filter_step_f32(void* stream, const float* z, const float* y, const float* y_prev,
                           float* y_next, void* yt_hi, void* yt_lo, const float* params, int step,
                           int batch, int64_t n, int64_t b, int64_t ldt);
+ /* ps_fd_round_control_f32: per-round control of the subspace iteration for `batch` factors with
+ * Ritz values theta [batch][b] (descending) and residual norms res [batch][b]: writes the params
+ * rows {ctr, e, sigma1, degree <= `degree`} of the Chebyshev filter, converged[j] (the k wanted
+ * pairs have residuals <= tol * theta_1 or sit in the float32 noise floor n * 2.4e-7 * theta_1) and
+ * summary = {all converged, max degree, min degree, any wanted relative residual > 2e-2}. */
+int ps_fd_round_control_f32(void* stream, const float* theta, const float* res, int batch, int b,
+                            int k, int n, float tol, int degree, float* params,
+                            int32_t* converged, int32_t* summary);
 int ps_chol_rinv_max_n(void);
 int ps_chol_rinv_batched_f32(void* stream, const float* gram, float* out, int b, int batch,
                              float drop_rel);

@@ -167,6 +167,9 @@ _SIGNATURES = {
     "ps_fd_filter_step_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "ps_fd_round_control_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                   C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ps_chol_rinv_max_n": (C.c_int, []),
     "ps_chol_rinv_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]),

@@ -147,6 +147,51 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const float* gram, float
   }
 }
 
+
+// Per-round control of the subspace iteration (precondition_amd/subspace.py), one thread per
+// factor: convergence of the k wanted Ritz pairs, the scaled Chebyshev filter's interval and
+// per-factor degree (theta_1 may be amplified over theta_k by at most ~1e2 = exp(4.6)), written
+// as the params rows ps_fd_filter_step_f32 reads.  summary = {all converged, max degree, min
+// degree, largest wanted relative residual above 2e-2}: ONE small host read per round instead of
+// ~40 elementwise launches and two.
+__device__ inline float fd_acosh(float v) {
+  v = fminf(fmaxf(v, 1.f), 1e30f);
+  return logf(v) + log1pf(sqrtf(fmaxf(1.f - 1.f / (v * v), 0.f)));
+}
+__global__ void fd_round_control_kernel(const float* theta, const float* res, int batch, int b,
+                                        int k, int n, float tol, int degree, float* params,
+                                        int* converged, int* summary) {
+  __shared__ int s_all, s_max, s_min, s_plain;
+  if (threadIdx.x == 0) { s_all = 1; s_max = 1; s_min = degree; s_plain = 0; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < batch; j += blockDim.x) {
+    const float* th = theta + (int64_t)j * b;
+    const float* rs = res + (int64_t)j * b;
+    const float top = fmaxf(th[0], 1e-30f);
+    bool conv = true, plain = false;
+    for (int i = 0; i < k; ++i) {
+      const bool wanted = th[i] > n * 2.4e-7f * top;
+      conv = conv && (rs[i] <= tol * top || !wanted);
+      plain = plain || (rs[i] / top > 2e-2f);
+    }
+    const float cut = fmaxf(th[b - 1], 0.f);
+    const float e = fmaxf(0.5f * cut, 1e-30f * top), ctr = 0.5f * cut;
+    const float a0 = top * (1.0f + 1e-6f);
+    const float sigma1 = e / (a0 - ctr);
+    const float xk = fmaxf(th[k - 1], 1e-30f * top);
+    const float spread = fmaxf(fd_acosh((top - ctr) / e) - fd_acosh((xk - ctr) / e), 1e-6f);
+    const float deg = fminf(fmaxf(floorf(4.6f / spread), 1.f), (float)degree);
+    params[4 * j + 0] = ctr; params[4 * j + 1] = e; params[4 * j + 2] = sigma1; params[4 * j + 3] = deg;
+    converged[j] = conv ? 1 : 0;
+    if (!conv) atomicAnd(&s_all, 0);
+    atomicMax(&s_max, (int)deg);
+    atomicMin(&s_min, (int)deg);
+    if (plain) atomicOr(&s_plain, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { summary[0] = s_all; summary[1] = s_max; summary[2] = s_min; summary[3] = s_plain; }
+}
+
 }  // namespace psk
 
 using namespace psk;
@@ -184,6 +229,19 @@ extern "C" int ps_chol_rinv_batched_f32(void* stream, const float* gram, float* 
   }
   hipLaunchKernelGGL(chol_rinv_kernel, dim3((unsigned)batch), dim3(256), lds,
                      (hipStream_t)stream, gram, out, b, drop_rel);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_fd_round_control_f32(void* stream, const float* theta, const float* res,
+                                       int batch, int b, int k, int n, float tol, int degree,
+                                       float* params, int32_t* converged, int32_t* summary) {
+  PS_DEVICE_CHECK();
+  if (!theta || !res || !params || !converged || !summary || batch < 1 || b < 1 || k < 1 || k > b ||
+      degree < 1)
+    return PS_EINVAL;
+  hipLaunchKernelGGL(fd_round_control_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, theta, res,
+                     batch, b, k, n, tol, degree, params, converged, summary);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -494,6 +494,25 @@ def fd_filter_step(z, y, y_prev, y_next, params, step, want_bf16=True, split=Tru
 
 
 @_device_guarded
+def fd_round_control(theta, res, k, n, tol, degree):
+  """Per-round control of the subspace iteration on the device (ps_fd_round_control_f32).
+  Returns (params [B, 4] float32, converged [B] int32, summary [4] int32 = all converged, max
+  degree, min degree, plain-bf16 allowed), all on the device."""
+  _require_gpu(theta, "fd_round_control")
+  bsz, b = (int(v) for v in theta.shape)
+  theta = theta.contiguous()
+  res = res.contiguous()
+  params = torch.empty((bsz, 4), dtype=torch.float32, device=theta.device)
+  conv = torch.empty((bsz,), dtype=torch.int32, device=theta.device)
+  summ = torch.empty((4,), dtype=torch.int32, device=theta.device)
+  check(lib().ps_fd_round_control_f32(_stream(), theta.data_ptr(), res.data_ptr(), bsz, b, int(k),
+                                      int(n), float(tol), int(degree), params.data_ptr(),
+                                      conv.data_ptr(), summ.data_ptr()),
+        "ps_fd_round_control_f32")
+  return params, conv, summ
+
+
+@_device_guarded
 def chol_rinv_batched(gram: torch.Tensor, drop_rel: float = 1e-10) -> torch.Tensor:
   """R^-1 of the Cholesky factors G_j = R^T R of the stacked symmetric matrices [B, b, b]
   (float64 arithmetic on the device, b <= ps_chol_rinv_max_n()); directions whose pivot is

@@ -19,6 +19,7 @@ reconstructed covariance, as the reference's own tests do (DST:770-885).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -243,6 +244,85 @@ def _fd_update_root(new_grad: torch.Tensor, p: int, rank: int = 0,
       generate_fd_metrics=generate_fd_metrics, new_grad_is_gram=new_grad_is_gram)])[0]
 
 
+def _fd_group_key(kw):
+  """Calls that can share the stacked fast path of _fd_update_root_group: no padding, no
+  diagnostics, the block method applies, and identical scalars."""
+  ng, prev, rank = kw["new_grad"], kw.get("prev"), kw.get("rank", 0)
+  d = int(ng.shape[0])
+  ps = d if kw.get("padding_start") is None else int(kw["padding_start"])
+  want_fd = bool(kw.get("generate_fd_metrics") and kw.get("generate_training_metrics", True))
+  if (prev is None or rank <= 0 or ps != d or want_fd or d < SUBSPACE_MIN_N or
+      4 * (rank + 33) > d or os.environ.get("PS_FD_STACKED", "1") == "0"):
+    return None
+  return (d, rank, kw["p"], float(kw.get("decay", 1.0)), float(kw.get("ridge_epsilon", 1e-6)),
+          float(kw.get("error_tolerance", 1e-6)), bool(kw.get("relative_matrix_epsilon", True)),
+          bool(kw.get("new_grad_is_gram", False)), ng.device)
+
+
+def _fd_update_root_group(calls, key):
+  """_fd_update_root (DS:1123-1290) for factors that share their sizes and scalars: every
+  O(d r) / O(r) step runs ONCE on tensors stacked over the factors (one launch per operation
+  for the whole group, two host reads per call instead of three per factor), the arithmetic of
+  _fd_prepare / _fd_finish term for term.  Returns None for a factor whose block iteration did
+  not converge (the caller sends it through the general path)."""
+  from . import subspace
+  d, rank, p, decay, ridge_eps, err_tol, rel, is_gram, dev = key
+  bsz, r = len(calls), rank
+  prev = torch.stack([kw["prev"] for kw in calls])                       # [B, d, r + 2]
+  sketch = prev[:, :, :r]
+  fwd_eigvals = prev[:, d - r:, -1]                                       # [B, r]
+  tail = prev[:, 1, -1]                                                   # [B]
+  if rel:
+    ridge = ridge_eps * torch.clamp(fwd_eigvals[:, 0], min=err_tol)
+  else:
+    ridge = torch.full((bsz,), ridge_eps * max(1.0, err_tol), dtype=torch.float32, device=dev)
+  weighted = (sketch * torch.sqrt(fwd_eigvals + ridge[:, None])[:, None, :]).contiguous()
+  # C = decay * W W^T + R R^T (the SVD's u, s^2)
+  c = torch.empty((bsz, d, d), dtype=torch.float32, device=dev)
+  kernels.gemm_grouped([(weighted[j], weighted[j], c[j], False, True) for j in range(bsz)])
+  for j, kw in enumerate(calls):
+    g = kw["new_grad"]
+    gram = g if is_gram else kernels.matmul(g.contiguous(), g.contiguous(), transb=True)
+    torch.add(gram, c[j], alpha=decay, out=c[j])
+  c = (c + c.transpose(1, 2)).mul_(0.5)
+  e, u, conv, _ = subspace.top_eigenpairs_batched(list(c.unbind(0)), r + 1)   # e [B, r+1] desc
+  # ---- _fd_finish, stacked ----
+  noise = d * 1.2e-7 * torch.clamp(e.max(dim=1, keepdim=True).values, min=0.0)
+  e = torch.where(e <= noise, torch.zeros_like(e), e)
+  s_ = torch.sqrt(torch.clamp(e, min=0.0))
+  cutoff = s_[:, r]
+  rho_t = cutoff ** 2
+  top_eigs = s_[:, :r]
+  deflated = (top_eigs - cutoff[:, None]) * (top_eigs + cutoff[:, None])
+  eigvecs = u[:, :, :r].clone()
+  tail = tail * decay
+  new_tail = tail + rho_t
+  alpha = -1.0 / p
+  new_const = torch.where(new_tail <= 0, torch.zeros_like(new_tail), new_tail ** alpha)
+  new_tail = torch.where(new_tail <= 0, torch.zeros_like(new_tail), new_tail)
+  deflated = torch.where(deflated <= 0, torch.zeros_like(deflated), deflated)
+  eigvecs = eigvecs * (deflated > 0)[:, None, :]
+  norms = torch.linalg.vector_norm(eigvecs, dim=1)
+  safe = (0.99 <= norms) & (norms <= 1.01)
+  eigvecs = eigvecs * safe[:, None, :]
+  deflated = deflated * safe
+  eigvecs = eigvecs / torch.where(safe, norms, torch.ones_like(norms))[:, None, :]
+  upshifted = torch.square(top_eigs) + tail[:, None]
+  upshifted = upshifted * (deflated > 0.0)
+  upshifted = torch.where(upshifted <= 0, torch.zeros_like(upshifted), upshifted)
+  inverted = torch.where(upshifted <= 0, torch.zeros_like(upshifted), upshifted ** alpha)
+  has_zeros = (deflated <= 0).any(dim=1) | (new_tail <= 0)
+  packed = torch.zeros((bsz, d, r + 2), dtype=torch.float32, device=dev)   # DS:555-592
+  packed[:, :, :r] = eigvecs
+  packed[:, :r, -2] = inverted
+  packed[:, 0, -1] = new_const
+  packed[:, 1, -1] = new_tail
+  packed[:, d - r:, -1] = deflated
+  packed[:, -1, -2] = has_zeros.to(torch.float32)
+  ok = conv.cpu().tolist()
+  return [(packed[j], _metrics(0.0)) if ok[j] else None for j in range(bsz)]
+
+
 def _fd_update_root_batched(calls) -> list:
   """_fd_update_root for a list of keyword dicts.  The eigen-step of all of them runs
   batched: covariance updates of size >= SUBSPACE_MIN_N take their leading rank+1
@@ -251,7 +331,18 @@ def _fd_update_root_batched(calls) -> list:
   n_calls = len(calls)
   results = [None] * n_calls
   preps = [None] * n_calls
+  # stacked fast path for groups of equal-sized factors without padding (config 5)
+  by_key = {}
   for i, kw in enumerate(calls):
+    key = _fd_group_key(kw)
+    if key is not None:
+      by_key.setdefault(key, []).append(i)
+  for key, idxs in by_key.items():
+    for i, res in zip(idxs, _fd_update_root_group([calls[i] for i in idxs], key)):
+      results[i] = res
+  for i, kw in enumerate(calls):
+    if results[i] is not None:
+      continue
     preps[i] = _fd_prepare(**{k: v for k, v in kw.items()
                               if k not in ("generate_training_metrics", "generate_fd_metrics")})
     preps[i]["want_fd"] = bool(kw.get("generate_fd_metrics") and

@@ -156,38 +156,48 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   converged = torch.zeros((bsz,), dtype=torch.bool, device=dev)
   outer = 0
   for outer in range(1, max_outer + 1):
-    top = theta[:, :1].clamp_min(1e-30)
-    # pairs inside the float32 noise floor of the solver count as converged zeros
-    wanted = theta[:, :k] > n * 2.4e-7 * top
-    converged = ((res[:, :k] <= tol * top) | ~wanted).all(dim=1)
-    if bool(converged.all()):
-      break
-    # Chebyshev filter: damp [0, theta_b], scaled to 1 at theta_1
-    cut = theta[:, -1:].clamp_min(0.0)
-    e = (0.5 * cut).clamp_min(1e-30 * top)[:, :, None]
-    ctr = (0.5 * cut)[:, :, None]
-    a0 = (top * (1.0 + 1e-6))[:, :, None]
-    sigma1 = e / (a0 - ctr)
-    sigma = sigma1
-    # Per-matrix degree: the filter may amplify theta_1 over theta_k by at most ~1e2,
-    # else the block collapses onto the leading directions in float32 (its Gram matrix
-    # is then conditioned 1e4, which the eigen-QR + polish below still resolves).
-    # T_m(x) ~ exp(m acosh x) / 2 with x = (theta - ctr) / e.
-    def _acosh(v):
-      v = v.clamp(1.0, 1e30)  # log v + log(1 + sqrt(1 - v^-2)): no overflow for huge v
-      return torch.log(v) + torch.log1p(torch.sqrt((1.0 - 1.0 / (v * v)).clamp_min(0.0)))
+    fused = _fused_filter()
+    if fused:
+      # convergence test + filter interval + per-factor degree in ONE small launch and one host
+      # read (csrc/fd.hip fd_round_control_kernel; the torch form below is the same arithmetic)
+      params, conv_i, summ = _K().fd_round_control(theta, res, k, n, tol, degree)
+      all_conv, max_deg, min_deg, plain_ok = summ.tolist()
+      converged = conv_i.bool()
+      if all_conv:
+        break
+      plain = mode == "bf16" and bool(plain_ok)
+    else:
+      top = theta[:, :1].clamp_min(1e-30)
+      # pairs inside the float32 noise floor of the solver count as converged zeros
+      wanted = theta[:, :k] > n * 2.4e-7 * top
+      converged = ((res[:, :k] <= tol * top) | ~wanted).all(dim=1)
+      if bool(converged.all()):
+        break
+      # Chebyshev filter: damp [0, theta_b], scaled to 1 at theta_1
+      cut = theta[:, -1:].clamp_min(0.0)
+      e = (0.5 * cut).clamp_min(1e-30 * top)[:, :, None]
+      ctr = (0.5 * cut)[:, :, None]
+      a0 = (top * (1.0 + 1e-6))[:, :, None]
+      sigma1 = e / (a0 - ctr)
+      sigma = sigma1
+      # Per-matrix degree: the filter may amplify theta_1 over theta_k by at most ~1e2,
+      # else the block collapses onto the leading directions in float32 (its Gram matrix
+      # is then conditioned 1e4, which the eigen-QR + polish below still resolves).
+      # T_m(x) ~ exp(m acosh x) / 2 with x = (theta - ctr) / e.
+      def _acosh(v):
+        v = v.clamp(1.0, 1e30)  # log v + log(1 + sqrt(1 - v^-2)): no overflow for huge v
+        return torch.log(v) + torch.log1p(torch.sqrt((1.0 - 1.0 / (v * v)).clamp_min(0.0)))
 
-    xk = theta[:, k - 1:k].clamp_min(1e-30 * top)
-    spread = (_acosh((top - ctr[:, :, 0]) / e[:, :, 0]) -
-              _acosh((xk - ctr[:, :, 0]) / e[:, :, 0])).clamp_min(1e-6)
-    deg = torch.clamp(torch.floor(4.6 / spread), 1, degree)[:, :, None]   # [B, 1, 1]
-    max_deg, min_deg = (int(v) for v in torch.stack((deg.max(), deg.min())).tolist())
-    # plain bf16 operands only while the wanted residuals are far above its 2^-9 floor
-    plain = mode == "bf16" and float((res[:, :k] / top).max()) > 2e-2
-    if _fused_filter():
+      xk = theta[:, k - 1:k].clamp_min(1e-30 * top)
+      spread = (_acosh((top - ctr[:, :, 0]) / e[:, :, 0]) -
+                _acosh((xk - ctr[:, :, 0]) / e[:, :, 0])).clamp_min(1e-6)
+      deg = torch.clamp(torch.floor(4.6 / spread), 1, degree)[:, :, None]   # [B, 1, 1]
+      max_deg, min_deg = (int(v) for v in torch.stack((deg.max(), deg.min())).tolist())
+      # plain bf16 operands only while the wanted residuals are far above its 2^-9 floor
+      plain = mode == "bf16" and float((res[:, :k] / top).max()) > 2e-2
+    if fused:
       # One fused launch per step (csrc/fd.hip): the recurrence for every factor + the bf16
       # hi / lo transposed copy of the new iterate that the next C @ Y product reads.
-      params = torch.cat((ctr[:, :, 0], e[:, :, 0], sigma1[:, :, 0], deg[:, :, 0]), dim=1).contiguous()
       bufs = [x, torch.empty_like(x), torch.empty_like(x)]   # y_prev, y, y_next rotate
       want16 = c16 is not None
       # z = C x is current from the Rayleigh-Ritz step
