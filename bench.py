@@ -644,7 +644,10 @@ def main():
                       "ridge 1e-6 relative, Newton",
           "blocks_per_gpu": nb, "n": n, "p": p,
           "parallelism": f"blocks partitioned over {world} GPU(s)" +
-                         (", RCCL all-gather of roots in the timed region" if multi else ""),
+                         (", %s all-gather of roots in the timed region" % (
+                             "RCCL" if (multi and not SELFTEST and
+                                        not os.environ.get("PS_BENCH_ONE_DEVICE")) else "gloo (dev)")
+                          if multi else ""),
           "newton_iters_per_block": {"min": float(iters.min()), "max": float(iters.max())},
           "max_newton_error": float(np.nanmax(errs)),
           # whole step (power iteration, init, control, copy-out included), EXECUTED flops
@@ -681,7 +684,7 @@ def main():
         # inside this run: see the file named here (2 x FETCH_SIZE + WRITE_SIZE per the gfx950
         # rule); null in this line by design
         "traffic": None,
-        "traffic_source": "profiles/r03_pmc_cfg2_summary.json (rocprofv3 --pmc, separate passes)",
+        "traffic_source": "profiles/r03_cfg2_pmc_by_kernel.json / r03_headline_pmc_by_kernel.json (rocprofv3 --pmc, separate passes)",
         "clock": clock,
         "frac_of_peak_at_measured_clock": (round(ach / clock["peak_at_clock_tflops"], 4)
                                            if "peak_at_clock_tflops" in clock else None),

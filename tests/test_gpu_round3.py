@@ -243,3 +243,54 @@ def test_diag_mfma_clock(device):
   # an MFMA-only loop reaches most of the fp32 MFMA peak at the clock it runs at
   cus = torch.cuda.get_device_properties(device).multi_processor_count
   assert tf.value > 0.8 * cus * 4 * 64 * ghz.value / 1e3, (tf.value, ghz.value)
+
+
+# ---------------------------------------------------------------------------
+def _two_rank_gpu_worker(rank, world, port, ret):
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  if root not in sys.path:
+    sys.path.insert(0, root)
+  import torch.distributed as dist
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    from precondition_amd import comm
+    dev = torch.device("cuda:0")
+    sizes = [256, 384, 256, 200, 512, 256, 384]          # odd count: a padding slot on 2 ranks
+    exps = [4, 2, 4, 4, 2, 4, 2]
+    stats = [torch.tensor(wishart(n, 4 * n, 900 + i), device=dev) for i, n in enumerate(sizes)]
+    base, base_m = comm.sharded_inverse_pth_roots(stats, exps, group=None)
+    out = {}
+    for ownership in ("reference", "lpt"):
+      for overlap in (False, True):
+        roots, met = comm.sharded_inverse_pth_roots(
+            stats, exps, group=dist.group.WORLD, ownership=ownership, overlap=overlap,
+            overlap_min_bytes=0)
+        torch.cuda.synchronize()
+        # (column 6, the power-iteration step count, is 0 where a phase was handed its largest
+        # eigenvalues by the hoisted power iteration)
+        ok = (all(torch.equal(a, b) for a, b in zip(roots, base)) and
+              torch.equal(met[:, :6], base_m[:, :6]))
+        out[(ownership, overlap)] = bool(ok)
+    ret[rank] = out
+  finally:
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_hip_roots_gathered_over_gloo(device):
+  """The N > 1 product path on GPU tensors with the HIP kernels: two processes (one GPU, so the
+  process group is gloo and the gather is staged through the host -- RCCL refuses two ranks on
+  one device) own disjoint statistics, root them with ps_newton_root_batched_f32 and gather: every
+  rank ends with the single-process roots and metrics bit for bit, in list order, for both
+  ownership modes and for the one- and two-phase (overlap) layouts."""
+  import socket
+  import torch.multiprocessing as mp
+  s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+  ctx = mp.get_context("spawn")
+  mgr = ctx.Manager()
+  ret = mgr.dict()
+  mp.spawn(_two_rank_gpu_worker, args=(2, port, ret), nprocs=2, join=True)
+  for rank in range(2):
+    assert all(ret[rank].values()), (rank, dict(ret[rank]))
