@@ -177,7 +177,7 @@ class Workload:
     """FLOPs the MFMA pipe actually executes for them: the product kernels compute only
     the upper tile triangle of each symmetric product."""
     it = self.metrics[:, 5].double().mean().item()
-    return self.flops() * executed_fraction(self.n, self.p, it)
+    return self.flops() * executed_fraction(self.n, self.p, it, self.metrics[:, 7].double().mean().item())
 
 
 # ---------------------------------------------------------------------------
@@ -258,7 +258,7 @@ class VitBWorkload:
     for i, s in enumerate(flat):
       n = int(s.shape[0])
       f += (m[i, 5] * c_of_p(self.exps[i]) * 2.0 * float(n) ** 3 *
-            (executed_fraction(n, self.exps[i], m[i, 5]) if executed else 1.0))
+            (executed_fraction(n, self.exps[i], m[i, 5], m[i, 7]) if executed else 1.0))
     return f  # roots of ALL ranks (metrics are gathered), statistics not included
 
 
@@ -413,7 +413,7 @@ def profile_stage_kernel(work):
   return stage_ms.value, launches.value, pi_ms.value, other_ms.value
 
 
-def executed_fraction(n, p=4, iters=8.0):
+def executed_fraction(n, p=4, iters=8.0, avg_steps=None):
   """Share of the algorithmic c(p) * 2n^3 flops per Newton step that the product kernel
   issues on the MFMA pipe.  Symmetric mode (the default): every product runs only the
   tiles with tm <= tn of its T x T tile grid ((T+1)/(2T) of the work) except the M update
@@ -426,7 +426,10 @@ def executed_fraction(n, p=4, iters=8.0):
   if os.environ.get("PS_NEWTON_SYMMETRIC", "1") == "0":
     return (c * it - 1.0) / (c * it)
   from precondition_amd import _lib
-  navg = min(float(_lib.lib().ps_newton_averaged_steps()), float(iters))
+  # steps whose M update ran in full: column PS_M_AVG_STEPS of the metrics table when the caller
+  # has it (the rule is data dependent: newton_avg_next), else the cap
+  navg = float(avg_steps) if avg_steps is not None else float(_lib.lib().ps_newton_averaged_steps())
+  navg = min(navg, float(iters))
   t = (n + 127) // 128
   half = (t + 1) / (2.0 * t)
   per_step = (c - 1) * half + (navg / it) * 1.0 + (1 - navg / it) * half
@@ -652,7 +655,7 @@ def main():
           "max_newton_error": float(np.nanmax(errs)),
           # whole step (power iteration, init, control, copy-out included), EXECUTED flops
           "executed_frac_of_f32_mfma_peak": round(
-              flops * executed_fraction(n, p, float(iters.mean())) / sec / 1e12 /
+              flops * executed_fraction(n, p, float(iters.mean()), float(work.metrics[:, 7].mean())) / sec / 1e12 /
               (PEAK_F32_MFMA_TFLOPS * world), 4),
       },
   }
@@ -664,7 +667,7 @@ def main():
     line["clock"] = clock
     stage_ms, launches, pi_ms, other_ms = profile_stage_kernel(work)
     fl1 = work.flops()
-    ex = executed_fraction(n, p, float(iters.mean()))
+    ex = executed_fraction(n, p, float(iters.mean()), float(work.metrics[:, 7].mean()))
     alg = fl1 / (stage_ms * 1e-3) / 1e12 if stage_ms > 0 else 0.0
     ach = alg * ex
     persistent = os.environ.get("PS_NEWTON_PERSISTENT", "0") != "0"
@@ -744,7 +747,8 @@ def main():
     torch.cuda.empty_cache()
     hw = Workload("headline_64x1024_p4", rank, world, dev, multi)
     hsec, hflops = timed(hw, max(2, args.steps // 2), 1, multi)
-    hex_ = executed_fraction(1024, 4, float(hw.metrics[:, 5].double().mean().item()))
+    hex_ = executed_fraction(1024, 4, float(hw.metrics[:, 5].double().mean().item()),
+                             float(hw.metrics[:, 7].double().mean().item()))
     head = {"workload": "64 blocks/GPU of 1024x1024 fp32, p=4",
             "value": round(hflops / hsec / 1e9, 1), "unit": "GFLOP/s (algorithmic, SURVEY 8d)",
             "ms_per_step": round(hsec * 1e3, 3),

@@ -84,9 +84,9 @@ enum {
   PS_M_RETRIES = 4,      /* total_retries = number of tries (>=1) */
   PS_M_TOTAL_ITERS = 5,  /* inner iterations summed over all tries (for FLOP accounting) */
   PS_M_POWER_ITERS = 6,  /* power-iteration steps executed */
-  PS_M_ASYMMETRY = 7,    /* max|X - X^T| / max|X| of the full M update X of the first step of
-                            the last try (0 if that step did not average): the commutator
-                            noise of the iterates, ~1e-7 well conditioned, ~1e-5 at cond 1e4 */
+  PS_M_AVG_STEPS = 7,    /* Newton root: number of steps, summed over tries, whose M update was computed in
+                            full and averaged with its transpose (ps_newton_averaged_steps; for FLOP
+                            accounting) */
   PS_METRICS_STRIDE = 8
 };
 
@@ -195,12 +195,14 @@ int ps_mat_power_f32(void* stream, const float* m, int n, int ldm, int p,
 size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
                                       const int32_t* p,
                                       const int32_t* padding_start);
-/* Number of leading Newton steps of every try in which the M update (DS:845) of an exactly
- * symmetric block is computed in full and averaged with its transpose instead of being
- * mirrored from its upper tile triangle (default 4; PS_NEWTON_AVG_STEPS overrides; see
- * csrc/newton.hip TileFlags: at cond ~7e3, p = 4 the error against the float64 root is
- * 9.3e-4 mirrored everywhere, 1.76e-4 with 4 averaged steps, 1.96e-4 with full products
- * in this library's summation order and 1.26e-4 in NumPy's).  For FLOP accounting. */
+/* Number of leading Newton steps of a try in which the M update (DS:845) of an exactly symmetric
+ * block is computed in full and averaged with its transpose instead of being mirrored from its
+ * upper tile triangle (default 4; PS_NEWTON_AVG_STEPS overrides, 0 = mirrored everywhere).  With
+ * the opt-in PS_NEWTON_AVG_ERR=t, steps after the second stop averaging once max|M - I| <= t
+ * (csrc/newton.hip newton_avg_next: at cond ~7e3, p = 4 the error against the float64 root is
+ * 9.3e-4 mirrored everywhere, 2.8e-4 with 2 averaged steps, 1.76e-4 with 4, 1.96e-4 with full
+ * products in this library's summation order and 1.26e-4 in NumPy's).  The count per block is
+ * column PS_M_AVG_STEPS of the metrics table. */
 int ps_newton_averaged_steps(void);
 int ps_newton_root_batched_f32(void* stream, const float* const* a,
                                const int32_t* n, const int32_t* lda,

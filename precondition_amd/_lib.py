@@ -30,7 +30,7 @@ def symmetry_code(symmetry) -> int:
       raise ValueError(f"symmetry must be one of {sorted(_SYMMETRY)}, got {symmetry!r}")
   return int(symmetry)
 (PS_M_ERROR, PS_M_ITERS, PS_M_ERROR_RATIO, PS_M_MAX_EV, PS_M_RETRIES,
- PS_M_TOTAL_ITERS, PS_M_POWER_ITERS, PS_M_ASYMMETRY) = range(8)
+ PS_M_TOTAL_ITERS, PS_M_POWER_ITERS, PS_M_AVG_STEPS) = range(8)
 
 
 class PsError(RuntimeError):

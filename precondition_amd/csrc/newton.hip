@@ -55,7 +55,8 @@ constexpr int NBK = 16;        // K-tile depth of the Newton products
 constexpr int MAX_PROD = 8;    // products per Newton step (p <= 64)
 constexpr int NTEMP = 5;
 constexpr int NQ = 8;          // item queues (one per XCD)
-constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 4;
+constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 4;      // averaged leading steps of a try
+constexpr float PS_NEWTON_AVG_ERR_DEFAULT = 0.f;   // opt-in: stop averaging once max|M - I| <= this
 
 
 enum Phase { PH_INIT = 0, PH_ACTIVE = 1, PH_DONE = 2 };
@@ -91,7 +92,7 @@ struct NewtonState {
   // NEXT step still averages (newton_avg_next: a fixed number of leading steps)
   unsigned asym_bits, xmax_bits;
   int avg_on;
-  float asym_first;   // relative asymmetry measured in the first step of the last try
+  float asym_first;   // number of steps (all tries) whose M update was averaged: PS_M_AVG_STEPS
   int power_iters;
   // arrival counters of the persistent execution
   unsigned c_init1, c_init2, c_join, c_copy;
@@ -456,16 +457,18 @@ __device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, Newto
   }
 }
 
-// Does step `it` (the one about to run) average its M update?  The first `navg` steps of a
-// try do.  (An adaptive rule was tried and dropped: neither the measured asymmetry
-// max|X - X^T| / max|X| of the full product — 2-4e-7 on Wishart blocks of cond 10, 5-9e-7 at
-// cond 1e4 — nor the elementwise error max|M - I| of the first steps separates the blocks
-// that need the averaging from those that do not; what decides is the conditioning, which
-// only the iteration count reveals, afterwards.  The asymmetry of the first step is still
-// reported per block, PS_M_ASYMMETRY.)
-__device__ inline bool newton_avg_next(int it, int navg, unsigned asym_bits, unsigned xmax_bits) {
-  (void)asym_bits; (void)xmax_bits;
-  return it < navg;
+// Does step `it` (the one about to run) average its M update?  The first `navg` (4) steps of a
+// try do, and -- only when the opt-in threshold `thr` (PS_NEWTON_AVG_ERR, default 0 = off) is
+// set -- steps after the second stop early once the error max|M - I| has dropped below it.
+// Measured (tools/dev_avg_sweep.py, dev_avg_adaptive.py): root error vs float64 of the cond 7e3,
+// p = 4, 1024^2 block of the ViT-B tree 2.8e-4 with 2 averaged steps, 1.76e-4 with 4, 1.66e-4
+// with 6 (the oracle's full products 1.26e-4); a cond-10 Wishart block is 1e-6 from float64 with
+// any count.  The elementwise error does NOT separate those two block classes early enough to
+// steer the count (0.69 vs 0.81 after two steps, both falling), which is why the default stays
+// the fixed 4 (about +4 % on the headline) and the threshold is an opt-in.  The number of
+// averaged steps is reported per block in the metrics table (PS_M_AVG_STEPS) for FLOP accounting.
+__device__ inline bool newton_avg_next(int it, int navg, float err, float thr) {
+  return it < 2 ? it < navg : (it < navg && err > thr);
 }
 
 // ---- (re)initialisation of a try (DS:866-875), tile bodies ----------------------------
@@ -563,7 +566,7 @@ __device__ inline void write_metrics(float* metrics, int b, float err, int it, f
   float* m = metrics + (int64_t)b * PS_METRICS_STRIDE;
   m[PS_M_ERROR] = err; m[PS_M_ITERS] = (float)it; m[PS_M_ERROR_RATIO] = ratio;
   m[PS_M_RETRIES] = (float)tries; m[PS_M_TOTAL_ITERS] = (float)total_iters;
-  m[PS_M_MAX_EV] = max_ev; m[PS_M_POWER_ITERS] = (float)pit; m[PS_M_ASYMMETRY] = asym_first;
+  m[PS_M_MAX_EV] = max_ev; m[PS_M_POWER_ITERS] = (float)pit; m[PS_M_AVG_STEPS] = asym_first;
 }
 
 // ==================================================================================
@@ -640,7 +643,7 @@ __device__ inline void finish_try(NewtonState* st) {
 // Newton step (DS:848 carry + DS:836-840 condition).
 __global__ __launch_bounds__(256) void newton_control_kernel(
     NewtonState* states, int nblocks, int mode, int num_iters, float tol, int gen,
-    HostStatus* status, int navg) {
+    HostStatus* status, int navg, float avg_thr) {
   __shared__ int s_nd, s_ni;
   if (threadIdx.x == 0) { s_nd = 0; s_ni = 0; }
   __syncthreads();
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
       st->ratio = 1.f;
       st->it = 0;
       st->asym_bits = 0; st->xmax_bits = 0;
-      st->avg_on = newton_avg_next(0, navg, 0u, 0u) ? 1 : 0;
+      st->avg_on = newton_avg_next(0, navg, st->err, avg_thr) ? 1 : 0;
       const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
       if (cont) st->phase = PH_ACTIVE; else finish_try(st);
     } else if (mode == 1 && st->phase == PH_ACTIVE) {
@@ -664,9 +667,8 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
       st->it += 1;
       st->total_iters += 1;
       st->cur ^= 1;
-      if (st->it == 1 && st->avg_on)
-        st->asym_first = st->xmax_bits ? __uint_as_float(st->asym_bits) / __uint_as_float(st->xmax_bits) : 0.f;
-      st->avg_on = (st->avg_on && newton_avg_next(st->it, navg, st->asym_bits, st->xmax_bits)) ? 1 : 0;
+      if (st->avg_on) st->asym_first += 1.f;   // averaged steps so far (all tries)
+      st->avg_on = (st->avg_on && newton_avg_next(st->it, navg, st->err, avg_thr)) ? 1 : 0;
       st->asym_bits = 0; st->xmax_bits = 0;
       const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
       if (!cont) finish_try(st);
@@ -766,7 +768,8 @@ struct PArgs {
   int nlive;          // blocks with n >= 1
   int num_iters;
   float tol;
-  int navg;           // leading steps of a try whose M update is averaged (TileFlags)
+  int navg;           // cap of the averaged steps of a try (TileFlags, newton_avg_next)
+  float avg_thr;      // ... which last while max|M - I| is above this
   int grid;           // workgroups of the persistent launch (exit tokens per queue)
   int nq;             // queues in use (1..NQ); workgroup w serves queue w % nq
   u64* prof;          // dev (PS_NEWTON_PROF=1): [grid][8] per-workgroup time split, else NULL
@@ -890,7 +893,7 @@ __device__ inline void p_control_init(const PArgs& pa, const NewtonBlock* nb, Ne
   ast(&st->it, 0);
   ast(&st->asym_bits, 0u);
   ast(&st->xmax_bits, 0u);
-  const int avg0 = newton_avg_next(0, pa.navg, 0u, 0u) ? 1 : 0;
+  const int avg0 = newton_avg_next(0, pa.navg, ald(&st->err), pa.avg_thr) ? 1 : 0;
   ast(&st->avg_on, avg0);
   const bool cont = 0 < pa.num_iters && err > pa.tol;
   if (cont) { ast(&st->phase, (int)PH_ACTIVE); p_start_step(pa, nb, b, cur, avg0); }
@@ -913,8 +916,9 @@ __device__ inline void p_control_step(const PArgs& pa, const NewtonBlock* nb, Ne
   ast(&st->cur, ncur);
   const unsigned ab = ald(&st->asym_bits), xb = ald(&st->xmax_bits);
   const int was = ald(&st->avg_on);
-  if (it == 1 && was) ast(&st->asym_first, xb ? __uint_as_float(ab) / __uint_as_float(xb) : 0.f);
-  const int avg = (was && newton_avg_next(it, pa.navg, ab, xb)) ? 1 : 0;
+  (void)ab; (void)xb;
+  if (was) ast(&st->asym_first, ald(&st->asym_first) + 1.f);
+  const int avg = (was && newton_avg_next(it, pa.navg, new_err, pa.avg_thr)) ? 1 : 0;
   ast(&st->avg_on, avg);
   ast(&st->asym_bits, 0u);
   ast(&st->xmax_bits, 0u);
@@ -1442,6 +1446,8 @@ static int newton_driver(
   // Leading steps of every try whose M update is computed in full and averaged with its
   // transpose (TileFlags above).  PS_NEWTON_AVG_STEPS overrides (0 = mirrored everywhere).
   const int navg = ps_newton_averaged_steps();
+  const float avg_thr = [] { const char* e = getenv("PS_NEWTON_AVG_ERR");
+                             return e ? (float)atof(e) : PS_NEWTON_AVG_ERR_DEFAULT; }();
   Plan pl;
   make_plan(pl, batch, n, p, padding_start, staged);
   if (!pl.ok) return PS_EUNSUPPORTED;
@@ -1528,6 +1534,7 @@ static int newton_driver(
     pa.prof = dev_prof ? lo.prof : nullptr;
     pa.grid = grid;
     pa.navg = navg;
+    pa.avg_thr = avg_thr;
     pa.nq = pl.nq;
     if (dev_prof) PS_HIP(hipMemsetAsync(lo.prof, 0, sizeof(u64) * 12 * 4096, st));
     if (pl.nlive > 0) {
@@ -1619,7 +1626,7 @@ static int newton_driver(
         hipLaunchKernelGGL(newton_init2_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
                            lo.states, lo.init_tiles);
         hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
-                           batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr, navg);
+                           batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr, navg, avg_thr);
         prof.end();
       }
       for (int s = 0; s < pl.nstages; ++s) {
@@ -1641,7 +1648,7 @@ static int newton_driver(
         prof.end();
       }
       hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
-                         batch, 1, num_iters, error_tolerance, g, slot, navg);
+                         batch, 1, num_iters, error_tolerance, g, slot, navg, avg_thr);
       if ((rc = (int)hipGetLastError()) != 0) break;
       if ((rc = (int)hipEventRecord(ev[g & 1], st)) != 0) break;
       ++executed;

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_host_code_is_clean_under_asan_and_ubsan():
   if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
     pytest.skip("no hipcc")
-  r = subprocess.run(["make", "-C", os.path.join(ROOT, "precondition_amd", "csrc"), "-j",
+  r = subprocess.run(["make", "-C", os.path.join(ROOT, "precondition_amd", "csrc"), "-f", "Makefile.asan", "-j",
                       str(min(8, os.cpu_count() or 4)), "asan-host"],
                      capture_output=True, text=True, timeout=900)
   tail = (r.stdout + r.stderr)[-3000:]
