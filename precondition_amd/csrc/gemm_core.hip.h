@@ -96,8 +96,32 @@ struct TileLoader {
     }
   }
 
+  // Unguarded loads address memory as (wave-uniform 64-bit base) + (one 32-bit byte offset per
+  // lane): base = tile origin advanced to K-tile k0 and to the v-th group of rows, offset = the
+  // lane's position inside the first group.  The uniform part lives in SGPRs (global_load ...
+  // saddr form), so a tile costs ONE address VGPR per operand instead of a 64-bit pair per load:
+  // with two register sets in flight that is the difference between 256 VGPRs + scratch and none.
+  // The offset spans at most ROWS_PER_V rows of the operand, far below 2^32 bytes.
+  static constexpr int ROWS_PER_V = LAYOUT == KC ? NTHREADS / (BK / 4) : NTHREADS / (TILE / 4);
+  __device__ static inline uint32_t lane_byte_offset(int ld, int tid) {
+    int mn, k;
+    coords(0, tid, mn, k);
+    return 4u * (LAYOUT == KC ? (uint32_t)mn * (uint32_t)ld + (uint32_t)k
+                              : (uint32_t)k * (uint32_t)ld + (uint32_t)mn);
+  }
+
   __device__ static inline void load(const Operand& op, int k0, int tid,
                                      f32x4 (&r)[NV]) {
+    if (!GUARD) {
+      const uint32_t off = lane_byte_offset(op.ld, tid);
+      const float* base = LAYOUT == KC ? op.p + (int64_t)op.mn0 * op.ld + k0
+                                       : op.p + (int64_t)k0 * op.ld + op.mn0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        r[v] = *(const f32x4 PS_GLOBAL*)((const char PS_GLOBAL*)(base + (int64_t)(v * ROWS_PER_V) * op.ld) +
+                                         (uint64_t)off);
+      return;
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int mn, k;

@@ -574,7 +574,7 @@ __device__ inline void write_metrics(float* metrics, int b, float err, int it, f
 // ==================================================================================
 // DEEP = false: 3 workgroups per CU.  DEEP = true: two-K-tile-deep register prefetch, 2 per CU.
 template <int BK, bool DEEP, bool X6 = false>
-__global__ __launch_bounds__(256, DEEP ? 2 : 3) void newton_stage_kernel(
+__global__ __launch_bounds__(256, (DEEP && BK == 32) ? 2 : 3) void newton_stage_kernel(
     const NewtonBlock* blocks, NewtonState* states, const NewtonTask* tasks,
     const TileEntry* tiles, int ntiles, int navg) {
   extern __shared__ __align__(16) float smem[];  // SmemCfg<BK>::TOTAL floats

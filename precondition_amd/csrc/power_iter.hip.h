@@ -363,6 +363,13 @@ struct PiWait {
   const pi_granule* abort;
   bool dead;
 };
+// Address = wave-uniform base + a 32-bit byte offset per lane: keeps the uniform part of the
+// hand-off addresses in SGPRs (saddr form) instead of one hoisted 64-bit VGPR pair per granule
+// stream -- with three tiles in registers those pairs were what spilled to scratch.
+template <typename T>
+__device__ __forceinline__ T* pi_at(T* ubase, uint32_t byte_off) {
+  return (T*)((char*)ubase + (uint64_t)byte_off);
+}
 // Polls until the granule carries `tag`.
 __device__ __forceinline__ float pi_await(const pi_granule* p, pi_granule g, unsigned tag,
                                           PiWait* w) {
@@ -477,9 +484,9 @@ __device__ inline void pi_tile_from_regs(const PiBlock* pb, const f32x4 (&x)[16]
   }
   __syncthreads();
   if (tid < PT) {
-    pi_publish(P + ((int64_t)I * t + J) * PT + tid, stage[0][tid], tag);
+    pi_publish(pi_at(P + ((int64_t)I * t + J) * PT, 8u * (uint32_t)tid), stage[0][tid], tag);
     if (offdiag)
-      pi_publish(P + ((int64_t)J * t + I) * PT + tid,
+      pi_publish(pi_at(P + ((int64_t)J * t + I) * PT, 8u * (uint32_t)tid),
                  asym ? stage[1][tid]
                       : ((wpart[0][tid] + wpart[1][tid]) + wpart[2][tid]) + wpart[3][tid],
                  tag);
@@ -537,8 +544,15 @@ static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void p
     // ---- hop 1: partial products of this workgroup's tiles ----
 #pragma unroll
     for (int k = 0; k < NT; ++k)
-      if (k < te.ntile)
-        pi_tile_from_regs(pb, x[k], te.I[k], te.J[k], vn, P, tag, wpart[k], stage[k], asym, tid);
+      if (k < te.ntile) {
+        // the tile coordinates are re-read as opaque values in every step: everything derived
+        // from them (LDS and slab addresses of three tiles) is then recomputed with a few
+        // scalar / VALU adds per step instead of being hoisted out of the iteration loop into
+        // VGPRs that the 192 registers of matrix data leave no room for (they went to scratch)
+        int Ik = te.I[k], Jk = te.J[k];
+        asm volatile("" : "+s"(Ik), "+s"(Jk));
+        pi_tile_from_regs(pb, x[k], Ik, Jk, vn, P, tag, wpart[k], stage[k], asym, tid);
+      }
     float sv[2] = {0.f, 0.f}, ssv[2] = {0.f, 0.f};
     if (t <= PI_ONE_HOP_T) {
       // small blocks: every workgroup sums the whole slab itself (one hand-off latency per
@@ -571,7 +585,7 @@ static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void p
       for (int k = 0; k < NT; ++k) {
         if (k < te.ntile && te.I[k] == te.J[k] && tid < PT) {
           const int X = te.I[k];
-          const pi_granule* p = P + (int64_t)X * t * PT + tid;
+          const pi_granule* p = pi_at(P + (int64_t)X * t * PT, 8u * (uint32_t)tid);
           float y = 0.f;
           int Y = 0;
           for (; Y + 4 <= t; Y += 4) {
@@ -584,14 +598,15 @@ static __global__ __launch_bounds__(256, NT >= 3 ? 2 : (NT == 2 ? 3 : 4)) void p
             y = (((y + p0) + p1) + p2) + p3;
           }
           for (; Y < t; ++Y) y += pi_await(p + Y * PT, pi_peek(p + Y * PT), tag, &wt);
-          pi_publish(Yg + X * PT + tid, y, tag);
+          pi_publish(pi_at(Yg + X * PT, 8u * (uint32_t)tid), y, tag);
         }
       }
       // ---- gather y; pi_red_kernel's reduction, its 512 threads as 2 virtual threads each ----
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         for (int j = tid + 256 * v; j < tp; j += 512) {
-          const float y = pi_await(Yg + j, pi_peek(Yg + j), tag, &wt);
+          const pi_granule* yp = pi_at(Yg, 8u * (uint32_t)j);
+          const float y = pi_await(yp, pi_peek(yp), tag, &wt);
           ysm[j] = y;
           sv[v] += vn[j] * y;   // DS:637
           ssv[v] += y * y;

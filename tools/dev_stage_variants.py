@@ -1,0 +1,23 @@
+"""Dev: A/B of the Newton stage-kernel variants (PS_NEWTON_BK / PS_NEWTON_DEEP are read once per
+process, so each variant runs in a child process)."""
+import os, subprocess, sys
+CHILD = r'''
+import sys; sys.path.insert(0, ".")
+import torch, bench, time
+from precondition_amd import kernels as K
+dev = torch.device("cuda:0")
+for name in ("cfg2_256x512_p4", "headline_64x1024_p4"):
+  st, p = bench.make_blocks(name, 0, dev); mats = list(st.unbind(0))
+  for _ in range(3): r, m = K.matrix_inverse_pth_root_batched(mats, [p]*len(mats))
+  best = 1e9
+  for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): r, m = K.matrix_inverse_pth_root_batched(mats, [p]*len(mats))
+    torch.cuda.synchronize(); best = min(best, (time.perf_counter()-t0)/5*1e3)
+  print("   ", name, "%.2f ms" % best, "checksum %.9e" % float(torch.stack(r).double().abs().sum()), flush=True)
+  del st, mats, r; torch.cuda.empty_cache()
+'''
+for bk, deep in (("32", "1"), ("16", "1"), ("32", "1"), ("16", "1"), ("16", "0"), ("32", "0")):
+  env = dict(os.environ, PS_NEWTON_BK=bk, PS_NEWTON_DEEP=deep)
+  print("BK", bk, "DEEP", deep, flush=True)
+  subprocess.run([sys.executable, "-c", CHILD], env=env, check=False, timeout=300)
