@@ -442,6 +442,12 @@ int ps_chol_rinv_max_n(void);
 int ps_chol_rinv_batched_f32(void* stream, const float* gram, float* out, int b, int batch,
                              float drop_rel);
 
+/* Diagnostic microbenchmark: the fp32 MFMA rate (TFLOP/s) of a loop of 16 MFMAs interleaved with
+ * valu_per_16 (0, 4, 8, 16, 32 or 64) independent VALU adds (wide != 0: 64-bit v_lshl_add_u64),
+ * with wgs_per_cu (1 or 2) workgroups of 4 wavefronts per CU.  Shows what ordinary VALU work in
+ * a K loop costs the fp32 MFMA pipe.  Synchronises the stream.  PS_EINVAL for other counts. */
+int ps_diag_mfma_mix(void* stream, int valu_per_16, int wide, int wgs_per_cu,
+                     double* mfma_f32_tflops);
 /* ---- health of the resident power iteration; diagnostics --------------------------------
  * The resident execution of the power iteration (one launch, matrices in registers) spin-waits
  * on the workgroups of a block's team and is launched at the co-resident capacity of an

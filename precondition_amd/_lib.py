@@ -177,6 +177,7 @@ _SIGNATURES = {
     "ps_power_iteration_health": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ps_power_iteration_reset_health": (C.c_int, []),
     "ps_diag_spin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "ps_diag_mfma_mix": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "ps_diag_mfma_clock": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "ps_profile_enable": (C.c_int, [C.c_int]),
     "ps_profile_reset": (C.c_int, []),

@@ -113,7 +113,11 @@ struct TileLoader {
   __device__ static inline void load(const Operand& op, int k0, int tid,
                                      f32x4 (&r)[NV]) {
     if (!GUARD) {
-      const uint32_t off = lane_byte_offset(op.ld, tid);
+      uint32_t off = lane_byte_offset(op.ld, tid);
+      // opaque per call: keeps the zero-extension of the offset next to the loads (instruction
+      // selection sees "SGPR base + zext(VGPR)" and emits the saddr form; hoisted out of the K
+      // loop it becomes a 64-bit VGPR add per load, and VALU work costs fp32-MFMA cycles)
+      asm volatile("" : "+v"(off));
       const float* base = LAYOUT == KC ? op.p + (int64_t)op.mn0 * op.ld + k0
                                        : op.p + (int64_t)k0 * op.ld + op.mn0;
 #pragma unroll
@@ -236,6 +240,204 @@ __device__ inline void zero_acc(f32x16 (&acc)[2][2]) {
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 }
 
+// The two register sets of the DEEP K loop, split in two calls so that a caller that walks a
+// list of tiles can issue the first loads of its NEXT tile before the epilogue of the current
+// one (deep_issue_first), and enter that tile's K loop with them in flight (deep_run).
+template <int LA, int LB, int BK, bool GUARD>
+struct DeepSets {
+  f32x4 ra0[TileLoader<LA, BK, GUARD>::NV], rb0[TileLoader<LB, BK, GUARD>::NV];
+  f32x4 ra1[TileLoader<LA, BK, GUARD>::NV], rb1[TileLoader<LB, BK, GUARD>::NV];
+};
+
+// Issues the global loads of K-tiles 0 and 1 (set 0 and set 1).
+template <int LA, int LB, int BK, bool GUARD>
+__device__ inline void deep_issue_first(const Operand& A, const Operand& B, int Kext,
+                                        DeepSets<LA, LB, BK, GUARD>& r) {
+  using LdA = TileLoader<LA, BK, GUARD>;
+  using LdB = TileLoader<LB, BK, GUARD>;
+  const int tid = threadIdx.x;
+  const int nk = (Kext + BK - 1) / BK;
+  LdA::load(A, 0, tid, r.ra0);
+  LdB::load(B, 0, tid, r.rb0);
+  // unconditional (see deep_run): a one-K-tile product re-reads K-tile 0 into the unused set
+  const int k1 = nk > 1 ? BK : 0;
+  LdA::load(A, k1, tid, r.ra1);
+  LdB::load(B, k1, tid, r.rb1);
+}
+
+// acc += A * B with K-tiles 0 and 1 already requested by deep_issue_first.  Ends with a barrier.
+template <int LA, int LB, int BK, bool GUARD>
+__device__ inline void deep_run(const Operand& A, const Operand& B, int Kext, float* smem,
+                                f32x16 (&acc)[2][2], DeepSets<LA, LB, BK, GUARD>& r,
+                                unsigned long long* t_fill = nullptr) {
+  using LdA = TileLoader<LA, BK, GUARD>;
+  using LdB = TileLoader<LB, BK, GUARD>;
+  constexpr int OPS = SmemCfg<BK>::op_size(LA);
+  constexpr int STG = SmemCfg<BK>::op_size(LA) + SmemCfg<BK>::op_size(LB);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wm = wave >> 1;
+  const int wn = wave & 1;
+  const int nk = (Kext + BK - 1) / BK;
+  LdA::store(smem, tid, r.ra0);
+  LdB::store(smem + OPS, tid, r.rb0);
+  __syncthreads();
+  if (t_fill != nullptr && tid == 0) *t_fill = __builtin_amdgcn_s_memrealtime();  // dev trace
+  float* s0 = smem;
+  float* s1 = smem + STG;
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even iteration: tile kt in s0; set 1 holds tile kt+1; set 0 is free -> tile kt+2
+    // The loads are UNCONDITIONAL: the vmcnt the compiler puts in front of the LDS writes of the
+    // other set must hold on every path, and with a skipped load on one path it has to assume
+    // that the set's loads are the youngest ones in flight -- every K-tile then waited for the
+    // loads issued one K-tile (not two) earlier.  Past the end of the product the request
+    // re-reads the last K-tile (a cache hit that nobody uses).
+    LdA::load(A, min(kt + 2, nk - 1) * BK, tid, r.ra0);
+    LdB::load(B, min(kt + 2, nk - 1) * BK, tid, r.rb0);
+    compute_ktile<LA, LB, BK>(s0, s0 + OPS, acc, wm, wn, lane);
+    if (kt + 1 < nk) {
+      LdA::store(s1, tid, r.ra1);
+      LdB::store(s1 + OPS, tid, r.rb1);
+    }
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd iteration: tile kt+1 in s1; set 0 holds tile kt+2; set 1 is free -> tile kt+3
+    LdA::load(A, min(kt + 3, nk - 1) * BK, tid, r.ra1);
+    LdB::load(B, min(kt + 3, nk - 1) * BK, tid, r.rb1);
+    compute_ktile<LA, LB, BK>(s1, s1 + OPS, acc, wm, wn, lane);
+    if (kt + 2 < nk) {
+      LdA::store(s0, tid, r.ra0);
+      LdB::store(s0 + OPS, tid, r.rb0);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- software-pipelined K loop (KC x MC operands, BK = 32, unguarded) -----------------------
+// deep_run's K-tile body lets the compiler place the fragment reads: it issues each ds_read just
+// before its first use (minimal registers), so a wavefront that is alone on its SIMD stalls on
+// LDS latency several times per 16-MFMA chunk and once more, with a drained MFMA pipe, at the
+// barrier that ends every K-tile (tools/dev_stage_trace.py: a workgroup that is alone on its CU
+// runs its K loop at 0.58 of the MFMA rate, two at 0.8).  Here the schedule is explicit:
+//   * fragments are double buffered by 8-deep chunk: the ds_reads of chunk c+1 are issued between
+//     the MFMA groups of chunk c (sched_barrier fences keep the order);
+//   * the next K-tile's LDS image is written during chunk 1 and the workgroup barrier sits
+//     BEFORE chunk 3, whose MFMAs then cover the reads of chunk 0 of the next K-tile: no drained
+//     pipe at the K-tile boundary.  Safe with two LDS stages: every read of a stage is issued
+//     before the barrier of its K-tile (and waited for by it), and the stage is next written
+//     after that barrier.
+// Same MFMA order per accumulator as compute_ktile: bit-identical results.  The global loads of
+// K-tile t+2 are issued at the top of K-tile t and consumed during chunk 1 of K-tile t+1.
+struct FragKM {
+  float a[2][4], b[2][4];
+};
+
+template <int BK>
+__device__ __forceinline__ void pipe_read_a(const float* sA, int c, int wm, int i, int h, FragKM& f) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(
+        sA + (wm * 64 + t * 32 + i) * SmemCfg<BK>::KC_LD + 8 * c + 4 * h);
+    f.a[t][0] = v[0]; f.a[t][1] = v[1]; f.a[t][2] = v[2]; f.a[t][3] = v[3];
+  }
+}
+template <int BK>
+__device__ __forceinline__ void pipe_read_b(const float* sB, int c, int s, int wn, int i, int h,
+                                            FragKM& f) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    f.b[t][s] = sB[(8 * c + 4 * h + s) * SmemCfg<BK>::MC_LD + wn * 64 + t * 32 + i];
+}
+__device__ __forceinline__ void pipe_mfma(const FragKM& f, int s, f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][s], f.b[tn][s], acc[tm][tn], 0, 0, 0);
+}
+#define PS_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// One chunk: the 16 MFMAs on `use`, with the reads of chunk (cn) of image (nA, nB) into `nxt`
+// spread between the MFMA groups (rd = false: nothing to read).
+template <int BK>
+__device__ __forceinline__ void pipe_chunk(const FragKM& use, FragKM& nxt, const float* nA,
+                                           const float* nB, int cn, bool rd, int wm, int wn, int i,
+                                           int h, f32x16 (&acc)[2][2]) {
+  pipe_mfma(use, 0, acc);
+  PS_FENCE();
+  if (rd) { pipe_read_a<BK>(nA, cn, wm, i, h, nxt); pipe_read_b<BK>(nB, cn, 0, wn, i, h, nxt); }
+  PS_FENCE();
+  pipe_mfma(use, 1, acc);
+  PS_FENCE();
+  if (rd) { pipe_read_b<BK>(nB, cn, 1, wn, i, h, nxt); pipe_read_b<BK>(nB, cn, 2, wn, i, h, nxt);
+            pipe_read_b<BK>(nB, cn, 3, wn, i, h, nxt); }
+  PS_FENCE();
+  pipe_mfma(use, 2, acc);
+  pipe_mfma(use, 3, acc);
+  PS_FENCE();
+}
+
+template <int BK>
+__device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kext, float* smem,
+                                     f32x16 (&acc)[2][2], DeepSets<KC, MC, BK, false>& r,
+                                     unsigned long long* t_fill = nullptr) {
+  static_assert(BK == 32, "four 8-deep chunks per K-tile");
+  using LdA = TileLoader<KC, BK, false>;
+  using LdB = TileLoader<MC, BK, false>;
+  constexpr int OPS = SmemCfg<BK>::op_size(KC);
+  constexpr int STG = SmemCfg<BK>::op_size(KC) + SmemCfg<BK>::op_size(MC);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const int nk = (Kext + BK - 1) / BK;
+  float* s0 = smem;
+  float* s1 = smem + STG;
+  LdA::store(s0, tid, r.ra0);
+  LdB::store(s0 + OPS, tid, r.rb0);
+  __syncthreads();
+  if (t_fill != nullptr && tid == 0) *t_fill = __builtin_amdgcn_s_memrealtime();  // dev trace
+  FragKM f0, f1;
+  pipe_read_a<BK>(s0, 0, wm, i, h, f0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) pipe_read_b<BK>(s0 + OPS, 0, s, wn, i, h, f0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    // ---- even K-tile: image in s0; set 1 holds K-tile kt+1 (-> s1); set 0 is free -> kt+2 ----
+    {
+      const bool nxt = kt + 1 < nk;
+      LdA::load(A, min(kt + 2, nk - 1) * BK, tid, r.ra0);   // unconditional: see deep_run
+      LdB::load(B, min(kt + 2, nk - 1) * BK, tid, r.rb0);
+      PS_FENCE();
+      pipe_chunk<BK>(f0, f1, s0, s0 + OPS, 1, true, wm, wn, i, h, acc);
+      if (nxt) { LdA::store(s1, tid, r.ra1); LdB::store(s1 + OPS, tid, r.rb1); }
+      PS_FENCE();
+      pipe_chunk<BK>(f1, f0, s0, s0 + OPS, 2, true, wm, wn, i, h, acc);
+      pipe_chunk<BK>(f0, f1, s0, s0 + OPS, 3, true, wm, wn, i, h, acc);
+      __syncthreads();
+      PS_FENCE();
+      pipe_chunk<BK>(f1, f0, s1, s1 + OPS, 0, nxt, wm, wn, i, h, acc);
+      if (!nxt) break;
+    }
+    // ---- odd K-tile: image in s1; set 0 holds K-tile kt+2 (-> s0); set 1 is free -> kt+3 ----
+    {
+      const bool nxt = kt + 2 < nk;
+      LdA::load(A, min(kt + 3, nk - 1) * BK, tid, r.ra1);
+      LdB::load(B, min(kt + 3, nk - 1) * BK, tid, r.rb1);
+      PS_FENCE();
+      pipe_chunk<BK>(f0, f1, s1, s1 + OPS, 1, true, wm, wn, i, h, acc);
+      if (nxt) { LdA::store(s0, tid, r.ra0); LdB::store(s0 + OPS, tid, r.rb0); }
+      PS_FENCE();
+      pipe_chunk<BK>(f1, f0, s1, s1 + OPS, 2, true, wm, wn, i, h, acc);
+      pipe_chunk<BK>(f0, f1, s1, s1 + OPS, 3, true, wm, wn, i, h, acc);
+      __syncthreads();
+      PS_FENCE();
+      pipe_chunk<BK>(f1, f0, s0, s0 + OPS, 0, nxt, wm, wn, i, h, acc);
+    }
+  }
+  // every LDS read was waited for by the barrier of the last K-tile: smem is free
+}
+
 // Accumulating form: acc += A * B over k in [0, Kext).
 // DEEP = false: the global loads of K-tile t+1 are issued at the top of iteration t and
 //   written to the other LDS buffer at its bottom (one K-tile of MFMAs covers their latency).
@@ -246,9 +448,10 @@ __device__ inline void zero_acc(f32x16 (&acc)[2][2]) {
 //   workgroup's K loop cannot go faster than one memory round trip per K-tile even when the
 //   MFMA pipe is free (measured: 6900 cycles per K-tile whether 2 or 3 workgroups shared
 //   the CU).  Same summation order, bit-identical results.
-template <int LA, int LB, int BK, bool GUARD, bool DEEP = false>
+template <int LA, int LB, int BK, bool GUARD, bool DEEP = false, bool PIPE = false>
 __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int Kext,
-                                       float* smem, f32x16 (&acc)[2][2]) {
+                                       float* smem, f32x16 (&acc)[2][2],
+                                       unsigned long long* t_fill = nullptr) {
   using LdA = TileLoader<LA, BK, GUARD>;
   using LdB = TileLoader<LB, BK, GUARD>;
   constexpr int OPS = SmemCfg<BK>::op_size(LA);
@@ -285,50 +488,20 @@ __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int K
     return;
   }
   // ---- two register sets, loop unrolled by two so that the set indices are static ----
-  f32x4 ra0[LdA::NV], rb0[LdB::NV], ra1[LdA::NV], rb1[LdB::NV];
-  LdA::load(A, 0, tid, ra0);
-  LdB::load(B, 0, tid, rb0);
-  if (nk > 1) {
-    LdA::load(A, BK, tid, ra1);
-    LdB::load(B, BK, tid, rb1);
-  }
-  LdA::store(smem, tid, ra0);
-  LdB::store(smem + OPS, tid, rb0);
-  __syncthreads();
-  float* s0 = smem;
-  float* s1 = smem + STG;
-  for (int kt = 0; kt < nk; kt += 2) {
-    // even iteration: tile kt in s0; set 1 holds tile kt+1; set 0 is free -> tile kt+2
-    if (kt + 2 < nk) {
-      LdA::load(A, (kt + 2) * BK, tid, ra0);
-      LdB::load(B, (kt + 2) * BK, tid, rb0);
-    }
-    compute_ktile<LA, LB, BK>(s0, s0 + OPS, acc, wm, wn, lane);
-    if (kt + 1 < nk) {
-      LdA::store(s1, tid, ra1);
-      LdB::store(s1 + OPS, tid, rb1);
-    }
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    // odd iteration: tile kt+1 in s1; set 0 holds tile kt+2; set 1 is free -> tile kt+3
-    if (kt + 3 < nk) {
-      LdA::load(A, (kt + 3) * BK, tid, ra1);
-      LdB::load(B, (kt + 3) * BK, tid, rb1);
-    }
-    compute_ktile<LA, LB, BK>(s1, s1 + OPS, acc, wm, wn, lane);
-    if (kt + 2 < nk) {
-      LdA::store(s0, tid, ra0);
-      LdB::store(s0 + OPS, tid, rb0);
-    }
-    __syncthreads();
-  }
+  DeepSets<LA, LB, BK, GUARD> sets;
+  deep_issue_first<LA, LB, BK, GUARD>(A, B, Kext, sets);
+  if constexpr (PIPE && LA == KC && LB == MC && BK == 32 && !GUARD)
+    deep_run_pipe<BK>(A, B, Kext, smem, acc, sets, t_fill);
+  else
+    deep_run<LA, LB, BK, GUARD>(A, B, Kext, smem, acc, sets, t_fill);
 }
 
-template <int LA, int LB, int BK, bool GUARD, bool DEEP = false>
+template <int LA, int LB, int BK, bool GUARD, bool DEEP = false, bool PIPE = false>
 __device__ inline void gemm_tile(const Operand& A, const Operand& B, int Kext,
-                                 float* smem, f32x16 (&acc)[2][2]) {
+                                 float* smem, f32x16 (&acc)[2][2],
+                                 unsigned long long* t_fill = nullptr) {
   zero_acc(acc);
-  gemm_tile_accum<LA, LB, BK, GUARD, DEEP>(A, B, Kext, smem, acc);
+  gemm_tile_accum<LA, LB, BK, GUARD, DEEP, PIPE>(A, B, Kext, smem, acc, t_fill);
 }
 
 // Accumulator element -> (row, col) inside the 128x128 tile (C/D layout of the

@@ -55,6 +55,7 @@ constexpr int NBK = 16;        // K-tile depth of the Newton products
 constexpr int MAX_PROD = 8;    // products per Newton step (p <= 64)
 constexpr int NTEMP = 5;
 constexpr int NQ = 8;          // item queues (one per XCD)
+constexpr bool PS_NEWTON_PIPE_DEFAULT = true;
 constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 4;      // averaged leading steps of a try
 constexpr float PS_NEWTON_AVG_ERR_DEFAULT = 0.f;   // opt-in: stop averaging once max|M - I| <= this
 
@@ -329,15 +330,18 @@ __device__ __forceinline__ void gemm_tile_bf16x6_sym(const float* A, const float
   }
 }
 
-template <int BK, bool WT, bool DEEP, bool X6 = false>
+template <bool WT>
+__device__ __forceinline__ void newton_tile_epilogue(const NewtonBlock* nb, NewtonState* st, int prod,
+                                                     int cur, int tm_, int tn_, int flags,
+                                                     float* smem, f32x16 (&acc)[2][2]);
+
+template <int BK, bool WT, bool DEEP, bool X6 = false, bool PIPE = false>
 __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, NewtonState* st, int prod,
                                            int cur, int tm_, int tn_, int flags,
                                            float* smem, unsigned long long* stamp = nullptr) {
-  const bool mirror = (flags & TF_MIRROR) != 0;
   const int n = nb->n, ld = nb->npad;
   Operand A{resolve(nb, nb->pa[prod], cur), ld, tm_ * TILE, ld, ld, true};
   Operand B{resolve(nb, nb->pb[prod], cur), ld, tn_ * TILE, ld, ld, true};
-  float* C = resolve(nb, nb->pc[prod], cur);
   f32x16 acc[2][2];
   // Near convergence (max|M - I| < 1e-3 at the start of the step) the split products' noise floor
   // (~2e-6 in max|M - I| on cond 1e4 blocks) is above the 1e-6 stop threshold of DS:836, so the
@@ -345,8 +349,21 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
   if (X6 && *nb->asym == 0 && st->err > 1e-3f)
     gemm_tile_bf16x6_sym(A.p, B.p, ld, A.mn0, B.mn0, ld, smem, acc);
   else
-    gemm_tile<KC, MC, BK, false, DEEP>(A, B, n, smem, acc);
+    gemm_tile<KC, MC, BK, false, DEEP, PIPE>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr);
 
+  if (stamp != nullptr && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();  // dev profile
+  newton_tile_epilogue<WT>(nb, st, prod, cur, tm_, tn_, flags, smem, acc);
+}
+
+// Epilogue of one product tile: stores (direct + mirrored), the averaged M update, and for the
+// M update the next Mi and the error.  All 256 threads; smem free; ends without a barrier.
+template <bool WT>
+__device__ __forceinline__ void newton_tile_epilogue(const NewtonBlock* nb, NewtonState* st, int prod,
+                                                     int cur, int tm_, int tn_, int flags,
+                                                     float* smem, f32x16 (&acc)[2][2]) {
+  const bool mirror = (flags & TF_MIRROR) != 0;
+  const int n = nb->n, ld = nb->npad;
+  float* C = resolve(nb, nb->pc[prod], cur);
   // Addressing of the direct stores: everything but a per-lane 32-bit offset is wave-uniform
   // (kept in SGPRs), so the 64 (or 128) stores of the epilogue need no per-store address
   // registers: element r of block (tm, tn) of this wavefront lies at
@@ -357,7 +374,6 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
   const int wm = wave >> 1, wn = wave & 1;
   const int lane_off = 4 * (lane >> 5) * ld + (lane & 31);
   const int lane_row = 4 * (lane >> 5), lane_col = lane & 31;
-  if (stamp != nullptr && tid == 0) *stamp = __builtin_amdgcn_s_memrealtime();  // dev profile
   const bool plain = prod != nb->nprod - 1 || (flags & TF_RAW) != 0;
   if (plain || (flags & TF_SELFAVG) != 0) {
 #pragma unroll
@@ -430,7 +446,7 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
 // compute the transposed position as a product of its own; symmetric blocks mirror it, except
 // the M update of the first steps of a try (avg), which is computed in full and averaged
 // with its transpose (see TileFlags).
-template <int BK, bool WT, bool DEEP, bool X6 = false>
+template <int BK, bool WT, bool DEEP, bool X6 = false, bool PIPE = false>
 __device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, NewtonState* st, int prod,
                                            int cur, int avg, int tm, int tn, float* smem,
                                            unsigned long long* stamp = nullptr) {
@@ -452,7 +468,7 @@ __device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, Newto
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first pass's tile is re-read
       __syncthreads();
     }
-    newton_product_tile<BK, WT, DEEP, X6>(nb, st, prod, cur, pass ? tn : tm, pass ? tm : tn,
+    newton_product_tile<BK, WT, DEEP, X6, PIPE>(nb, st, prod, cur, pass ? tn : tm, pass ? tm : tn,
                                           pass ? f1 : f0, smem, stamp);
   }
 }
@@ -573,11 +589,16 @@ __device__ inline void write_metrics(float* metrics, int b, float err, int it, f
 // staged execution (PS_NEWTON_PERSISTENT=0)
 // ==================================================================================
 // DEEP = false: 3 workgroups per CU.  DEEP = true: two-K-tile-deep register prefetch, 2 per CU.
-template <int BK, bool DEEP, bool X6 = false>
+// TRACE (dev, PS_NEWTON_TRACE=<file>): one record of 8 x u64 per tile -- launch sequence number,
+// tile index | product << 32, HW_ID | XCC_ID << 32, and the 100 MHz clock at the start of the
+// tile, after its first LDS fill, at the end of its (last) K loop and at its end.
+template <int BK, bool DEEP, bool X6 = false, bool TRACE = false, bool PIPE = false>
 __global__ __launch_bounds__(256, (DEEP && BK == 32) ? 2 : 3) void newton_stage_kernel(
     const NewtonBlock* blocks, NewtonState* states, const NewtonTask* tasks,
-    const TileEntry* tiles, int ntiles, int navg) {
+    const TileEntry* tiles, int ntiles, int navg, unsigned long long* trace = nullptr,
+    unsigned trace_seq = 0, unsigned trace_cap = 0) {
   extern __shared__ __align__(16) float smem[];  // SmemCfg<BK>::TOTAL floats
+  __shared__ unsigned long long s_trace[2];
   (void)navg;
   // gridDim.x == ntiles: one tile per workgroup (hardware dispatch).  A smaller grid
   // (PS_NEWTON_GRID) walks the list with stride gridDim.x; the next tile's descriptors are
@@ -593,10 +614,30 @@ __global__ __launch_bounds__(256, (DEEP && BK == 32) ? 2 : 3) void newton_stage_
     if (more) te_n = tiles[xcd_remap(inext, ntiles)];
     const NewtonBlock* nb = &blocks[tk.block];
     NewtonState* st = &states[tk.block];
+    unsigned long long t0 = 0;
+    if (TRACE) {
+      t0 = __builtin_amdgcn_s_memrealtime();
+      if (threadIdx.x == 0) s_trace[0] = s_trace[1] = 0;
+    }
     // P0 of step 0 (H0 Mi, H0 a scaled identity) was written by newton_init2_tile
     if (st->phase == PH_ACTIVE && !(tk.prod == 0 && st->it == 0))
-      newton_product_item<BK, false, DEEP, X6>(nb, st, tk.prod, st->cur, st->avg_on, te.tm,
-                                               te.tn, smem);
+      newton_product_item<BK, false, DEEP, X6, PIPE>(nb, st, tk.prod, st->cur, st->avg_on, te.tm,
+                                                     te.tn, smem, TRACE ? s_trace : nullptr);
+    if (TRACE && threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left the CU
+      const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+      const unsigned rec = atomicAdd(reinterpret_cast<unsigned*>(trace), 1u);
+      if (rec < trace_cap) {
+        unsigned long long* r = trace + 8 + 8 * (size_t)rec;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+        r[0] = trace_seq;
+        r[1] = (unsigned long long)(unsigned)i | ((unsigned long long)(unsigned)tk.prod << 32);
+        r[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        r[3] = t0; r[4] = s_trace[1]; r[5] = s_trace[0]; r[6] = t3;
+        r[7] = (unsigned long long)(unsigned)te.tm | ((unsigned long long)(unsigned)te.tn << 32);
+      }
+    }
     if (!more) break;
     tk = tasks[te_n.task];
     te = te_n;
@@ -1604,6 +1645,35 @@ static int newton_driver(
   // opt-in arithmetic of the products (read per call: the bench times both modes in one process)
   const bool x6_mode = [] { const char* e = getenv("PS_NEWTON_PRODUCTS");
                             return e && strcmp(e, "bf16x6") == 0; }();
+  // explicitly software-pipelined K loop (gemm_core.hip.h deep_run_pipe): PS_NEWTON_PIPE = 0 | 1
+  const bool pipe_mode = [] { const char* e = getenv("PS_NEWTON_PIPE");
+                              return e ? atoi(e) != 0 : PS_NEWTON_PIPE_DEFAULT; }();
+  static bool pipe_attr = false;
+  if (!pipe_attr) {
+    pipe_attr = true;
+    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true, false, false, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
+    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true, false, true, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
+  }
+  // dev trace of the product kernel (PS_NEWTON_TRACE=<file>: records appended per call)
+  constexpr unsigned TRACE_CAP = 1u << 20;
+  static unsigned long long* trace_buf = nullptr;
+  static unsigned trace_seq = 0;
+  const char* trace_path = getenv("PS_NEWTON_TRACE");
+  if (trace_path && !trace_buf) {
+    if (hipMalloc(&trace_buf, (8 + 8 * (size_t)TRACE_CAP) * sizeof(unsigned long long)) != hipSuccess)
+      trace_buf = nullptr;
+    else
+      (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true, false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(SmemCfg<32>::TOTAL * sizeof(float)));
+  }
+  if (!trace_path) { /* tracing off for this call */ }
+  unsigned long long* const trace_on = trace_path ? trace_buf : nullptr;
+  if (trace_on) (void)hipMemsetAsync(trace_on, 0, 64, st);
   const int ninit = (int)pl.init_tiles.size();
   int executed = 0;
   if (ninit > 0) {
@@ -1636,7 +1706,19 @@ static int newton_driver(
   hipLaunchKernelGGL((newton_stage_kernel<BKV, DEEPV>), dim3(stage_grid(nt)), dim3(256),    \
                      SmemCfg<BKV>::TOTAL * sizeof(float), st, lo.blocks, lo.states,         \
                      lo.tasks[s], lo.tiles[s], nt, navg)
-        if (x6_mode)
+        if (pipe_mode && !x6_mode && trace_on)
+          hipLaunchKernelGGL((newton_stage_kernel<32, true, false, true, true>), dim3(stage_grid(nt)),
+                             dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
+                             lo.tasks[s], lo.tiles[s], nt, navg, trace_on, trace_seq++, TRACE_CAP);
+        else if (pipe_mode && !x6_mode)
+          hipLaunchKernelGGL((newton_stage_kernel<32, true, false, false, true>), dim3(stage_grid(nt)),
+                             dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
+                             lo.tasks[s], lo.tiles[s], nt, navg);
+        else if (trace_on)
+          hipLaunchKernelGGL((newton_stage_kernel<32, true, false, true>), dim3(stage_grid(nt)),
+                             dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
+                             lo.tasks[s], lo.tiles[s], nt, navg, trace_on, trace_seq++, TRACE_CAP);
+        else if (x6_mode)
           hipLaunchKernelGGL((newton_stage_kernel<32, true, true>), dim3(stage_grid(nt)), dim3(256),
                              SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
                              lo.tasks[s], lo.tiles[s], nt, navg);
@@ -1684,6 +1766,15 @@ static int newton_driver(
   prof.end();
   PS_LAUNCH_CHECK();
   prof.finish();
+  if (trace_on) {   // dev only: waits for the stream and appends this call's records to the file
+    PS_HIP(hipStreamSynchronize(st));
+    unsigned long long head[8];
+    PS_HIP(hipMemcpy(head, trace_on, sizeof(head), hipMemcpyDeviceToHost));
+    const size_t nrec = std::min<size_t>((unsigned)head[0], TRACE_CAP);
+    std::vector<unsigned long long> rec(8 * nrec);
+    if (nrec) PS_HIP(hipMemcpy(rec.data(), trace_on + 8, rec.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_path, "ab")) { fwrite(rec.data(), 8, rec.size(), f); fclose(f); }
+  }
   if (iters_executed_host) *iters_executed_host = executed;
   return PS_OK;
 }

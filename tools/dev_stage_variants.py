@@ -17,7 +17,10 @@ for name in ("cfg2_256x512_p4", "headline_64x1024_p4"):
   print("   ", name, "%.2f ms" % best, "checksum %.9e" % float(torch.stack(r).double().abs().sum()), flush=True)
   del st, mats, r; torch.cuda.empty_cache()
 '''
-for bk, deep in (("32", "1"), ("16", "1"), ("32", "1"), ("16", "1"), ("16", "0"), ("32", "0")):
-  env = dict(os.environ, PS_NEWTON_BK=bk, PS_NEWTON_DEEP=deep)
-  print("BK", bk, "DEEP", deep, flush=True)
+combos = [dict(PS_NEWTON_PIPE=pp) for pp in ("1", "0", "1", "0")]
+if len(sys.argv) > 1 and sys.argv[1] == "bk":
+  combos = [dict(PS_NEWTON_BK=bk, PS_NEWTON_DEEP=deep) for bk, deep in (("32", "1"), ("16", "1"), ("16", "0"), ("32", "0"))]
+for c in combos:
+  env = dict(os.environ, **c)
+  print(c, flush=True)
   subprocess.run([sys.executable, "-c", CHILD], env=env, check=False, timeout=300)
