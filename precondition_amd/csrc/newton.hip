@@ -164,7 +164,50 @@ __device__ inline float* resolve(const NewtonBlock* nb, int id, int cur) {
 // steps), first 6 steps 1.66e-4, every step 1.65e-4 (+10...14 %); on well-conditioned blocks
 // all variants are at 1e-6.  The H update and the squares (exactly symmetric for
 // symmetric input) stay mirrored (tools/dev_sym_accuracy.py: averaging them changes nothing).
-enum TileFlags { TF_MIRROR = 1, TF_RAW = 2, TF_AVG = 4, TF_SELFAVG = 8 };
+//   TF_SELFSYM  diagonal tile of a product of two different symmetric matrices: X is replaced by
+//               (X + X^T) / 2 in registers (through LDS) before it is stored
+enum TileFlags { TF_MIRROR = 1, TF_RAW = 2, TF_AVG = 4, TF_SELFAVG = 8, TF_SELFSYM = 16 };
+
+// acc <- (acc + acc^T) / 2 for a DIAGONAL 128x128 tile.  A product A B of two different
+// symmetric matrices is symmetric only up to rounding inside its diagonal blocks (off the
+// diagonal the mirror store makes the iterate bitwise symmetric; squares A A are bitwise
+// symmetric by themselves).  With this the iterates are bitwise symmetric everywhere, which is
+// what lets newton_product_tile read element (k, n) of the right operand as B[n][k].  The tile
+// goes through LDS in two halves of 64 rows (image row stride 132: the layout and the read
+// pattern of average_with_transposed_tile); smem: 64*132 floats, free; ends with a barrier.
+__device__ inline void symmetrize_diag_tile(f32x16 (&acc)[2][2], float* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int TLD = 132;
+  const f32x16 keep = acc[1][0];   // rows of half 1 / columns of half 0: changed in half 0
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    // image of the tile rows with row bit 5 == h: S[ci][col], ci = (row >> 6) * 32 + (row & 31)
+    float* wrow = smem + (wm * 32 + 4 * (lane >> 5)) * TLD + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = (h == 1 && tn == 0) ? keep[4 * g + j] : acc[h][tn][4 * g + j];
+          wrow[(8 * g + j) * TLD + tn * 32] = v;
+        }
+    __syncthreads();
+    const float* trow = smem + (wn * 32 + (lane & 31)) * TLD + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(trow + tm * 32 + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[tm][h][4 * g + j] = __fmul_rn(0.5f, __fadd_rn(acc[tm][h][4 * g + j], pv[j]));
+      }
+    __syncthreads();
+  }
+}
 
 // acc <- (acc + P^T) / 2 with P the 128x128 tile of C at (prow0, pcol0) (the transposed
 // position of the accumulator tile).  P's rows are staged through LDS in two halves with the
@@ -348,6 +391,17 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
   // last steps of a block run the exact float32 products: same stop decisions as the parity path.
   if (X6 && *nb->asym == 0 && st->err > 1e-3f)
     gemm_tile_bf16x6_sym(A.p, B.p, ld, A.mn0, B.mn0, ld, smem, acc);
+  else if (*nb->asym == 0)
+    // Exactly symmetric input block (sym_check): element (k, n) of the right operand is read as
+    // B[n][k], i.e. both operands are staged k-contiguous and every fragment read is a 16-byte
+    // ds_read with an immediate offset -- 4 LDS instructions per 16 MFMAs instead of 6-10 and no
+    // address arithmetic in the K loop (VALU work costs fp32-MFMA cycles: tools/dev_mfma_mix.py).
+    // The iterates are bitwise symmetric outside their diagonal 128 x 128 blocks (mirror store);
+    // inside those, a product of two DIFFERENT symmetric matrices is symmetric only up to
+    // rounding, so this reads the transposed diagonal block of B: the same class of perturbation
+    // as the mirroring itself (section 4a), identical in every execution (staged, persistent,
+    // all K-loop variants take this branch), same k order.
+    gemm_tile<KC, KC, BK, false, DEEP, PIPE>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr);
   else
     gemm_tile<KC, MC, BK, false, DEEP, PIPE>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr);
 
@@ -374,6 +428,7 @@ __device__ __forceinline__ void newton_tile_epilogue(const NewtonBlock* nb, Newt
   const int wm = wave >> 1, wn = wave & 1;
   const int lane_off = 4 * (lane >> 5) * ld + (lane & 31);
   const int lane_row = 4 * (lane >> 5), lane_col = lane & 31;
+  if ((flags & TF_SELFSYM) != 0) symmetrize_diag_tile(acc, smem);
   const bool plain = prod != nb->nprod - 1 || (flags & TF_RAW) != 0;
   if (plain || (flags & TF_SELFAVG) != 0) {
 #pragma unroll
@@ -455,7 +510,7 @@ __device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, Newto
   if (!sym) {
     passes = tm != tn ? 2 : 1;
   } else if (!(avg && prod == nb->nprod - 1)) {
-    f0 = tm != tn ? TF_MIRROR : 0;
+    f0 = tm != tn ? TF_MIRROR : (nb->pa[prod] != nb->pb[prod] ? TF_SELFSYM : 0);
   } else if (tm == tn) {
     f0 = TF_SELFAVG;
   } else {
@@ -1031,7 +1086,7 @@ constexpr bool PERSIST_WT = false;
 // LDS of a product workgroup: the A (k-contiguous) and B (mn-contiguous) images, double
 // buffered, and at least the 64 x 129 floats of the mirror-store staging.
 template <int BK>
-constexpr int PSMEM = SmemCfg<BK>::total(KC, MC) > 64 * 132 ? SmemCfg<BK>::total(KC, MC) : 64 * 132;
+constexpr int PSMEM = SmemCfg<BK>::TOTAL > 64 * 132 ? SmemCfg<BK>::TOTAL : 64 * 132;
 
 // DEEP = false: 3 workgroups per CU (<= 168 VGPRs).  DEEP = true: two-K-tile-deep register
 // prefetch in the K loop, 2 workgroups per CU (the second register set does not fit in 168).
