@@ -314,7 +314,7 @@ __device__ inline void deep_run(const Operand& A, const Operand& B, int Kext, fl
   }
 }
 
-// ---- software-pipelined K loop (KC x MC or KC x KC operands, BK = 32, unguarded) ------------
+// ---- software-pipelined K loop (any operand layouts, BK = 32, unguarded) --------------------
 // deep_run's K-tile body lets the compiler place the fragment reads: it issues each ds_read just
 // before its first use (minimal registers), so a wavefront that is alone on its SIMD stalls on
 // LDS latency several times per 16-MFMA chunk and once more, with a drained MFMA pipe, at the
@@ -333,13 +333,19 @@ struct FragKM {
   float a[2][4], b[2][4];
 };
 
-template <int BK>
+template <int BK, int LA = KC>
 __device__ __forceinline__ void pipe_read_a(const float* sA, int c, int wm, int i, int h, FragKM& f) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(
-        sA + (wm * 64 + t * 32 + i) * SmemCfg<BK>::KC_LD + 8 * c + 4 * h);
-    f.a[t][0] = v[0]; f.a[t][1] = v[1]; f.a[t][2] = v[2]; f.a[t][3] = v[3];
+    if (LA == KC) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(
+          sA + (wm * 64 + t * 32 + i) * SmemCfg<BK>::KC_LD + 8 * c + 4 * h);
+      f.a[t][0] = v[0]; f.a[t][1] = v[1]; f.a[t][2] = v[2]; f.a[t][3] = v[3];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        f.a[t][s] = sA[(8 * c + 4 * h + s) * SmemCfg<BK>::MC_LD + wm * 64 + t * 32 + i];
+    }
   }
 }
 template <int BK>
@@ -370,14 +376,14 @@ __device__ __forceinline__ void pipe_mfma(const FragKM& f, int s, f32x16 (&acc)[
 
 // One chunk: the 16 MFMAs on `use`, with the reads of chunk (cn) of image (nA, nB) into `nxt`
 // spread between the MFMA groups (rd = false: nothing to read).
-template <int BK, int LB>
+template <int BK, int LA, int LB>
 __device__ __forceinline__ void pipe_chunk(const FragKM& use, FragKM& nxt, const float* nA,
                                            const float* nB, int cn, bool rd, int wm, int wn, int i,
                                            int h, f32x16 (&acc)[2][2]) {
   pipe_mfma(use, 0, acc);
   PS_FENCE();
   if (rd) {
-    pipe_read_a<BK>(nA, cn, wm, i, h, nxt);
+    pipe_read_a<BK, LA>(nA, cn, wm, i, h, nxt);
     if (LB == MC) pipe_read_b<BK>(nB, cn, 0, wn, i, h, nxt);
   }
   PS_FENCE();
@@ -397,15 +403,15 @@ __device__ __forceinline__ void pipe_chunk(const FragKM& use, FragKM& nxt, const
   PS_FENCE();
 }
 
-template <int BK, int LB>
+template <int BK, int LA, int LB>
 __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kext, float* smem,
-                                     f32x16 (&acc)[2][2], DeepSets<KC, LB, BK, false>& r,
+                                     f32x16 (&acc)[2][2], DeepSets<LA, LB, BK, false>& r,
                                      unsigned long long* t_fill = nullptr) {
   static_assert(BK == 32, "four 8-deep chunks per K-tile");
-  using LdA = TileLoader<KC, BK, false>;
+  using LdA = TileLoader<LA, BK, false>;
   using LdB = TileLoader<LB, BK, false>;
-  constexpr int OPS = SmemCfg<BK>::op_size(KC);
-  constexpr int STG = SmemCfg<BK>::op_size(KC) + SmemCfg<BK>::op_size(LB);
+  constexpr int OPS = SmemCfg<BK>::op_size(LA);
+  constexpr int STG = SmemCfg<BK>::op_size(LA) + SmemCfg<BK>::op_size(LB);
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -418,7 +424,7 @@ __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kex
   __syncthreads();
   if (t_fill != nullptr && tid == 0) *t_fill = __builtin_amdgcn_s_memrealtime();  // dev trace
   FragKM f0, f1;
-  pipe_read_a<BK>(s0, 0, wm, i, h, f0);
+  pipe_read_a<BK, LA>(s0, 0, wm, i, h, f0);
   if (LB == MC) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) pipe_read_b<BK>(s0 + OPS, 0, s, wn, i, h, f0);
@@ -432,14 +438,14 @@ __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kex
       LdA::load(A, min(kt + 2, nk - 1) * BK, tid, r.ra0);   // unconditional: see deep_run
       LdB::load(B, min(kt + 2, nk - 1) * BK, tid, r.rb0);
       PS_FENCE();
-      pipe_chunk<BK, LB>(f0, f1, s0, s0 + OPS, 1, true, wm, wn, i, h, acc);
+      pipe_chunk<BK, LA, LB>(f0, f1, s0, s0 + OPS, 1, true, wm, wn, i, h, acc);
       if (nxt) { LdA::store(s1, tid, r.ra1); LdB::store(s1 + OPS, tid, r.rb1); }
       PS_FENCE();
-      pipe_chunk<BK, LB>(f1, f0, s0, s0 + OPS, 2, true, wm, wn, i, h, acc);
-      pipe_chunk<BK, LB>(f0, f1, s0, s0 + OPS, 3, true, wm, wn, i, h, acc);
+      pipe_chunk<BK, LA, LB>(f1, f0, s0, s0 + OPS, 2, true, wm, wn, i, h, acc);
+      pipe_chunk<BK, LA, LB>(f0, f1, s0, s0 + OPS, 3, true, wm, wn, i, h, acc);
       __syncthreads();
       PS_FENCE();
-      pipe_chunk<BK, LB>(f1, f0, s1, s1 + OPS, 0, nxt, wm, wn, i, h, acc);
+      pipe_chunk<BK, LA, LB>(f1, f0, s1, s1 + OPS, 0, nxt, wm, wn, i, h, acc);
       if (!nxt) break;
     }
     // ---- odd K-tile: image in s1; set 0 holds K-tile kt+2 (-> s0); set 1 is free -> kt+3 ----
@@ -448,14 +454,14 @@ __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kex
       LdA::load(A, min(kt + 3, nk - 1) * BK, tid, r.ra1);
       LdB::load(B, min(kt + 3, nk - 1) * BK, tid, r.rb1);
       PS_FENCE();
-      pipe_chunk<BK, LB>(f0, f1, s1, s1 + OPS, 1, true, wm, wn, i, h, acc);
+      pipe_chunk<BK, LA, LB>(f0, f1, s1, s1 + OPS, 1, true, wm, wn, i, h, acc);
       if (nxt) { LdA::store(s0, tid, r.ra0); LdB::store(s0 + OPS, tid, r.rb0); }
       PS_FENCE();
-      pipe_chunk<BK, LB>(f1, f0, s1, s1 + OPS, 2, true, wm, wn, i, h, acc);
-      pipe_chunk<BK, LB>(f0, f1, s1, s1 + OPS, 3, true, wm, wn, i, h, acc);
+      pipe_chunk<BK, LA, LB>(f1, f0, s1, s1 + OPS, 2, true, wm, wn, i, h, acc);
+      pipe_chunk<BK, LA, LB>(f0, f1, s1, s1 + OPS, 3, true, wm, wn, i, h, acc);
       __syncthreads();
       PS_FENCE();
-      pipe_chunk<BK, LB>(f1, f0, s0, s0 + OPS, 0, nxt, wm, wn, i, h, acc);
+      pipe_chunk<BK, LA, LB>(f1, f0, s0, s0 + OPS, 0, nxt, wm, wn, i, h, acc);
     }
   }
   // every LDS read was waited for by the barrier of the last K-tile: smem is free
@@ -513,8 +519,8 @@ __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int K
   // ---- two register sets, loop unrolled by two so that the set indices are static ----
   DeepSets<LA, LB, BK, GUARD> sets;
   deep_issue_first<LA, LB, BK, GUARD>(A, B, Kext, sets);
-  if constexpr (PIPE && LA == KC && BK == 32 && !GUARD)
-    deep_run_pipe<BK, LB>(A, B, Kext, smem, acc, sets, t_fill);
+  if constexpr (PIPE && BK == 32 && !GUARD)
+    deep_run_pipe<BK, LA, LB>(A, B, Kext, smem, acc, sets, t_fill);
   else
     deep_run<LA, LB, BK, GUARD>(A, B, Kext, smem, acc, sets, t_fill);
 }

@@ -93,6 +93,8 @@ struct NewtonState {
   // NEXT step still averages (newton_avg_next: a fixed number of leading steps)
   unsigned asym_bits, xmax_bits;
   int avg_on;
+  int general;        // != 0: the block is not exactly symmetric (copy of *NewtonBlock::asym, written
+                      // by newton_setup_kernel: one dependent load less at the head of every tile)
   float asym_first;   // number of steps (all tries) whose M update was averaged: PS_M_AVG_STEPS
   int power_iters;
   // arrival counters of the persistent execution
@@ -105,10 +107,13 @@ struct NewtonTask {
   int prod;
 };
 
+// Stage tile lists: task = block | product << 24 (no second table between a tile and its block);
+// init tile list: task = block.
 struct TileEntry {
   int task;
   short tm, tn;
 };
+constexpr int TE_BLOCK_MASK = 0xffffff;
 
 struct HostStatus {
   int gen;
@@ -389,9 +394,9 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
   // Near convergence (max|M - I| < 1e-3 at the start of the step) the split products' noise floor
   // (~2e-6 in max|M - I| on cond 1e4 blocks) is above the 1e-6 stop threshold of DS:836, so the
   // last steps of a block run the exact float32 products: same stop decisions as the parity path.
-  if (X6 && *nb->asym == 0 && st->err > 1e-3f)
+  if (X6 && st->general == 0 && st->err > 1e-3f)
     gemm_tile_bf16x6_sym(A.p, B.p, ld, A.mn0, B.mn0, ld, smem, acc);
-  else if (*nb->asym == 0)
+  else if (st->general == 0)
     // Exactly symmetric input block (sym_check): element (k, n) of the right operand is read as
     // B[n][k], i.e. both operands are staged k-contiguous and every fragment read is a 16-byte
     // ds_read with an immediate offset -- 4 LDS instructions per 16 MFMAs instead of 6-10 and no
@@ -505,7 +510,7 @@ template <int BK, bool WT, bool DEEP, bool X6 = false, bool PIPE = false>
 __device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, NewtonState* st, int prod,
                                            int cur, int avg, int tm, int tn, float* smem,
                                            unsigned long long* stamp = nullptr) {
-  const bool sym = *nb->asym == 0;
+  const bool sym = st->general == 0;
   int passes = 1, f0 = 0, f1 = 0;
   if (!sym) {
     passes = tm != tn ? 2 : 1;
@@ -649,7 +654,7 @@ __device__ inline void write_metrics(float* metrics, int b, float err, int it, f
 // tile, after its first LDS fill, at the end of its (last) K loop and at its end.
 template <int BK, bool DEEP, bool X6 = false, bool TRACE = false, bool PIPE = false>
 __global__ __launch_bounds__(256, (DEEP && BK == 32) ? 2 : 3) void newton_stage_kernel(
-    const NewtonBlock* blocks, NewtonState* states, const NewtonTask* tasks,
+    const NewtonBlock* blocks, NewtonState* states,
     const TileEntry* tiles, int ntiles, int navg, unsigned long long* trace = nullptr,
     unsigned trace_seq = 0, unsigned trace_cap = 0) {
   extern __shared__ __align__(16) float smem[];  // SmemCfg<BK>::TOTAL floats
@@ -661,7 +666,7 @@ __global__ __launch_bounds__(256, (DEEP && BK == 32) ? 2 : 3) void newton_stage_
   const int stride = gridDim.x;
   int i = blockIdx.x;
   TileEntry te = tiles[xcd_remap(i, ntiles)];
-  NewtonTask tk = tasks[te.task];
+  NewtonTask tk{te.task & TE_BLOCK_MASK, te.task >> 24};
   while (true) {
     const int inext = i + stride;
     const bool more = inext < ntiles;
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(256, (DEEP && BK == 32) ? 2 : 3) void newton_stage_
       }
     }
     if (!more) break;
-    tk = tasks[te_n.task];
+    tk = NewtonTask{te_n.task & TE_BLOCK_MASK, te_n.task >> 24};
     te = te_n;
     i = inext;
     __syncthreads();  // smem (reduction scratch of the epilogue) is reused by the next tile
@@ -797,6 +802,7 @@ __global__ void newton_setup_kernel(NewtonState* states, const PiBlock* pis, int
     else { max_ev = pis[b].lambda; pit = pis[b].iters; }
   }
   st->max_ev = max_ev;
+  st->general = *pis[b].asym;
   st->power_iters = pit;
   st->ridge = __fmul_rn(ridge_epsilon, fmaxf(max_ev, 1e-25f));
   // fmaxf drops a NaN max_ev; jnp.maximum propagates it.
@@ -1236,7 +1242,6 @@ struct Plan {
   int nlive = 0;
   // staged execution
   int nstages = 0;
-  std::vector<std::vector<NewtonTask>> stage_tasks;
   std::vector<std::vector<TileEntry>> stage_tiles;
   std::vector<TileEntry> init_tiles;  // one per (block, tile)
   PiPlan pip;
@@ -1340,7 +1345,6 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
   for (auto& c : pl.chains)
     if (!c.empty())
       pl.nstages = std::max(pl.nstages, stage_of(c.size() - 1, c.size()) + 1);
-  pl.stage_tasks.assign(pl.nstages, {});
   pl.stage_tiles.assign(pl.nstages, {});
   for (int b = 0; b < batch; ++b) {
     auto& c = pl.chains[b];
@@ -1350,11 +1354,9 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
       for (int tn = 0; tn < t; ++tn) pl.init_tiles.push_back({b, (short)tm, (short)tn});
     for (size_t k = 0; k < c.size(); ++k) {
       const int s = stage_of(k, c.size());
-      const int tid = (int)pl.stage_tasks[s].size();
-      pl.stage_tasks[s].push_back({b, (int)k});
       for (int tm = 0; tm < t; ++tm)
         for (int tn = tm; tn < t; ++tn)
-          pl.stage_tiles[s].push_back({tid, (short)tm, (short)tn});
+          pl.stage_tiles[s].push_back({b | ((int)k << 24), (short)tm, (short)tn});
     }
   }
 }
@@ -1375,7 +1377,6 @@ struct WsLayout {
   PControl* ctl;
   u64* slots;
   u64* prof;
-  NewtonTask* tasks[MAX_PROD];
   TileEntry* tiles[MAX_PROD];
   TileEntry* init_tiles;
   std::vector<float*> mat[10];
@@ -1394,9 +1395,8 @@ size_t carve(Plan& pl, Arena& ar, WsLayout* lo, bool staged) {
             lo->prof = prof; }
   if (staged) {
     for (int s = 0; s < pl.nstages; ++s) {
-      NewtonTask* t = ar.take<NewtonTask>(pl.stage_tasks[s].size());
       TileEntry* e = ar.take<TileEntry>(pl.stage_tiles[s].size());
-      if (lo) { lo->tasks[s] = t; lo->tiles[s] = e; }
+      if (lo) { lo->tiles[s] = e; }
     }
     TileEntry* it = ar.take<TileEntry>(pl.init_tiles.size());
     if (lo) { lo->init_tiles = it; }
@@ -1607,8 +1607,6 @@ static int newton_driver(
   };
   if (staged) {
     for (int s = 0; s < pl.nstages; ++s) {
-      PS_RC(psh::upload_async(st, lo.tasks[s], pl.stage_tasks[s].data(),
-                              sizeof(NewtonTask) * pl.stage_tasks[s].size()));
       PS_RC(psh::upload_async(st, lo.tiles[s], pl.stage_tiles[s].data(),
                               sizeof(TileEntry) * pl.stage_tiles[s].size()));
     }
@@ -1760,23 +1758,23 @@ static int newton_driver(
 #define PS_STAGE(BKV, DEEPV)                                                              \
   hipLaunchKernelGGL((newton_stage_kernel<BKV, DEEPV>), dim3(stage_grid(nt)), dim3(256),    \
                      SmemCfg<BKV>::TOTAL * sizeof(float), st, lo.blocks, lo.states,         \
-                     lo.tasks[s], lo.tiles[s], nt, navg)
+                     lo.tiles[s], nt, navg)
         if (pipe_mode && !x6_mode && trace_on)
           hipLaunchKernelGGL((newton_stage_kernel<32, true, false, true, true>), dim3(stage_grid(nt)),
                              dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tasks[s], lo.tiles[s], nt, navg, trace_on, trace_seq++, TRACE_CAP);
+                             lo.tiles[s], nt, navg, trace_on, trace_seq++, TRACE_CAP);
         else if (pipe_mode && !x6_mode)
           hipLaunchKernelGGL((newton_stage_kernel<32, true, false, false, true>), dim3(stage_grid(nt)),
                              dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tasks[s], lo.tiles[s], nt, navg);
+                             lo.tiles[s], nt, navg);
         else if (trace_on)
           hipLaunchKernelGGL((newton_stage_kernel<32, true, false, true>), dim3(stage_grid(nt)),
                              dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tasks[s], lo.tiles[s], nt, navg, trace_on, trace_seq++, TRACE_CAP);
+                             lo.tiles[s], nt, navg, trace_on, trace_seq++, TRACE_CAP);
         else if (x6_mode)
           hipLaunchKernelGGL((newton_stage_kernel<32, true, true>), dim3(stage_grid(nt)), dim3(256),
                              SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tasks[s], lo.tiles[s], nt, navg);
+                             lo.tiles[s], nt, navg);
         else if (stage_bk == 32 && stage_deep) PS_STAGE(32, true);
         else if (stage_bk == 32) PS_STAGE(32, false);
         else if (stage_deep) PS_STAGE(16, true);
