@@ -3,7 +3,7 @@ process, so each variant runs in a child process)."""
 import os, subprocess, sys
 CHILD = r'''
 import sys; sys.path.insert(0, ".")
-import torch, bench, time
+import torch, bench, time, os
 from precondition_amd import kernels as K
 dev = torch.device("cuda:0")
 for name in ("cfg2_256x512_p4", "headline_64x1024_p4"):
@@ -16,8 +16,17 @@ for name in ("cfg2_256x512_p4", "headline_64x1024_p4"):
     torch.cuda.synchronize(); best = min(best, (time.perf_counter()-t0)/5*1e3)
   print("   ", name, "%.2f ms" % best, "checksum %.9e" % float(torch.stack(r).double().abs().sum()), flush=True)
   del st, mats, r; torch.cuda.empty_cache()
+if "vit" in os.environ.get("PS_DEV_EXTRA", ""):
+  w = bench.VitBWorkload(0, 1, dev, None)
+  for _ in range(2): w.step()
+  best = 1e9
+  for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(2): w.step()
+    torch.cuda.synchronize(); best = min(best, (time.perf_counter()-t0)/2*1e3)
+  print("    vit_b %.1f ms" % best, flush=True)
 '''
-combos = [dict(PS_NEWTON_PIPE=pp) for pp in ("1", "0", "1", "0")]
+combos = [dict(PS_NEWTON_WALK=w) for w in ("0", "1", "0", "1")]
 if len(sys.argv) > 1 and sys.argv[1] == "bk":
   combos = [dict(PS_NEWTON_BK=bk, PS_NEWTON_DEEP=deep) for bk, deep in (("32", "1"), ("16", "1"), ("16", "0"), ("32", "0"))]
 for c in combos:
