@@ -10,7 +10,9 @@
 * the eigh root path of blocks of more than 128 rows (DS:943-1030): one-sided block Jacobi on the
   Cholesky factor against the oracle's LAPACK root, the fallback for inputs that are not
   positive definite, mixed batches, and both executions of the sweep loop;
-* ps_diag_mfma_clock returns a plausible clock.
+* ps_diag_mfma_clock returns a plausible clock; ps_diag_mfma_mix shows the VALU / MFMA trade;
+* round-3 product kernel: roots of symmetric inputs are bitwise symmetric; the K-loop variants and
+  the traced kernel are bit-identical.
 """
 import ctypes as C
 import os
@@ -243,6 +245,66 @@ def test_diag_mfma_clock(device):
   # an MFMA-only loop reaches most of the fp32 MFMA peak at the clock it runs at
   cus = torch.cuda.get_device_properties(device).multi_processor_count
   assert tf.value > 0.8 * cus * 4 * 64 * ghz.value / 1e3, (tf.value, ghz.value)
+
+
+def test_diag_mfma_mix(device):
+  """VALU work between fp32 MFMAs costs MFMA throughput (what the K-loop design rests on)."""
+  st = torch.cuda.current_stream().cuda_stream
+  tf = {}
+  for nv in (0, 64):
+    v = C.c_double()
+    assert L().ps_diag_mfma_mix(st, nv, 0, 1, C.byref(v)) == 0
+    tf[nv] = v.value
+  assert tf[0] > 100.0 and tf[64] < 0.9 * tf[0], tf
+  v = C.c_double()
+  assert L().ps_diag_mfma_mix(st, 5, 0, 1, C.byref(v)) != 0   # unsupported mix
+
+
+@pytest.mark.parametrize("n,k,p", [(300, 900, 4), (512, 2048, 2), (1000, 1100, 4), (96, 400, 4)])
+def test_newton_root_of_symmetric_input_is_bitwise_symmetric(n, k, p, device):
+  """Round 3: the iterates of an exactly symmetric block are bitwise symmetric (mirror store off
+  the diagonal, (X + X^T)/2 inside the diagonal tiles of the M and H updates), which is what
+  allows the product kernel to read the right operand transposed.  Observable at the boundary:
+  the returned root equals its transpose bit for bit, and still matches the oracle (DS:702)."""
+  a = wishart(n, k, 300 + n)
+  a_d = torch.tensor(a, device=device)
+  r, m = K().matrix_inverse_pth_root_batched([a_d], [p])
+  h = r[0]
+  assert torch.equal(h, h.t().contiguous())
+  h_ref, m_ref = orc.matrix_inverse_pth_root(a, p)
+  rel = np.linalg.norm(h.cpu().numpy() - h_ref) / np.linalg.norm(h_ref)
+  assert rel < (5e-3 if n == 1000 else 1e-4), rel   # 1000 x 1100: cond ~1e6 (two f32 evaluations differ)
+  assert abs(float(m[0, 1]) - m_ref["inverse_pth_root_iters"]) <= (1 if n == 1000 else 0)
+
+
+def test_newton_product_kernel_variants_bit_identical_and_trace(device, monkeypatch, tmp_path):
+  """The explicitly pipelined K loop (default), the compiler-scheduled one (PS_NEWTON_PIPE=0) and
+  the traced kernel (PS_NEWTON_TRACE) compute the same bits; the trace holds one 64-byte record
+  per tile with ordered time stamps."""
+  arrs = [wishart(512, 2048, 80), wishart(384, 768, 81), wishart(130, 600, 82)]
+  asym = wishart(256, 512, 83); asym[2, 9] *= 1.0001     # a block that is not exactly symmetric
+  arrs.append(asym)
+  mats = [torch.tensor(a, device=device) for a in arrs]
+  ps = [4, 2, 4, 4]
+  r1, m1 = K().matrix_inverse_pth_root_batched(mats, ps)
+  monkeypatch.setenv("PS_NEWTON_PIPE", "0")
+  r0, m0 = K().matrix_inverse_pth_root_batched(mats, ps)
+  monkeypatch.delenv("PS_NEWTON_PIPE")
+  path = tmp_path / "stage_trace.bin"
+  monkeypatch.setenv("PS_NEWTON_TRACE", str(path))
+  rt, mt = K().matrix_inverse_pth_root_batched(mats, ps)
+  monkeypatch.delenv("PS_NEWTON_TRACE")
+  for i in range(len(mats)):
+    assert torch.equal(r1[i], r0[i]) and torch.equal(r1[i], rt[i]), i
+  assert torch.equal(m1, m0) and torch.equal(m1, mt)
+  rec = np.fromfile(str(path), dtype=np.uint64).reshape(-1, 8)
+  assert len(rec) > 0
+  t0, t3 = rec[:, 3].astype(np.int64), rec[:, 6].astype(np.int64)
+  assert np.all(t3 >= t0)
+  ran = rec[:, 5] > 0                                   # tiles that executed a K loop
+  assert ran.any()
+  tf, tk = rec[ran, 4].astype(np.int64), rec[ran, 5].astype(np.int64)
+  assert np.all(tf >= t0[ran]) and np.all(tk >= tf) and np.all(t3[ran] >= tk)
 
 
 # ---------------------------------------------------------------------------
