@@ -235,14 +235,20 @@ class VitBWorkload:
           f += 2.0 * d * blk.numel() * (t + 1) / (2.0 * t)
     return f
 
-  def stats_step(self):
+  def stats_step(self, subset=None):
+    """subset: None = every statistic; "matrix" / "vector" = only the statistics of blocks whose
+    contraction length is >= 128 / is 1 (the MFMA-bound and the HBM-bound part of the launch)."""
     from precondition_amd import kernels as K
     items = []
     for pc, g, st in zip(self.pcs, self.grads, self.stats):
       items.extend(pc.statistics_update_items(st, g, st))  # in place
     if self.world > 1:
       items = [it for it, m in zip(items, self.mine) if m]
+    if subset is not None:
+      kdim = lambda it: it[0].numel() // it[0].shape[it[1]]
+      items = [it for it in items if (kdim(it) >= 128) == (subset == "matrix")]
     K.stats_update_grouped(items, 0.999, 1.0 - 0.999)
+    return items
 
   def step(self):
     from precondition_amd import comm
@@ -827,6 +833,26 @@ def main():
         vw.stats_step()
         ev1.record(); _sync()
         st_ms += ev0.elapsed_time(ev1) / 5
+      # the two halves of the launch by themselves: matrix-shaped blocks (MFMA-bound) and the
+      # d x d outer products of the vector blocks (HBM-bound: 8 d^2 bytes each)
+      st_part = {}
+      for sub in ("matrix", "vector"):
+        vw.stats_step(sub); _sync()
+        ms = 0.0
+        for _ in range(5):
+          ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          for _f in range(4):
+            torch.mm(filler, filler)
+          ev0.record()
+          its = vw.stats_step(sub)
+          ev1.record(); _sync()
+          ms += ev0.elapsed_time(ev1) / 5
+        fl = by = 0.0
+        for g_, axis_, _o, _n in its:
+          d_ = g_.shape[axis_]; t_ = (d_ + 127) // 128
+          fl += 2.0 * d_ * g_.numel() * (t_ + 1) / (2.0 * t_)
+          by += 8.0 * d_ * d_
+        st_part[sub] = (ms, fl, by, len(its))
       del filler
     st_fl = vw.stats_flops / (world if world > 1 else 1)  # owner-only statistics when sharded
     st_ex = vw.stats_executed_flops() / (world if world > 1 else 1)
@@ -851,7 +877,21 @@ def main():
             "ms_per_tree": round(st_ms, 3),
             "timing": "HIP events around the grouped call on the launch stream (descriptor "
                       "upload + kernel; the stream is kept busy while the host builds the "
-                      "descriptors)"},
+                      "descriptors)",
+            **({} if SELFTEST else {
+                "matrix_blocks": {
+                    "statistics": st_part["matrix"][3], "ms": round(st_part["matrix"][0], 3),
+                    "bound": "mfma", "achieved_tflops": round(
+                        st_part["matrix"][1] / (st_part["matrix"][0] * 1e-3) / 1e12, 2),
+                    "frac": round(st_part["matrix"][1] / (st_part["matrix"][0] * 1e-3) / 1e12 /
+                                  PEAK_F32_MFMA_TFLOPS, 4)},
+                "vector_blocks": {
+                    "statistics": st_part["vector"][3], "ms": round(st_part["vector"][0], 3),
+                    "bound": "hbm", "peak_GBps": 8000,
+                    "achieved_GBps": round(st_part["vector"][2] / (st_part["vector"][0] * 1e-3) / 1e9, 1),
+                    "frac": round(st_part["vector"][2] / (st_part["vector"][0] * 1e-3) / 8e12, 4),
+                    "note": "w1 S + w2 g g^T of a vector block reads and writes its d x d "
+                            "statistic once: 8 d^2 bytes, no MFMA work; launched alone"}})},
         "newton_iters": {"min": float(vm[:, 1].min()), "max": float(vm[:, 1].max()),
                          "mean": round(float(vm[:, 1].mean()), 2)},
         "retries_max": float(vm[:, 4].max()),

@@ -401,11 +401,9 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
     // B[n][k], i.e. both operands are staged k-contiguous and every fragment read is a 16-byte
     // ds_read with an immediate offset -- 4 LDS instructions per 16 MFMAs instead of 6-10 and no
     // address arithmetic in the K loop (VALU work costs fp32-MFMA cycles: tools/dev_mfma_mix.py).
-    // The iterates are bitwise symmetric outside their diagonal 128 x 128 blocks (mirror store);
-    // inside those, a product of two DIFFERENT symmetric matrices is symmetric only up to
-    // rounding, so this reads the transposed diagonal block of B: the same class of perturbation
-    // as the mirroring itself (section 4a), identical in every execution (staged, persistent,
-    // all K-loop variants take this branch), same k order.
+    // Exact because the iterates are bitwise symmetric: mirror store off the diagonal,
+    // symmetrize_diag_tile inside the diagonal tiles (section 4a).  Same k order as the
+    // mn-contiguous path; every execution (staged, persistent, all K-loop variants) takes it.
     gemm_tile<KC, KC, BK, false, DEEP, PIPE>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr);
   else
     gemm_tile<KC, MC, BK, false, DEEP, PIPE>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr);

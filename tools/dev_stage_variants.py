@@ -26,7 +26,7 @@ if "vit" in os.environ.get("PS_DEV_EXTRA", ""):
     torch.cuda.synchronize(); best = min(best, (time.perf_counter()-t0)/2*1e3)
   print("    vit_b %.1f ms" % best, flush=True)
 '''
-combos = [dict(PS_NEWTON_WALK=w) for w in ("0", "1", "0", "1")]
+combos = [dict(PS_NEWTON_AVG_STEPS=w) for w in ("4", "0", "2", "4")]
 if len(sys.argv) > 1 and sys.argv[1] == "bk":
   combos = [dict(PS_NEWTON_BK=bk, PS_NEWTON_DEEP=deep) for bk, deep in (("32", "1"), ("16", "1"), ("16", "0"), ("32", "0"))]
 for c in combos:
