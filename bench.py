@@ -298,11 +298,13 @@ def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
     from precondition_amd import kernels as K
     b = 96
     cs = [torch.randn((d, d), generator=gen, device=dev) for _ in range(factors)]
-    c16 = [K.to_bf16(c, split=True) for c in cs]
+    tiled = os.environ.get("PS_FD_TILED", "1") != "0"   # the layout subspace.py uses
+    c16 = [K.to_bf16(c, split=True, tiled=tiled) for c in cs]
     y = torch.randn((factors * d, b), generator=gen, device=dev)
     z = torch.empty((factors, d, b), device=dev)
     yt = K.to_bf16(y, split=True, transpose=True)
-    items = [((c16[j][0], c16[j][1]), (yt[0][:, j * d:(j + 1) * d], yt[1][:, j * d:(j + 1) * d]),
+    items = [(c16[j] if tiled else (c16[j][0], c16[j][1]),
+              (yt[0][:, j * d:(j + 1) * d], yt[1][:, j * d:(j + 1) * d]),
               z[j]) for j in range(factors)]
     K.gemm_bf16_grouped(items); _sync()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

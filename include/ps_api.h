@@ -300,13 +300,20 @@ int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count, void*
  * accumulated).  Requirements: k % 32 == 0, lda % 8 == 0, ldb % 8 == 0, 16-byte aligned
  * bases (PS_EUNSUPPORTED otherwise).
  * ps_convert_f32_to_bf16 produces the operands: dst_hi[r][c] = bf16(src[r][c]) (round to
- * nearest even), dst_lo (may be NULL) = bf16(src - hi); transpose != 0 writes dst[c][r]. */
+ * nearest even), dst_lo (may be NULL) = bf16(src - hi); transpose = 1 writes dst[c][r];
+ * transpose = 2 writes the tile-blocked layout of a left operand (a_tiled): tile (i, j) of 128
+ * rows x 32 columns is contiguous at ((i * (cols / 32) + j) * 4096) elements, so that a product
+ * streams whole DRAM pages of it (cols % 32 == 0; the destination holds ceil(rows/128)*128*cols
+ * elements, ldd is ignored). */
 typedef struct {
   const void* a_hi; const void* a_lo;   /* bf16 [m][k], leading dimension lda (elements) */
   const void* b_hi; const void* b_lo;   /* bf16 [n][k], leading dimension ldb */
   float* c;                             /* float32 [m][n], leading dimension ldc */
   int32_t m, n, k;
   int64_t lda, ldb, ldc;
+  int32_t a_tiled;   /* != 0: the A planes are tile-blocked (ps_convert_f32_to_bf16, transpose = 2):
+                        [ceil(m/128)][k/32][128][32], rows past m zero; lda is ignored */
+  int32_t reserved;  /* 0 */
 } ps_gemm_bf16_desc;
 
 int ps_convert_f32_to_bf16(void* stream, const float* src, void* dst_hi, void* dst_lo,

@@ -51,7 +51,8 @@ class GemmBf16Desc(C.Structure):
   """Mirror of ps_gemm_bf16_desc."""
   _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("b_hi", C.c_void_p),
               ("b_lo", C.c_void_p), ("c", C.c_void_p), ("m", C.c_int32), ("n", C.c_int32),
-              ("k", C.c_int32), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64)]
+              ("k", C.c_int32), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+              ("a_tiled", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TransformDesc(C.Structure):

@@ -38,6 +38,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // bound by the bytes a CU can take in (A rows from HBM plus the iterate's K-slices from L2,
 // 3.5 MB per workgroup), not by line granularity.
 constexpr int HBK = 32;
+#ifndef PS_HSETS
+#define PS_HSETS 2
+#endif
+constexpr int HSETS = PS_HSETS;   // register sets of global loads in flight per workgroup (even)
 constexpr int HLD = HBK + 8;      // LDS row stride in bf16 elements (80 bytes)
 constexpr int HOP = TILE * HLD;   // bf16 elements of one operand image
 
@@ -49,6 +53,7 @@ struct HTask {
   int64_t lda, ldb, ldc;
   int ksplit, kchunk;   // split-K (deterministic two-pass), as in ps_gemm_grouped_f32
   float* partial;       // [ksplit][m][n] when ksplit > 1
+  int a_tiled;          // A planes in the tile-blocked layout (ps_convert_f32_to_bf16 mode 2)
 };
 struct HTile { int task; short tm, tn; int ks; };
 
@@ -63,8 +68,13 @@ __device__ inline void hload(const uint16_t* base, int64_t ld, int row0, int row
   for (int v = 0; v < HV; ++v) {
     const int f = tid + 256 * v;
     const int row = f / HCPR, kc = (f % HCPR) * 8;
-    u32x4 t = {0u, 0u, 0u, 0u};
-    if (row0 + row < rows) t = gload16(base + (int64_t)(row0 + row) * ld + k0 + kc);
+    // unconditional load of a clamped row, masked afterwards: a predicated load is compiled as a
+    // branch around it, and with loads on conditional paths the compiler's vmcnt waits fall back
+    // to vmcnt(0) -- no second register set would ever be in flight
+    const int rr = min(row0 + row, rows - 1);
+    const unsigned keep = row0 + row < rows ? 0xffffffffu : 0u;
+    u32x4 t = gload16(base + (int64_t)rr * ld + k0 + kc);
+    t.x &= keep; t.y &= keep; t.z &= keep; t.w &= keep;
     r[v] = t;
   }
 }
@@ -97,57 +107,78 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
   const int nk = (min(tk.kchunk, tk.k - kbeg) + HBK - 1) / HBK;   // (checked on the host)
   f32x16 acc[2][2];
   zero_acc(acc);
-  u32x4 ra[SA][HV], rb[SB][HV];
-  hload(tk.a_hi, tk.lda, row0, tk.m, kbeg, tid, ra[0]);
-  if (SA == 2) hload(tk.a_lo, tk.lda, row0, tk.m, kbeg, tid, ra[SA - 1]);
-  hload(tk.b_hi, tk.ldb, col0, tk.n, kbeg, tid, rb[0]);
-  if (SB == 2) hload(tk.b_lo, tk.ldb, col0, tk.n, kbeg, tid, rb[SB - 1]);
-  hstore(hs, tid, ra[0]);
-  if (SA == 2) hstore(hs + HOP, tid, ra[SA - 1]);
-  hstore(hs + SA * HOP, tid, rb[0]);
-  if (SB == 2) hstore(hs + (SA + 1) * HOP, tid, rb[SB - 1]);
+  u32x4 ra[HSETS][SA][HV], rb[HSETS][SB][HV];
+  // Tile-blocked A (the 4096^2 covariance of the FD branch): tile (tm, kt) is 128 x 32 bf16 =
+  // 8 KB CONTIGUOUS, so a workgroup streams whole DRAM pages; row-major, every K-tile touches
+  // 128 half cache lines that lie 8 KB apart (65536 concurrent row streams over the chip: the
+  // product ran at 0.44 of the HBM peak whatever the prefetch depth).  Same loader: a tile is a
+  // 128 x 32 matrix with leading dimension 32 (rows beyond m are zero padding in the buffer).
+  const bool at = tk.a_tiled != 0;
+  const int64_t a_ld = at ? HBK : tk.lda;
+  const int a_row0 = at ? 0 : row0, a_rows = at ? TILE : tk.m;
+  const int64_t a_tile0 = at ? (int64_t)te.tm * (tk.k / HBK) * (TILE * HBK) : 0;
+  const uint16_t* a_hi = tk.a_hi + a_tile0;
+  const uint16_t* a_lo = SA == 2 ? tk.a_lo + a_tile0 : nullptr;
+  // element offset of K-tile k0 / HBK inside the row panel
+  auto a_off = [&](int k0) { return at ? (int64_t)(k0 / HBK) * (TILE * HBK) : (int64_t)0; };
+  auto a_k = [&](int k0) { return at ? 0 : k0; };
+  // HSETS register sets of global loads in flight (tile t lives in set t % HSETS from its request,
+  // issued when that set was last written to LDS, until it is written to the LDS stage at the
+  // bottom of K-tile t - 1).  Requests past the end re-read the last K-tile: unconditional loads
+  // keep the compiler's vmcnt exact.  Measured on the cfg5 product (8 x 4096^2 @ 4096 x 96, hi/lo):
+  // 1, 2 or 4 sets make no difference (0.150-0.156 ms) -- the product is not bound by the
+  // latency a workgroup can cover; the tile-blocked A layout is what moved it (0.167 -> 0.150).
+  auto load_set = [&](int sidx, int t) {
+    const int k0 = kbeg + min(t, nk - 1) * HBK;
+    hload(a_hi + a_off(k0), a_ld, a_row0, a_rows, a_k(k0), tid, ra[sidx][0]);
+    if (SA == 2) hload(a_lo + a_off(k0), a_ld, a_row0, a_rows, a_k(k0), tid, ra[sidx][SA - 1]);
+    hload(tk.b_hi, tk.ldb, col0, tk.n, k0, tid, rb[sidx][0]);
+    if (SB == 2) hload(tk.b_lo, tk.ldb, col0, tk.n, k0, tid, rb[sidx][SB - 1]);
+  };
+  auto store_set = [&](int sidx, uint16_t* dst) {
+    hstore(dst, tid, ra[sidx][0]);
+    if (SA == 2) hstore(dst + HOP, tid, ra[sidx][SA - 1]);
+    hstore(dst + SA * HOP, tid, rb[sidx][0]);
+    if (SB == 2) hstore(dst + (SA + 1) * HOP, tid, rb[sidx][SB - 1]);
+  };
+#pragma unroll
+  for (int u = 0; u < HSETS; ++u) load_set(u, u);
+  store_set(0, hs);
   __syncthreads();
   const int fr = lane & 31, fk = 8 * (lane >> 5);
-  for (int kt = 0; kt < nk; ++kt) {
-    uint16_t* cur = hs + (kt & 1) * STG;
-    uint16_t* nxt = hs + ((kt + 1) & 1) * STG;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      const int k0 = kbeg + (kt + 1) * HBK;
-      hload(tk.a_hi, tk.lda, row0, tk.m, k0, tid, ra[0]);
-      if (SA == 2) hload(tk.a_lo, tk.lda, row0, tk.m, k0, tid, ra[SA - 1]);
-      hload(tk.b_hi, tk.ldb, col0, tk.n, k0, tid, rb[0]);
-      if (SB == 2) hload(tk.b_lo, tk.ldb, col0, tk.n, k0, tid, rb[SB - 1]);
-    }
+  for (int kt = 0; kt < nk; kt += HSETS) {
 #pragma unroll
-    for (int ks = 0; ks < HBK / 16; ++ks) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+    for (int u = 0; u < HSETS; ++u) {
+      const int t = kt + u;
+      if (t >= nk) break;
+      uint16_t* cur = hs + (u & 1) * STG;          // HSETS is even: t & 1 == u & 1
+      uint16_t* nxt = hs + ((u + 1) & 1) * STG;
+      load_set(u, t + HSETS);                      // set u was written to LDS one K-tile ago
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ah[t] = hfrag(cur, wm * 64 + t * 32 + fr, ks * 16 + fk);
-        if (SA == 2) al[t] = hfrag(cur + HOP, wm * 64 + t * 32 + fr, ks * 16 + fk);
-        bh[t] = hfrag(cur + SA * HOP, wn * 64 + t * 32 + fr, ks * 16 + fk);
-        if (SB == 2) bl[t] = hfrag(cur + (SA + 1) * HOP, wn * 64 + t * 32 + fr, ks * 16 + fk);
-      }
+      for (int ks = 0; ks < HBK / 16; ++ks) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          // small terms first: lo*hi + hi*lo, then hi*hi (lo*lo ~ 2^-18 relative is dropped)
-          if (SA == 2)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          if (SB == 2)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+          ah[q] = hfrag(cur, wm * 64 + q * 32 + fr, ks * 16 + fk);
+          if (SA == 2) al[q] = hfrag(cur + HOP, wm * 64 + q * 32 + fr, ks * 16 + fk);
+          bh[q] = hfrag(cur + SA * HOP, wn * 64 + q * 32 + fr, ks * 16 + fk);
+          if (SB == 2) bl[q] = hfrag(cur + (SA + 1) * HOP, wn * 64 + q * 32 + fr, ks * 16 + fk);
         }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            // small terms first: lo*hi + hi*lo, then hi*hi (lo*lo ~ 2^-18 relative is dropped)
+            if (SA == 2)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            if (SB == 2)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          }
+      }
+      if (t + 1 < nk) store_set((u + 1) % HSETS, nxt);
+      __syncthreads();
     }
-    if (more) {
-      hstore(nxt, tid, ra[0]);
-      if (SA == 2) hstore(nxt + HOP, tid, ra[SA - 1]);
-      hstore(nxt + SA * HOP, tid, rb[0]);
-      if (SB == 2) hstore(nxt + (SA + 1) * HOP, tid, rb[SB - 1]);
-    }
-    __syncthreads();
   }
   float* out = tk.ksplit > 1 ? tk.partial + (int64_t)te.ks * tk.m * tk.n : tk.c;
   const int64_t ldo = tk.ksplit > 1 ? tk.n : tk.ldc;
@@ -198,11 +229,15 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* src, uint16_
   __syncthreads();
   for (int e = tid; e < 64 * 64; e += 256) {
     const int a = e >> 6, b = e & 63;          // output tile coordinates (row a, col b)
-    const int r = transpose ? b : a, c = transpose ? a : b;
+    const int r = transpose == 1 ? b : a, c = transpose == 1 ? a : b;
     if (r0 + r >= rows || c0 + c >= cols) continue;
     const float x = t[r][c];
     const __bf16 h = (__bf16)x;                 // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
-    const int64_t o = transpose ? (int64_t)(c0 + c) * ldd + r0 + r : (int64_t)(r0 + r) * ldd + c0 + c;
+    int64_t o = transpose == 1 ? (int64_t)(c0 + c) * ldd + r0 + r : (int64_t)(r0 + r) * ldd + c0 + c;
+    if (transpose == 2) {   // tile-blocked: [row tile of 128][k tile of 32][128][32]
+      const int gr = r0 + r, gc = c0 + c;
+      o = ((int64_t)(gr / TILE) * (cols / HBK) + gc / HBK) * (TILE * HBK) + (gr % TILE) * HBK + gc % HBK;
+    }
     hi[o] = __builtin_bit_cast(uint16_t, h);
     if (lo != nullptr) {
       const __bf16 l = (__bf16)(x - (float)h);
@@ -219,8 +254,19 @@ extern "C" int ps_convert_f32_to_bf16(void* stream, const float* src, void* dst_
                                       void* dst_lo, int64_t rows, int64_t cols, int64_t lds,
                                       int64_t ldd, int transpose) {
   PS_DEVICE_CHECK();
-  if (!src || !dst_hi || rows < 1 || cols < 1 || lds < cols || ldd < (transpose ? rows : cols))
+  if (!src || !dst_hi || rows < 1 || cols < 1 || lds < cols || transpose < 0 || transpose > 2 ||
+      (transpose != 2 && ldd < (transpose ? rows : cols)))
     return PS_EINVAL;
+  if (transpose == 2) {
+    // tile-blocked operand of ps_gemm_bf16_grouped (a_tiled): the destination holds
+    // ceil(rows / 128) * 128 * cols elements; rows past `rows` must read as zero
+    if (cols % HBK != 0) return PS_EUNSUPPORTED;
+    const size_t bytes = (size_t)((rows + TILE - 1) / TILE) * TILE * (size_t)cols * sizeof(uint16_t);
+    if (rows % TILE != 0) {
+      PS_HIP(hipMemsetAsync(dst_hi, 0, bytes, (hipStream_t)stream));
+      if (dst_lo) PS_HIP(hipMemsetAsync(dst_lo, 0, bytes, (hipStream_t)stream));
+    }
+  }
   const int64_t tr = (rows + 63) / 64, tc = (cols + 63) / 64;
   if (tr * tc > 0x7fffffff) return PS_EUNSUPPORTED;
   hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)(tr * tc)), dim3(256), 0,
@@ -274,18 +320,19 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
   const size_t total_tiles = htiles(desc, count);
   for (int i = 0; i < count; ++i) {
     const ps_gemm_bf16_desc& d = desc[i];
-    if (!d.a_hi || !d.b_hi || !d.c || d.m < 1 || d.n < 1 || d.k < 1 || d.lda < d.k ||
-        d.ldb < d.k || d.ldc < d.n)
+    if (!d.a_hi || !d.b_hi || !d.c || d.m < 1 || d.n < 1 || d.k < 1 ||
+        (!d.a_tiled && d.lda < d.k) || d.ldb < d.k || d.ldc < d.n)
       return PS_EINVAL;
     // 16-byte loads of 8 consecutive k: k, both leading dimensions and the bases aligned
-    if (d.k % HBK != 0 || d.lda % 8 != 0 || d.ldb % 8 != 0 || ((uintptr_t)d.a_hi % 16) != 0 ||
+    if (d.k % HBK != 0 || (!d.a_tiled && d.lda % 8 != 0) || d.ldb % 8 != 0 || ((uintptr_t)d.a_hi % 16) != 0 ||
         ((uintptr_t)d.b_hi % 16) != 0 || (d.a_lo && ((uintptr_t)d.a_lo % 16) != 0) ||
         (d.b_lo && ((uintptr_t)d.b_lo % 16) != 0))
       return PS_EUNSUPPORTED;
     const int g = (d.a_lo ? 2 : 0) + (d.b_lo ? 1 : 0);
     const int tid = (int)tasks[g].size();
     HTask t{(const uint16_t*)d.a_hi, (const uint16_t*)d.a_lo, (const uint16_t*)d.b_hi,
-            (const uint16_t*)d.b_lo, d.c, d.m, d.n, d.k, d.lda, d.ldb, d.ldc, 1, d.k, nullptr};
+            (const uint16_t*)d.b_lo, d.c, d.m, d.n, d.k, d.lda, d.ldb, d.ldc, 1, d.k, nullptr,
+            d.a_tiled ? 1 : 0};
     const int sp = hsplit_for(total_tiles, d.k);
     if (sp > 1) {
       t.kchunk = psh::round_up((d.k + sp - 1) / sp, HBK);

@@ -414,14 +414,34 @@ def gemm_grouped(items):
   check(rc, "ps_gemm_grouped_f32")
 
 
+class TiledBf16:
+  """Left operand of gemm_bf16_grouped in the tile-blocked layout (to_bf16(..., tiled=True)):
+  `hi` / `lo` are flat bfloat16 buffers of ceil(rows / 128) * 128 * cols elements."""
+
+  def __init__(self, hi, lo, rows, cols):
+    self.hi, self.lo, self.rows, self.cols = hi, lo, rows, cols
+
+
 @_device_guarded
-def to_bf16(x: torch.Tensor, split: bool = False, transpose: bool = False):
+def to_bf16(x: torch.Tensor, split: bool = False, transpose: bool = False, tiled: bool = False):
   """float32 [r, c] -> bfloat16 operand(s) for gemm_bf16_grouped: (hi, lo | None), each
-  [r, c] (or [c, r] with transpose), round to nearest even; lo = bf16(x - hi)."""
+  [r, c] (or [c, r] with transpose), round to nearest even; lo = bf16(x - hi).  tiled: a
+  TiledBf16 (128 x 32 tiles contiguous: the layout a big left operand should have, it is streamed
+  from HBM once per product; needs c % 32 == 0)."""
   _require_gpu(x, "to_bf16")
   if x.dim() != 2:
     raise ValueError("to_bf16 expects a 2-D tensor")
   r, c = int(x.shape[0]), int(x.shape[1])
+  if tiled:
+    if transpose or c % 32 != 0:
+      raise ValueError("tiled bf16 operands: no transpose, columns a multiple of 32")
+    numel = ((r + 127) // 128) * 128 * c
+    hi = torch.empty((numel,), dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty((numel,), dtype=torch.bfloat16, device=x.device) if split else None
+    rc = lib().ps_convert_f32_to_bf16(_stream(), x.data_ptr(), hi.data_ptr(),
+                                      lo.data_ptr() if split else None, r, c, _as_2d_ld(x), c, 2)
+    check(rc, "ps_convert_f32_to_bf16")
+    return TiledBf16(hi, lo, r, c)
   shape = (c, r) if transpose else (r, c)
   hi = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
   lo = torch.empty(shape, dtype=torch.bfloat16, device=x.device) if split else None
@@ -442,7 +462,22 @@ def gemm_bf16_grouped(items):
   from ._lib import GemmBf16Desc
   descs = (GemmBf16Desc * len(items))()
   dev = items[0][2].device
-  for d, ((a_hi, a_lo), (b_hi, b_lo), c) in zip(descs, items):
+  for d, (a, (b_hi, b_lo), c) in zip(descs, items):
+    if isinstance(a, TiledBf16):   # tile-blocked left operand (to_bf16(..., tiled=True))
+      _require_gpu(c, "gemm_bf16_grouped")
+      m, k, n = a.rows, a.cols, int(b_hi.shape[0])
+      if int(b_hi.shape[1]) != k or tuple(c.shape) != (m, n):
+        raise ValueError("gemm_bf16_grouped shape mismatch")
+      for t in (b_hi, b_lo):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 2 or
+                              (t.shape[1] > 1 and t.stride(1) != 1)):
+          raise ValueError("gemm_bf16_grouped expects row-contiguous 2-D bfloat16 device tensors")
+      d.a_hi, d.a_lo = a.hi.data_ptr(), (a.lo.data_ptr() if a.lo is not None else None)
+      d.b_hi, d.b_lo = b_hi.data_ptr(), (b_lo.data_ptr() if b_lo is not None else None)
+      d.c, d.m, d.n, d.k = c.data_ptr(), m, n, k
+      d.lda, d.ldb, d.ldc, d.a_tiled = k, _as_2d_ld(b_hi), _as_2d_ld(c), 1
+      continue
+    a_hi, a_lo = a
     for t in (a_hi, a_lo, b_hi, b_lo):
       if t is not None and (t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 2 or
                             (t.shape[1] > 1 and t.stride(1) != 1)):

@@ -18,6 +18,7 @@ The caller falls back to the full eigendecomposition if this does not converge.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence, Tuple
 
 import torch
@@ -116,6 +117,16 @@ def _filter_precision(n: int) -> str:
   return mode if n % 32 == 0 else "f32"
 
 
+def _a_operand(c16_j, plain):
+  """Left operand of a C @ Y product: the hi/lo pair (or hi alone in plain mode) of the
+  covariance, row-major tuple or tile-blocked TiledBf16."""
+  from .kernels import TiledBf16
+  if isinstance(c16_j, TiledBf16):
+    return TiledBf16(c16_j.hi, None if plain else c16_j.lo, c16_j.rows, c16_j.cols)
+  return (c16_j[0], None if plain else c16_j[1])
+
+
+
 def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e-5,
                            degree: int = 12, max_outer: int = 14, oversample: int = 31,
                            seed: int = 1729):
@@ -130,7 +141,9 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   mode = _filter_precision(n)
   c16 = None
   if mode != "f32":  # the covariance is converted ONCE per call (hi/lo pair)
-    c16 = [_K().to_bf16(m, split=True) for m in c]
+    # tile-blocked (128 x 32 tiles contiguous): the product streams whole DRAM pages of C
+    tiled = n % 32 == 0 and os.environ.get("PS_FD_TILED", "1") != "0"
+    c16 = [_K().to_bf16(m, split=True, tiled=tiled) for m in c]
 
   def filter_product(y, z, plain):
     """z[j] = C_j @ y[j] for all j (y, z: [B, n, b])."""
@@ -142,7 +155,7 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
     items = []
     for j in range(bsz):
       bt = (yt_hi[:, j * n:(j + 1) * n], None if plain else yt_lo[:, j * n:(j + 1) * n])
-      a = (c16[j][0], None if plain else c16[j][1])
+      a = _a_operand(c16[j], plain)
       items.append((a, bt, z[j]))
     _K().gemm_bf16_grouped(items)
 
@@ -209,7 +222,7 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
           items = []
           for j in range(bsz):
             bt = (yt[0][:, j * n:(j + 1) * n], None if plain else yt[1][:, j * n:(j + 1) * n])
-            a = (c16[j][0], None if plain else c16[j][1])
+            a = _a_operand(c16[j], plain)
             items.append((a, bt, z[j]))
           _K().gemm_bf16_grouped(items)
         else:
