@@ -98,7 +98,12 @@ enum {
  *   PS_SYMMETRY_VERIFY  (default) every block is tested on the device, a_ij == a_ji bit
  *                       for bit; blocks that fail take the full products.
  *   PS_SYMMETRY_ASSUME  the caller guarantees exact symmetry (skips the test pass).
- *   PS_SYMMETRY_GENERAL full products for every block. */
+ *   PS_SYMMETRY_GENERAL full products for every block.
+ * For a block on the symmetric path the Newton iterates are kept bitwise symmetric (mirrored
+ * off the diagonal tiles, (X + X^T)/2 inside them) and the right operand of every product is
+ * read transposed: the returned root equals its transpose bit for bit.  A block passed under
+ * PS_SYMMETRY_ASSUME that is NOT exactly symmetric gets the root of a nearby symmetric matrix
+ * without a diagnostic: use VERIFY (0.13 ms for 256 x 512^2) unless symmetry is certain. */
 enum { PS_SYMMETRY_VERIFY = 0, PS_SYMMETRY_ASSUME = 1, PS_SYMMETRY_GENERAL = 2 };
 
 int ps_version(void);
