@@ -18,8 +18,9 @@ for cfg in sys.argv[1:] or ["default"]:
   eps = 1e-6 * w.max()
   h64 = (v * (w + eps) ** -0.5) @ v.T
   h = ew.roots[0].cpu().numpy()
-  print("%-60s %.1f ms sweeps %d-%d errmetric %.2e  root vs f64 %.2e" % (
+  print("%-60s %.1f ms sweeps %d-%d errmetric %.2e  root vs f64 %.2e  checksum %.12e" % (
       cfg, dt * 1e3, m[:, 5].min(), m[:, 5].max(), m[:, 0].max(),
-      np.linalg.norm(h - h64) / np.linalg.norm(h64)), flush=True)
+      np.linalg.norm(h - h64) / np.linalg.norm(h64),
+      float(sum(r.double().abs().sum() for r in ew.roots))), flush=True)
   for k in env:
     os.environ.pop(k)

@@ -26,7 +26,7 @@ if "vit" in os.environ.get("PS_DEV_EXTRA", ""):
     torch.cuda.synchronize(); best = min(best, (time.perf_counter()-t0)/2*1e3)
   print("    vit_b %.1f ms" % best, flush=True)
 '''
-combos = [dict(PS_NEWTON_AVG_STEPS=w) for w in ("4", "0", "2", "4")]
+combos = [dict(), dict(PS_NEWTON_PIPE="0", PS_NEWTON_BK="16", PS_NEWTON_DEEP="1"), dict(PS_NEWTON_PIPE="0", PS_NEWTON_BK="16", PS_NEWTON_DEEP="0"), dict(), dict(PS_NEWTON_PIPE="0", PS_NEWTON_BK="16", PS_NEWTON_DEEP="1")]
 if len(sys.argv) > 1 and sys.argv[1] == "bk":
   combos = [dict(PS_NEWTON_BK=bk, PS_NEWTON_DEEP=deep) for bk, deep in (("32", "1"), ("16", "1"), ("16", "0"), ("32", "0"))]
 for c in combos:
