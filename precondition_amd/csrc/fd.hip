@@ -99,25 +99,28 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const float* gram, float
   }
   __syncthreads();
   const double thresh = (double)drop_rel * s_max;
+  // Left-looking factorisation, one thread per row: column c of L needs only the finished
+  // columns k < c, so every row forms its dot product sum_k L[r][k] L[c][k] before the pivot is
+  // known (row c's own partner values are one broadcast LDS read per term); two barriers per
+  // column and one LDS write per element (the right-looking form updated the whole trailing
+  // block per column with an integer division per element: 0.35 ms for 8 x 96^2).
+  const int r = tid;
   for (int c = 0; c < b; ++c) {
-    if (tid == 0) {
-      const double d = S[c * ldS + c];
-      const bool ok = d > thresh && d > 0.0 && d < 1.0e300;
+    double acc = 0.0;
+    if (r >= c && r < b) {
+      acc = S[r * ldS + c];
+      for (int k = 0; k < c; ++k) acc = fma(-S[r * ldS + k], S[c * ldS + k], acc);
+    }
+    if (r == c) {
+      const bool ok = acc > thresh && acc > 0.0 && acc < 1.0e300;
       s_drop[c] = ok ? 0 : 1;
-      s_d = ok ? sqrt(d) : 1.0;
+      s_d = ok ? sqrt(acc) : 1.0;
     }
     __syncthreads();
-    const double d = s_d;
-    const bool dropped = s_drop[c] != 0;
-    if (tid > c && tid < b) S[tid * ldS + c] = dropped ? 0.0 : S[tid * ldS + c] / d;
-    if (tid == 0) S[c * ldS + c] = d;
-    __syncthreads();
-    if (!dropped) {
-      const int w = b - 1 - c;
-      for (int e = tid; e < w * w; e += 256) {
-        const int r = c + 1 + e / w, cc = c + 1 + e % w;
-        if (cc <= r) S[r * ldS + cc] = fma(-S[r * ldS + c], S[cc * ldS + c], S[r * ldS + cc]);
-      }
+    if (r >= c && r < b) {
+      const double d = s_d;
+      const bool dropped = s_drop[c] != 0;
+      S[r * ldS + c] = r == c ? d : (dropped ? 0.0 : acc / d);
     }
     __syncthreads();
   }
