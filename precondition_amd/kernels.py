@@ -466,6 +466,11 @@ def gemm_bf16_grouped(items):
     if isinstance(a, TiledBf16):   # tile-blocked left operand (to_bf16(..., tiled=True))
       _require_gpu(c, "gemm_bf16_grouped")
       m, k, n = a.rows, a.cols, int(b_hi.shape[0])
+      need = ((m + 127) // 128) * 128 * k
+      for t in (a.hi, a.lo):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_cuda or not t.is_contiguous()
+                              or t.numel() != need):
+          raise ValueError("gemm_bf16_grouped: malformed tile-blocked operand")
       if int(b_hi.shape[1]) != k or tuple(c.shape) != (m, n):
         raise ValueError("gemm_bf16_grouped shape mismatch")
       for t in (b_hi, b_lo):

@@ -307,6 +307,29 @@ def test_newton_product_kernel_variants_bit_identical_and_trace(device, monkeypa
   assert np.all(tf >= t0[ran]) and np.all(tk >= tf) and np.all(t3[ran] >= tk)
 
 
+@pytest.mark.parametrize("m,k,n", [(300, 256, 96), (512, 1024, 64), (128, 32, 7)])
+def test_bf16_gemm_tile_blocked_left_operand_bit_identical(m, k, n, device):
+  """ps_convert_f32_to_bf16 mode 2 + ps_gemm_bf16_desc.a_tiled (the covariance layout of the FD
+  branch, DS:1123-1290's products): the same product bit for bit as the row-major operand, with
+  and without the lo parts, for row counts that are not a multiple of the tile."""
+  g = torch.Generator(device=device).manual_seed(m + k + n)
+  a = torch.randn((m, k), generator=g, device=device)
+  b = torch.randn((n, k), generator=g, device=device)
+  b16 = K().to_bf16(b, split=True)
+  row = K().to_bf16(a, split=True)
+  til = K().to_bf16(a, split=True, tiled=True)
+  for split in (True, False):
+    c0 = torch.empty((m, n), device=device); c1 = torch.full((m, n), float("nan"), device=device)
+    bb = (b16[0], b16[1] if split else None)
+    K().gemm_bf16_grouped([((row[0], row[1] if split else None), bb, c0)])
+    t = K().TiledBf16(til.hi, til.lo if split else None, m, k)
+    K().gemm_bf16_grouped([(t, bb, c1)])
+    assert torch.equal(c0, c1), split
+    ref = (a.double() @ b.double().t()).float()
+    tol = 2e-4 if split else 3e-2
+    assert float((c1 - ref).norm() / ref.norm()) < tol
+
+
 # ---------------------------------------------------------------------------
 def _two_rank_gpu_worker(rank, world, port, ret):
   import sys
