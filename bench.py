@@ -695,7 +695,7 @@ def main():
         # inside this run: see the file named here (2 x FETCH_SIZE + WRITE_SIZE per the gfx950
         # rule); null in this line by design
         "traffic": None,
-        "traffic_source": "profiles/r03_cfg2_pmc_by_kernel.json / r03_headline_pmc_by_kernel.json (rocprofv3 --pmc, separate passes)",
+        "traffic_source": "profiles/r03b_cfg2_pmc_by_kernel.json / r03b_headline_pmc_by_kernel.json (rocprofv3 --pmc, separate passes: 945 / 1166 MB per stage launch)",
         "clock": clock,
         "frac_of_peak_at_measured_clock": (round(ach / clock["peak_at_clock_tflops"], 4)
                                            if "peak_at_clock_tflops" in clock else None),
