@@ -404,6 +404,44 @@ def test_bench_multi_rank_control_flow_over_gloo(tmp_path):
   assert "cpu_baseline" not in line   # rank 0 at N = 1 only
 
 
+def test_bench_plain_launch_starts_its_own_ranks(tmp_path):
+  """`python bench.py --gpus 2` WITHOUT torchrun (how the driver launches --gpus 1): bench.py must
+  start the two ranks itself, relay exactly one line with n_gpus == 2 and two ranks seen in the
+  top-level config, and exit with the launcher's status."""
+  import json
+  import subprocess
+  env = {k: v for k, v in os.environ.items()
+         if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+  env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+  cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_selftest_launcher.py"), "--gpus", "2",
+         "--steps", "2", "--warmup", "1", "--no-extras"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout[-2000:]
+  line = json.loads(lines[0])
+  assert line["n_gpus"] == 2 and line["config"]["rccl_ranks_seen"] == 2
+  assert line["multi_gpu"]["world_size"] == 2
+  assert line["config"]["headline_1024"]["ms_per_step"] > 0
+
+
+def test_bench_refuses_rank_counts_it_cannot_run(tmp_path):
+  """A plain `bench.py --gpus 2` on a node with fewer than 2 GPUs exits non-zero with a message
+  and prints no JSON line; so does a launcher/--gpus mismatch."""
+  import subprocess
+  import torch
+  env = {k: v for k, v in os.environ.items()
+         if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+  if torch.cuda.device_count() < 2:
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "{" not in r.stdout
+  env["WORLD_SIZE"] = "2"
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env,
+                     capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+  assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "{" not in r.stdout
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_vit_b_ownership_tables_and_gather_layout(world):
   """The 395 statistics of the ViT-B tree (cfg4) over 2 / 4 / 8 ranks, no communication:
