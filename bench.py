@@ -84,13 +84,25 @@ class Workload:
     self.gathered = (torch.empty((world * nb, n, n), dtype=torch.float32, device=dev)
                      if self.multi else None)
     self.metrics = None
+    self.hint = None       # host copy of the previous recompute's iteration counts
+    self.options = {}      # per-call modes (ps_options), e.g. {"products": "bf16x6"}
+
+  def refresh_hint(self):
+    """What the optimizer does once per recompute (its failure select reads the metrics table on
+    the host, DS:2936-2950): last recompute's inverse_pth_root_iters become the next call's
+    ps_options.iters_hint.  Called outside the timed region (one sync + a [blocks] D2H copy)."""
+    if self.metrics is not None and not self.name.startswith("eigh"):
+      self.hint = self.metrics[:, 1].detach().cpu().numpy().astype(np.float32)
 
   def _roots(self, lo, hi, max_ev=None):
     from precondition_amd import kernels as K
+    opts = dict(self.options)
+    if self.hint is not None:
+      opts["iters_hint"] = self.hint[lo:hi]
     _, m = K.matrix_inverse_pth_root_batched(
         list(self.stats[lo:hi].unbind(0)), [self.p] * (hi - lo),
         padding_starts=[self.n] * (hi - lo), out=list(self.roots[lo:hi].unbind(0)),
-        eigh=self.name.startswith("eigh"), max_ev=max_ev)
+        eigh=self.name.startswith("eigh"), max_ev=max_ev, options=opts or None)
     return m
 
   def split_point(self):
@@ -217,6 +229,7 @@ class VitBWorkload:
     owner = comm.ownership_table(sizes, self.exps, world, "lpt")
     self.mine = [o == rank for o in owner]
     self.metrics = None
+    self.hint = None
     self.stats_flops = 0.0  # whole tree (all ranks together)
     for pc, g in zip(self.pcs, self.grads):
       for blk in pc.partitioned_blocks(g):
@@ -236,8 +249,9 @@ class VitBWorkload:
     return f
 
   def stats_step(self, subset=None):
-    """subset: None = every statistic; "matrix" / "vector" = only the statistics of blocks whose
-    contraction length is >= 128 / is 1 (the MFMA-bound and the HBM-bound part of the launch)."""
+    """subset: None = every statistic; "vector" = only the statistics of blocks whose contraction
+    length is 1 (d x d outer products: the HBM-bound part of the launch); "matrix" = all others
+    (the MFMA-bound part)."""
     from precondition_amd import kernels as K
     items = []
     for pc, g, st in zip(self.pcs, self.grads, self.stats):
@@ -246,7 +260,7 @@ class VitBWorkload:
       items = [it for it, m in zip(items, self.mine) if m]
     if subset is not None:
       kdim = lambda it: it[0].numel() // it[0].shape[it[1]]
-      items = [it for it in items if (kdim(it) >= 128) == (subset == "matrix")]
+      items = [it for it in items if (kdim(it) > 1) == (subset == "matrix")]
     K.stats_update_grouped(items, 0.999, 1.0 - 0.999)
     return items
 
@@ -254,8 +268,15 @@ class VitBWorkload:
     from precondition_amd import comm
     self.stats_step()
     flat = [s for st in self.stats for s in st]
+    # owner-only statistics: the ownership must not move between steps, so the hint steers the
+    # per-block accuracy policy only (hint_in_ownership=False)
     _, self.metrics = comm.sharded_inverse_pth_roots(
-        flat, self.exps, group=self.group, ownership="lpt", pi_first=True)
+        flat, self.exps, group=self.group, ownership="lpt", pi_first=True,
+        iters_hint=self.hint, hint_in_ownership=False)
+
+  def refresh_hint(self):
+    if self.metrics is not None:
+      self.hint = self.metrics[:, 1].detach().cpu().numpy().astype(np.float32).tolist()
 
   def flops(self, executed=False):
     m = self.metrics.cpu().numpy()
@@ -377,6 +398,7 @@ def timed(work, steps, warmup, multi):
   import torch.distributed as dist
   for _ in range(warmup):
     work.step()
+    work.refresh_hint()
   _sync()
   if multi:
     dist.barrier()
@@ -536,27 +558,25 @@ def newton_bf16x6_leg(dev, clock):
   PS_NEWTON_PRODUCTS=bf16x6 = three-way bf16 split of both operands, six partial products per
   product on v_mfma_f32_32x32x16_bf16 with float32 accumulation (~2^-22 relative), exact float32
   products for the last steps of a block (max|M - I| < 1e-3).  Same workloads, same timing."""
-  out = {"mode": "PS_NEWTON_PRODUCTS=bf16x6 (csrc/newton.hip gemm_tile_bf16x6_sym); the default "
-                 "exact-float32 numbers are the top-level ones"}
-  old = os.environ.get("PS_NEWTON_PRODUCTS")
-  try:
-    for name in ("cfg2_256x512_p4", "headline_64x1024_p4"):
-      w = Workload(name, 0, 1, dev)
-      os.environ["PS_NEWTON_PRODUCTS"] = "f32"
-      f32_sec, _ = timed(w, 3, 1, False)
-      os.environ["PS_NEWTON_PRODUCTS"] = "bf16x6"
+  out = {"mode": "ps_options.products = bf16x6 / bf16x3 (what the factory's precision=HIGH / DEFAULT "
+                 "select; csrc/newton.hip gemm_tile_bf16x_sym); the default exact-float32 numbers "
+                 "are the top-level ones"}
+  for name in ("cfg2_256x512_p4", "headline_64x1024_p4"):
+    w = Workload(name, 0, 1, dev)
+    row = {}
+    for mode in ("f32", "bf16x6", "bf16x3"):   # one process, three modes: they are arguments
+      w.options = {"products": mode}
       sec, fl = timed(w, 3, 1, False)
-      out[name] = {"ms_per_step": round(sec * 1e3, 3), "ms_per_step_f32_products": round(f32_sec * 1e3, 3),
+      row[mode] = {"ms_per_step": round(sec * 1e3, 3),
                    "algorithmic_gflops": round(fl / sec / 1e9, 1),
-                   "newton_iters": {"min": float(w.metrics[:, 1].min()), "max": float(w.metrics[:, 1].max())},
-                   "parity_vs_oracle": parity_sample(w, count=4)}
-      del w
-      torch.cuda.empty_cache()
-  finally:
-    if old is None:
-      os.environ.pop("PS_NEWTON_PRODUCTS", None)
-    else:
-      os.environ["PS_NEWTON_PRODUCTS"] = old
+                   "newton_iters": {"min": float(w.metrics[:, 1].min()), "max": float(w.metrics[:, 1].max())}}
+      if mode != "f32":
+        row[mode]["parity_vs_oracle"] = parity_sample(w, count=4)
+    out[name] = {"ms_per_step": row["bf16x6"]["ms_per_step"],
+                 "ms_per_step_f32_products": row["f32"]["ms_per_step"],
+                 "ms_per_step_bf16x3": row["bf16x3"]["ms_per_step"], "by_mode": row}
+    del w
+    torch.cuda.empty_cache()
   return out
 
 
@@ -730,7 +750,8 @@ def main():
         # inside this run: see the file named here (2 x FETCH_SIZE + WRITE_SIZE per the gfx950
         # rule); null in this line by design
         "traffic": None,
-        "traffic_source": "profiles/r03b_cfg2_pmc_by_kernel.json / r03b_headline_pmc_by_kernel.json (rocprofv3 --pmc, separate passes: 945 / 1166 MB per stage launch)",
+        "traffic_source": "profiles/r04_cfg2_pmc_by_kernel.json / r04_headline_pmc_by_kernel.json "
+                          "(rocprofv3 --pmc, separate passes; tools/prof_pmc.sh)",
         "clock": clock,
         "frac_of_peak_at_measured_clock": (round(ach / clock["peak_at_clock_tflops"], 4)
                                            if "peak_at_clock_tflops" in clock else None),
@@ -842,6 +863,7 @@ def main():
     vsteps = 2
     for _ in range(1):
       vw.step()
+      vw.refresh_hint()
     _sync()
     if multi:
       dist.barrier()
@@ -946,7 +968,8 @@ def main():
       from precondition_amd import comm as _comm   # roots of the statistics as they are NOW
       _flat = [s_ for st_ in vw.stats for s_ in st_]
       _roots, _met = _comm.sharded_inverse_pth_roots(_flat, vw.exps, group=None, ownership="lpt",
-                                                     pi_first=True)
+                                                     pi_first=True, iters_hint=vw.hint,
+                                                     hint_in_ownership=False)
       _sync()
       line["vit_b_cfg4"]["parity_vs_oracle"] = parity_sample_vit_b(vw, _roots, _met)
       del _roots, _met, _flat

@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 200 /* 0.2.0 */
+#define PS_VERSION 300 /* 0.3.0 */
 
 enum {
   PS_OK = 0,
@@ -108,6 +108,75 @@ enum { PS_SYMMETRY_VERIFY = 0, PS_SYMMETRY_ASSUME = 1, PS_SYMMETRY_GENERAL = 2 }
 
 int ps_version(void);
 const char* ps_error_string(int code);
+
+/* ---- per-call options of the root entry points (ps_*_root_batched_opt_f32) -------------------
+ * Everything that selects HOW a root is computed is an argument: two callers in one process (or
+ * two calls of one caller) may use different modes; nothing below is process state.  The plain
+ * entry points (ps_newton_root_batched_f32, ...) are the *_opt_* ones with options = NULL =
+ * ps_options_init() defaults.  Zero-initialising the struct and setting struct_size also gives the
+ * defaults, except where a field says otherwise.
+ *
+ * products — arithmetic of the n^3 products of the Newton iteration (DS:845-846, mat_power
+ *   DS:671-674).  The reference passes jax.lax.Precision through `precision` (DS:599, 708):
+ *     PS_PRODUCTS_F32     (Precision.HIGHEST, the reference's default) exact float32 products on
+ *                         v_mfma_f32_32x32x2_f32; the parity path.
+ *     PS_PRODUCTS_BF16X6  (Precision.HIGH) three-way bf16 split of both operands, six partial
+ *                         products on v_mfma_f32_32x32x16_bf16, ~2^-22 relative; the last steps
+ *                         of a block (max|M - I| < 1e-3) run in exact float32.
+ *     PS_PRODUCTS_BF16X3  (Precision.DEFAULT) two-way split, three partial products, ~2^-16
+ *                         relative; exact float32 once max|M - I| < 3e-2.
+ *   The bf16 modes apply to exactly symmetric blocks; other blocks run float32 in the same call.
+ * accumulation — how a float32 product sums over k (PS_PRODUCTS_F32 only):
+ *     PS_ACCUM_SEGMENTED  (default) the M-side products (the powering chain and M' = Mi^p M) of
+ *                         blocks NOT marked fast by iters_hint are summed in segments of 128
+ *                         (blocked summation): on ill-conditioned blocks the root is then closer
+ *                         to the float64 root than NumPy/OpenBLAS's float32 evaluation of the same
+ *                         iteration (0.75x its error; one chain: 1.3x).
+ *     PS_ACCUM_CHAIN      one fmaf chain over the whole k range everywhere (rounds 1-3).
+ * averaged_steps — leading Newton steps of a try whose M update is computed in full and averaged
+ *   with its transpose instead of being mirrored (section "symmetry" below); -1 = default (4).
+ * iters_hint / iters_hint_stride / fast_max_iters — HOST pointer to one float per block (block b
+ *   at iters_hint[b * iters_hint_stride]): the block's inverse_pth_root_iters at the PREVIOUS
+ *   recompute (a host copy of column PS_M_ITERS of that call's metrics, stride PS_METRICS_STRIDE;
+ *   the optimizer reads that table on the host anyway for the failure select of DS:2936-2950 and
+ *   its state carries it, DS:338-351).  A block whose hint is in [1, fast_max_iters] (default 8:
+ *   condition number below ~1e2) is well conditioned: it takes 0 averaged steps and plain chains,
+ *   which is exact to 1e-6 there and ~4 % faster; a call whose blocks are all fast runs the
+ *   two-register-set product kernel, any other call the CAREFUL instantiation (one register set,
+ *   the other set's registers hold the segment totals).  NULL, 0 or NaN = no hint = the careful
+ *   path.  Statistics move slowly (beta2 ~ 0.999), so last recompute's count is a sound predictor;
+ *   a block that turns out slower than its hint is only less accurate, never wrong.
+ * execution — PS_EXEC_STAGED (default: one launch per product stage, one host event wait per
+ *   Newton step, one step behind the GPU) or PS_EXEC_PERSISTENT (one dataflow kernel, no host wait).
+ * power_iteration — PS_PI_AUTO (resident when the chip is free, else streaming), PS_PI_STREAMING,
+ *   PS_PI_RESIDENT (= AUTO: residency is never forced); pi_timeout_ms: deadline of a resident
+ *   launch's waits, < 0 = default 5000, 0 = every wait counts as expired (tests).
+ * eigh_* — ps_eigh_root_batched_opt_f32: eigh_sweep_tol (<= 0: default 2e-6) is the scaled
+ *   off-diagonal bound that ends the one-sided Jacobi sweeps; eigh_streams (0: default 2).
+ * The PS_* environment variables of earlier rounds survive only as a developer override, read in
+ * ONE function (csrc/options.cpp ps_dev_env_overrides) and only when PS_DEV_ENV=1 is set. */
+enum { PS_PRODUCTS_F32 = 0, PS_PRODUCTS_BF16X6 = 1, PS_PRODUCTS_BF16X3 = 2 };
+enum { PS_ACCUM_SEGMENTED = 0, PS_ACCUM_CHAIN = 1 };
+enum { PS_EXEC_STAGED = 0, PS_EXEC_PERSISTENT = 1 };
+enum { PS_PI_AUTO = 0, PS_PI_STREAMING = 1, PS_PI_RESIDENT = 2 };
+typedef struct {
+  uint32_t struct_size;        /* sizeof(ps_options) of the caller's build */
+  int32_t products;            /* PS_PRODUCTS_* */
+  int32_t accumulation;        /* PS_ACCUM_* */
+  int32_t averaged_steps;      /* -1 = default */
+  const float* iters_hint;     /* HOST array, may be NULL */
+  int32_t iters_hint_stride;   /* in floats; 0 is read as 1 */
+  int32_t fast_max_iters;      /* <= 0 = default (8) */
+  float averaged_err_threshold;/* > 0: steps after the second stop averaging once max|M - I| <= it */
+  int32_t execution;           /* PS_EXEC_* */
+  int32_t power_iteration;     /* PS_PI_* */
+  int32_t pi_timeout_ms;       /* < 0 = default */
+  float eigh_sweep_tol;        /* <= 0 = default */
+  int32_t eigh_streams;        /* 0 = default */
+  int32_t reserved[6];         /* 0 */
+} ps_options;
+/* Fills *opt with the defaults (struct_size = sizeof(ps_options)). */
+void ps_options_init(ps_options* opt);
 
 /* v0 of power_iteration: first n values of
  * numpy.random.RandomState(1729).uniform(-1, 1, n).astype(float32) (DS:642-643),
@@ -169,6 +238,15 @@ int ps_power_iteration_batched_f32(void* stream, const float* const* a,
                                    float* out_v, int32_t ldv, int symmetry,
                                    void* workspace, size_t workspace_bytes);
 
+int ps_power_iteration_batched_opt_f32(void* stream, const float* const* a,
+                                       const int32_t* n, const int32_t* lda,
+                                       const int32_t* padding_start, int batch,
+                                       int num_iters, float error_tolerance,
+                                       float* out_lambda, int32_t* out_iters,
+                                       float* out_v, int32_t ldv, int symmetry,
+                                       void* workspace, size_t workspace_bytes,
+                                       const ps_options* options);
+
 /* ---- mat_power (DS:655-678): out = m^p, same multiplication order ------------ */
 size_t ps_mat_power_workspace_bytes(int n, int p);
 int ps_mat_power_f32(void* stream, const float* m, int n, int ldm, int p,
@@ -218,6 +296,18 @@ int ps_newton_root_batched_f32(void* stream, const float* const* a,
                                float* metrics, void* workspace,
                                size_t workspace_bytes, int32_t* iters_executed_host);
 
+/* The same call with options (NULL = defaults).  max_ev: NULL, or the device array of
+ * ps_newton_root_batched_maxev_f32 (then relative_matrix_epsilon is taken as 1). */
+int ps_newton_root_batched_opt_f32(void* stream, const float* const* a,
+                                   const int32_t* n, const int32_t* lda,
+                                   const int32_t* p, const int32_t* padding_start,
+                                   int batch, int num_iters, float ridge_epsilon,
+                                   float error_tolerance, int relative_matrix_epsilon,
+                                   const float* max_ev, int symmetry, float* const* out,
+                                   const int32_t* ldo, float* metrics, void* workspace,
+                                   size_t workspace_bytes, int32_t* iters_executed_host,
+                                   const ps_options* options);
+
 /* Same with the largest eigenvalue GIVEN (device array max_ev[batch]) instead of the
  * power iteration: the lobpcg_topk_precondition branch of matrix_inverse_pth_root already
  * has it from the top-k eigenpairs (DS:813-817) and roots the DEFLATED matrix (DS:804-812).
@@ -240,6 +330,14 @@ int ps_eigh_root_batched_f32(void* stream, const float* const* a, const int32_t*
                              int relative_matrix_epsilon, float* const* out,
                              const int32_t* ldo, float* metrics, void* workspace,
                              size_t workspace_bytes);
+
+int ps_eigh_root_batched_opt_f32(void* stream, const float* const* a, const int32_t* n,
+                                 const int32_t* lda, const int32_t* p,
+                                 const int32_t* padding_start, int batch,
+                                 float ridge_epsilon, float error_tolerance,
+                                 int relative_matrix_epsilon, float* const* out,
+                                 const int32_t* ldo, float* metrics, void* workspace,
+                                 size_t workspace_bytes, const ps_options* options);
 
 /* ---- plain batched symmetric eigendecomposition (jnp.linalg.eigh, DS:1007/1071) ----
  * a[b]: symmetric [n[b], n[b]].  evals[b]: n[b] floats; evecs[b]: [n[b], n[b]] with

@@ -96,8 +96,97 @@ class StatsDesc(C.Structure):
   ]
 
 
+PS_PRODUCTS = {"f32": 0, "bf16x6": 1, "bf16x3": 2}
+PS_ACCUM = {"segmented": 0, "chain": 1}
+PS_EXEC = {"staged": 0, "persistent": 1}
+PS_PI = {"auto": 0, "streaming": 1, "resident": 2}
+
+
+class PsOptions(C.Structure):
+  """Mirror of ps_options (include/ps_api.h): per-call modes of the root entry points."""
+  _fields_ = [
+      ("struct_size", C.c_uint32),
+      ("products", C.c_int32),
+      ("accumulation", C.c_int32),
+      ("averaged_steps", C.c_int32),
+      ("iters_hint", C.c_void_p),
+      ("iters_hint_stride", C.c_int32),
+      ("fast_max_iters", C.c_int32),
+      ("averaged_err_threshold", C.c_float),
+      ("execution", C.c_int32),
+      ("power_iteration", C.c_int32),
+      ("pi_timeout_ms", C.c_int32),
+      ("eigh_sweep_tol", C.c_float),
+      ("eigh_streams", C.c_int32),
+      ("reserved", C.c_int32 * 6),
+  ]
+
+
+def make_options(options=None):
+  """dict / None -> (PsOptions, keepalive).  Keys: products ('f32' | 'bf16x6' | 'bf16x3'),
+  accumulation ('segmented' | 'chain'), averaged_steps, iters_hint (host float array, one per
+  block: last recompute's inverse_pth_root_iters), fast_max_iters, averaged_err_threshold,
+  execution ('staged' | 'persistent'), power_iteration ('auto' | 'streaming' | 'resident'),
+  pi_timeout_ms, eigh_sweep_tol, eigh_streams.  Unknown keys raise."""
+  import numpy as np
+  o = PsOptions()
+  lib().ps_options_init(C.byref(o))
+  keep = []
+  if not options:
+    return o, keep
+  opts = dict(options)
+  def enum(key, table):
+    v = opts.pop(key, None)
+    if v is None:
+      return
+    if isinstance(v, str):
+      if v not in table:
+        raise ValueError(f"{key} must be one of {sorted(table)}, got {v!r}")
+      v = table[v]
+    setattr(o, key, int(v))
+  enum("products", PS_PRODUCTS)
+  enum("accumulation", PS_ACCUM)
+  enum("execution", PS_EXEC)
+  enum("power_iteration", PS_PI)
+  for key in ("averaged_steps", "fast_max_iters", "pi_timeout_ms", "eigh_streams"):
+    if opts.get(key) is not None:
+      setattr(o, key, int(opts[key]))
+    opts.pop(key, None)
+  for key in ("averaged_err_threshold", "eigh_sweep_tol"):
+    if opts.get(key) is not None:
+      setattr(o, key, float(opts[key]))
+    opts.pop(key, None)
+  hint = opts.pop("iters_hint", None)
+  if hint is not None:
+    if hasattr(hint, "detach"):   # a torch tensor: the hint is a HOST array (one sync if on the device)
+      hint = hint.detach().to("cpu").numpy()
+    h = np.ascontiguousarray(np.asarray(hint, dtype=np.float32).reshape(-1))
+    keep.append(h)
+    o.iters_hint = h.ctypes.data
+    o.iters_hint_stride = 1
+  if opts:
+    raise ValueError(f"unknown option(s): {sorted(opts)}")
+  return o, keep
+
+
 # name -> (restype, argtypes); every symbol include/ps_api.h declares.
 _SIGNATURES = {
+    "ps_options_init": (None, [C.POINTER(PsOptions)]),
+    "ps_newton_root_batched_opt_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                   C.c_void_p, C.POINTER(PsOptions)]),
+    "ps_eigh_root_batched_opt_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                   C.POINTER(PsOptions)]),
+    "ps_power_iteration_batched_opt_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_size_t,
+                   C.POINTER(PsOptions)]),
     "ps_version": (C.c_int, []),
     "ps_error_string": (C.c_char_p, [C.c_int]),
     "ps_power_iteration_v0": (C.c_int, [C.c_int, C.c_void_p]),

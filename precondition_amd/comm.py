@@ -53,32 +53,56 @@ def reference_ownership(num_statistics: int, world: int) -> List[int]:
   return [i // b for i in range(num_statistics)]
 
 
-def cost_balanced_ownership(sizes: Sequence[int], exponents: Sequence[int],
-                            world: int) -> List[int]:
-  """Longest-processing-time assignment on cost c(p) * n^3 (perf mode; the
-  gathered result order is unchanged because results are addressed by index)."""
+def block_costs(sizes: Sequence[int], exponents: Sequence[int],
+                iters_hint: Optional[Sequence[float]] = None) -> List[float]:
+  """Cost model of one root: iterations x products per iteration x tiles of a symmetric product.
+  c(p) products of T (T + 1) / 2 tiles of 128 x 128 x n each (T = ceil(n / 128): the product
+  kernel's unit of work, so a 768^2 block costs 21 tile-products of K = 768 and a 1000^2 one 36
+  of K = 1024), times the Newton iterations the block took at the PREVIOUS recompute when the
+  caller has them (`iters_hint`, the optimizer state's inverse_pth_root_iters: ViT-B blocks take
+  7-17) and a neutral 10 otherwise."""
 
   def c_of_p(p):
     return int(np.floor(np.log2(p))) + bin(int(p)).count("1") - 1 + 2 if p > 0 else 1
 
-  order = sorted(range(len(sizes)),
-                 key=lambda i: -(c_of_p(exponents[i]) * float(sizes[i]) ** 3))
+  out = []
+  for i, (n, p) in enumerate(zip(sizes, exponents)):
+    t = (int(n) + 127) // 128
+    it = 10.0
+    if iters_hint is not None:
+      h = float(iters_hint[i])
+      if h >= 1.0 and h == h:
+        it = h
+    out.append(it * c_of_p(p) * (t * (t + 1) / 2.0) * (t * 128.0))
+  return out
+
+
+def cost_balanced_ownership(sizes: Sequence[int], exponents: Sequence[int],
+                            world: int,
+                            iters_hint: Optional[Sequence[float]] = None) -> List[int]:
+  """Longest-processing-time assignment on `block_costs` (perf mode; the gathered result order
+  is unchanged because results are addressed by index).  `iters_hint` must be identical on every
+  rank (it is when it comes from the gathered metrics table of the previous recompute)."""
+  cost = block_costs(sizes, exponents, iters_hint)
+  order = sorted(range(len(sizes)), key=lambda i: (-cost[i], i))
   load = [0.0] * world
   owner = [0] * len(sizes)
   for i in order:
     r = int(np.argmin(load))
     owner[i] = r
-    load[r] += c_of_p(exponents[i]) * float(sizes[i]) ** 3
+    load[r] += cost[i]
   return owner
 
 
 def ownership_table(sizes: Sequence[int], exponents: Sequence[int], world: int,
-                    ownership: str = "reference") -> List[int]:
-  """owner[i] of every statistic; a pure function of shapes, identical on every rank."""
+                    ownership: str = "reference",
+                    iters_hint: Optional[Sequence[float]] = None) -> List[int]:
+  """owner[i] of every statistic; a pure function of shapes (and, for "lpt", of the previous
+  recompute's gathered iteration counts), identical on every rank."""
   if ownership == "reference":
     return reference_ownership(len(sizes), world)
   if ownership == "lpt":
-    return cost_balanced_ownership(sizes, exponents, world)
+    return cost_balanced_ownership(sizes, exponents, world, iters_hint)
   raise ValueError(f"unknown ownership {ownership!r}")
 
 
@@ -110,6 +134,9 @@ def sharded_inverse_pth_roots(
     sizes: Optional[Sequence[int]] = None,
     pi_first: Optional[bool] = None,
     metrics_cols: int = METRICS_STRIDE,
+    iters_hint: Optional[Sequence[float]] = None,
+    options: Optional[dict] = None,
+    hint_in_ownership: bool = True,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
 
@@ -135,11 +162,23 @@ def sharded_inverse_pth_roots(
   bit-identical results.
   `metrics_cols` (needs `compute_fn`): width of the gathered metrics rows when the
   per-statistic diagnostics are wider than the 8 PS_M_* columns (FDDiagnostics).
+  `iters_hint` (HOST floats, one per statistic, identical on every rank): the Newton iteration
+  counts of the previous recompute (column 1 of the metrics this function returned then).  They
+  weight the "lpt" ownership (unless `hint_in_ownership` is False: owner-only statistics need an
+  ownership that never moves) and are handed to the root call as ps_options.iters_hint (well
+  conditioned blocks skip the averaged M updates and the segmented accumulation).
+  `options`: per-call modes of the HIP root (kernels._lib.make_options), e.g. the product
+  arithmetic the factory's `precision` selects.
   """
   n_stats = len(statistics)
   world, rank = world_and_rank(group)
   sizes = [int(s) for s in sizes] if sizes is not None else [int(s.shape[0]) for s in statistics]
-  owner = ownership_table(sizes, exponents, world, ownership)
+  if iters_hint is not None:
+    iters_hint = [float(h) for h in iters_hint]
+    if len(iters_hint) != n_stats:
+      raise ValueError("iters_hint must hold one value per statistic")
+  owner = ownership_table(sizes, exponents, world, ownership,
+                          iters_hint if hint_in_ownership else None)
   hip_root = root_fn is None
   if root_fn is None:
     from . import kernels
@@ -184,71 +223,114 @@ def sharded_inverse_pth_roots(
   lam_of = None
   if pi_first is None:
     pi_first = n_phases == 2 and hip_root
-  if (pi_first and n_phases == 2 and compute_fn is None and not eigh and
-      relative_matrix_epsilon):
+  all_mine = [i for i in range(n_stats) if owner[i] == rank]
+  pi_options = {k: v for k, v in (options or {}).items() if k in ("power_iteration", "pi_timeout_ms")}
+
+  def _expired_waits():
+    import ctypes
+    from . import _lib
+    n = ctypes.c_uint(0)
+    _lib.lib().ps_power_iteration_health(ctypes.addressof(n), None, None)
+    return n.value
+
+  def _power_iteration():
     from . import kernels
-    all_mine = [i for i in range(n_stats) if owner[i] == rank]
-    if all_mine:
-      lam, _ = kernels.power_iteration_batched([statistics[i] for i in all_mine],
-                                               padding_starts=[sizes[i] for i in all_mine])
-      lam_of = {i: k for k, i in enumerate(all_mine)}
+    lam_, _ = kernels.power_iteration_batched([statistics[i] for i in all_mine],
+                                              padding_starts=[sizes[i] for i in all_mine],
+                                              options=pi_options or None)
+    return lam_
+
+  pi_expired_before = None
+  if (pi_first and n_phases == 2 and compute_fn is None and not eigh and
+      relative_matrix_epsilon and all_mine):
+    # The standalone power iteration has no in-call recovery of an expired resident wait (the
+    # root call's own power iteration has): the count is read here and again after the first
+    # root call, which waits on the host for GPU progress and therefore sees the power iteration
+    # finished; if it moved, `lam` holds NaN for the blocks of the team that gave up -- the
+    # process is on the streaming kernels from then on, so the eigenvalues are recomputed and
+    # the phase is rooted again.
+    pi_expired_before = _expired_waits() if hip_root else None
+    lam = _power_iteration()
+    lam_of = {i: k for k, i in enumerate(all_mine)}
   gathered, gathered_metrics, handles = [], [], []
   in_flight = 0
-  for ph in range(n_phases):
-    buf_elems = max(max(fill[ph]), 1)
-    max_count = max(max(count[ph]), 1)
-    send = torch.empty((buf_elems,), dtype=torch.float32, device=dev)
-    mine = [i for i in range(n_stats) if owner[i] == rank and phase_of[i] == ph]
-    send_metrics = torch.zeros((max_count, metrics_cols), dtype=torch.float32, device=dev)
-    if mine:
-      outs = [send[offsets[i]:offsets[i] + elems[i]] for i in mine]
-      if not raw:
-        outs = [o.view(sizes[i], cols[i]) for o, i in zip(outs, mine)]
-      if compute_fn is not None:
-        m = compute_fn(mine, outs)
+  try:
+    for ph in range(n_phases):
+      buf_elems = max(max(fill[ph]), 1)
+      max_count = max(max(count[ph]), 1)
+      send = torch.empty((buf_elems,), dtype=torch.float32, device=dev)
+      mine = [i for i in range(n_stats) if owner[i] == rank and phase_of[i] == ph]
+      send_metrics = torch.zeros((max_count, metrics_cols), dtype=torch.float32, device=dev)
+      if mine:
+        outs = [send[offsets[i]:offsets[i] + elems[i]] for i in mine]
+        if not raw:
+          outs = [o.view(sizes[i], cols[i]) for o, i in zip(outs, mine)]
+        if compute_fn is not None:
+          m = compute_fn(mine, outs)
+        else:
+          extra = {}
+          if options or iters_hint is not None:
+            o = dict(options or {})
+            if iters_hint is not None and not eigh:
+              o["iters_hint"] = np.asarray([iters_hint[i] for i in mine], dtype=np.float32)
+            extra["options"] = o
+
+          def _root():
+            kw = dict(extra)
+            if lam_of is not None:
+              kw["max_ev"] = lam[[lam_of[i] for i in mine]]
+            return root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
+                           [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
+                           relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
+                           out=outs, **kw)
+
+          _, m = _root()
+          if pi_expired_before is not None:
+            if _expired_waits() != pi_expired_before:
+              lam = _power_iteration()     # streaming execution now (ps_power_iteration_health)
+              _, m = _root()
+            pi_expired_before = None       # checked once: later phases reuse the repaired `lam`
+        send_metrics[:len(mine)] = m
+      if group is None:
+        gathered.append(send.unsqueeze(0))
+        gathered_metrics.append(send_metrics.unsqueeze(0))
+        continue
+      import torch.distributed as dist
+      # flat outputs (concatenation form) are accepted by both RCCL and gloo
+      g = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
+      gm = torch.empty((world * max_count * metrics_cols,), dtype=torch.float32, device=dev)
+      if dist.get_backend(group) == "gloo" and send.is_cuda:
+        # gloo has no device all-gather: stage through the host (functional fallback
+        # for single-GPU debugging; the production backend is RCCL)
+        g_h = torch.empty(g.shape, dtype=torch.float32)
+        m_h = torch.empty(gm.shape, dtype=torch.float32)
+        dist.all_gather_into_tensor(g_h, send.cpu(), group=group)
+        dist.all_gather_into_tensor(m_h, send_metrics.reshape(-1).cpu(), group=group)
+        g.copy_(g_h)
+        gm.copy_(m_h)
+      elif n_phases == 2 and send.is_cuda:
+        in_flight += _collective_in_flight(+1)
+        handles.append(dist.all_gather_into_tensor(g, send, group=group, async_op=True))
+        handles.append(dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group,
+                                                   async_op=True))
+        handles.append((send, send_metrics))  # keep the send buffers alive until wait()
       else:
-        extra = {}
-        if lam_of is not None:
-          extra["max_ev"] = lam[[lam_of[i] for i in mine]]
-        _, m = root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
-                       [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
-                       relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
-                       out=outs, **extra)
-      send_metrics[:len(mine)] = m
-    if group is None:
-      gathered.append(send.unsqueeze(0))
-      gathered_metrics.append(send_metrics.unsqueeze(0))
-      continue
-    import torch.distributed as dist
-    # flat outputs (concatenation form) are accepted by both RCCL and gloo
-    g = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
-    gm = torch.empty((world * max_count * metrics_cols,), dtype=torch.float32, device=dev)
-    if dist.get_backend(group) == "gloo" and send.is_cuda:
-      # gloo has no device all-gather: stage through the host (functional fallback
-      # for single-GPU debugging; the production backend is RCCL)
-      g_h = torch.empty(g.shape, dtype=torch.float32)
-      m_h = torch.empty(gm.shape, dtype=torch.float32)
-      dist.all_gather_into_tensor(g_h, send.cpu(), group=group)
-      dist.all_gather_into_tensor(m_h, send_metrics.reshape(-1).cpu(), group=group)
-      g.copy_(g_h)
-      gm.copy_(m_h)
-    elif n_phases == 2 and send.is_cuda:
-      in_flight += _collective_in_flight(+1)
-      handles.append(dist.all_gather_into_tensor(g, send, group=group, async_op=True))
-      handles.append(dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group,
-                                                 async_op=True))
-      handles.append((send, send_metrics))  # keep the send buffers alive until wait()
-    else:
-      dist.all_gather_into_tensor(g, send, group=group)
-      dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group)
-    gathered.append(g.view(world, buf_elems))
-    gathered_metrics.append(gm.view(world, max_count, metrics_cols))
-  for h in handles:
-    if hasattr(h, "wait"):
-      h.wait()
-  while in_flight > 0:
-    _collective_in_flight(-1)
-    in_flight -= 1
+        dist.all_gather_into_tensor(g, send, group=group)
+        dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group)
+      gathered.append(g.view(world, buf_elems))
+      gathered_metrics.append(gm.view(world, max_count, metrics_cols))
+  finally:
+    # also on an exception from a root / compute call or a later all-gather: outstanding
+    # gathers are waited for and the library's in-flight count is restored (a count left above
+    # zero would keep the whole process off the resident power iteration)
+    try:
+      for h in handles:
+        if hasattr(h, "wait"):
+          h.wait()
+    finally:
+      while in_flight > 0:
+        _collective_in_flight(-1)
+        in_flight -= 1
 
   roots = [
       gathered[phase_of[i]][owner[i], offsets[i]:offsets[i] + elems[i]] for i in range(n_stats)

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "common.h"
+#include "options.h"
 #include "gemm_core.hip.h"
 #include "power_iter.hip.h"
 
@@ -1102,10 +1103,8 @@ using psh::Arena;
 
 namespace {
 
-bool small_eigh_enabled() {  // dev A/B: PS_EIGH_SMALL=0 sends every size through the blocked driver
-  const char* e = getenv("PS_EIGH_SMALL");
-  return !e || atoi(e) != 0;
-}
+// dev A/B (psh::Options::eigh_small = 0): every size goes through the blocked driver
+bool small_eigh_enabled() { return psh::resolve(nullptr).eigh_small != 0; }
 
 struct EPlan {
   int batch = 0, max_n = 0, max_nb = 0;
@@ -1232,8 +1231,11 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                        int batch, float ridge_epsilon, float error_tolerance,
                        int relative_matrix_epsilon, float* const* out, const int32_t* ldo,
                        float* const* evals_out, float* metrics, void* workspace,
-                       size_t workspace_bytes) {
+                       size_t workspace_bytes, const ps_options* options) {
   PS_DEVICE_CHECK();
+  bool bad_options = false;
+  const psh::Options opt = psh::resolve(options, &bad_options);
+  if (bad_options) return PS_EINVAL;
   if (batch <= 0 || !a || !n || !lda || !out || !ldo || !workspace) return PS_EINVAL;
   if (mode == 0 && (!p || !metrics)) return PS_EINVAL;
   if (mode == 1 && !evals_out) return PS_EINVAL;
@@ -1246,6 +1248,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   EPlan pl;
   make_eplan(pl, batch, n, padding_start);
   finish_eplan(pl);
+  pl.pip.set_options(opt);
   if (pl.max_n > 16384) return PS_EUNSUPPORTED;
   Arena ar(workspace, workspace_bytes);
   ELayout lo;
@@ -1361,7 +1364,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
         e = hipStreamSynchronize(st);  // one sync per sweep (a sweep is tens of ms)
         if (e != hipSuccess) return (int)e;
         if (slot->gen != gen) return PS_EINTERNAL;
-        if (getenv("PS_EIGH_TRACE"))
+        if (opt.eigh_trace)
           fprintf(stderr, "eigh sweep %d: tol %.1e max off_rel (start of sweep) %.3e active %d\n",
                   gen, tol, slot->max_off, slot->active);
         ++gen;
@@ -1379,8 +1382,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
           small_attr = true;
         }
-        static const int small_refresh = [] {
-          const char* e = getenv("PS_EIGH_SMALL_REFRESH"); return e ? atoi(e) : 1; }();
+        const int small_refresh = opt.eigh_small_refresh;
         hipLaunchKernelGGL(eigh_small_kernel, dim3((unsigned)pl.small_ids.size()), dim3(SE_T),
                            small_lds, st, lo.blocks, lo.small_ids, small_refresh);
         PS_LAUNCH_CHECK();
@@ -1391,7 +1393,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     if (mode == 1 && !any_big) return PS_OK;  // the kernel wrote sorted pairs to the outputs
     // Root mode, blocks of more than 128 rows: one-sided block Jacobi on the Cholesky factor
     // (eigh_cj.hip.h).  PS_EIGH_CJ=0 restores the blocked two-sided solver for everything.
-    const int cj_on = [] { const char* e = getenv("PS_EIGH_CJ"); return e ? atoi(e) : 1; }();
+    const int cj_on = opt.eigh_cj;
     bool run_two_sided = any_big;
     // After the one-sided sweeps U is orthogonal to the sweep tolerance, so the Newton-Schulz polish
     // of the two-sided solver is off (root error unchanged to three digits on every test
@@ -1399,20 +1401,16 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     // ~300 float32 updates of a column, which is 0.1-0.2 absolute on eigenvalues of 1e4 in the
     // error metric max|u^T D u - diag(e)| (DS:1017-1021, failure threshold 0.1), and the refined
     // values are 20-30 % closer to float64 on rank-deficient-plus-ridge inputs.
-    const int cj_refine = [] { const char* e = getenv("PS_EIGH_CJ_REFINE"); return e ? atoi(e) : 1; }();
-    const int cj_polish = [] { const char* e = getenv("PS_EIGH_CJ_POLISH"); return e ? atoi(e) : 0; }();
+    const int cj_refine = opt.eigh_cj_refine;
+    const int cj_polish = opt.eigh_cj_polish;
     if (cj_on && mode == 0 && any_big) {
-      const float cj_tol = [] {
-        const char* e = getenv("PS_EIGH_CJ_TOL"); return e ? (float)atof(e) : 2e-6f; }();
-      const int cj_inner = [] {
-        const char* e = getenv("PS_EIGH_CJ_INNER"); return e ? atoi(e) : 2; }();
-      const float cj_done = [] {   // inner iteration: stop after a sweep below this cosine
-        const char* e = getenv("PS_EIGH_CJ_DONE"); return e ? (float)atof(e) : 1e-3f; }();
-      const int cj_max_sweeps = [] {
-        const char* e = getenv("PS_EIGH_CJ_MAX_SWEEPS"); return e ? atoi(e) : 24; }();
-      const int cj_stationary = [] { const char* e = getenv("PS_EIGH_CJ_STATIONARY"); return e ? atoi(e) : 1; }();
-      const float cj_one_below = [] { const char* e = getenv("PS_EIGH_CJ_ONE_BELOW"); return e ? (float)atof(e) : 0.1f; }();
-      const int cj_sort = [] { const char* e = getenv("PS_EIGH_CJ_SORT"); return e ? atoi(e) : 1; }();
+      const float cj_tol = opt.eigh_sweep_tol;
+      const int cj_inner = opt.eigh_cj_inner;
+      const float cj_done = opt.eigh_cj_done;   // inner iteration: stop after a sweep below this cosine
+      const int cj_max_sweeps = opt.eigh_cj_max_sweeps;
+      const int cj_stationary = opt.eigh_cj_stationary;
+      const float cj_one_below = opt.eigh_cj_one_below;
+      const int cj_sort = opt.eigh_cj_sort;
       const size_t piv_lds = (size_t)(2 * SE_MAXN * SE_LD + 32 + 3 * SE_MAXN) * sizeof(float);
       static bool piv_attr = false;
       if (!piv_attr) {
@@ -1449,7 +1447,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
           continue;
         }
         run_two_sided = slot->pad_ > 0;
-        if (getenv("PS_EIGH_TRACE"))
+        if (opt.eigh_trace)
           fprintf(stderr, "eigh cj: Cholesky done, %d block(s) fall back to the two-sided solver\n",
                   slot->pad_);
         break;
@@ -1461,14 +1459,14 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       // everything on the caller's stream).  The host stays one sweep ahead of the GPU (it waits
       // for the status of sweep s - 1 only after sweep s is queued), so the streams never
       // drain; converged blocks' workgroups exit at once.
-      const int nstreams = [] { const char* e = getenv("PS_EIGH_CJ_STREAMS"); return e ? atoi(e) : 2; }();
+      const int nstreams = opt.eigh_streams;
       static thread_local hipStream_t side = nullptr;
       static thread_local hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
       if (!side) PS_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       for (int i = 0; i < 3; ++i)
         if (!side_ev[i]) PS_HIP(hipEventCreateWithFlags(&side_ev[i], hipEventDisableTiming));
       // K-tile depth of the update products: 8 = 20 KB of LDS, which fits beside a pivot workgroup
-      const int cj_ubk = [] { const char* e = getenv("PS_EIGH_CJ_UBK"); return e ? atoi(e) : 8; }();
+      const int cj_ubk = opt.eigh_cj_ubk;
       const bool two = nstreams >= 2 && !pl.cj_pair[1].empty();
       hipStream_t gs[2] = {st, two ? side : st};
       if (two) {   // everything queued so far on the caller's stream happens before the side stream starts
@@ -1510,7 +1508,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
             PS_HIP(hipEventSynchronize(g == 0 ? cj_ev[(s - 1) & 1] : side_ev[(s - 1) & 1]));
             EStatus* prev = &status[(2 * (gen - 2) + g) % 64];
             if (prev->gen != gen - 2) return PS_EINTERNAL;
-            if (getenv("PS_EIGH_TRACE"))
+            if (opt.eigh_trace)
               fprintf(stderr, "eigh cj sweep %d group %d: max scaled Gram entry %.3e, %d block(s) still sweeping\n",
                       gen - 2 - first_gen, g, prev->max_off, prev->active);
             if (prev->active == 0) done[g] = true;
@@ -1536,8 +1534,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                        (int)GB_V, (int)GB_X, (int)GB_W, (int)GE_STORE);
     hipLaunchKernelGGL(eigh_set_active_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
                        batch, 1);  // V <-> W
-    static const int f64_reproject = [] {
-      const char* e = getenv("PS_EIGH_F64_REPROJECT"); return e ? atoi(e) : 1; }();
+    const int f64_reproject = opt.eigh_f64_reproject;
     if (f64_reproject && any_big) {
       hipLaunchKernelGGL(eigh_reproject_f64_kernel<0>, dim3(4 * nsq), blk, 0, st, lo.blocks, lo.sq);
       hipLaunchKernelGGL(eigh_reproject_f64_kernel<1>, dim3(4 * nsq), blk, 0, st, lo.blocks, lo.sq);
@@ -1553,10 +1550,8 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     // phase 3: the absolute off-norm says nothing about the small eigenvalues of a graded
     // spectrum: sweep on while the largest SCALED off-diagonal entry is above the float32
     // floor (well-conditioned inputs are far below it after phase 2 and skip this)
-    static const float scaled_tol = [] {
-      const char* e = getenv("PS_EIGH_SCALED_TOL"); return e ? (float)atof(e) : 1e-5f; }();
-    static const int extra_sweeps = [] {
-      const char* e = getenv("PS_EIGH_EXTRA_SWEEPS"); return e ? atoi(e) : 4; }();
+    const float scaled_tol = opt.eigh_scaled_tol;
+    const int extra_sweeps = opt.eigh_extra_sweeps;
     for (int extra = 0; any_big && extra <= extra_sweeps; ++extra) {
       EStatus* slot = &status[gen % 64];
       slot->gen = -1;
@@ -1567,7 +1562,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       if (e != hipSuccess) return (int)e;
       if ((e = hipStreamSynchronize(st)) != hipSuccess) return (int)e;
       if (slot->gen != gen) return PS_EINTERNAL;
-      if (getenv("PS_EIGH_TRACE"))
+      if (opt.eigh_trace)
         fprintf(stderr, "eigh scaled off-diagonal max %.3e, %d block(s) above %.1e\n",
                 slot->max_off, slot->active, scaled_tol);
       ++gen;
@@ -1576,8 +1571,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     }
     }
     {
-      static const int final_polish = [] {
-        const char* e = getenv("PS_EIGH_FINAL_POLISH"); return e ? atoi(e) : 1; }();
+      const int final_polish = opt.eigh_final_polish;
       // the sweeps after the re-projection let V drift from orthogonality again by a few
       // eps32 per sweep: one more Newton-Schulz step V <- V (1.5 I - 0.5 V^T V) (two products)
       // takes most graded / rank-deficient cases to LAPACK-float32's error to three digits
@@ -1609,8 +1603,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                          (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_ERR);
     } else {
     {
-      static int refine = -1;
-      if (refine < 0) { const char* e = getenv("PS_EIGH_REFINE"); refine = e ? atoi(e) != 0 : 1; }
+      const int refine = opt.eigh_refine;
       if (refine && !pl.rq_tiles.empty() && (run_two_sided || cj_refine || !pl.small_ids.empty())) {
         hipLaunchKernelGGL(eigh_rayleigh_f64_kernel, dim3((unsigned)pl.rq_tiles.size()), blk, 0, st,
                            lo.blocks, lo.rq);
@@ -1651,7 +1644,20 @@ extern "C" int ps_eigh_root_batched_f32(void* stream, const float* const* a,
                                         size_t workspace_bytes) {
   return eigh_driver(0, stream, a, n, lda, p, padding_start, batch, ridge_epsilon,
                      error_tolerance, relative_matrix_epsilon, out, ldo, nullptr, metrics,
-                     workspace, workspace_bytes);
+                     workspace, workspace_bytes, nullptr);
+}
+
+extern "C" int ps_eigh_root_batched_opt_f32(void* stream, const float* const* a,
+                                            const int32_t* n, const int32_t* lda,
+                                            const int32_t* p, const int32_t* padding_start,
+                                            int batch, float ridge_epsilon,
+                                            float error_tolerance, int relative_matrix_epsilon,
+                                            float* const* out, const int32_t* ldo,
+                                            float* metrics, void* workspace,
+                                            size_t workspace_bytes, const ps_options* options) {
+  return eigh_driver(0, stream, a, n, lda, p, padding_start, batch, ridge_epsilon,
+                     error_tolerance, relative_matrix_epsilon, out, ldo, nullptr, metrics,
+                     workspace, workspace_bytes, options);
 }
 
 extern "C" int ps_eigh_sorted_max_n(void) { return small_eigh_enabled() ? SE_MAXN : 0; }
@@ -1661,5 +1667,5 @@ extern "C" int ps_eigh_batched_f32(void* stream, const float* const* a, const in
                                    float* const* evecs, const int32_t* ldv, void* workspace,
                                    size_t workspace_bytes) {
   return eigh_driver(1, stream, a, n, lda, nullptr, nullptr, batch, 0.f, 0.f, 0, evecs, ldv,
-                     evals, nullptr, workspace, workspace_bytes);
+                     evals, nullptr, workspace, workspace_bytes, nullptr);
 }

@@ -240,6 +240,40 @@ __device__ inline void zero_acc(f32x16 (&acc)[2][2]) {
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 }
 
+
+// ---- segmented accumulation (ps_options.accumulation = PS_ACCUM_SEGMENTED) ------------------
+// The fp32 MFMA is one fmaf chain over k per output element: its rounding error grows like
+// sqrt(K) * eps relative to sum |a||b|.  With `seg` set the chain is cut every SEG_K = 128 values of
+// k: the finished segment is added to a second register set (`total`) and the chain restarts from
+// zero -- blocked summation, error ~ (sqrt(SEG_K) + sqrt(K / SEG_K)) * eps.  Measured on the cond
+// ~3.5e3 (n = 512) and ~7e3 (n = 1024) p = 4 blocks of the ViT-B state (tools/dev_chain_accuracy.py,
+// bit-level emulation of the chains): root error vs float64 1.30x NumPy/OpenBLAS's with one chain,
+// 1.00x (to the last digit) with segments of 256 -- OpenBLAS's own K blocking on the build box --
+// and 0.75x with 128.  64 v_add per segment and 64 more registers; same MFMA work.  Only the
+// SEGV instantiations carry `total`: the default product kernel (two register sets of loads, two
+// workgroups per CU, 220 VGPRs) has no room for it, so the careful kernel runs ONE workgroup per CU
+// with the whole register file (a lone workgroup keeps the fp32 MFMA pipe ~94 % as busy as two).
+constexpr int SEG_K = 128;
+__device__ __forceinline__ void seg_flush(f32x16 (&acc)[2][2], f32x16 (&total)[2][2]) {
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        total[tm][tn][r] = __fadd_rn(total[tm][tn][r], acc[tm][tn][r]);
+        acc[tm][tn][r] = 0.f;
+      }
+}
+__device__ __forceinline__ void seg_finish(f32x16 (&acc)[2][2], const f32x16 (&total)[2][2]) {
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = __fadd_rn(total[tm][tn][r], acc[tm][tn][r]);
+}
+
 // The two register sets of the DEEP K loop, split in two calls so that a caller that walks a
 // list of tiles can issue the first loads of its NEXT tile before the epilogue of the current
 // one (deep_issue_first), and enter that tile's K loop with them in flight (deep_run).
@@ -266,20 +300,23 @@ __device__ inline void deep_issue_first(const Operand& A, const Operand& B, int 
 }
 
 // acc += A * B with K-tiles 0 and 1 already requested by deep_issue_first.  Ends with a barrier.
-template <int LA, int LB, int BK, bool GUARD>
+template <int LA, int LB, int BK, bool GUARD, bool SEGV = false>
 __device__ inline void deep_run(const Operand& A, const Operand& B, int Kext, float* smem,
                                 f32x16 (&acc)[2][2], DeepSets<LA, LB, BK, GUARD>& r,
-                                unsigned long long* t_fill = nullptr) {
+                                unsigned long long* t_fill = nullptr, bool seg = false) {
   using LdA = TileLoader<LA, BK, GUARD>;
   using LdB = TileLoader<LB, BK, GUARD>;
   constexpr int OPS = SmemCfg<BK>::op_size(LA);
   constexpr int STG = SmemCfg<BK>::op_size(LA) + SmemCfg<BK>::op_size(LB);
+  constexpr int SEGT = SEG_K / BK;   // K-tiles per segment (even)
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
   const int wm = wave >> 1;
   const int wn = wave & 1;
   const int nk = (Kext + BK - 1) / BK;
+  f32x16 total[SEGV ? 2 : 1][SEGV ? 2 : 1];
+  if constexpr (SEGV) zero_acc(total);
   LdA::store(smem, tid, r.ra0);
   LdB::store(smem + OPS, tid, r.rb0);
   __syncthreads();
@@ -311,7 +348,10 @@ __device__ inline void deep_run(const Operand& A, const Operand& B, int Kext, fl
       LdB::store(s0 + OPS, tid, r.rb0);
     }
     __syncthreads();
+    if constexpr (SEGV) { if (seg && (kt + 2) % SEGT == 0 && kt + 2 < nk) seg_flush(acc, total); }
   }
+  if constexpr (SEGV) { if (seg) seg_finish(acc, total); }
+  (void)total; (void)SEGT;
 }
 
 // ---- software-pipelined K loop (any operand layouts, BK = 32, unguarded) --------------------
@@ -403,11 +443,15 @@ __device__ __forceinline__ void pipe_chunk(const FragKM& use, FragKM& nxt, const
   PS_FENCE();
 }
 
-template <int BK, int LA, int LB>
+template <int BK, int LA, int LB, bool SEGV = false>
 __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kext, float* smem,
                                      f32x16 (&acc)[2][2], DeepSets<LA, LB, BK, false>& r,
-                                     unsigned long long* t_fill = nullptr) {
+                                     unsigned long long* t_fill = nullptr, bool seg = false) {
   static_assert(BK == 32, "four 8-deep chunks per K-tile");
+  constexpr int SEGT = SEG_K / BK;
+  f32x16 total[SEGV ? 2 : 1][SEGV ? 2 : 1];
+  if constexpr (SEGV) zero_acc(total);
+  (void)total; (void)SEGT; (void)seg;
   using LdA = TileLoader<LA, BK, false>;
   using LdB = TileLoader<LB, BK, false>;
   constexpr int OPS = SmemCfg<BK>::op_size(LA);
@@ -462,8 +506,13 @@ __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kex
       __syncthreads();
       PS_FENCE();
       pipe_chunk<BK, LA, LB>(f1, f0, s0, s0 + OPS, 0, nxt, wm, wn, i, h, acc);
+      // all MFMAs of K-tiles <= kt + 1 are issued (the chunk above only READS K-tile kt + 2)
+      if constexpr (SEGV) {
+        if (seg && (kt + 2) % SEGT == 0 && nxt) { seg_flush(acc, total); PS_FENCE(); }
+      }
     }
   }
+  if constexpr (SEGV) { if (seg) seg_finish(acc, total); }
   // every LDS read was waited for by the barrier of the last K-tile: smem is free
 }
 
@@ -477,10 +526,10 @@ __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kex
 //   workgroup's K loop cannot go faster than one memory round trip per K-tile even when the
 //   MFMA pipe is free (measured: 6900 cycles per K-tile whether 2 or 3 workgroups shared
 //   the CU).  Same summation order, bit-identical results.
-template <int LA, int LB, int BK, bool GUARD, bool DEEP = false, bool PIPE = false>
+template <int LA, int LB, int BK, bool GUARD, bool DEEP = false, bool PIPE = false, bool SEGV = false>
 __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int Kext,
                                        float* smem, f32x16 (&acc)[2][2],
-                                       unsigned long long* t_fill = nullptr) {
+                                       unsigned long long* t_fill = nullptr, bool seg = false) {
   using LdA = TileLoader<LA, BK, GUARD>;
   using LdB = TileLoader<LB, BK, GUARD>;
   constexpr int OPS = SmemCfg<BK>::op_size(LA);
@@ -499,6 +548,10 @@ __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int K
     LdA::store(smem, tid, ra);
     LdB::store(smem + OPS, tid, rb);
     __syncthreads();
+    constexpr int SEGT = SEG_K / BK;
+    f32x16 total[SEGV ? 2 : 1][SEGV ? 2 : 1];
+    if constexpr (SEGV) zero_acc(total);
+    (void)total; (void)SEGT;
     for (int kt = 0; kt < nk; ++kt) {
       float* cur = smem + (kt & 1) * STG;
       float* nxt = smem + ((kt + 1) & 1) * STG;
@@ -513,24 +566,26 @@ __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int K
         LdB::store(nxt + OPS, tid, rb);
       }
       __syncthreads();
+      if constexpr (SEGV) { if (seg && (kt + 1) % SEGT == 0 && more) seg_flush(acc, total); }
     }
+    if constexpr (SEGV) { if (seg) seg_finish(acc, total); }
     return;
   }
   // ---- two register sets, loop unrolled by two so that the set indices are static ----
   DeepSets<LA, LB, BK, GUARD> sets;
   deep_issue_first<LA, LB, BK, GUARD>(A, B, Kext, sets);
   if constexpr (PIPE && BK == 32 && !GUARD)
-    deep_run_pipe<BK, LA, LB>(A, B, Kext, smem, acc, sets, t_fill);
+    deep_run_pipe<BK, LA, LB, SEGV>(A, B, Kext, smem, acc, sets, t_fill, seg);
   else
-    deep_run<LA, LB, BK, GUARD>(A, B, Kext, smem, acc, sets, t_fill);
+    deep_run<LA, LB, BK, GUARD, SEGV>(A, B, Kext, smem, acc, sets, t_fill, seg);
 }
 
-template <int LA, int LB, int BK, bool GUARD, bool DEEP = false, bool PIPE = false>
+template <int LA, int LB, int BK, bool GUARD, bool DEEP = false, bool PIPE = false, bool SEGV = false>
 __device__ inline void gemm_tile(const Operand& A, const Operand& B, int Kext,
                                  float* smem, f32x16 (&acc)[2][2],
-                                 unsigned long long* t_fill = nullptr) {
+                                 unsigned long long* t_fill = nullptr, bool seg = false) {
   zero_acc(acc);
-  gemm_tile_accum<LA, LB, BK, GUARD, DEEP, PIPE>(A, B, Kext, smem, acc, t_fill);
+  gemm_tile_accum<LA, LB, BK, GUARD, DEEP, PIPE, SEGV>(A, B, Kext, smem, acc, t_fill, seg);
 }
 
 // Accumulator element -> (row, col) inside the 128x128 tile (C/D layout of the

@@ -47,6 +47,7 @@
 
 #include "common.h"
 #include "gemm_core.hip.h"
+#include "options.h"
 #include "power_iter.hip.h"
 
 namespace psk {
@@ -55,9 +56,6 @@ constexpr int NBK = 16;        // K-tile depth of the Newton products
 constexpr int MAX_PROD = 8;    // products per Newton step (p <= 64)
 constexpr int NTEMP = 5;
 constexpr int NQ = 8;          // item queues (one per XCD)
-constexpr bool PS_NEWTON_PIPE_DEFAULT = true;
-constexpr int PS_NEWTON_AVG_STEPS_DEFAULT = 4;      // averaged leading steps of a try
-constexpr float PS_NEWTON_AVG_ERR_DEFAULT = 0.f;   // opt-in: stop averaging once max|M - I| <= this
 
 
 enum Phase { PH_INIT = 0, PH_ACTIVE = 1, PH_DONE = 2 };
@@ -97,6 +95,10 @@ struct NewtonState {
                       // by newton_setup_kernel: one dependent load less at the head of every tile)
   float asym_first;   // number of steps (all tries) whose M update was averaged: PS_M_AVG_STEPS
   int power_iters;
+  // per-block policy, set by the host from the call's options and the caller's iteration-count
+  // hint (ps_options.iters_hint): averaged leading steps of a try, and whether the M-side products
+  // are summed in segments (gemm_core.hip.h SEG_K)
+  int navg, seg;
   // arrival counters of the persistent execution
   unsigned c_init1, c_init2, c_join, c_copy;
   unsigned c_prod[MAX_PROD];
@@ -287,7 +289,8 @@ __device__ __forceinline__ void x_load(const float* p, int ld, int mn0, int k0, 
     r[v] = gload4(p + (int64_t)(mn0 + row) * ld + k0 + k4);
   }
 }
-// registers -> the three bf16 planes of one operand image
+// registers -> the three (TERMS = 6) or two (TERMS = 3: hi, mid) bf16 planes of one operand image
+template <int TERMS>
 __device__ __forceinline__ void x_split_store(uint16_t* img, int tid, const f32x4 (&r)[XNV]) {
 #pragma unroll
   for (int v = 0; v < XNV; ++v) {
@@ -299,12 +302,13 @@ __device__ __forceinline__ void x_split_store(uint16_t* img, int tid, const f32x
       const __bf16 h = (__bf16)x;
       const float r1 = x - (float)h;
       const __bf16 m = (__bf16)r1;
-      hi[e] = h; mid[e] = m; lo[e] = (__bf16)(r1 - (float)m);
+      hi[e] = h; mid[e] = m;
+      if (TERMS == 6) lo[e] = (__bf16)(r1 - (float)m);
     }
     uint16_t* d = img + row * XLD + k4;
     *reinterpret_cast<xbf16x4*>(d) = hi;
     *reinterpret_cast<xbf16x4*>(d + XPLANE) = mid;
-    *reinterpret_cast<xbf16x4*>(d + 2 * XPLANE) = lo;
+    if (TERMS == 6) *reinterpret_cast<xbf16x4*>(d + 2 * XPLANE) = lo;
   }
 }
 __device__ __forceinline__ xbf16x8 x_frag(const uint16_t* plane, int row, int k) {
@@ -314,9 +318,12 @@ __device__ __forceinline__ xbf16x8 x_frag(const uint16_t* plane, int row, int k)
 // acc = A[tile rows of A] * B[tile rows of B]^T over k in [0, Kext) (Kext a multiple of 32: npad
 // is a multiple of 128 and the padding is zero).  One LDS stage (61 KB: 2 workgroups per CU), two
 // register sets of global loads in flight; ends with a barrier.
-__device__ __forceinline__ void gemm_tile_bf16x6_sym(const float* A, const float* B, int ld,
-                                                     int am0, int bn0, int Kext, float* smem_f,
-                                                     f32x16 (&acc)[2][2]) {
+// TERMS = 3 (PS_PRODUCTS_BF16X3, Precision.DEFAULT): x = hi + mid only, products mid*hi + hi*mid +
+// hi*hi: ~2^-16 relative per product at half the MFMA passes and two thirds of the LDS traffic.
+template <int TERMS>
+__device__ __forceinline__ void gemm_tile_bf16x_sym(const float* A, const float* B, int ld,
+                                                    int am0, int bn0, int Kext, float* smem_f,
+                                                    f32x16 (&acc)[2][2]) {
   uint16_t* sA = reinterpret_cast<uint16_t*>(smem_f);
   uint16_t* sB = sA + 3 * XPLANE;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -329,8 +336,8 @@ __device__ __forceinline__ void gemm_tile_bf16x6_sym(const float* A, const float
   x_load(A, ld, am0, 0, tid, ra0);
   x_load(B, ld, bn0, 0, tid, rb0);
   if (nk > 1) { x_load(A, ld, am0, XBK, tid, ra1); x_load(B, ld, bn0, XBK, tid, rb1); }
-  x_split_store(sA, tid, ra0);
-  x_split_store(sB, tid, rb0);
+  x_split_store<TERMS>(sA, tid, ra0);
+  x_split_store<TERMS>(sB, tid, rb0);
   __syncthreads();
   auto compute = [&]() {
 #pragma unroll
@@ -339,17 +346,20 @@ __device__ __forceinline__ void gemm_tile_bf16x6_sym(const float* A, const float
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int ar = wm * 64 + t * 32 + fr, br = wn * 64 + t * 32 + fr, k = ks * 16 + fk;
-        ah[t] = x_frag(sA, ar, k); am[t] = x_frag(sA + XPLANE, ar, k); al[t] = x_frag(sA + 2 * XPLANE, ar, k);
-        bh[t] = x_frag(sB, br, k); bm[t] = x_frag(sB + XPLANE, br, k); bl[t] = x_frag(sB + 2 * XPLANE, br, k);
+        ah[t] = x_frag(sA, ar, k); am[t] = x_frag(sA + XPLANE, ar, k);
+        bh[t] = x_frag(sB, br, k); bm[t] = x_frag(sB + XPLANE, br, k);
+        if (TERMS == 6) { al[t] = x_frag(sA + 2 * XPLANE, ar, k); bl[t] = x_frag(sB + 2 * XPLANE, br, k); }
       }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {   // small terms first
           f32x16 c = acc[tm][tn];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tm], bm[tn], c, 0, 0, 0);
+          if (TERMS == 6) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tm], bm[tn], c, 0, 0, 0);
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tm], bh[tn], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bm[tn], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], c, 0, 0, 0);
@@ -363,16 +373,16 @@ __device__ __forceinline__ void gemm_tile_bf16x6_sym(const float* A, const float
     compute();
     __syncthreads();
     if (kt + 1 >= nk) break;
-    x_split_store(sA, tid, ra1);
-    x_split_store(sB, tid, rb1);
+    x_split_store<TERMS>(sA, tid, ra1);
+    x_split_store<TERMS>(sB, tid, rb1);
     __syncthreads();
     // odd: tile kt+1 in LDS; set 0 holds tile kt+2; set 1 is free -> tile kt+3
     if (kt + 3 < nk) { x_load(A, ld, am0, (kt + 3) * XBK, tid, ra1); x_load(B, ld, bn0, (kt + 3) * XBK, tid, rb1); }
     compute();
     __syncthreads();
     if (kt + 2 < nk) {
-      x_split_store(sA, tid, ra0);
-      x_split_store(sB, tid, rb0);
+      x_split_store<TERMS>(sA, tid, ra0);
+      x_split_store<TERMS>(sB, tid, rb0);
       __syncthreads();
     }
   }
@@ -383,7 +393,7 @@ __device__ __forceinline__ void newton_tile_epilogue(const NewtonBlock* nb, Newt
                                                      int cur, int tm_, int tn_, int flags,
                                                      float* smem, f32x16 (&acc)[2][2]);
 
-template <int BK, bool WT, bool DEEP, bool X6 = false, bool PIPE = false>
+template <int BK, bool WT, bool DEEP, int XM = 0, bool PIPE = false, bool CAREFUL = false>
 __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, NewtonState* st, int prod,
                                            int cur, int tm_, int tn_, int flags,
                                            float* smem, unsigned long long* stamp = nullptr) {
@@ -394,8 +404,15 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
   // Near convergence (max|M - I| < 1e-3 at the start of the step) the split products' noise floor
   // (~2e-6 in max|M - I| on cond 1e4 blocks) is above the 1e-6 stop threshold of DS:836, so the
   // last steps of a block run the exact float32 products: same stop decisions as the parity path.
-  if (X6 && st->general == 0 && st->err > 1e-3f)
-    gemm_tile_bf16x6_sym(A.p, B.p, ld, A.mn0, B.mn0, ld, smem, acc);
+  // Segmented accumulation (ps_options.accumulation): the M-side products -- everything but the H
+  // update, product 0 -- of blocks that the caller's hint does not mark well conditioned.
+  // Only the CAREFUL instantiations carry the second accumulator set (the driver launches them when
+  // the call has at least one such block).
+  const bool seg = CAREFUL && st->seg != 0 && prod != 0;
+  if (XM == 6 && st->general == 0 && st->err > 1e-3f)
+    gemm_tile_bf16x_sym<6>(A.p, B.p, ld, A.mn0, B.mn0, ld, smem, acc);
+  else if (XM == 3 && st->general == 0 && st->err > 3e-2f)
+    gemm_tile_bf16x_sym<3>(A.p, B.p, ld, A.mn0, B.mn0, ld, smem, acc);
   else if (st->general == 0)
     // Exactly symmetric input block (sym_check): element (k, n) of the right operand is read as
     // B[n][k], i.e. both operands are staged k-contiguous and every fragment read is a 16-byte
@@ -404,9 +421,9 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
     // Exact because the iterates are bitwise symmetric: mirror store off the diagonal,
     // symmetrize_diag_tile inside the diagonal tiles (section 4a).  Same k order as the
     // mn-contiguous path; every execution (staged, persistent, all K-loop variants) takes it.
-    gemm_tile<KC, KC, BK, false, DEEP, PIPE>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr);
+    gemm_tile<KC, KC, BK, false, DEEP, PIPE, CAREFUL>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr, seg);
   else
-    gemm_tile<KC, MC, BK, false, DEEP, PIPE>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr);
+    gemm_tile<KC, MC, BK, false, DEEP, PIPE, CAREFUL>(A, B, n, smem, acc, stamp ? stamp + 1 : nullptr, seg);
 
   if (stamp != nullptr && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();  // dev profile
   newton_tile_epilogue<WT>(nb, st, prod, cur, tm_, tn_, flags, smem, acc);
@@ -504,7 +521,7 @@ __device__ __forceinline__ void newton_tile_epilogue(const NewtonBlock* nb, Newt
 // compute the transposed position as a product of its own; symmetric blocks mirror it, except
 // the M update of the first steps of a try (avg), which is computed in full and averaged
 // with its transpose (see TileFlags).
-template <int BK, bool WT, bool DEEP, bool X6 = false, bool PIPE = false>
+template <int BK, bool WT, bool DEEP, int XM = 0, bool PIPE = false, bool CAREFUL = false>
 __device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, NewtonState* st, int prod,
                                            int cur, int avg, int tm, int tn, float* smem,
                                            unsigned long long* stamp = nullptr) {
@@ -526,7 +543,7 @@ __device__ __forceinline__ void newton_product_item(const NewtonBlock* nb, Newto
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first pass's tile is re-read
       __syncthreads();
     }
-    newton_product_tile<BK, WT, DEEP, X6, PIPE>(nb, st, prod, cur, pass ? tn : tm, pass ? tm : tn,
+    newton_product_tile<BK, WT, DEEP, XM, PIPE, CAREFUL>(nb, st, prod, cur, pass ? tn : tm, pass ? tm : tn,
                                           pass ? f1 : f0, smem, stamp);
   }
 }
@@ -650,8 +667,11 @@ __device__ inline void write_metrics(float* metrics, int b, float err, int it, f
 // TRACE (dev, PS_NEWTON_TRACE=<file>): one record of 8 x u64 per tile -- launch sequence number,
 // tile index | product << 32, HW_ID | XCC_ID << 32, and the 100 MHz clock at the start of the
 // tile, after its first LDS fill, at the end of its (last) K loop and at its end.
-template <int BK, bool DEEP, bool X6 = false, bool TRACE = false, bool PIPE = false>
-__global__ __launch_bounds__(256, (DEEP && BK == 32) ? 2 : 3) void newton_stage_kernel(
+// CAREFUL: segmented accumulation for the blocks that ask for it; the second accumulator set does
+// not fit beside two register sets of loads at two workgroups per CU, so this instantiation runs
+// one workgroup per CU with the whole register file.
+template <int BK, bool DEEP, int XM = 0, bool TRACE = false, bool PIPE = false, bool CAREFUL = false>
+__global__ __launch_bounds__(256, CAREFUL ? 1 : ((DEEP && BK == 32) ? 2 : 3)) void newton_stage_kernel(
     const NewtonBlock* blocks, NewtonState* states,
     const TileEntry* tiles, int ntiles, int navg, unsigned long long* trace = nullptr,
     unsigned trace_seq = 0, unsigned trace_cap = 0) {
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(256, (DEEP && BK == 32) ? 2 : 3) void newton_stage_
     }
     // P0 of step 0 (H0 Mi, H0 a scaled identity) was written by newton_init2_tile
     if (st->phase == PH_ACTIVE && !(tk.prod == 0 && st->it == 0))
-      newton_product_item<BK, false, DEEP, X6, PIPE>(nb, st, tk.prod, st->cur, st->avg_on, te.tm,
+      newton_product_item<BK, false, DEEP, XM, PIPE, CAREFUL>(nb, st, tk.prod, st->cur, st->avg_on, te.tm,
                                                      te.tn, smem, TRACE ? s_trace : nullptr);
     if (TRACE && threadIdx.x == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left the CU
@@ -742,7 +762,7 @@ __device__ inline void finish_try(NewtonState* st) {
 // Newton step (DS:848 carry + DS:836-840 condition).
 __global__ __launch_bounds__(256) void newton_control_kernel(
     NewtonState* states, int nblocks, int mode, int num_iters, float tol, int gen,
-    HostStatus* status, int navg, float avg_thr) {
+    HostStatus* status, float avg_thr) {
   __shared__ int s_nd, s_ni;
   if (threadIdx.x == 0) { s_nd = 0; s_ni = 0; }
   __syncthreads();
@@ -755,7 +775,7 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
       st->ratio = 1.f;
       st->it = 0;
       st->asym_bits = 0; st->xmax_bits = 0;
-      st->avg_on = newton_avg_next(0, navg, st->err, avg_thr) ? 1 : 0;
+      st->avg_on = newton_avg_next(0, st->navg, st->err, avg_thr) ? 1 : 0;
       const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
       if (cont) st->phase = PH_ACTIVE; else finish_try(st);
     } else if (mode == 1 && st->phase == PH_ACTIVE) {
@@ -767,7 +787,7 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
       st->total_iters += 1;
       st->cur ^= 1;
       if (st->avg_on) st->asym_first += 1.f;   // averaged steps so far (all tries)
-      st->avg_on = (st->avg_on && newton_avg_next(st->it, navg, st->err, avg_thr)) ? 1 : 0;
+      st->avg_on = (st->avg_on && newton_avg_next(st->it, st->navg, st->err, avg_thr)) ? 1 : 0;
       st->asym_bits = 0; st->xmax_bits = 0;
       const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
       if (!cont) finish_try(st);
@@ -868,7 +888,6 @@ struct PArgs {
   int nlive;          // blocks with n >= 1
   int num_iters;
   float tol;
-  int navg;           // cap of the averaged steps of a try (TileFlags, newton_avg_next)
   float avg_thr;      // ... which last while max|M - I| is above this
   int grid;           // workgroups of the persistent launch (exit tokens per queue)
   int nq;             // queues in use (1..NQ); workgroup w serves queue w % nq
@@ -993,7 +1012,7 @@ __device__ inline void p_control_init(const PArgs& pa, const NewtonBlock* nb, Ne
   ast(&st->it, 0);
   ast(&st->asym_bits, 0u);
   ast(&st->xmax_bits, 0u);
-  const int avg0 = newton_avg_next(0, pa.navg, ald(&st->err), pa.avg_thr) ? 1 : 0;
+  const int avg0 = newton_avg_next(0, ald(&st->navg), ald(&st->err), pa.avg_thr) ? 1 : 0;
   ast(&st->avg_on, avg0);
   const bool cont = 0 < pa.num_iters && err > pa.tol;
   if (cont) { ast(&st->phase, (int)PH_ACTIVE); p_start_step(pa, nb, b, cur, avg0); }
@@ -1018,7 +1037,7 @@ __device__ inline void p_control_step(const PArgs& pa, const NewtonBlock* nb, Ne
   const int was = ald(&st->avg_on);
   (void)ab; (void)xb;
   if (was) ast(&st->asym_first, ald(&st->asym_first) + 1.f);
-  const int avg = (was && newton_avg_next(it, pa.navg, new_err, pa.avg_thr)) ? 1 : 0;
+  const int avg = (was && newton_avg_next(it, ald(&st->navg), new_err, pa.avg_thr)) ? 1 : 0;
   ast(&st->avg_on, avg);
   ast(&st->asym_bits, 0u);
   ast(&st->xmax_bits, 0u);
@@ -1094,8 +1113,8 @@ constexpr int PSMEM = SmemCfg<BK>::TOTAL > 64 * 132 ? SmemCfg<BK>::TOTAL : 64 * 
 
 // DEEP = false: 3 workgroups per CU (<= 168 VGPRs).  DEEP = true: two-K-tile-deep register
 // prefetch in the K loop, 2 workgroups per CU (the second register set does not fit in 168).
-template <int BK, bool DEEP>
-__global__ __launch_bounds__(256, DEEP ? 2 : 3) void newton_persistent_kernel(PArgs pa) {
+template <int BK, bool DEEP, bool CAREFUL = false>
+__global__ __launch_bounds__(256, (DEEP || CAREFUL) ? 2 : 3) void newton_persistent_kernel(PArgs pa) {
   extern __shared__ __align__(16) float smem[];  // PSMEM<BK> floats + 16
   float* scratch = smem + PSMEM<BK>;             // 16 floats of control scratch
   u64* s_item = reinterpret_cast<u64*>(scratch + 12);
@@ -1145,7 +1164,7 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void newton_persistent_kernel(PA
     NewtonState* st = &pa.states[b];
     if (kind == IT_PROD) {
       if (!(prod == 0 && ald(&st->it) == 0))   // step-0 P0: written by newton_init2_tile
-        newton_product_item<BK, PERSIST_WT, DEEP>(nb, st, prod, bit, avg, tm, tn, smem,
+        newton_product_item<BK, PERSIST_WT, DEEP, 0, false, CAREFUL>(nb, st, prod, bit, avg, tm, tn, smem,
                                       pa.prof ? s_stamp : nullptr);
     } else if (kind == IT_INIT1) {
       newton_init1_tile<PERSIST_WT>(nb, ald(&st->ridge_try), tm, tn, scratch);
@@ -1241,6 +1260,8 @@ struct Plan {
   // staged execution
   int nstages = 0;
   std::vector<std::vector<TileEntry>> stage_tiles;
+  // the same tiles in the order used while M updates are averaged (two-pass tiles first)
+  std::vector<std::vector<TileEntry>> stage_tiles_avg;
   std::vector<TileEntry> init_tiles;  // one per (block, tile)
   PiPlan pip;
   int max_n = 0;
@@ -1254,10 +1275,7 @@ struct Plan {
 // (~10 us of 143 us) that the hardware dispatcher does for free, and the MFMA pipe of a CU
 // stays shared by only 3 workgroups either way.  PS_NEWTON_PERSISTENT=1 selects the
 // persistent kernel (no host round trip at all: the call only enqueues).
-bool persistent_mode() {
-  const char* e = getenv("PS_NEWTON_PERSISTENT");
-  return e ? (atoi(e) != 0) : false;
-}
+// (selected per call: ps_options.execution)
 
 void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
                const int32_t* padding_start, bool staged) {
@@ -1357,15 +1375,31 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
           pl.stage_tiles[s].push_back({b | ((int)k << 24), (short)tm, (short)tn});
     }
   }
+  // Launches of steps that average the M update: the off-diagonal tiles of that product run two
+  // passes (TF_RAW + TF_AVG), twice as long as every other tile of the launch.  Workgroup i runs
+  // list entry xcd_remap(i): XCD x walks its contiguous chunk of the list in order, so inside every
+  // chunk the two-pass tiles are moved to the front (longest first: the one-pass tiles fill the
+  // tail of the launch instead of waiting behind it; same tiles per XCD, so a block's operands
+  // stay in one L2).
+  pl.stage_tiles_avg = pl.stage_tiles;
+  for (int s = 0; s < pl.nstages; ++s) {
+    auto& v = pl.stage_tiles_avg[s];
+    const int nt = (int)v.size(), q = nt >> 3, r = nt & 7;
+    int first = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int cnt = x < r ? q + 1 : q;
+      std::stable_partition(v.begin() + first, v.begin() + first + cnt, [&](const TileEntry& te) {
+        const int b = te.task & TE_BLOCK_MASK, k = te.task >> 24;
+        return k == (int)pl.chains[b].size() - 1 && te.tm != te.tn;
+      });
+      first += cnt;
+    }
+  }
 }
 
 // dev A/B: PS_NEWTON_GRID=g caps the stage launches at g workgroups that loop over the tile
 // list (0 / unset: one workgroup per tile).
-static int stage_grid(int ntiles) {
-  static const int cap = [] {
-    const char* e = getenv("PS_NEWTON_GRID");
-    return e ? atoi(e) : 0;
-  }();
+static int stage_grid(int ntiles, int cap) {
   return cap > 0 ? std::min(cap, ntiles) : ntiles;
 }
 
@@ -1376,6 +1410,7 @@ struct WsLayout {
   u64* slots;
   u64* prof;
   TileEntry* tiles[MAX_PROD];
+  TileEntry* tiles_avg[MAX_PROD];
   TileEntry* init_tiles;
   std::vector<float*> mat[10];
   std::vector<float*> sumsq;
@@ -1394,7 +1429,8 @@ size_t carve(Plan& pl, Arena& ar, WsLayout* lo, bool staged) {
   if (staged) {
     for (int s = 0; s < pl.nstages; ++s) {
       TileEntry* e = ar.take<TileEntry>(pl.stage_tiles[s].size());
-      if (lo) { lo->tiles[s] = e; }
+      TileEntry* e2 = ar.take<TileEntry>(pl.stage_tiles[s].size());
+      if (lo) { lo->tiles[s] = e; lo->tiles_avg[s] = e2; }
     }
     TileEntry* it = ar.take<TileEntry>(pl.init_tiles.size());
     if (lo) { lo->init_tiles = it; }
@@ -1475,12 +1511,7 @@ HostStatus* pinned_status() {
 // BK16+deep 13.73 / 22.39, BK32 14.51 / 22.76, BK32+deep 13.57 / 21.70).  Persistent execution:
 // off by default (3 workgroups per CU cover each other's dequeue / epilogue phases better).
 // PS_NEWTON_DEEP = 0 | 1 and PS_NEWTON_BK = 16 | 32 override.
-bool deep_mode(bool dflt) {
-  const char* e = getenv("PS_NEWTON_DEEP");
-  return e ? atoi(e) != 0 : dflt;
-}
-
-int persistent_grid(size_t lds_bytes, bool deep) {
+int persistent_grid(size_t lds_bytes, bool deep, int wg_per_cu) {
   static int grid[2] = {0, 0};
   if (grid[deep] == 0) {
     int dev = 0, cus = 256, occ = deep ? 2 : 3;
@@ -1493,8 +1524,7 @@ int persistent_grid(size_t lds_bytes, bool deep) {
     int q = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, 256, lds_bytes) == hipSuccess && q >= 1)
       occ = q;
-    const char* e = getenv("PS_NEWTON_WG_PER_CU");
-    if (e && atoi(e) > 0) occ = atoi(e);
+    if (wg_per_cu > 0) occ = wg_per_cu;
     grid[deep] = cus * occ;
   }
   return grid[deep];
@@ -1502,10 +1532,7 @@ int persistent_grid(size_t lds_bytes, bool deep) {
 
 }  // namespace
 
-extern "C" int ps_newton_averaged_steps(void) {
-  const char* e = getenv("PS_NEWTON_AVG_STEPS");
-  return e ? std::max(0, atoi(e)) : PS_NEWTON_AVG_STEPS_DEFAULT;
-}
+extern "C" int ps_newton_averaged_steps(void) { return psh::resolve(nullptr).averaged_steps; }
 
 extern "C" size_t ps_newton_root_workspace_bytes(int batch, const int32_t* n,
                                                  const int32_t* p,
@@ -1523,8 +1550,12 @@ static int newton_driver(
     const int32_t* p, const int32_t* padding_start, int batch, int num_iters,
     float ridge_epsilon, float error_tolerance, int relative_matrix_epsilon,
     const float* max_ev_given, int symmetry, float* const* out, const int32_t* ldo,
-    float* metrics, void* workspace, size_t workspace_bytes, int32_t* iters_executed_host) {
+    float* metrics, void* workspace, size_t workspace_bytes, int32_t* iters_executed_host,
+    const ps_options* options) {
   PS_DEVICE_CHECK();
+  bool bad_options = false;
+  const psh::Options opt = psh::resolve(options, &bad_options);
+  if (bad_options) return PS_EINVAL;
   if (batch <= 0 || !a || !n || !lda || !p || !out || !ldo || !metrics || !workspace ||
       num_iters < 1 || symmetry < PS_SYMMETRY_VERIFY || symmetry > PS_SYMMETRY_GENERAL)
     return PS_EINVAL;
@@ -1532,20 +1563,18 @@ static int newton_driver(
   for (int b = 0; b < batch; ++b)
     if (n[b] < 1 || lda[b] < n[b] || ldo[b] < n[b] || !a[b] || !out[b]) return PS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const bool staged = !persistent_mode();
-  {
-    const char* e = getenv("PS_NEWTON_SYMMETRIC");  // dev: 0 forces the full products
-    if (e && atoi(e) == 0) symmetry = PS_SYMMETRY_GENERAL;
-  }
+  const bool staged = opt.execution != PS_EXEC_PERSISTENT;
+  if (opt.force_general) symmetry = PS_SYMMETRY_GENERAL;   // dev
   // Leading steps of every try whose M update is computed in full and averaged with its
-  // transpose (TileFlags above).  PS_NEWTON_AVG_STEPS overrides (0 = mirrored everywhere).
-  const int navg = ps_newton_averaged_steps();
-  const float avg_thr = [] { const char* e = getenv("PS_NEWTON_AVG_ERR");
-                             return e ? (float)atof(e) : PS_NEWTON_AVG_ERR_DEFAULT; }();
+  // transpose (TileFlags above); per block 0 when the caller's hint marks it well conditioned.
+  const int navg = opt.averaged_steps;
+  const float avg_thr = opt.averaged_err_threshold;
+  const int seg_on = (opt.accumulation == PS_ACCUM_SEGMENTED && opt.products == PS_PRODUCTS_F32) ? 1 : 0;
   Plan pl;
   make_plan(pl, batch, n, p, padding_start, staged);
   if (!pl.ok) return PS_EUNSUPPORTED;
   if (pl.max_n > 16384) return PS_EUNSUPPORTED;
+  pl.pip.set_options(opt);
   Arena ar(workspace, workspace_bytes);
   WsLayout lo;
   carve(pl, ar, &lo, staged);
@@ -1554,6 +1583,7 @@ static int newton_driver(
   // ---- upload plan (pinned staging ring: no stream synchronisation) ------------------
   std::vector<NewtonBlock> hb(batch);
   std::vector<NewtonState> hs(batch);
+  bool any_careful = false, any_avg = false;
   for (int b = 0; b < batch; ++b) {
     NewtonBlock& nb = hb[b];
     NewtonState& ns = hs[b];
@@ -1579,6 +1609,14 @@ static int newton_driver(
     }
     ns.phase = pl.n_eff[b] >= 1 ? PH_INIT : PH_DONE;
     ns.ratio = 1.f;
+    // A block whose hint (its Newton iteration count at the previous recompute) lies in
+    // [1, fast_max_iters] is well conditioned: mirrored M updates and plain chains are exact to 1e-6
+    // there.  Every other block (no hint, NaN, a slow block) takes the careful path.
+    const float hv = opt.iters_hint ? opt.iters_hint[(size_t)b * opt.iters_hint_stride] : 0.f;
+    const bool fast = hv >= 1.f && hv <= (float)opt.fast_max_iters;   // false for NaN
+    ns.navg = fast ? 0 : navg;
+    ns.seg = fast ? 0 : seg_on;
+    if (pl.n_eff[b] >= 1) { any_careful |= ns.seg != 0; any_avg |= ns.navg > 0; }
   }
   ProfRun prof(st);
   // Everything from the descriptor upload to the seeded loop state; run again (on the streaming
@@ -1607,6 +1645,9 @@ static int newton_driver(
     for (int s = 0; s < pl.nstages; ++s) {
       PS_RC(psh::upload_async(st, lo.tiles[s], pl.stage_tiles[s].data(),
                               sizeof(TileEntry) * pl.stage_tiles[s].size()));
+      if (any_avg && opt.avg_lpt)
+        PS_RC(psh::upload_async(st, lo.tiles_avg[s], pl.stage_tiles_avg[s].data(),
+                                sizeof(TileEntry) * pl.stage_tiles_avg[s].size()));
     }
     PS_RC(psh::upload_async(st, lo.init_tiles, pl.init_tiles.data(),
                             sizeof(TileEntry) * pl.init_tiles.size()));
@@ -1620,12 +1661,11 @@ static int newton_driver(
     pa.metrics = metrics; pa.qcap = (unsigned)pl.qcap; pa.nblocks = batch;
     pa.nlive = pl.nlive; pa.num_iters = num_iters; pa.tol = error_tolerance;
     const size_t lds = (PSMEM<NBK> + 16) * sizeof(float);
-    const bool deep = deep_mode(false);
-    const int grid = std::min(persistent_grid(lds, deep), 4096);
-    const bool dev_prof = getenv("PS_NEWTON_PROF") != nullptr;
+    const bool deep = opt.persistent_deep != 0;
+    const int grid = std::min(persistent_grid(lds, deep || any_careful, opt.wg_per_cu), 4096);
+    const bool dev_prof = opt.newton_prof;
     pa.prof = dev_prof ? lo.prof : nullptr;
     pa.grid = grid;
-    pa.navg = navg;
     pa.avg_thr = avg_thr;
     pa.nq = pl.nq;
     if (dev_prof) PS_HIP(hipMemsetAsync(lo.prof, 0, sizeof(u64) * 12 * 4096, st));
@@ -1638,7 +1678,9 @@ static int newton_driver(
       prof.end();
       PS_LAUNCH_CHECK();
       prof.begin(0);
-      if (deep)
+      if (any_careful)
+        hipLaunchKernelGGL((newton_persistent_kernel<NBK, false, true>), dim3(grid), dim3(256), lds, st, pa);
+      else if (deep)
         hipLaunchKernelGGL((newton_persistent_kernel<NBK, true>), dim3(grid), dim3(256), lds, st, pa);
       else
         hipLaunchKernelGGL((newton_persistent_kernel<NBK, false>), dim3(grid), dim3(256), lds, st, pa);
@@ -1675,52 +1717,37 @@ static int newton_driver(
   // ---- staged execution --------------------------------------------------------------
   HostStatus* status = pinned_status();
   if (!status) return PS_EINTERNAL;
-  // K-tile depth of the product kernel: 32 (73.7 KB LDS => exactly 2 workgroups per
-  // CU, half the barriers) or 16 (40 KB, 3 per CU).  PS_NEWTON_BK overrides.
-  // Variant of the product kernel (dev A/B): PS_NEWTON_BK = 16 | 32, PS_NEWTON_DEEP = 0 | 1.
-  static int stage_bk = 0, stage_deep = 0;
-  if (stage_bk == 0) {
-    const char* e = getenv("PS_NEWTON_BK");
-    stage_bk = (e && atoi(e) == 16) ? 16 : 32;
-    stage_deep = deep_mode(true) ? 1 : 0;
-    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
-    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
-    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
-  }
-  // opt-in arithmetic of the products (read per call: the bench times both modes in one process)
-  const bool x6_mode = [] { const char* e = getenv("PS_NEWTON_PRODUCTS");
-                            return e && strcmp(e, "bf16x6") == 0; }();
-  // explicitly software-pipelined K loop (gemm_core.hip.h deep_run_pipe): PS_NEWTON_PIPE = 0 | 1
-  const bool pipe_mode = [] { const char* e = getenv("PS_NEWTON_PIPE");
-                              return e ? atoi(e) != 0 : PS_NEWTON_PIPE_DEFAULT; }();
-  static bool pipe_attr = false;
-  if (!pipe_attr) {
-    pipe_attr = true;
-    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true, false, false, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
-    (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true, false, true, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(SmemCfg<32>::TOTAL * sizeof(float)));
+  // Variant of the product kernel.  Default: BK = 32, two register sets of global loads, the
+  // explicitly software-pipelined K loop (gemm_core.hip.h deep_run_pipe), 2 workgroups per CU;
+  // the other instantiations are developer A/B variants (psh::Options::stage_bk / stage_deep /
+  // pipe).  The bf16-split arithmetic has its own instantiations.
+  const int stage_bk = opt.stage_bk, stage_deep = opt.stage_deep;
+  const int xmode = opt.products == PS_PRODUCTS_BF16X6 ? 6 : (opt.products == PS_PRODUCTS_BF16X3 ? 3 : 0);
+  const bool pipe_mode = opt.pipe != 0 && stage_bk == 32 && stage_deep;
+  {
+    static std::once_flag attr_once;   // kernel attributes are per process (one device per process)
+    std::call_once(attr_once, [] {
+      const int lds = (int)(SmemCfg<32>::TOTAL * sizeof(float));
+      const void* fns[] = {(const void*)newton_stage_kernel<32, false>,
+                           (const void*)newton_stage_kernel<32, true>,
+                           (const void*)newton_stage_kernel<32, true, 6>,
+                           (const void*)newton_stage_kernel<32, true, 3>,
+                           (const void*)newton_stage_kernel<32, true, 0, false, true>,
+                           (const void*)newton_stage_kernel<32, true, 0, false, true, true>,
+                           (const void*)newton_stage_kernel<32, true, 0, true, true>,
+                           (const void*)newton_stage_kernel<32, true, 0, true>};
+      for (const void* f : fns)
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
   }
   // dev trace of the product kernel (PS_NEWTON_TRACE=<file>: records appended per call)
   constexpr unsigned TRACE_CAP = 1u << 20;
   static unsigned long long* trace_buf = nullptr;
   static unsigned trace_seq = 0;
-  const char* trace_path = getenv("PS_NEWTON_TRACE");
+  const char* trace_path = opt.newton_trace;
   if (trace_path && !trace_buf) {
     if (hipMalloc(&trace_buf, (8 + 8 * (size_t)TRACE_CAP) * sizeof(unsigned long long)) != hipSuccess)
       trace_buf = nullptr;
-    else
-      (void)hipFuncSetAttribute((const void*)newton_stage_kernel<32, true, false, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(SmemCfg<32>::TOTAL * sizeof(float)));
   }
   if (!trace_path) { /* tracing off for this call */ }
   unsigned long long* const trace_on = trace_path ? trace_buf : nullptr;
@@ -1737,6 +1764,7 @@ static int newton_driver(
     const int cap = 6 * (num_iters + 2) + 4;
     bool need_init = true, pi_retried = false;
     int rc = 0;
+    int since_init = 0;   // steps since the last (re)initialisation launch: < navg => averaged M updates
     for (int g = 0; g < cap; ++g) {
       HostStatus* slot = &status[g % 64];
       slot->gen = -1;
@@ -1747,41 +1775,44 @@ static int newton_driver(
         hipLaunchKernelGGL(newton_init2_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
                            lo.states, lo.init_tiles);
         hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
-                           batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr, navg, avg_thr);
+                           batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr, avg_thr);
         prof.end();
+        since_init = 0;
       }
+      const bool avg_order = any_avg && opt.avg_lpt && since_init < navg;
+      ++since_init;
       for (int s = 0; s < pl.nstages; ++s) {
         const int nt = (int)pl.stage_tiles[s].size();
         prof.begin(0);
-#define PS_STAGE(BKV, DEEPV)                                                              \
-  hipLaunchKernelGGL((newton_stage_kernel<BKV, DEEPV>), dim3(stage_grid(nt)), dim3(256),    \
-                     SmemCfg<BKV>::TOTAL * sizeof(float), st, lo.blocks, lo.states,         \
-                     lo.tiles[s], nt, navg)
-        if (pipe_mode && !x6_mode && trace_on)
-          hipLaunchKernelGGL((newton_stage_kernel<32, true, false, true, true>), dim3(stage_grid(nt)),
-                             dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tiles[s], nt, navg, trace_on, trace_seq++, TRACE_CAP);
-        else if (pipe_mode && !x6_mode)
-          hipLaunchKernelGGL((newton_stage_kernel<32, true, false, false, true>), dim3(stage_grid(nt)),
-                             dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tiles[s], nt, navg);
+        const TileEntry* tl = avg_order ? lo.tiles_avg[s] : lo.tiles[s];
+        const dim3 grid(stage_grid(nt, opt.grid_cap));
+        const size_t lds = SmemCfg<32>::TOTAL * sizeof(float);
+#define PS_STAGE(...)                                                                       \
+  hipLaunchKernelGGL((newton_stage_kernel<__VA_ARGS__>), grid, dim3(256), lds, st, lo.blocks, \
+                     lo.states, tl, nt, navg)
+        if (pipe_mode && xmode == 0 && trace_on)
+          hipLaunchKernelGGL((newton_stage_kernel<32, true, 0, true, true>), grid, dim3(256), lds, st,
+                             lo.blocks, lo.states, tl, nt, navg, trace_on, trace_seq++, TRACE_CAP);
+        else if (pipe_mode && xmode == 0 && any_careful) PS_STAGE(32, true, 0, false, true, true);
+        else if (pipe_mode && xmode == 0) PS_STAGE(32, true, 0, false, true);
         else if (trace_on)
-          hipLaunchKernelGGL((newton_stage_kernel<32, true, false, true>), dim3(stage_grid(nt)),
-                             dim3(256), SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tiles[s], nt, navg, trace_on, trace_seq++, TRACE_CAP);
-        else if (x6_mode)
-          hipLaunchKernelGGL((newton_stage_kernel<32, true, true>), dim3(stage_grid(nt)), dim3(256),
-                             SmemCfg<32>::TOTAL * sizeof(float), st, lo.blocks, lo.states,
-                             lo.tiles[s], nt, navg);
+          hipLaunchKernelGGL((newton_stage_kernel<32, true, 0, true>), grid, dim3(256), lds, st,
+                             lo.blocks, lo.states, tl, nt, navg, trace_on, trace_seq++, TRACE_CAP);
+        else if (xmode == 6) PS_STAGE(32, true, 6);
+        else if (xmode == 3) PS_STAGE(32, true, 3);
         else if (stage_bk == 32 && stage_deep) PS_STAGE(32, true);
         else if (stage_bk == 32) PS_STAGE(32, false);
-        else if (stage_deep) PS_STAGE(16, true);
-        else PS_STAGE(16, false);
+        else if (stage_deep)
+          hipLaunchKernelGGL((newton_stage_kernel<16, true>), grid, dim3(256),
+                             SmemCfg<16>::TOTAL * sizeof(float), st, lo.blocks, lo.states, tl, nt, navg);
+        else
+          hipLaunchKernelGGL((newton_stage_kernel<16, false>), grid, dim3(256),
+                             SmemCfg<16>::TOTAL * sizeof(float), st, lo.blocks, lo.states, tl, nt, navg);
 #undef PS_STAGE
         prof.end();
       }
       hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
-                         batch, 1, num_iters, error_tolerance, g, slot, navg, avg_thr);
+                         batch, 1, num_iters, error_tolerance, g, slot, avg_thr);
       if ((rc = (int)hipGetLastError()) != 0) break;
       if ((rc = (int)hipEventRecord(ev[g & 1], st)) != 0) break;
       ++executed;
@@ -1795,6 +1826,7 @@ static int newton_driver(
           // (CUs held by another stream's kernels): its blocks carry a NaN eigenvalue.  The
           // process is on the streaming execution from now on (PiPlan::resident_enabled);
           // queue the whole call again behind what is already queued and start over.
+          pl.pip.allow_resident = false;
           if ((rc = enqueue_front()) != 0) break;
           need_init = true;
           g = -1;
@@ -1871,7 +1903,20 @@ extern "C" int ps_power_iteration_batched_f32(
     const int32_t* padding_start, int batch, int num_iters, float error_tolerance,
     float* out_lambda, int32_t* out_iters, float* out_v, int32_t ldv, int symmetry,
     void* workspace, size_t workspace_bytes) {
+  return ps_power_iteration_batched_opt_f32(stream, a, n, lda, padding_start, batch, num_iters,
+                                            error_tolerance, out_lambda, out_iters, out_v, ldv,
+                                            symmetry, workspace, workspace_bytes, nullptr);
+}
+
+extern "C" int ps_power_iteration_batched_opt_f32(
+    void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
+    const int32_t* padding_start, int batch, int num_iters, float error_tolerance,
+    float* out_lambda, int32_t* out_iters, float* out_v, int32_t ldv, int symmetry,
+    void* workspace, size_t workspace_bytes, const ps_options* options) {
   PS_DEVICE_CHECK();
+  bool bad_options = false;
+  const psh::Options opt = psh::resolve(options, &bad_options);
+  if (bad_options) return PS_EINVAL;
   if (batch <= 0 || !a || !n || !lda || !out_lambda || !workspace || num_iters < 1 ||
       symmetry < PS_SYMMETRY_VERIFY || symmetry > PS_SYMMETRY_GENERAL)
     return PS_EINVAL;
@@ -1880,6 +1925,7 @@ extern "C" int ps_power_iteration_batched_f32(
   hipStream_t st = (hipStream_t)stream;
   PiPlan pp;
   pi_plan_from_args(pp, batch, n, padding_start);
+  pp.set_options(opt);
   if (pp.max_n > 16384) return PS_EUNSUPPORTED;
   if (out_v && ldv < pp.max_n) return PS_EINVAL;
   Arena ar(workspace, workspace_bytes);
@@ -1905,7 +1951,18 @@ extern "C" int ps_newton_root_batched_f32(
     size_t workspace_bytes, int32_t* iters_executed_host) {
   return newton_driver(stream, a, n, lda, p, padding_start, batch, num_iters, ridge_epsilon,
                        error_tolerance, relative_matrix_epsilon, nullptr, symmetry, out, ldo,
-                       metrics, workspace, workspace_bytes, iters_executed_host);
+                       metrics, workspace, workspace_bytes, iters_executed_host, nullptr);
+}
+
+extern "C" int ps_newton_root_batched_opt_f32(
+    void* stream, const float* const* a, const int32_t* n, const int32_t* lda,
+    const int32_t* p, const int32_t* padding_start, int batch, int num_iters,
+    float ridge_epsilon, float error_tolerance, int relative_matrix_epsilon, const float* max_ev,
+    int symmetry, float* const* out, const int32_t* ldo, float* metrics, void* workspace,
+    size_t workspace_bytes, int32_t* iters_executed_host, const ps_options* options) {
+  return newton_driver(stream, a, n, lda, p, padding_start, batch, num_iters, ridge_epsilon,
+                       error_tolerance, max_ev ? 1 : relative_matrix_epsilon, max_ev, symmetry, out,
+                       ldo, metrics, workspace, workspace_bytes, iters_executed_host, options);
 }
 
 extern "C" int ps_newton_root_batched_maxev_f32(
@@ -1917,5 +1974,5 @@ extern "C" int ps_newton_root_batched_maxev_f32(
   if (!max_ev) return PS_EINVAL;
   return newton_driver(stream, a, n, lda, p, padding_start, batch, num_iters, ridge_epsilon,
                        error_tolerance, 1, max_ev, symmetry, out, ldo, metrics, workspace,
-                       workspace_bytes, iters_executed_host);
+                       workspace_bytes, iters_executed_host, nullptr);
 }

@@ -1,0 +1,62 @@
+// options.h — every mode switch of the library, resolved once per call.
+//
+// psh::resolve(ps_options*) turns the caller's ps_options (include/ps_api.h; NULL = defaults)
+// into the flat struct below.  The fields after `dev` have no public spelling: they are A/B
+// switches of the kernels' development and keep their defaults unless the process runs with
+// PS_DEV_ENV=1, in which case ps_dev_env_overrides() -- the ONLY function of the library that
+// reads the environment -- applies the PS_* variables of earlier rounds on top.
+#pragma once
+#include "../../include/ps_api.h"
+
+namespace psh {
+
+struct Options {
+  // ---- public (ps_options) --------------------------------------------------------------------
+  int products = PS_PRODUCTS_F32;
+  int accumulation = PS_ACCUM_SEGMENTED;
+  int averaged_steps = 4;
+  const float* iters_hint = nullptr;
+  int iters_hint_stride = 1;
+  int fast_max_iters = 8;
+  float averaged_err_threshold = 0.f;
+  int execution = PS_EXEC_STAGED;
+  int power_iteration = PS_PI_AUTO;
+  double pi_timeout_ms = 5000.0;
+  float eigh_sweep_tol = 2e-6f;
+  int eigh_streams = 2;
+  // ---- dev (environment, PS_DEV_ENV=1 only) -----------------------------------------------------
+  bool force_general = false;      // PS_NEWTON_SYMMETRIC=0: full products for every block
+  int stage_bk = 32;               // PS_NEWTON_BK = 16 | 32
+  int stage_deep = 1;              // PS_NEWTON_DEEP
+  int persistent_deep = 0;         // PS_NEWTON_DEEP (persistent execution)
+  int pipe = 1;                    // PS_NEWTON_PIPE
+  int grid_cap = 0;                // PS_NEWTON_GRID
+  int wg_per_cu = 0;               // PS_NEWTON_WG_PER_CU
+  bool newton_prof = false;        // PS_NEWTON_PROF
+  const char* newton_trace = nullptr;  // PS_NEWTON_TRACE=<file>
+  int avg_lpt = 1;                 // PS_NEWTON_AVG_LPT: two-pass tiles first in averaged launches
+  int eigh_small = 1;              // PS_EIGH_SMALL
+  int eigh_small_refresh = 1;      // PS_EIGH_SMALL_REFRESH
+  bool eigh_trace = false;         // PS_EIGH_TRACE
+  int eigh_cj = 1;                 // PS_EIGH_CJ
+  int eigh_cj_refine = 1;          // PS_EIGH_CJ_REFINE
+  int eigh_cj_polish = 0;          // PS_EIGH_CJ_POLISH
+  int eigh_cj_inner = 2;           // PS_EIGH_CJ_INNER
+  float eigh_cj_done = 1e-3f;      // PS_EIGH_CJ_DONE
+  int eigh_cj_max_sweeps = 24;     // PS_EIGH_CJ_MAX_SWEEPS
+  int eigh_cj_stationary = 1;      // PS_EIGH_CJ_STATIONARY
+  float eigh_cj_one_below = 0.1f;  // PS_EIGH_CJ_ONE_BELOW
+  int eigh_cj_sort = 1;            // PS_EIGH_CJ_SORT
+  int eigh_cj_ubk = 8;             // PS_EIGH_CJ_UBK
+  int eigh_f64_reproject = 1;      // PS_EIGH_F64_REPROJECT
+  float eigh_scaled_tol = 1e-5f;   // PS_EIGH_SCALED_TOL
+  int eigh_extra_sweeps = 4;       // PS_EIGH_EXTRA_SWEEPS
+  int eigh_final_polish = 1;       // PS_EIGH_FINAL_POLISH
+  int eigh_refine = 1;             // PS_EIGH_REFINE
+};
+
+// PS_EINVAL-style validation is the caller's: resolve() clamps what it does not understand to the
+// defaults and reports it through *bad (may be NULL).
+Options resolve(const ps_options* user, bool* bad = nullptr);
+
+}  // namespace psh

@@ -33,6 +33,7 @@
 
 #include "common.h"
 #include "gemm_core.hip.h"
+#include "options.h"
 
 namespace psk {
 
@@ -817,15 +818,22 @@ struct PiPlan {
     PiHealth& h = health();
     return h.expired ? *reinterpret_cast<volatile unsigned*>(h.expired) : 0u;
   }
-  static unsigned long long timeout_ticks() {   // of the 100 MHz constant clock; read per call
-    const char* e = getenv("PS_PI_TIMEOUT_MS");
-    const double ms = e ? atof(e) : 5000.0;
-    return (unsigned long long)(std::max(ms, 0.0) * 1.0e5);   // 0: every wait counts as expired (tests)
+  // Per-call choices (ps_options.power_iteration / pi_timeout_ms, set by the drivers from
+  // psh::Options): whether this call may use the resident execution at all, and the deadline of
+  // a resident launch's waits.
+  bool allow_resident = true;
+  double timeout_ms = 5000.0;
+  void set_options(const psh::Options& o) {
+    allow_resident = o.power_iteration != PS_PI_STREAMING;
+    timeout_ms = o.pi_timeout_ms;
+  }
+  unsigned long long timeout_ticks() const {   // of the 100 MHz constant clock
+    return (unsigned long long)(std::max(timeout_ms, 0.0) * 1.0e5);   // 0: every wait counts as expired (tests)
   }
 
-  static bool resident_enabled() {  // read per call: tests switch executions in one process
-    const char* e = getenv("PS_PI_RESIDENT");
-    if (e && e[0] == '0') return false;
+  // Process health only (expired waits so far, collectives in flight): what is shared between
+  // callers is the CHIP, not a mode.
+  static bool resident_enabled() {
     PiHealth& h = health();
     return h.expired != nullptr && *h.expired == 0 && h.collectives.load() == 0;
   }
@@ -858,7 +866,7 @@ struct PiPlan {
   }
 
   // Enqueues the whole iteration.  Resident execution (default): one launch per co-resident
-  // pass, matrices in registers.  Streaming execution (PS_PI_RESIDENT=0, teams larger than the
+  // pass, matrices in registers.  Streaming execution (PS_PI_STREAMING, teams larger than the
   // chip, or a resident launch in flight on another stream): 2 launches per step, fixed
   // count (data-dependent stops are taken on the device; stopped blocks' workgroups exit at
   // once).  Same arithmetic, bit-identical results.
@@ -867,7 +875,7 @@ struct PiPlan {
     const size_t red_shm = (size_t)((max_n + PT - 1) / PT) * PT * sizeof(float);  // <= 64 KB
     if (batch == 0) return 0;
     const size_t res_lds = 2 * red_shm;
-    const int cap = (resident_enabled() && num_iters > 0 && res_lds <= 48 * 1024)
+    const int cap = (allow_resident && resident_enabled() && num_iters > 0 && res_lds <= 48 * 1024)
                         ? resident_capacity(res_lds) : 0;
     int biggest = 0;
     for (int i = 0; i < batch; ++i) biggest = std::max(biggest, team[i]);

@@ -150,7 +150,16 @@ def distributed_shampoo(
     _backend_for_testing: Any = None,
 ):
   """Returns GradientTransformation(init_fn, update_fn); see module docstring."""
-  del precision, tensordot_precision  # always exact-f32 MFMA
+  # `precision` (DS:599, 708, 1883: the jax.lax.Precision of the Newton products) selects the
+  # product arithmetic of the root calls: HIGHEST / None -> exact float32 MFMA (the parity
+  # path, the reference's default), HIGH -> bf16x6, DEFAULT -> bf16x3 (kernels.products_for_
+  # precision, ps_options.products).  `tensordot_precision` (the Gram updates, DS:1469) is
+  # validated the same way; the statistics kernel always accumulates exact float32 products
+  # (None, the reference's default there, means "highest the backend has").
+  from .kernels import products_for_precision
+  root_options = {"products": products_for_precision(precision)}
+  products_for_precision(tensordot_precision)
+  del tensordot_precision
   # (the partition specs describe XLA shardings; here the stacked statistics are always
   # split along their leading axis over the ranks of the process group)
   del statistics_partition_spec, preconditioner_partition_spec
@@ -596,6 +605,18 @@ def distributed_shampoo(
         return rows
 
     root_fn = backend.matrix_inverse_pth_root_batched
+    # Newton iteration counts of the PREVIOUS recompute, from the state (DS:338-351; zeros before
+    # the first one = no hint): they steer the per-block accuracy policy of the root call
+    # (ps_options.iters_hint) and weight the "lpt" ownership.  One small D2H per recompute.
+    iters_hint = None
+    if (generate_training_metrics and not eigh and compression_rank == 0 and
+        not lobpcg_topk_precondition):
+      its = [st_.training_metrics.inverse_pth_root_iters for st_, num in zip(states, counts)
+             if num > 0]
+      if its and all(isinstance(t_, torch.Tensor) and t_.numel() > 0 for t_ in its):
+        flat = torch.cat([t_.reshape(-1).to(torch.float32) for t_ in its])
+        if flat.numel() == len(sizes):
+          iters_hint = flat.cpu().tolist()
     if lobpcg_topk_precondition:
       # top-k deflated roots (DS:787-812, 889-928); blocks not larger than k (possible
       # here because nothing is padded to max_size) take the plain iteration
@@ -642,7 +663,9 @@ def distributed_shampoo(
         _, m = root_fn(
             [statistics[i] for i in indices], [exponents[i] for i in indices],
             [sizes[i] for i in indices], ridge_epsilon=matrix_epsilon,
-            relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh, out=tmp)
+            relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh, out=tmp,
+            options=dict(root_options, **({} if iters_hint is None or eigh else {
+                "iters_hint": [iters_hint[i] for i in indices]})))
         backend.quantize_grouped(tmp, qdt_second_moment, True,
                                  out=[_unpack(o, sizes[i]) for o, i in zip(outs, indices)])
         return m
@@ -653,7 +676,9 @@ def distributed_shampoo(
         ownership=block_ownership, root_fn=root_fn, out_cols=out_cols,
         compute_fn=compute_fn, payload_elems=payload_elems, sizes=sizes,
         pi_first=(_backend_for_testing is None and not lobpcg_topk_precondition),
-        metrics_cols=metrics_cols if compute_fn is not None else comm.METRICS_STRIDE)
+        metrics_cols=metrics_cols if compute_fn is not None else comm.METRICS_STRIDE,
+        iters_hint=iters_hint, hint_in_ownership=not shard_statistics,
+        options=(root_options if (compute_fn is None and not lobpcg_topk_precondition) else None))
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
     if quantize_second_moment:
       roots = [QuantizedValue(*_unpack(r, n), qdt_second_moment, True, [n, n])

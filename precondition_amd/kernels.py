@@ -115,6 +115,7 @@ def matrix_inverse_pth_root_batched(
     out: Optional[Sequence[torch.Tensor]] = None,
     max_ev: Optional[torch.Tensor] = None,
     symmetry="verify",
+    options=None,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """vmap(matrix_inverse_pth_root) over independent blocks (DS:2742-2744).
 
@@ -124,6 +125,9 @@ def matrix_inverse_pth_root_batched(
   being found by the power iteration (the lobpcg branch, DS:813-817).
   `symmetry`: 'verify' | 'assume' | 'general' (_lib.symmetry_code): the reference takes
   any square matrix; exactly symmetric blocks get the half-work symmetric products.
+  `options`: per-call modes (dict, see _lib.make_options / ps_options in include/ps_api.h):
+  product arithmetic (the reference's `precision`), accumulation, averaged steps, the
+  iteration-count hint of the previous recompute, execution, power-iteration execution.
   """
   batch = len(matrices)
   if batch == 0:
@@ -148,15 +152,18 @@ def matrix_inverse_pth_root_batched(
                         device=dev)
   L = lib()
   pad_ptr = None if pad is None else pad.ctypes.data
+  popt, _keep = _lib.make_options(options)
+  if popt.iters_hint and len(_keep[0]) != batch:
+    raise ValueError(f"iters_hint must hold one value per block ({batch}), got {len(_keep[0])}")
   if eigh:
     nbytes = L.ps_eigh_root_workspace_bytes(batch, n.ctypes.data)
     ws = _workspace(nbytes, dev)
-    rc = L.ps_eigh_root_batched_f32(
+    rc = L.ps_eigh_root_batched_opt_f32(
         _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
         p.ctypes.data, pad_ptr, batch, ridge_epsilon, error_tolerance,
         int(relative_matrix_epsilon), o_ptrs.ctypes.data, ldo.ctypes.data,
-        metrics.data_ptr(), ws.data_ptr(), ws.numel())
-    check(rc, "ps_eigh_root_batched_f32")
+        metrics.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(popt))
+    check(rc, "ps_eigh_root_batched_opt_f32")
   else:
     nbytes = L.ps_newton_root_workspace_bytes(batch, n.ctypes.data,
                                               p.ctypes.data, pad_ptr)
@@ -164,29 +171,42 @@ def matrix_inverse_pth_root_batched(
       raise _lib.PsError("ps_newton_root_workspace_bytes: unsupported exponent")
     ws = _workspace(nbytes, dev)
     iters = C.c_int32(0)
+    mev_ptr = None
     if max_ev is not None:
       if not relative_matrix_epsilon:
         raise ValueError("max_ev only applies to the relative-epsilon form")
       mev = max_ev.to(torch.float32).contiguous()
       if not mev.is_cuda or mev.numel() != batch:
         raise ValueError("max_ev must be a device tensor with one value per block")
-      rc = L.ps_newton_root_batched_maxev_f32(
-          _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
-          p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
-          error_tolerance, mev.data_ptr(), _lib.symmetry_code(symmetry), o_ptrs.ctypes.data,
-          ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
-          C.addressof(iters))
-      check(rc, "ps_newton_root_batched_maxev_f32")
-    else:
-      rc = L.ps_newton_root_batched_f32(
-          _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
-          p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
-          error_tolerance, int(relative_matrix_epsilon), _lib.symmetry_code(symmetry),
-          o_ptrs.ctypes.data,
-          ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
-          C.addressof(iters))
-      check(rc, "ps_newton_root_batched_f32")
+      mev_ptr = mev.data_ptr()
+    rc = L.ps_newton_root_batched_opt_f32(
+        _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
+        p.ctypes.data, pad_ptr, batch, num_iters, ridge_epsilon,
+        error_tolerance, int(relative_matrix_epsilon), mev_ptr, _lib.symmetry_code(symmetry),
+        o_ptrs.ctypes.data, ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
+        C.addressof(iters), C.byref(popt))
+    check(rc, "ps_newton_root_batched_opt_f32")
   return list(out), metrics
+
+
+def products_for_precision(precision) -> str:
+  """The reference's `precision` kwarg (jax.lax.Precision, DS:599, 708, 1883) -> ps_options.products:
+  HIGHEST (the reference's default) / None -> 'f32' (exact float32 MFMA, the parity path);
+  HIGH -> 'bf16x6' (three-way bf16 split, what XLA calls bf16_3x... float32-faithful);
+  DEFAULT -> 'bf16x3'.  Accepts the enum member (anything with a .name), its name in any case,
+  or one of the ps_options spellings."""
+  if precision is None:
+    return "f32"
+  name = getattr(precision, "name", precision)
+  if not isinstance(name, str):
+    raise ValueError(f"precision must be None, a jax.lax.Precision member or a string, got {precision!r}")
+  key = name.strip().lower()
+  table = {"highest": "f32", "float32": "f32", "fp32": "f32", "f32": "f32",
+           "high": "bf16x6", "bfloat16_3x": "bf16x6", "bf16_3x": "bf16x6", "bf16x6": "bf16x6",
+           "default": "bf16x3", "bfloat16": "bf16x3", "bf16": "bf16x3", "bf16x3": "bf16x3"}
+  if key not in table:
+    raise ValueError(f"unknown precision {precision!r}")
+  return table[key]
 
 
 def matrix_inverse_pth_root(matrix: torch.Tensor, p: int, num_iters: int = 100,
@@ -200,7 +220,8 @@ def matrix_inverse_pth_root(matrix: torch.Tensor, p: int, num_iters: int = 100,
   """Single-matrix form with the reference's signature (DS:702-715).  Returns
   (root, TrainingMetrics)."""
   from .state import TrainingMetrics
-  del precision, prev
+  del prev
+  options = {"products": products_for_precision(precision)}
   if lobpcg_topk_precondition:
     if eigh:
       raise ValueError("lobpcg_topk_precondition applies to the Newton branch")
@@ -218,7 +239,7 @@ def matrix_inverse_pth_root(matrix: torch.Tensor, p: int, num_iters: int = 100,
       [matrix], [p], None if padding_start is None else [padding_start],
       num_iters=num_iters, ridge_epsilon=ridge_epsilon,
       error_tolerance=error_tolerance,
-      relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh)
+      relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh, options=options)
   return roots[0], TrainingMetrics(
       inverse_pth_root_errors=m[0, 0], inverse_pth_root_iters=m[0, 1],
       final_error_ratio=m[0, 2], max_eigen_value=m[0, 3], total_retries=m[0, 4])
@@ -294,8 +315,10 @@ def power_iteration(matrix: torch.Tensor, num_iters: int = 100,
 
 @_device_guarded
 def power_iteration_batched(matrices: Sequence[torch.Tensor], num_iters=100,
-                            error_tolerance=1e-6, padding_starts=None, symmetry="verify"):
-  """Returns (lambda[batch], iters[batch])."""
+                            error_tolerance=1e-6, padding_starts=None, symmetry="verify",
+                            options=None):
+  """Returns (lambda[batch], iters[batch]).  `options`: power_iteration / pi_timeout_ms of
+  _lib.make_options."""
   batch = len(matrices)
   dev = matrices[0].device
   for m in matrices:
@@ -308,12 +331,13 @@ def power_iteration_batched(matrices: Sequence[torch.Tensor], num_iters=100,
   L = lib()
   ws = _workspace(L.ps_power_iteration_workspace_bytes(batch, n.ctypes.data), dev)
   a_ptrs = _ptrs(matrices)
-  rc = L.ps_power_iteration_batched_f32(
+  popt, _keep = _lib.make_options(options)
+  rc = L.ps_power_iteration_batched_opt_f32(
       _stream(), a_ptrs.ctypes.data, n.ctypes.data, lda.ctypes.data,
       None if pad is None else pad.ctypes.data, batch, num_iters,
       error_tolerance, lam.data_ptr(), its.data_ptr(), None, 0,
-      _lib.symmetry_code(symmetry), ws.data_ptr(), ws.numel())
-  check(rc, "ps_power_iteration_batched_f32")
+      _lib.symmetry_code(symmetry), ws.data_ptr(), ws.numel(), C.byref(popt))
+  check(rc, "ps_power_iteration_batched_opt_f32")
   return lam, its
 
 

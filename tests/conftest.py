@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Tests that A/B developer switches of the kernels (PS_NEWTON_PIPE, PS_EIGH_CJ, ...) do it through
+# the environment; the library reads it in ONE function and only under PS_DEV_ENV=1
+# (csrc/options.hip).  Every public mode is an argument (ps_options) and is tested as one.
+os.environ.setdefault("PS_DEV_ENV", "1")
+
+
 def pytest_configure(config):
   config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

@@ -15,7 +15,9 @@ def stats_update_grouped(items, w1, w2):
 
 def matrix_inverse_pth_root_batched(matrices, ps, padding_starts=None, num_iters=100,
                                     ridge_epsilon=1e-6, error_tolerance=1e-6,
-                                    relative_matrix_epsilon=True, eigh=False, out=None):
+                                    relative_matrix_epsilon=True, eigh=False, out=None,
+                                    options=None):
+  del options  # execution modes of the HIP library (ps_options): nothing to select on the oracle
   roots, rows = [], []
   for i, (m, p) in enumerate(zip(matrices, ps)):
     pad = None if padding_starts is None else int(padding_starts[i])

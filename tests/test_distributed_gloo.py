@@ -538,3 +538,16 @@ def test_vit_b_statistics_gather_order_four_ranks(world, ownership):
   mp.spawn(_vitb_worker, args=(world, _free_port(), ownership, ret), nprocs=world, join=True)
   assert all(ret[r][0] for r in range(world))
   assert sum(ret[r][1] for r in range(world)) == 395
+
+
+def test_cost_model_uses_iteration_counts():
+  """LPT ownership weighs a block by last recompute's Newton iterations (ViT-B: 7-17)."""
+  from precondition_amd import comm
+  sizes = [1024] * 8
+  exps = [4] * 8
+  hint = [16, 16, 8, 8, 8, 8, 8, 8]
+  owner = comm.ownership_table(sizes, exps, 2, "lpt", hint)
+  load = [sum(h for h, o in zip(hint, owner) if o == r) for r in (0, 1)]
+  assert load == [40, 40], (owner, load)
+  flat = comm.ownership_table(sizes, exps, 2, "lpt")
+  assert sorted(flat.count(r) for r in (0, 1)) == [4, 4]

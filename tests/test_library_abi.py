@@ -58,3 +58,52 @@ def test_no_cpu_fallback():
     kernels.matrix_inverse_pth_root_batched([torch.eye(4)], [4])
   with pytest.raises(_lib.PsError, match="no CPU path"):
     kernels.gram_weighted_update(torch.eye(4), torch.ones(4, 3), 0, 1.0, 1.0)
+
+
+def test_options_defaults_validation_and_precision_mapping():
+  """ps_options: defaults from ps_options_init, the dict front end, and the reference's
+  `precision` kwarg (DS:599, 708, 1883) mapped onto the product arithmetic."""
+  from precondition_amd import kernels
+  o, keep = _lib.make_options(None)
+  assert o.struct_size == ctypes.sizeof(_lib.PsOptions) and not keep
+  assert (o.products, o.accumulation, o.averaged_steps, o.execution) == (0, 0, -1, 0)
+  assert _lib.lib().ps_newton_averaged_steps() == 4
+  o, keep = _lib.make_options({"products": "bf16x6", "execution": "persistent",
+                               "iters_hint": [8, 14, 0], "fast_max_iters": 9,
+                               "power_iteration": "streaming", "pi_timeout_ms": 0})
+  assert (o.products, o.execution, o.power_iteration, o.pi_timeout_ms) == (1, 1, 1, 0)
+  assert o.fast_max_iters == 9 and o.iters_hint == keep[0].ctypes.data and keep[0].dtype == np.float32
+  with pytest.raises(ValueError):
+    _lib.make_options({"products": "fp8"})
+  with pytest.raises(ValueError):
+    _lib.make_options({"no_such_option": 1})
+
+  class P:  # stands for jax.lax.Precision members
+    def __init__(self, name):
+      self.name = name
+  assert kernels.products_for_precision(None) == "f32"
+  assert kernels.products_for_precision(P("HIGHEST")) == "f32"
+  assert kernels.products_for_precision(P("HIGH")) == "bf16x6"
+  assert kernels.products_for_precision("default") == "bf16x3"
+  with pytest.raises(ValueError):
+    kernels.products_for_precision("int4")
+  from precondition_amd.distributed_shampoo import distributed_shampoo
+  distributed_shampoo(0.1, 32, precision=P("HIGH"), tensordot_precision=None)
+  with pytest.raises(ValueError):
+    distributed_shampoo(0.1, 32, precision="nonsense")
+
+
+def test_environment_is_read_in_one_function_only():
+  """Modes are arguments (ps_options); getenv survives in csrc/options.hip alone, behind
+  PS_DEV_ENV."""
+  csrc = os.path.join(ROOT, "precondition_amd", "csrc")
+  offenders = []
+  for name in sorted(os.listdir(csrc)):
+    if name.endswith((".hip", ".h")) and name != "options.hip":
+      if "getenv" in open(os.path.join(csrc, name)).read():
+        offenders.append(name)
+  assert not offenders, offenders
+  src = open(os.path.join(csrc, "options.hip")).read()
+  assert src.count("void ps_dev_env_overrides(") == 1 and 'getenv("PS_DEV_ENV")' in src
+  body = src[src.index("void ps_dev_env_overrides("):src.index("}  // namespace\n")]
+  assert src.count("getenv(") == body.count("getenv(")
