@@ -289,6 +289,67 @@ class VitBWorkload:
     return f  # roots of ALL ranks (metrics are gathered), statistics not included
 
 
+def vit_b_rank_share(vw, dev, worlds=(2, 4, 8), reps=3):
+  """Stand-in for the multi-GPU curve this builder cannot run (one GPU per lease): for a world of
+  W ranks, the share of the ViT-B recompute that the MOST LOADED rank would execute -- the Gram
+  updates of the statistics it owns + their roots, no gather -- timed on this one GPU, with the
+  ownership the multi-rank run would use (LPT on comm.block_costs with last recompute's iteration
+  counts).  `gather_ms_projected` prices the all-gather of DS:2876 at 7 xGMI links x 153 GB/s per
+  GPU (direct algorithm: every rank receives (W - 1) / W of the roots); `projected_step_ms` is
+  their sum (no overlap assumed), `projected_speedup` = the measured 1-rank step / that."""
+  from precondition_amd import comm
+  from precondition_amd import kernels as K
+  flat = [s_ for st_ in vw.stats for s_ in st_]
+  sizes = [int(s_.shape[0]) for s_ in flat]
+  hint = vw.hint
+  items_all = []
+  for pc, g, st in zip(vw.pcs, vw.grads, vw.stats):
+    items_all.extend(pc.statistics_update_items(st, g, st))
+  cost = comm.block_costs(sizes, vw.exps, hint)
+  out = {"ownership": "lpt on iterations x c(p) x tiles (comm.block_costs)", "worlds": {}}
+  root_bytes = float(sum(4 * n * n for n in sizes))
+
+  def run(idx):
+    its = [items_all[i] for i in idx]
+    mats = [flat[i] for i in idx]
+    opts = {"iters_hint": np.asarray([hint[i] for i in idx], np.float32)} if hint is not None else None
+    ms = []
+    for _ in range(reps):
+      _sync()
+      t0 = time.perf_counter()
+      K.stats_update_grouped(its, 0.999, 1.0 - 0.999)
+      _, m = K.matrix_inverse_pth_root_batched(mats, [vw.exps[i] for i in idx],
+                                               padding_starts=[sizes[i] for i in idx], options=opts)
+      _sync()
+      ms.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ms)), m
+
+  one_ms, _ = run(list(range(len(flat))))
+  out["one_rank_ms"] = round(one_ms, 2)
+  for w in worlds:
+    owner = comm.ownership_table(sizes, vw.exps, w, "lpt", hint)
+    load = [sum(c for c, o in zip(cost, owner) if o == r) for r in range(w)]
+    crit = int(np.argmax(load))
+    idx = [i for i, o in enumerate(owner) if o == crit]
+    ms, m = run(idx)
+    mm = m.cpu().numpy()
+    fl = sum(mm[k, 5] * c_of_p(vw.exps[i]) * 2.0 * float(sizes[i]) ** 3 for k, i in enumerate(idx))
+    fl_ex = sum(mm[k, 5] * c_of_p(vw.exps[i]) * 2.0 * float(sizes[i]) ** 3 *
+                executed_fraction(sizes[i], vw.exps[i], mm[k, 5], mm[k, 7]) for k, i in enumerate(idx))
+    # tiles of the largest product stage of this share on the 512 resident workgroup slots
+    tiles = sum(((n + 127) // 128) * ((n + 127) // 128 + 1) // 2 for n in (sizes[i] for i in idx))
+    gather_ms = root_bytes * (w - 1) / w / (7 * 153e9) * 1e3
+    out["worlds"][str(w)] = {
+        "statistics_of_critical_rank": len(idx), "load_imbalance_max_over_mean": round(max(load) / (sum(load) / w), 4),
+        "share_ms": round(ms, 2), "roots_executed_frac_of_f32_mfma_peak": round(fl_ex / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        "roots_algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+        "tile_rounds_per_stage_launch": round(tiles / 512.0, 2),
+        "gather_ms_projected": round(gather_ms, 3),
+        "projected_step_ms": round(ms + gather_ms, 2),
+        "projected_speedup": round(one_ms / (ms + gather_ms), 2)}
+  return out
+
+
 def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
   """BASELINE.json configs[4]: Frequent-Directions sketch updates (rank 64) of
   4096-dim factors: Gram of a [4096, 4096] gradient block + _fd_update_root, three
@@ -973,6 +1034,11 @@ def main():
       _sync()
       line["vit_b_cfg4"]["parity_vs_oracle"] = parity_sample_vit_b(vw, _roots, _met)
       del _roots, _met, _flat
+    if world == 1 and rank == 0 and not SELFTEST:
+      try:
+        line["vit_b_cfg4_rank_share"] = vit_b_rank_share(vw, dev)
+      except Exception as e:  # pylint: disable=broad-except
+        line["vit_b_cfg4_rank_share"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     del vw
     if world == 1 and rank == 0:
       # single-GPU side measurements: a failure in one of them must not cost the line
@@ -1013,8 +1079,15 @@ def main():
             else:
               os.environ[k] = v
 
+      def fd_one():   # per-rank share of configs[4] on 8 GPUs: one factor per GPU
+        r = fd_cfg5(dev, factors=1)
+        return {"workload": r["workload"], "ms_per_factor_update": r["ms_per_factor_update"],
+                "note": "BASELINE configs[4] over 8 GPUs = one 4096-dim factor per rank; no exchange "
+                        "step inside an FD update"}
+
       for key, fn in (("newton_bf16x6", lambda: newton_bf16x6_leg(dev, clock)),
                       ("fd_cfg5", lambda: fd_cfg5(dev)), ("fd_cfg5_f32_products", fd_f32),
+                      ("fd_cfg5_rank_share", fd_one),
                       ("quant_f3", lambda: quant_f3(dev)), ("eigh_cfg3", eigh_cfg3)):
         torch.cuda.empty_cache()
         try:

@@ -443,15 +443,11 @@ __device__ __forceinline__ void pipe_chunk(const FragKM& use, FragKM& nxt, const
   PS_FENCE();
 }
 
-template <int BK, int LA, int LB, bool SEGV = false>
+template <int BK, int LA, int LB>
 __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kext, float* smem,
                                      f32x16 (&acc)[2][2], DeepSets<LA, LB, BK, false>& r,
-                                     unsigned long long* t_fill = nullptr, bool seg = false) {
+                                     unsigned long long* t_fill = nullptr) {
   static_assert(BK == 32, "four 8-deep chunks per K-tile");
-  constexpr int SEGT = SEG_K / BK;
-  f32x16 total[SEGV ? 2 : 1][SEGV ? 2 : 1];
-  if constexpr (SEGV) zero_acc(total);
-  (void)total; (void)SEGT; (void)seg;
   using LdA = TileLoader<LA, BK, false>;
   using LdB = TileLoader<LB, BK, false>;
   constexpr int OPS = SmemCfg<BK>::op_size(LA);
@@ -506,14 +502,96 @@ __device__ inline void deep_run_pipe(const Operand& A, const Operand& B, int Kex
       __syncthreads();
       PS_FENCE();
       pipe_chunk<BK, LA, LB>(f1, f0, s0, s0 + OPS, 0, nxt, wm, wn, i, h, acc);
-      // all MFMAs of K-tiles <= kt + 1 are issued (the chunk above only READS K-tile kt + 2)
-      if constexpr (SEGV) {
-        if (seg && (kt + 2) % SEGT == 0 && nxt) { seg_flush(acc, total); PS_FENCE(); }
-      }
     }
   }
-  if constexpr (SEGV) { if (seg) seg_finish(acc, total); }
   // every LDS read was waited for by the barrier of the last K-tile: smem is free
+}
+
+// The same schedule with segmented accumulation, for products whose K extent is a multiple of
+// SEG_K (the Newton products: npad is a multiple of 128).  The loop runs over SEGMENTS of four
+// K-tiles with the flush `total += acc; acc = 0` at the end of each -- unconditional, so the two
+// accumulator sets have one definition each (a flush under `if` makes the register allocator copy
+// both sets at the merge point and spill ~400 registers).  ONE register set of global loads: the
+// loads of K-tile t + 1 are issued right after the set has been written to LDS in the middle of
+// K-tile t - 1, i.e. one K-tile of MFMA time ahead of their use (two sets: 1.25).  Writes acc
+// (does not accumulate into it).
+template <int BK, int LA, int LB>
+__device__ inline void deep_run_pipe_seg(const Operand& A, const Operand& B, int Kext, float* smem,
+                                         f32x16 (&acc)[2][2], unsigned long long* t_fill = nullptr) {
+  static_assert(BK == 32 && SEG_K == 4 * BK, "a segment is four K-tiles");
+  using LdA = TileLoader<LA, BK, false>;
+  using LdB = TileLoader<LB, BK, false>;
+  constexpr int OPS = SmemCfg<BK>::op_size(LA);
+  constexpr int STG = SmemCfg<BK>::op_size(LA) + SmemCfg<BK>::op_size(LB);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  // whole segments: the operands are zero beyond Kext up to the next multiple of 128 (the Newton
+  // workspace is padded to 128), and x + 0 * 0 = x exactly
+  const int nk = ((Kext + SEG_K - 1) / SEG_K) * (SEG_K / BK);
+  float* s0 = smem;
+  float* s1 = smem + STG;
+  f32x4 ra[LdA::NV], rb[LdB::NV];
+  f32x16 total[2][2];
+  zero_acc(acc);
+  zero_acc(total);
+  LdA::load(A, 0, tid, ra);
+  LdB::load(B, 0, tid, rb);
+  LdA::store(s0, tid, ra);
+  LdB::store(s0 + OPS, tid, rb);
+  LdA::load(A, BK, tid, ra);         // K-tile 1 (nk >= 4)
+  LdB::load(B, BK, tid, rb);
+  __syncthreads();
+  if (t_fill != nullptr && tid == 0) *t_fill = __builtin_amdgcn_s_memrealtime();  // dev trace
+  FragKM f0, f1;
+  pipe_read_a<BK, LA>(s0, 0, wm, i, h, f0);
+  if (LB == MC) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pipe_read_b<BK>(s0 + OPS, 0, s, wn, i, h, f0);
+  } else {
+    pipe_read_b_kc<BK>(s0 + OPS, 0, wn, i, h, f0);
+  }
+  for (int kt = 0; kt < nk; kt += 4) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int k0 = kt + 2 * half;
+      {  // even K-tile k0: image in s0; the set holds K-tile k0 + 1 (-> s1), then requests k0 + 2
+        pipe_chunk<BK, LA, LB>(f0, f1, s0, s0 + OPS, 1, true, wm, wn, i, h, acc);
+        LdA::store(s1, tid, ra); LdB::store(s1 + OPS, tid, rb);
+        PS_FENCE();
+        LdA::load(A, min(k0 + 2, nk - 1) * BK, tid, ra);   // unconditional (see deep_run)
+        LdB::load(B, min(k0 + 2, nk - 1) * BK, tid, rb);
+        PS_FENCE();
+        pipe_chunk<BK, LA, LB>(f1, f0, s0, s0 + OPS, 2, true, wm, wn, i, h, acc);
+        pipe_chunk<BK, LA, LB>(f0, f1, s0, s0 + OPS, 3, true, wm, wn, i, h, acc);
+        __syncthreads();
+        PS_FENCE();
+        pipe_chunk<BK, LA, LB>(f1, f0, s1, s1 + OPS, 0, true, wm, wn, i, h, acc);
+      }
+      {  // odd K-tile k0 + 1: image in s1; the set holds K-tile k0 + 2 (-> s0), then requests k0 + 3
+        const bool nxt = k0 + 2 < nk;
+        pipe_chunk<BK, LA, LB>(f0, f1, s1, s1 + OPS, 1, true, wm, wn, i, h, acc);
+        if (nxt) { LdA::store(s0, tid, ra); LdB::store(s0 + OPS, tid, rb); }
+        PS_FENCE();
+        LdA::load(A, min(k0 + 3, nk - 1) * BK, tid, ra);
+        LdB::load(B, min(k0 + 3, nk - 1) * BK, tid, rb);
+        PS_FENCE();
+        pipe_chunk<BK, LA, LB>(f1, f0, s1, s1 + OPS, 2, true, wm, wn, i, h, acc);
+        pipe_chunk<BK, LA, LB>(f0, f1, s1, s1 + OPS, 3, true, wm, wn, i, h, acc);
+        __syncthreads();
+        PS_FENCE();
+        pipe_chunk<BK, LA, LB>(f1, f0, s0, s0 + OPS, 0, nxt, wm, wn, i, h, acc);
+      }
+    }
+    // every MFMA of this segment is issued (the last chunk only READS the next K-tile)
+    seg_flush(acc, total);
+    PS_FENCE();
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = total[tm][tn];
 }
 
 // Accumulating form: acc += A * B over k in [0, Kext).
@@ -575,7 +653,7 @@ __device__ inline void gemm_tile_accum(const Operand& A, const Operand& B, int K
   DeepSets<LA, LB, BK, GUARD> sets;
   deep_issue_first<LA, LB, BK, GUARD>(A, B, Kext, sets);
   if constexpr (PIPE && BK == 32 && !GUARD)
-    deep_run_pipe<BK, LA, LB, SEGV>(A, B, Kext, smem, acc, sets, t_fill, seg);
+    deep_run_pipe<BK, LA, LB>(A, B, Kext, smem, acc, sets, t_fill);
   else
     deep_run<LA, LB, BK, GUARD, SEGV>(A, B, Kext, smem, acc, sets, t_fill, seg);
 }
@@ -584,8 +662,18 @@ template <int LA, int LB, int BK, bool GUARD, bool DEEP = false, bool PIPE = fal
 __device__ inline void gemm_tile(const Operand& A, const Operand& B, int Kext,
                                  float* smem, f32x16 (&acc)[2][2],
                                  unsigned long long* t_fill = nullptr, bool seg = false) {
-  zero_acc(acc);
-  gemm_tile_accum<LA, LB, BK, GUARD, DEEP, PIPE, SEGV>(A, B, Kext, smem, acc, t_fill, seg);
+  if constexpr (SEGV && PIPE && DEEP && BK == 32 && !GUARD) {
+    // two complete loops behind one uniform branch (the caller guarantees Kext % SEG_K == 0)
+    if (seg) {
+      deep_run_pipe_seg<BK, LA, LB>(A, B, Kext, smem, acc, t_fill);
+    } else {
+      zero_acc(acc);
+      gemm_tile_accum<LA, LB, BK, GUARD, DEEP, PIPE, false>(A, B, Kext, smem, acc, t_fill, false);
+    }
+  } else {
+    zero_acc(acc);
+    gemm_tile_accum<LA, LB, BK, GUARD, DEEP, PIPE, SEGV>(A, B, Kext, smem, acc, t_fill, seg);
+  }
 }
 
 // Accumulator element -> (row, col) inside the 128x128 tile (C/D layout of the

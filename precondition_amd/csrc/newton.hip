@@ -404,11 +404,12 @@ __device__ __forceinline__ void newton_product_tile(const NewtonBlock* nb, Newto
   // Near convergence (max|M - I| < 1e-3 at the start of the step) the split products' noise floor
   // (~2e-6 in max|M - I| on cond 1e4 blocks) is above the 1e-6 stop threshold of DS:836, so the
   // last steps of a block run the exact float32 products: same stop decisions as the parity path.
-  // Segmented accumulation (ps_options.accumulation): the M-side products -- everything but the H
-  // update, product 0 -- of blocks that the caller's hint does not mark well conditioned.
-  // Only the CAREFUL instantiations carry the second accumulator set (the driver launches them when
-  // the call has at least one such block).
-  const bool seg = CAREFUL && st->seg != 0 && prod != 0;
+  // Segmented accumulation (ps_options.accumulation): every product of a block that the caller's
+  // hint does not mark well conditioned (the M side decides the error of p = 4 roots, the H update
+  // that of p = 2 roots: tools/dev_chain_accuracy.py, dev_r4_newton.py).  Only the CAREFUL
+  // instantiations carry the second accumulator set (the driver launches them when the call has
+  // at least one such block); a block's arithmetic does not depend on what else is in the call.
+  const bool seg = CAREFUL && st->seg != 0;
   if (XM == 6 && st->general == 0 && st->err > 1e-3f)
     gemm_tile_bf16x_sym<6>(A.p, B.p, ld, A.mn0, B.mn0, ld, smem, acc);
   else if (XM == 3 && st->general == 0 && st->err > 3e-2f)
@@ -667,11 +668,11 @@ __device__ inline void write_metrics(float* metrics, int b, float err, int it, f
 // TRACE (dev, PS_NEWTON_TRACE=<file>): one record of 8 x u64 per tile -- launch sequence number,
 // tile index | product << 32, HW_ID | XCC_ID << 32, and the 100 MHz clock at the start of the
 // tile, after its first LDS fill, at the end of its (last) K loop and at its end.
-// CAREFUL: segmented accumulation for the blocks that ask for it; the second accumulator set does
-// not fit beside two register sets of loads at two workgroups per CU, so this instantiation runs
-// one workgroup per CU with the whole register file.
+// CAREFUL: segmented accumulation for the blocks that ask for it (gemm_core.hip.h
+// deep_run_pipe_seg: one register set of loads, the other set's registers hold the segment totals;
+// 251 VGPRs, no spills, two workgroups per CU like the default instantiation).
 template <int BK, bool DEEP, int XM = 0, bool TRACE = false, bool PIPE = false, bool CAREFUL = false>
-__global__ __launch_bounds__(256, CAREFUL ? 1 : ((DEEP && BK == 32) ? 2 : 3)) void newton_stage_kernel(
+__global__ __launch_bounds__(256, CAREFUL ? 2 : ((DEEP && BK == 32) ? 2 : 3)) void newton_stage_kernel(
     const NewtonBlock* blocks, NewtonState* states,
     const TileEntry* tiles, int ntiles, int navg, unsigned long long* trace = nullptr,
     unsigned trace_seq = 0, unsigned trace_cap = 0) {

@@ -210,8 +210,7 @@ def test_newton_bf16x6_products_opt_in_mode(device, monkeypatch):
   mats = [torch.tensor(a, device=device) for a in arrs]
   ps = [4, 2, 4, 4]
   r32, m32 = K().matrix_inverse_pth_root_batched(mats, ps)
-  monkeypatch.setenv("PS_NEWTON_PRODUCTS", "bf16x6")
-  r16, m16 = K().matrix_inverse_pth_root_batched(mats, ps)
+  r16, m16 = K().matrix_inverse_pth_root_batched(mats, ps, options={"products": "bf16x6"})
   m32, m16 = m32.cpu().numpy(), m16.cpu().numpy()
   differs = False
   for i, (a, p) in enumerate(zip(arrs, ps)):
@@ -222,17 +221,17 @@ def test_newton_bf16x6_products_opt_in_mode(device, monkeypatch):
     assert np.linalg.norm(h16 - h32) / np.linalg.norm(h32) < scale, i
     # same stop decisions as the default mode; the oracle's count is equal too except where the
     # 1e-6 threshold is within rounding of the last error (the cond ~1e6 block: +-1)
-    assert m16[i, 1] == m32[i, 1], (i, m16[i], m32[i])
+    assert abs(m16[i, 1] - m32[i, 1]) <= (1 if i == 2 else 0), (i, m16[i], m32[i])
     assert abs(m16[i, 1] - m_ref["inverse_pth_root_iters"]) <= (1 if i == 2 else 0), i
     assert m16[i, 4] == m_ref["total_retries"] == m32[i, 4], i
     differs |= not np.array_equal(h16, h32)
   assert differs, "the opt-in mode did not run"
-  # an asymmetric block takes the float32 products: bit-identical in both modes
+  # an asymmetric block takes the float32 products (plain chains: the split-product kernels carry
+  # no second accumulator set): bit-identical to the float32 mode with accumulation = "chain"
   asym = arrs[0].copy(); asym[3, 7] *= 1.0001
   a_d = torch.tensor(asym, device=device)
-  x16, _ = K().matrix_inverse_pth_root_batched([a_d], [4])
-  monkeypatch.delenv("PS_NEWTON_PRODUCTS")
-  x32, _ = K().matrix_inverse_pth_root_batched([a_d], [4])
+  x16, _ = K().matrix_inverse_pth_root_batched([a_d], [4], options={"products": "bf16x6"})
+  x32, _ = K().matrix_inverse_pth_root_batched([a_d], [4], options={"accumulation": "chain"})
   assert torch.equal(x16[0], x32[0])
 
 
@@ -286,13 +285,15 @@ def test_newton_product_kernel_variants_bit_identical_and_trace(device, monkeypa
   arrs.append(asym)
   mats = [torch.tensor(a, device=device) for a in arrs]
   ps = [4, 2, 4, 4]
-  r1, m1 = K().matrix_inverse_pth_root_batched(mats, ps)
+  # (the developer variants exist for the two-register-set kernel: accumulation = "chain")
+  chain = {"accumulation": "chain"}
+  r1, m1 = K().matrix_inverse_pth_root_batched(mats, ps, options=chain)
   monkeypatch.setenv("PS_NEWTON_PIPE", "0")
-  r0, m0 = K().matrix_inverse_pth_root_batched(mats, ps)
+  r0, m0 = K().matrix_inverse_pth_root_batched(mats, ps, options=chain)
   monkeypatch.delenv("PS_NEWTON_PIPE")
   path = tmp_path / "stage_trace.bin"
   monkeypatch.setenv("PS_NEWTON_TRACE", str(path))
-  rt, mt = K().matrix_inverse_pth_root_batched(mats, ps)
+  rt, mt = K().matrix_inverse_pth_root_batched(mats, ps, options=chain)
   monkeypatch.delenv("PS_NEWTON_TRACE")
   for i in range(len(mats)):
     assert torch.equal(r1[i], r0[i]) and torch.equal(r1[i], rt[i]), i
