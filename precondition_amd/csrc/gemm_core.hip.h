@@ -265,6 +265,14 @@ __device__ __forceinline__ void seg_flush(f32x16 (&acc)[2][2], f32x16 (&total)[2
         acc[tm][tn][r] = 0.f;
       }
 }
+__device__ __forceinline__ void seg_add(const f32x16 (&acc)[2][2], f32x16 (&total)[2][2]) {
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) total[tm][tn][r] = __fadd_rn(total[tm][tn][r], acc[tm][tn][r]);
+}
 __device__ __forceinline__ void seg_finish(f32x16 (&acc)[2][2], const f32x16 (&total)[2][2]) {
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
@@ -405,22 +413,27 @@ __device__ __forceinline__ void pipe_read_b_kc(const float* sB, int c, int wn, i
     f.b[t][0] = v[0]; f.b[t][1] = v[1]; f.b[t][2] = v[2]; f.b[t][3] = v[3];
   }
 }
+// ZERO_C: the chain restarts here -- the MFMA takes the constant 0 as its C operand (an inline
+// constant: no instruction is spent on clearing the accumulators of a new segment).
+template <bool ZERO_C = false>
 __device__ __forceinline__ void pipe_mfma(const FragKM& f, int s, f32x16 (&acc)[2][2]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][s], f.b[tn][s], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][s], f.b[tn][s],
+                                                         ZERO_C ? zero : acc[tm][tn], 0, 0, 0);
 }
 #define PS_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // One chunk: the 16 MFMAs on `use`, with the reads of chunk (cn) of image (nA, nB) into `nxt`
 // spread between the MFMA groups (rd = false: nothing to read).
-template <int BK, int LA, int LB>
+template <int BK, int LA, int LB, bool ZERO_C = false>
 __device__ __forceinline__ void pipe_chunk(const FragKM& use, FragKM& nxt, const float* nA,
                                            const float* nB, int cn, bool rd, int wm, int wn, int i,
                                            int h, f32x16 (&acc)[2][2]) {
-  pipe_mfma(use, 0, acc);
+  pipe_mfma<ZERO_C>(use, 0, acc);
   PS_FENCE();
   if (rd) {
     pipe_read_a<BK, LA>(nA, cn, wm, i, h, nxt);
@@ -534,7 +547,6 @@ __device__ inline void deep_run_pipe_seg(const Operand& A, const Operand& B, int
   float* s1 = smem + STG;
   f32x4 ra[LdA::NV], rb[LdB::NV];
   f32x16 total[2][2];
-  zero_acc(acc);
   zero_acc(total);
   LdA::load(A, 0, tid, ra);
   LdB::load(B, 0, tid, rb);
@@ -557,7 +569,10 @@ __device__ inline void deep_run_pipe_seg(const Operand& A, const Operand& B, int
     for (int half = 0; half < 2; ++half) {
       const int k0 = kt + 2 * half;
       {  // even K-tile k0: image in s0; the set holds K-tile k0 + 1 (-> s1), then requests k0 + 2
-        pipe_chunk<BK, LA, LB>(f0, f1, s0, s0 + OPS, 1, true, wm, wn, i, h, acc);
+        if (half == 0)   // first MFMAs of the segment: C = 0
+          pipe_chunk<BK, LA, LB, true>(f0, f1, s0, s0 + OPS, 1, true, wm, wn, i, h, acc);
+        else
+          pipe_chunk<BK, LA, LB>(f0, f1, s0, s0 + OPS, 1, true, wm, wn, i, h, acc);
         LdA::store(s1, tid, ra); LdB::store(s1 + OPS, tid, rb);
         PS_FENCE();
         LdA::load(A, min(k0 + 2, nk - 1) * BK, tid, ra);   // unconditional (see deep_run)
@@ -584,8 +599,9 @@ __device__ inline void deep_run_pipe_seg(const Operand& A, const Operand& B, int
         pipe_chunk<BK, LA, LB>(f1, f0, s0, s0 + OPS, 0, nxt, wm, wn, i, h, acc);
       }
     }
-    // every MFMA of this segment is issued (the last chunk only READS the next K-tile)
-    seg_flush(acc, total);
+    // every MFMA of this segment is issued (the last chunk only READS the next K-tile); the next
+    // segment's first MFMAs overwrite acc
+    seg_add(acc, total);
     PS_FENCE();
   }
 #pragma unroll

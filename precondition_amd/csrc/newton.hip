@@ -1611,12 +1611,14 @@ static int newton_driver(
     ns.phase = pl.n_eff[b] >= 1 ? PH_INIT : PH_DONE;
     ns.ratio = 1.f;
     // A block whose hint (its Newton iteration count at the previous recompute) lies in
-    // [1, fast_max_iters] is well conditioned: mirrored M updates and plain chains are exact to 1e-6
-    // there.  Every other block (no hint, NaN, a slow block) takes the careful path.
+    // [1, fast_max_iters] is well conditioned: mirrored M updates are exact to 1e-6 there.  Every
+    // other block (no hint, NaN, a slow block) averages the M update of its first steps.
     const float hv = opt.iters_hint ? opt.iters_hint[(size_t)b * opt.iters_hint_stride] : 0.f;
     const bool fast = hv >= 1.f && hv <= (float)opt.fast_max_iters;   // false for NaN
     ns.navg = fast ? 0 : navg;
-    ns.seg = fast ? 0 : seg_on;
+    // the accumulation mode is the call's, not the block's: a block's arithmetic does not depend
+    // on its hint beyond the averaged steps
+    ns.seg = seg_on;
     if (pl.n_eff[b] >= 1) { any_careful |= ns.seg != 0; any_avg |= ns.navg > 0; }
   }
   ProfRun prof(st);
