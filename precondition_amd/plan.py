@@ -16,7 +16,6 @@ optimizer keeps its general per-block path.
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -180,14 +179,10 @@ class TreePlan:
                                          ws.data_ptr(), ws.numel())
     check(rc, "ps_stats_update_grouped_f32")
 
-  def apply_preconditioners(self, grads_flat, precs_flat, results, symmetric_precs=False):
+  def apply_preconditioners(self, grads_flat, precs_flat, results):
     """Preconditioner.preconditioned_grad (DS:1645-1708) for every planned parameter:
     two grouped launches.  precs_flat: preconditioners in plan order; results[i]: contiguous
-    output of parameter i (None for skipped parameters).  `symmetric_precs`: the preconditioners
-    are bitwise symmetric (roots of the symmetric Newton / eigh paths, identities): the right
-    operand P[k][n] is then read as P[n][k] (transb = 1, same pointer and leading dimension), i.e.
-    k-contiguous -- 16-byte LDS fragment reads instead of four scalar ones in the product kernel
-    (gemm_core.hip.h KC image); same products in the same order, bit-identical results."""
+    output of parameter i (None for skipped parameters)."""
     if len(self.a_tbl) == 0:
       return
     dev = self.check_dense(grads_flat, "preconditioned_grad")
@@ -199,9 +194,7 @@ class TreePlan:
     pp = self._ptrs(precs_flat)
     rp = np.fromiter((0 if r is None else r.data_ptr() for r in results), np.uint64,
                      len(results))
-    symb = 1 if (symmetric_precs and os.environ.get("PS_APPLY_SYMB", "1") != "0") else 0
     ta = self.a_tbl.copy()
-    ta["transb"] = np.where(ta["m"] > 1, symb, 0)   # one-row products keep the streaming mat-vec
     ta["a"] = gp[self.a_param] + self.a_goff
     ta["b"] = pp[self.a_stat]
     ta["c"] = np.where(self.a_c_is_res, rp[self.a_param], xp) + self.a_coff
@@ -212,7 +205,6 @@ class TreePlan:
           if len(self.b_tbl) == 0:
             break
           tbl = self.b_tbl.copy()
-          tbl["transb"] = symb
           tbl["a"] = xp + self.b_xoff
           tbl["b"] = pp[self.b_stat]
           tbl["c"] = rp[self.b_param] + self.b_coff
