@@ -540,6 +540,18 @@ const char* ps_comm_last_error(void);
 int ps_fd_filter_step_f32(void* stream, const float* z, const float* y, const float* y_prev,
                           float* y_next, void* yt_hi, void* yt_lo, const float* params, int step,
                           int batch, int64_t n, int64_t b, int64_t ldt);
+/* ps_fd_filter_round_f32: a whole Chebyshev filter (steps 1 .. max_degree of ps_fd_filter_step_f32
+ * with the C @ Y product of ps_gemm_bf16_grouped between them) in one call.  desc[j] (HOST array,
+ * `batch` entries) describes z_j = C_j * Y_j with b_hi / b_lo pointing INTO yt_hi / yt_lo at
+ * factor j's columns (j * n elements, leading dimension ldt) -- the transposed bf16 copies every
+ * recurrence step rewrites -- and c = z + j * n * b.  y0 holds the current block (z = C y0 must be
+ * current), y1 and y2 are scratch of the same shape; *result_index (host) receives 0, 1 or 2: the
+ * buffer that holds the filtered block.  The product's task tables are built and uploaded once per
+ * call.  workspace: ps_gemm_bf16_grouped_workspace_bytes(desc, batch). */
+int ps_fd_filter_round_f32(void* stream, const ps_gemm_bf16_desc* desc, int batch, float* z,
+                           float* y0, float* y1, float* y2, void* yt_hi, void* yt_lo,
+                           const float* params, int max_degree, int64_t n, int64_t b, int64_t ldt,
+                           void* workspace, size_t workspace_bytes, int32_t* result_index);
  /* ps_fd_round_control_f32: per-round control of the subspace iteration for `batch` factors with
  * Ritz values theta [batch][b] (descending) and residual norms res [batch][b]: writes the params
  * rows {ctr, e, sigma1, degree <= `degree`} of the Chebyshev filter, converged[j] (the k wanted

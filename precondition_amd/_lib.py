@@ -257,6 +257,10 @@ _SIGNATURES = {
     "ps_fd_filter_step_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "ps_fd_filter_round_f32":
+        (C.c_int, [C.c_void_p, C.POINTER(GemmBf16Desc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
+                   C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ps_fd_round_control_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                    C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

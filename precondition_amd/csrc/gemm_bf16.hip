@@ -307,12 +307,19 @@ extern "C" size_t ps_gemm_bf16_grouped_workspace_bytes(const ps_gemm_bf16_desc* 
   return hbytes(desc, count);
 }
 
-extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc, int count,
-                                    void* workspace, size_t workspace_bytes) {
-  PS_DEVICE_CHECK();
+// A grouped product as a reusable plan: the task / tile tables are uploaded once (hplan_build) and
+// may be launched any number of times while the operand POINTERS stay the same (hplan_launch) --
+// the Chebyshev filter of the FD branch multiplies the same covariances by an iterate that is
+// rewritten in place ~12 times per round (ps_fd_filter_round_f32).
+struct HPlan {
+  struct Group { HTask* dt = nullptr; HTile* dl = nullptr; int nt = 0, ntasks = 0; bool any_split = false; };
+  Group g[4];
+};
+
+static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count, void* workspace,
+                       size_t workspace_bytes, HPlan& pl) {
   if (!desc || count <= 0 || !workspace) return PS_EINVAL;
   if (workspace_bytes < hbytes(desc, count)) return PS_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   // groups by (split of A, split of B)
   std::vector<HTask> tasks[4];
   std::vector<HTile> tiles[4];
@@ -345,43 +352,98 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
       for (int tn = 0; tn < (d.n + TILE - 1) / TILE; ++tn)
         for (int ks = 0; ks < t.ksplit; ++ks) tiles[g].push_back({tid, (short)tm, (short)tn, ks});
   }
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    const int big = (int)((size_t)2 * 4 * HOP * sizeof(uint16_t));
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 2>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<2, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<2, 2>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  });
   for (int g = 0; g < 4; ++g) {
     if (tasks[g].empty()) continue;
-    HTask* dt = ar.take<HTask>(tasks[g].size());
-    HTile* dl = ar.take<HTile>(tiles[g].size());
+    HPlan::Group& gr = pl.g[g];
+    gr.dt = ar.take<HTask>(tasks[g].size());
+    gr.dl = ar.take<HTile>(tiles[g].size());
     if (ar.overflow) return PS_EWORKSPACE;
-    PS_RC(psh::upload_async(st, dt, tasks[g].data(), sizeof(HTask) * tasks[g].size()));
-    PS_RC(psh::upload_async(st, dl, tiles[g].data(), sizeof(HTile) * tiles[g].size()));
-    const int nt = (int)tiles[g].size();
+    PS_RC(psh::upload_async(st, gr.dt, tasks[g].data(), sizeof(HTask) * tasks[g].size()));
+    PS_RC(psh::upload_async(st, gr.dl, tiles[g].data(), sizeof(HTile) * tiles[g].size()));
+    gr.nt = (int)tiles[g].size();
+    gr.ntasks = (int)tasks[g].size();
+    for (auto& t : tasks[g]) gr.any_split |= t.ksplit > 1;
+  }
+  return PS_OK;
+}
+
+static int hplan_launch(hipStream_t st, const HPlan& pl) {
+  for (int g = 0; g < 4; ++g) {
+    const HPlan::Group& gr = pl.g[g];
+    if (gr.nt == 0) continue;
     const int sa = (g & 2) ? 2 : 1, sb = (g & 1) ? 2 : 1;
     const size_t lds = (size_t)2 * (sa + sb) * HOP * sizeof(uint16_t);  // 40 .. 80 KiB
-    static bool attr_done = false;
-    if (!attr_done) {
-      const int big = (int)((size_t)2 * 4 * HOP * sizeof(uint16_t));
-      PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
-      PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<1, 2>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
-      PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<2, 1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
-      PS_HIP(hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<2, 2>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
-      attr_done = true;
-    }
     if (g == 0)
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 1>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 1>), dim3(gr.nt), dim3(256), lds, st, gr.dt, gr.dl, gr.nt);
     else if (g == 1)
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 2>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 2>), dim3(gr.nt), dim3(256), lds, st, gr.dt, gr.dl, gr.nt);
     else if (g == 2)
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<2, 1>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<2, 1>), dim3(gr.nt), dim3(256), lds, st, gr.dt, gr.dl, gr.nt);
     else
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<2, 2>), dim3(nt), dim3(256), lds, st, dt, dl, nt);
-    bool any_split = false;
-    for (auto& t : tasks[g]) any_split |= t.ksplit > 1;
-    if (any_split)
-      hipLaunchKernelGGL(gemm_bf16_splitk_reduce_kernel, dim3((unsigned)tasks[g].size(), 256),
-                         dim3(256), 0, st, dt);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<2, 2>), dim3(gr.nt), dim3(256), lds, st, gr.dt, gr.dl, gr.nt);
+    if (gr.any_split)
+      hipLaunchKernelGGL(gemm_bf16_splitk_reduce_kernel, dim3((unsigned)gr.ntasks, 256), dim3(256), 0,
+                         st, gr.dt);
     PS_LAUNCH_CHECK();
   }
+  return PS_OK;
+}
+
+extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc, int count,
+                                    void* workspace, size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
+  HPlan pl;
+  PS_RC(hplan_build((hipStream_t)stream, desc, count, workspace, workspace_bytes, pl));
+  return hplan_launch((hipStream_t)stream, pl);
+}
+
+// One whole Chebyshev filter of the subspace iteration (precondition_amd/subspace.py) in one call:
+//   step 1:            y1 = recurrence(z, y0)                           (z = C y0 is given)
+//   step s = 2..deg:   z = C y_{s-1}  (grouped bf16 product, plan built once)
+//                      y_s = recurrence(z, y_{s-1}, y_{s-2})
+// desc[j] describes z_j = C_j * yt_j^T with b_hi / b_lo pointing into the transposed bf16 copies
+// (yt_hi / yt_lo, leading dimension ldt) that every recurrence step rewrites; y0, y1, y2 are the
+// three rotating [batch][n][b] float32 iterates.  *result_index receives which of them holds the
+// filtered block.  ~3 launches per step and no host work between them (the Python loop spent ~40 us
+// per launch building descriptor tables: 10 of the 11 ms of a one-factor update).
+extern "C" int ps_fd_filter_round_f32(void* stream, const ps_gemm_bf16_desc* desc, int batch,
+                                      float* z, float* y0, float* y1, float* y2, void* yt_hi,
+                                      void* yt_lo, const float* params, int max_degree, int64_t n,
+                                      int64_t b, int64_t ldt, void* workspace,
+                                      size_t workspace_bytes, int32_t* result_index) {
+  PS_DEVICE_CHECK();
+  if (!desc || batch <= 0 || !z || !y0 || !y1 || !y2 || !params || max_degree < 1 || !result_index ||
+      (max_degree >= 2 && (!yt_hi || !workspace)))
+    return PS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const bool more = max_degree >= 2;
+  PS_RC(ps_fd_filter_step_f32(stream, z, y0, nullptr, y1, more ? yt_hi : nullptr,
+                              more ? yt_lo : nullptr, params, 1, batch, n, b, ldt));
+  float* bufs[3] = {y0, y1, y2};
+  int ip = 0, iy = 1, in = 2;
+  if (more) {
+    HPlan pl;
+    PS_RC(hplan_build(st, desc, batch, workspace, workspace_bytes, pl));
+    for (int step = 2; step <= max_degree; ++step) {
+      PS_RC(hplan_launch(st, pl));
+      const bool again = step < max_degree;
+      PS_RC(ps_fd_filter_step_f32(stream, z, bufs[iy], bufs[ip], bufs[in], again ? yt_hi : nullptr,
+                                  again ? yt_lo : nullptr, params, step, batch, n, b, ldt));
+      const int t = ip; ip = iy; iy = in; in = t;
+    }
+  }
+  *result_index = iy;
   return PS_OK;
 }

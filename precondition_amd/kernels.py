@@ -558,6 +558,56 @@ def fd_filter_step(z, y, y_prev, y_next, params, step, want_bf16=True, split=Tru
 
 
 @_device_guarded
+def fd_filter_round(c16, z, bufs, params, max_degree, plain=False):
+  """A whole Chebyshev filter of the subspace iteration in ONE library call
+  (ps_fd_filter_round_f32): steps 1 .. max_degree of the recurrence with the grouped bf16 product
+  z = C y between them.  c16[j]: the covariance of factor j as produced by to_bf16 (hi/lo pair or
+  TiledBf16); z: [B, n, b] float32 holding C @ bufs[0]; bufs: three [B, n, b] float32 tensors,
+  bufs[0] = the current block; params: [B, 4] from fd_round_control.  Returns the tensor of
+  `bufs` that holds the filtered block."""
+  from ._lib import GemmBf16Desc
+  bsz, n, b = (int(v) for v in z.shape)
+  for t in (z, *bufs, params):
+    _require_gpu(t, "fd_filter_round")
+    if not t.is_contiguous() or t.dtype != torch.float32:
+      raise ValueError("fd_filter_round expects contiguous float32 tensors")
+  if any(tuple(t.shape) != (bsz, n, b) for t in bufs) or tuple(params.shape) != (bsz, 4):
+    raise ValueError("fd_filter_round: shape mismatch")
+  dev = z.device
+  ldt = bsz * n
+  yt_hi = torch.empty((b, ldt), dtype=torch.bfloat16, device=dev)
+  yt_lo = None if plain else torch.empty((b, ldt), dtype=torch.bfloat16, device=dev)
+  descs = (GemmBf16Desc * bsz)()
+  for j, d in enumerate(descs):
+    a = c16[j]
+    if isinstance(a, TiledBf16):
+      if a.rows != n or a.cols != n:
+        raise ValueError("fd_filter_round: covariance shape mismatch")
+      d.a_hi, d.a_lo = a.hi.data_ptr(), (None if (plain or a.lo is None) else a.lo.data_ptr())
+      d.lda, d.a_tiled = n, 1
+    else:
+      a_hi, a_lo = a
+      if tuple(a_hi.shape) != (n, n):
+        raise ValueError("fd_filter_round: covariance shape mismatch")
+      d.a_hi, d.a_lo = a_hi.data_ptr(), (None if (plain or a_lo is None) else a_lo.data_ptr())
+      d.lda, d.a_tiled = _as_2d_ld(a_hi), 0
+    d.b_hi = yt_hi.data_ptr() + 2 * j * n
+    d.b_lo = None if plain else yt_lo.data_ptr() + 2 * j * n
+    d.c = z.data_ptr() + 4 * j * n * b
+    d.m, d.n, d.k = n, b, n
+    d.ldb, d.ldc = ldt, b
+  L = lib()
+  ws = _workspace(L.ps_gemm_bf16_grouped_workspace_bytes(descs, bsz), dev)
+  which = C.c_int32(-1)
+  rc = L.ps_fd_filter_round_f32(
+      _stream(), descs, bsz, z.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(),
+      yt_hi.data_ptr(), None if plain else yt_lo.data_ptr(), params.data_ptr(), int(max_degree), n, b,
+      ldt, ws.data_ptr(), ws.numel(), C.addressof(which))
+  check(rc, "ps_fd_filter_round_f32")
+  return bufs[which.value]
+
+
+@_device_guarded
 def fd_round_control(theta, res, k, n, tol, degree):
   """Per-round control of the subspace iteration on the device (ps_fd_round_control_f32).
   Returns (params [B, 4] float32, converged [B] int32, summary [4] int32 = all converged, max

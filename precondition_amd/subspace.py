@@ -168,6 +168,7 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   gemms = 1
   converged = torch.zeros((bsz,), dtype=torch.bool, device=dev)
   outer = 0
+  scratch = None   # two more [B, n, b] iterates of the filter, allocated once per call
   for outer in range(1, max_outer + 1):
     fused = _fused_filter()
     if fused:
@@ -208,7 +209,16 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
       max_deg, min_deg = (int(v) for v in torch.stack((deg.max(), deg.min())).tolist())
       # plain bf16 operands only while the wanted residuals are far above its 2^-9 floor
       plain = mode == "bf16" and float((res[:, :k] / top).max()) > 2e-2
-    if fused:
+    if fused and c16 is not None and os.environ.get("PS_FD_ROUND_CALL", "1") != "0":
+      # The whole filter in ONE library call (ps_fd_filter_round_f32): the product's task tables are
+      # uploaded once and the host does nothing between the ~3 launches of a step.
+      if scratch is None:
+        scratch = (torch.empty_like(x), torch.empty_like(x))
+      y_b = _K().fd_filter_round(c16, z, [x, scratch[0], scratch[1]], params, max_deg, plain=plain)
+      gemms += max(max_deg - 1, 0)
+      if y_b is not x:
+        x.copy_(y_b)
+    elif fused:
       # One fused launch per step (csrc/fd.hip): the recurrence for every factor + the bf16
       # hi / lo transposed copy of the new iterate that the next C @ Y product reads.
       bufs = [x, torch.empty_like(x), torch.empty_like(x)]   # y_prev, y, y_next rotate
