@@ -39,6 +39,7 @@
 #include "common.h"
 #include "options.h"
 #include "gemm_core.hip.h"
+#include "gemm_bf16x.hip.h"
 #include "power_iter.hip.h"
 
 namespace psk {
@@ -1467,6 +1468,16 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
         if (!side_ev[i]) PS_HIP(hipEventCreateWithFlags(&side_ev[i], hipEventDisableTiming));
       // K-tile depth of the update products: 8 = 20 KB of LDS, which fits beside a pivot workgroup
       const int cj_ubk = opt.eigh_cj_ubk;
+      // arithmetic of the update products [G_I G_J] Q: 1 = three-way bf16 split on the bf16 MFMA
+      const int cj_x6 = opt.eigh_update_bf16x6;
+      constexpr size_t x6_lds = 6 * (size_t)XPLANE * sizeof(uint16_t);
+      if (cj_x6) {
+        static std::once_flag x6_once;
+        std::call_once(x6_once, [] {
+          (void)hipFuncSetAttribute((const void*)cj_update_x6_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)x6_lds);
+        });
+      }
       const bool two = nstreams >= 2 && !pl.cj_pair[1].empty();
       hipStream_t gs[2] = {st, two ? side : st};
       if (two) {   // everything queued so far on the caller's stream happens before the side stream starts
@@ -1484,8 +1495,11 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                                np_g, r);
             hipLaunchKernelGGL(cj_pivot_kernel, dim3(np_g), dim3(SE_T), piv_lds, gs[g], lo.blocks,
                                lo.cj_pair[g], r, cj_tol, cj_inner, cj_done * cj_done, cj_sort,
-                               cj_stationary, cj_one_below);
-            if (cj_ubk == 8)
+                               cj_stationary, cj_one_below, cj_x6);
+            if (cj_x6)
+              hipLaunchKernelGGL(cj_update_x6_kernel, dim3(nr_g), blk, x6_lds, gs[g], lo.blocks,
+                                 lo.cj_row[g], nr_g, r);
+            else if (cj_ubk == 8)
               hipLaunchKernelGGL(cj_update_kernel_t<8>, dim3(nr_g), blk, 0, gs[g], lo.blocks,
                                  lo.cj_row[g], nr_g, r);
             else

@@ -400,7 +400,8 @@ __device__ inline int onesided_jacobi_lds_stationary(float* G, float* V, int* s_
 __global__ __launch_bounds__(SE_T) void cj_pivot_kernel(EighBlock* blocks, const ETile* tiles,
                                                         int round, float tol, int max_inner,
                                                         float done_cos2, int sort,
-                                                        int stationary, float one_below) {
+                                                        int stationary, float one_below,
+                                                        int store_transposed) {
   extern __shared__ __align__(16) float sem[];
   float* Gs = sem;                      // [128][132] column-major
   float* Vs = sem + SE_MAXN * SE_LD;
@@ -476,6 +477,14 @@ __global__ __launch_bounds__(SE_T) void cj_pivot_kernel(EighBlock* blocks, const
   }
   __syncthreads();
   float* Qg = eb->Q + (int64_t)te.k * JP * JP;
+  if (store_transposed) {
+    // Q^T[rank_j][k]: the k-contiguous right operand of cj_update_x6_kernel; rows of 512 bytes
+    for (int e = tid; e < JP * JP; e += SE_T) {
+      const int jc = e >> 7, k = e & 127;
+      gstore1(Qg + s_rank[jc] * JP + k, Vs[jc * SE_LD + k]);
+    }
+    return;
+  }
   for (int e = tid; e < JP * JP; e += SE_T) {
     const int k = e >> 7, jc = e & 127;          // Q[k][rank_j] = component k of eigenvector j
     gstore1(Qg + k * JP + s_rank[jc], Vs[jc * SE_LD + k]);
@@ -504,6 +513,45 @@ __global__ __launch_bounds__(256, 2) void cj_update_kernel_t(EighBlock* blocks, 
     Operand b{Qg + seg * JB * JP, JP, 0, JP, JB, true};       // (j,k) = Q[seg*64+k][j]
     gemm_tile_accum<KC, MC, UBK, false>(a, b, JB, smem, acc);
   }
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = te.t * TILE + acc_row(wm, i, r, lane);
+        const int c = acc_col(wn, j, lane);
+        const int col = c < JB ? I * JB + c : J * JB + (c - JB);
+        gstore1(X + (int64_t)row * ld + col, acc[i][j][r]);
+      }
+}
+
+// ---- the same update on the bf16 MFMA: both operands split three ways (gemm_bf16x.hip.h), six
+// partial products per product, float32 accumulation: ~2^-22 relative per product -- the size of
+// the float32 chain's own rounding at K = 128 -- at 6 / 16 of the float32 MFMA time, which turns
+// the update from an MFMA-bound into an HBM-bound kernel (it reads and writes G once per round)
+// and leaves the shared VALU / MFMA pipe to the pivot kernel of the other stream group.  The
+// rotation Q is orthogonal to float32 accuracy whatever the arithmetic of its application, so
+// G G^T = D holds to the product's rounding as before; the convergence test stays on the float32
+// Gram kernel.  Q arrives transposed (cj_pivot_kernel store_transposed): Q^T[c][k].
+__global__ __launch_bounds__(256, 2) void cj_update_x6_kernel(EighBlock* blocks, const ETile* tiles,
+                                                              int ntiles, int round) {
+  extern __shared__ __align__(16) float smem_x6[];   // 6 planes of 128 x 40 bf16 = 61,440 bytes
+  const ETile te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj_active || round >= eb->nb - 1) return;
+  if (reinterpret_cast<const int*>(eb->offpart)[round * eb->npairs + te.k] == 0) return;
+  int I, J;
+  rr_pair(eb->nb, round, te.k, I, J);
+  const int ld = eb->npad;
+  const float* Qt = eb->Q + (int64_t)te.k * JP * JP;
+  float* X = eb->X;
+  f32x16 acc[2][2];
+  // (m, k) = X[rt + m][cb + k], (c, k) = Q^T[c][seg * 64 + k]
+  gemm_tile_bf16x_sym<6, false>(X + I * JB, ld, te.t * TILE, Qt, JP, 0, JB, smem_x6, acc);
+  gemm_tile_bf16x_sym<6, true>(X + J * JB, ld, te.t * TILE, Qt + JB, JP, 0, JB, smem_x6, acc);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
