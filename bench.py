@@ -84,6 +84,8 @@ class Workload:
     self.gathered = (torch.empty((world * nb, n, n), dtype=torch.float32, device=dev)
                      if self.multi else None)
     self.metrics = None
+    self._ps = np.full(nb, self.p, np.int32)
+    self._pads = np.full(nb, n, np.int32)
     self.hint = None       # host copy of the previous recompute's iteration counts
     self.options = {}      # per-call modes (ps_options), e.g. {"products": "bf16x6"}
 
@@ -99,10 +101,11 @@ class Workload:
     opts = dict(self.options)
     if self.hint is not None:
       opts["iters_hint"] = self.hint[lo:hi]
+    # the reference's stacked form xs[b, n, n] (DS:2742): no per-block Python objects
     _, m = K.matrix_inverse_pth_root_batched(
-        list(self.stats[lo:hi].unbind(0)), [self.p] * (hi - lo),
-        padding_starts=[self.n] * (hi - lo), out=list(self.roots[lo:hi].unbind(0)),
-        eigh=self.name.startswith("eigh"), max_ev=max_ev, options=opts or None)
+        self.stats[lo:hi], self._ps[:hi - lo], padding_starts=self._pads[:hi - lo],
+        out=self.roots[lo:hi], eigh=self.name.startswith("eigh"), max_ev=max_ev,
+        options=opts or None)
     return m
 
   def split_point(self):

@@ -129,25 +129,55 @@ def matrix_inverse_pth_root_batched(
   product arithmetic (the reference's `precision`), accumulation, averaged steps, the
   iteration-count hint of the previous recompute, execution, power-iteration execution.
   """
-  batch = len(matrices)
-  if batch == 0:
-    return [], torch.empty((0, _lib.PS_METRICS_STRIDE), dtype=torch.float32)
-  dev = matrices[0].device
-  for m in matrices:
-    _require_gpu(m, "matrix_inverse_pth_root")
-    if m.dim() != 2 or m.shape[0] != m.shape[1]:
-      raise ValueError(f"expected square matrices, got {tuple(m.shape)}")
-  _same_device(list(matrices) + (list(out) if out is not None else []),
-               "matrix_inverse_pth_root")
-  n = _i32([m.shape[0] for m in matrices])
-  lda = _i32([_as_2d_ld(m) for m in matrices])
-  p = _i32(list(ps))
-  pad = None if padding_starts is None else _i32(list(padding_starts))
-  if out is None:
-    out = [torch.empty((int(k), int(k)), dtype=torch.float32, device=dev)
-           for k in n]
-  ldo = _i32([_as_2d_ld(o) for o in out])
-  a_ptrs, o_ptrs = _ptrs(matrices), _ptrs(out)
+  stacked = isinstance(matrices, torch.Tensor)
+  if stacked:
+    # The reference's own batched form, xs[b, n, n] (DS:2742-2744): one stacked tensor in, one
+    # stacked tensor out -- the pointer / size tables are arithmetic on the base address instead of
+    # a Python loop over b tensors (0.6 ms of host time per call at b = 256, which a recompute
+    # issued back to back with the previous one cannot hide).
+    xs = matrices
+    _require_gpu(xs, "matrix_inverse_pth_root")
+    if xs.dim() != 3 or xs.shape[1] != xs.shape[2] or xs.stride(2) != 1 or xs.dtype != torch.float32:
+      raise ValueError(f"expected a float32 [b, n, n] tensor with contiguous rows, got {tuple(xs.shape)}")
+    batch, nn = int(xs.shape[0]), int(xs.shape[1])
+    if batch == 0:
+      return xs.new_empty((0, nn, nn)), torch.empty((0, _lib.PS_METRICS_STRIDE), dtype=torch.float32)
+    dev = xs.device
+    if out is None:
+      out = torch.empty((batch, nn, nn), dtype=torch.float32, device=dev)
+    if (not isinstance(out, torch.Tensor) or tuple(out.shape) != (batch, nn, nn) or out.stride(2) != 1
+        or out.dtype != torch.float32 or out.device != dev):
+      raise ValueError("out must be a float32 [b, n, n] tensor on the same device")
+    n = np.full(batch, nn, np.int32)
+    lda = np.full(batch, int(xs.stride(1)), np.int32)
+    ldo = np.full(batch, int(out.stride(1)), np.int32)
+    steps = np.arange(batch, dtype=np.uint64)
+    a_ptrs = np.uint64(xs.data_ptr()) + steps * np.uint64(4 * int(xs.stride(0)))
+    o_ptrs = np.uint64(out.data_ptr()) + steps * np.uint64(4 * int(out.stride(0)))
+    p = _i32(list(ps))
+    pad = None if padding_starts is None else _i32(list(padding_starts))
+    if len(p) != batch or (pad is not None and len(pad) != batch):
+      raise ValueError("ps / padding_starts must hold one value per block")
+  else:
+    batch = len(matrices)
+    if batch == 0:
+      return [], torch.empty((0, _lib.PS_METRICS_STRIDE), dtype=torch.float32)
+    dev = matrices[0].device
+    for m in matrices:
+      _require_gpu(m, "matrix_inverse_pth_root")
+      if m.dim() != 2 or m.shape[0] != m.shape[1]:
+        raise ValueError(f"expected square matrices, got {tuple(m.shape)}")
+    _same_device(list(matrices) + (list(out) if out is not None else []),
+                 "matrix_inverse_pth_root")
+    n = _i32([m.shape[0] for m in matrices])
+    lda = _i32([_as_2d_ld(m) for m in matrices])
+    p = _i32(list(ps))
+    pad = None if padding_starts is None else _i32(list(padding_starts))
+    if out is None:
+      out = [torch.empty((int(k), int(k)), dtype=torch.float32, device=dev)
+             for k in n]
+    ldo = _i32([_as_2d_ld(o) for o in out])
+    a_ptrs, o_ptrs = _ptrs(matrices), _ptrs(out)
   metrics = torch.empty((batch, _lib.PS_METRICS_STRIDE), dtype=torch.float32,
                         device=dev)
   L = lib()
@@ -186,7 +216,7 @@ def matrix_inverse_pth_root_batched(
         o_ptrs.ctypes.data, ldo.ctypes.data, metrics.data_ptr(), ws.data_ptr(), ws.numel(),
         C.addressof(iters), C.byref(popt))
     check(rc, "ps_newton_root_batched_opt_f32")
-  return list(out), metrics
+  return (out if stacked else list(out)), metrics
 
 
 def products_for_precision(precision) -> str:

@@ -189,3 +189,21 @@ def test_sharded_roots_repair_eigenvalues_after_an_expired_power_iteration(devic
     assert rel(roots[i].cpu().numpy(), h_ref) < 5e-5
     assert np.isclose(met[i, 3], m_ref["max_eigen_value"], rtol=2e-5)
   L().ps_power_iteration_reset_health()
+
+
+def test_stacked_batch_form_bit_identical_to_list_form(device):
+  """matrix_inverse_pth_root_batched(xs[b, n, n]) -- the reference's own vmap signature
+  (DS:2742-2744) -- against the list form: same roots and metrics, also on a strided view."""
+  arrs = np.stack([wishart(200, 600, 90 + i) for i in range(5)])
+  xs = torch.tensor(arrs, device=device)
+  r_list, m_list = K().matrix_inverse_pth_root_batched(list(xs.unbind(0)), [4, 2, 4, 8, 1])
+  r_st, m_st = K().matrix_inverse_pth_root_batched(xs, [4, 2, 4, 8, 1])
+  assert isinstance(r_st, torch.Tensor) and tuple(r_st.shape) == (5, 200, 200)
+  assert torch.equal(m_list, m_st)
+  for i in range(5):
+    assert torch.equal(r_list[i], r_st[i])
+  big = torch.zeros((5, 256, 256), device=device)
+  big[:, :200, :200] = xs
+  out = torch.empty((5, 200, 200), device=device)
+  r_v, m_v = K().matrix_inverse_pth_root_batched(big[:, :200, :200], [4, 2, 4, 8, 1], out=out)
+  assert r_v is out and torch.equal(m_v, m_st) and torch.equal(out, r_st)
