@@ -354,9 +354,11 @@ int ps_eigh_batched_f32(void* stream, const float* const* a, const int32_t* n,
                         size_t workspace_bytes);
 
 /* ---- optional per-kernel timing of the Newton driver (bench/roofline only) ----
- * When enabled, ps_newton_root_batched_f32 brackets every product-stage launch
- * with a pair of HIP events on the caller's stream and, before returning,
- * accumulates their elapsed times (this makes the call synchronous).
+ * When enabled, ps_newton_root_batched_f32 brackets the product-stage launches of every
+ * Newton step (one launch per product stage, back to back) with a pair of HIP events on the
+ * caller's stream and, before returning, accumulates their elapsed times (this makes the call
+ * synchronous).  (A pair around EVERY launch perturbs what it measures: an event record is a
+ * queue packet of its own, and the next kernel no longer starts under the tail of the previous.)
  * ps_profile_get: total milliseconds and launch count of newton_stage_kernel,
  * milliseconds of the power-iteration launches, and of everything else the
  * call enqueued (init/control/copy-out), since the last ps_profile_reset. */
@@ -392,6 +394,19 @@ typedef struct {
 size_t ps_gemm_grouped_workspace_bytes(const ps_gemm_desc* desc, int count);
 int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count, void* workspace,
                         size_t workspace_bytes);
+
+/* The same grouped product as a reusable plan: the task / tile tables are built and uploaded into
+ * the caller's workspace once (create), and every launch is one or two kernel launches with no
+ * host-side table building.  The operand POINTERS, shapes and the workspace must stay unchanged
+ * and alive while the plan is used; the operands' CONTENTS may change between launches (the
+ * subspace iteration of the FD branch repeats the same products on the same buffers every round).
+ * Launches of one plan must be stream-ordered with each other (split-K partials live in the
+ * workspace).  destroy frees the host handle only. */
+typedef struct ps_gemm_plan ps_gemm_plan;
+int ps_gemm_grouped_plan_create(void* stream, const ps_gemm_desc* desc, int count, void* workspace,
+                                size_t workspace_bytes, ps_gemm_plan** plan);
+int ps_gemm_grouped_plan_launch(void* stream, const ps_gemm_plan* plan);
+int ps_gemm_grouped_plan_destroy(ps_gemm_plan* plan);
 
 /* ---- bf16-MFMA products of the Frequent-Directions branch (BASELINE configs[4]) --------
  * _fd_update_root (DS:1123-1290) needs the leading rank+1 singular pairs of the d x (rank+d)

@@ -229,6 +229,11 @@ _SIGNATURES = {
     "ps_gemm_grouped_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc), C.c_int]),
     "ps_gemm_grouped_f32":
         (C.c_int, [C.c_void_p, C.POINTER(GemmDesc), C.c_int, C.c_void_p, C.c_size_t]),
+    "ps_gemm_grouped_plan_create":
+        (C.c_int, [C.c_void_p, C.POINTER(GemmDesc), C.c_int, C.c_void_p, C.c_size_t,
+                   C.POINTER(C.c_void_p)]),
+    "ps_gemm_grouped_plan_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ps_gemm_grouped_plan_destroy": (C.c_int, [C.c_void_p]),
     "ps_convert_f32_to_bf16":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                    C.c_int64, C.c_int64, C.c_int]),

@@ -4,6 +4,8 @@
 
 #include <vector>
 
+#include <new>
+
 #include "common.h"
 #include "gemm_core.hip.h"
 
@@ -305,12 +307,22 @@ extern "C" size_t ps_gemm_grouped_workspace_bytes(const ps_gemm_desc* desc, int 
   return grouped_gemm_bytes(desc, count);
 }
 
-extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count,
-                                   void* workspace, size_t workspace_bytes) {
-  PS_DEVICE_CHECK();
+// A grouped product as a reusable plan (ps_gemm_grouped_plan_*): the task / tile tables are
+// built and uploaded once and the launch is two kernel launches with no host work -- the
+// subspace iteration of the FD branch repeats the same ~9 products on the same buffers every
+// round, and building their tables from Python (~90 us per product) was 4 of the 10 ms of a
+// one-factor update.
+struct ps_gemm_plan {
+  GTask* dt[4] = {nullptr, nullptr, nullptr, nullptr};
+  GTile* dl[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* di[4] = {nullptr, nullptr, nullptr, nullptr};
+  int ntiles[4] = {0, 0, 0, 0}, nsplit[4] = {0, 0, 0, 0};
+};
+
+static int gplan_build(hipStream_t st, const ps_gemm_desc* desc, int count, void* workspace,
+                       size_t workspace_bytes, ps_gemm_plan& pl) {
   if (!desc || count <= 0 || !workspace) return PS_EINVAL;
   if (workspace_bytes < grouped_gemm_bytes(desc, count)) return PS_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   std::vector<GTask> tasks[4];
   std::vector<GTile> tiles[4];
   std::vector<int> split_ids[4];
@@ -364,22 +376,20 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
       }
     psh::interleave_xcd_lists(lists, GTile{-1, 0, 0, 0}, tiles[g]);
   }
-  GTask* dt[4];
-  GTile* dl[4];
-  int* di[4];
   for (int g = 0; g < 4; ++g) {
-    dt[g] = ar.take<GTask>(std::max<size_t>(tasks[g].size(), 1));
-    dl[g] = ar.take<GTile>(std::max<size_t>(tiles[g].size(), 1));
-    di[g] = ar.take<int>(std::max<size_t>(split_ids[g].size(), 1));
+    pl.dt[g] = ar.take<GTask>(std::max<size_t>(tasks[g].size(), 1));
+    pl.dl[g] = ar.take<GTile>(std::max<size_t>(tiles[g].size(), 1));
+    pl.di[g] = ar.take<int>(std::max<size_t>(split_ids[g].size(), 1));
+    pl.ntiles[g] = (int)tiles[g].size();
+    pl.nsplit[g] = (int)split_ids[g].size();
   }
   if (ar.overflow) return PS_EWORKSPACE;
   for (int g = 0; g < 4; ++g) {
     if (tasks[g].empty()) continue;
-    PS_RC(psh::upload_async(st, dt[g], tasks[g].data(), sizeof(GTask) * tasks[g].size()));
-    PS_RC(psh::upload_async(st, dl[g], tiles[g].data(), sizeof(GTile) * tiles[g].size()));
-    PS_RC(psh::upload_async(st, di[g], split_ids[g].data(), sizeof(int) * split_ids[g].size()));
+    PS_RC(psh::upload_async(st, pl.dt[g], tasks[g].data(), sizeof(GTask) * tasks[g].size()));
+    PS_RC(psh::upload_async(st, pl.dl[g], tiles[g].data(), sizeof(GTile) * tiles[g].size()));
+    PS_RC(psh::upload_async(st, pl.di[g], split_ids[g].data(), sizeof(int) * split_ids[g].size()));
   }
-  const dim3 blk(256);
   static const bool lds_ok = [] {
     const void* ks[4] = {(const void*)gemm_grouped_kernel<KC, MC>, (const void*)gemm_grouped_kernel<KC, KC>,
                          (const void*)gemm_grouped_kernel<MC, MC>, (const void*)gemm_grouped_kernel<MC, KC>};
@@ -389,13 +399,18 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
     return true;
   }();
   (void)lds_ok;
+  return PS_OK;
+}
+
+static int gplan_launch(hipStream_t st, const ps_gemm_plan& pl) {
+  const dim3 blk(256);
 #define PS_GG(G, LA, LB)                                                                   \
-  if (!tasks[G].empty()) {                                                                 \
-    hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB>), dim3((unsigned)tiles[G].size()), blk, \
-                       GEMM_GROUPED_LDS_BYTES, st, dt[G], dl[G], (int)tiles[G].size());    \
-    if (!split_ids[G].empty())                                                             \
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)split_ids[G].size(), 256), \
-                         blk, 0, st, dt[G], di[G]);                                        \
+  if (pl.ntiles[G] > 0) {                                                                  \
+    hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB>), dim3((unsigned)pl.ntiles[G]), blk,   \
+                       GEMM_GROUPED_LDS_BYTES, st, pl.dt[G], pl.dl[G], pl.ntiles[G]);      \
+    if (pl.nsplit[G] > 0)                                                                  \
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)pl.nsplit[G], 256), blk, 0, \
+                         st, pl.dt[G], pl.di[G]);                                          \
   }
   PS_GG(0, KC, MC);
   PS_GG(1, KC, KC);
@@ -403,6 +418,39 @@ extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int c
   PS_GG(3, MC, KC);
 #undef PS_GG
   PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_gemm_grouped_f32(void* stream, const ps_gemm_desc* desc, int count,
+                                   void* workspace, size_t workspace_bytes) {
+  PS_DEVICE_CHECK();
+  ps_gemm_plan pl;
+  PS_RC(gplan_build((hipStream_t)stream, desc, count, workspace, workspace_bytes, pl));
+  return gplan_launch((hipStream_t)stream, pl);
+}
+
+extern "C" int ps_gemm_grouped_plan_create(void* stream, const ps_gemm_desc* desc, int count,
+                                           void* workspace, size_t workspace_bytes,
+                                           ps_gemm_plan** plan) {
+  PS_DEVICE_CHECK();
+  if (!plan) return PS_EINVAL;
+  *plan = nullptr;
+  ps_gemm_plan* pl = new (std::nothrow) ps_gemm_plan();
+  if (!pl) return PS_EINTERNAL;
+  const int rc = gplan_build((hipStream_t)stream, desc, count, workspace, workspace_bytes, *pl);
+  if (rc != 0) { delete pl; return rc; }
+  *plan = pl;
+  return PS_OK;
+}
+
+extern "C" int ps_gemm_grouped_plan_launch(void* stream, const ps_gemm_plan* plan) {
+  PS_DEVICE_CHECK();
+  if (!plan) return PS_EINVAL;
+  return gplan_launch((hipStream_t)stream, *plan);
+}
+
+extern "C" int ps_gemm_grouped_plan_destroy(ps_gemm_plan* plan) {
+  delete plan;
   return PS_OK;
 }
 

@@ -422,6 +422,39 @@ def _ld_2d(shapes: np.ndarray, strides: np.ndarray) -> np.ndarray:
   return np.where(shapes[:, 0] > 1, strides[:, 0], np.maximum(shapes[:, 1], 1))
 
 
+class GemmPlan:
+  """A grouped product whose task tables are built and uploaded ONCE (ps_gemm_grouped_plan_*):
+  `launch()` is one or two kernel launches with no host-side table building.  The operand tensors
+  of `items` (same form as gemm_grouped) are kept alive by the plan; their contents may change
+  between launches, their storage may not."""
+
+  def __init__(self, items):
+    self._keep = [t for it in items for t in it[:3]]
+    tbl, dev = _gemm_desc_table(items)
+    self._dev = dev
+    descs = C.cast(tbl.ctypes.data, C.POINTER(GemmDesc))
+    L = lib()
+    self._ws = _workspace(L.ps_gemm_grouped_workspace_bytes(descs, len(items)), dev)
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+      rc = L.ps_gemm_grouped_plan_create(_stream(), descs, len(items), self._ws.data_ptr(),
+                                         self._ws.numel(), C.byref(h))
+    check(rc, "ps_gemm_grouped_plan_create")
+    self._h = h
+
+  def launch(self):
+    with torch.cuda.device(self._dev):
+      check(lib().ps_gemm_grouped_plan_launch(_stream(), self._h), "ps_gemm_grouped_plan_launch")
+
+  def __del__(self):
+    h, self._h = getattr(self, "_h", None), None
+    if h:
+      try:
+        lib().ps_gemm_grouped_plan_destroy(h)
+      except Exception:  # pylint: disable=broad-except
+        pass
+
+
 @_device_guarded
 def gemm_grouped(items):
   """items: list of (a, b, c, transa, transb) with 2-D row-contiguous (possibly
@@ -430,6 +463,17 @@ def gemm_grouped(items):
   of blocks: per-item ctypes stores were the cost of a step)."""
   if not items:
     return
+  tbl, dev = _gemm_desc_table(items)
+  n_items = len(items)
+  descs = C.cast(tbl.ctypes.data, C.POINTER(GemmDesc))
+  L = lib()
+  ws = _workspace(L.ps_gemm_grouped_workspace_bytes(descs, n_items), dev)
+  rc = L.ps_gemm_grouped_f32(_stream(), descs, n_items, ws.data_ptr(), ws.numel())
+  check(rc, "ps_gemm_grouped_f32")
+
+
+def _gemm_desc_table(items):
+  """(descriptor table, device) of a gemm_grouped item list."""
   n_items = len(items)
   dev = items[0][0].device
   A = [it[0] for it in items]
@@ -461,11 +505,7 @@ def gemm_grouped(items):
   tbl["lda"] = _ld_2d(sa, np.array([t.stride() for t in A], np.int64))
   tbl["ldb"] = _ld_2d(sb, np.array([t.stride() for t in B], np.int64))
   tbl["ldc"] = _ld_2d(sc, np.array([t.stride() for t in Cm], np.int64))
-  descs = C.cast(tbl.ctypes.data, C.POINTER(GemmDesc))
-  L = lib()
-  ws = _workspace(L.ps_gemm_grouped_workspace_bytes(descs, n_items), dev)
-  rc = L.ps_gemm_grouped_f32(_stream(), descs, n_items, ws.data_ptr(), ws.numel())
-  check(rc, "ps_gemm_grouped_f32")
+  return tbl, dev
 
 
 class TiledBf16:
@@ -657,14 +697,17 @@ def fd_round_control(theta, res, k, n, tol, degree):
 
 
 @_device_guarded
-def chol_rinv_batched(gram: torch.Tensor, drop_rel: float = 1e-10) -> torch.Tensor:
+def chol_rinv_batched(gram: torch.Tensor, drop_rel: float = 1e-10, out=None) -> torch.Tensor:
   """R^-1 of the Cholesky factors G_j = R^T R of the stacked symmetric matrices [B, b, b]
   (float64 arithmetic on the device, b <= ps_chol_rinv_max_n()); directions whose pivot is
   below drop_rel * max diag(G_j) get a zero row and column."""
   _require_gpu(gram, "chol_rinv_batched")
   if gram.dim() != 3 or gram.shape[1] != gram.shape[2] or not gram.is_contiguous():
     raise ValueError("chol_rinv_batched expects a contiguous [B, b, b] tensor")
-  out = torch.empty_like(gram)
+  if out is None:
+    out = torch.empty_like(gram)
+  elif out.shape != gram.shape or not out.is_contiguous() or out.dtype != torch.float32:
+    raise ValueError("chol_rinv_batched: out must match gram")
   check(lib().ps_chol_rinv_batched_f32(_stream(), gram.data_ptr(), out.data_ptr(),
                                        int(gram.shape[1]), int(gram.shape[0]), float(drop_rel)),
         "ps_chol_rinv_batched_f32")

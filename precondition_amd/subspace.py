@@ -99,6 +99,59 @@ def _rayleigh_ritz(c: Sequence[torch.Tensor], x: torch.Tensor, z: torch.Tensor,
   return theta, res
 
 
+class _Planned:
+  """_orthonormalize and _rayleigh_ritz of one top_eigenpairs_batched call on persistent buffers,
+  every product a kernels.GemmPlan: the eight products of an outer round are built once per call
+  and launched ~6 times (PS_FD_PLANS=0 restores the per-product table building).  Same kernels,
+  same operands, same order: bit-identical results."""
+
+  def __init__(self, c, x, z, tmp):
+    K = _K()
+    bsz, n, b = x.shape
+    dev = x.device
+    self.c, self.x, self.z, self.tmp = c, x, z, tmp
+    mk = lambda: torch.empty((bsz, b, b), dtype=torch.float32, device=dev)
+    self.gram, self.m, self.polish, self.t, self.y = mk(), mk(), mk(), mk(), mk()
+    self.eye = torch.eye(b, dtype=torch.float32, device=dev)
+    R = range(bsz)
+    self.p_gram_x = K.GemmPlan([(x[j], x[j], self.gram[j], True, False) for j in R])
+    self.p_xm = K.GemmPlan([(x[j], self.m[j], tmp[j], False, False) for j in R])
+    self.p_gram_t = K.GemmPlan([(tmp[j], tmp[j], self.gram[j], True, False) for j in R])
+    self.p_pol = K.GemmPlan([(tmp[j], self.polish[j], x[j], False, False) for j in R])
+    self.p_cx = K.GemmPlan([(c[j], x[j], z[j], False, False) for j in R])
+    self.p_xtz = K.GemmPlan([(x[j], z[j], self.t[j], True, False) for j in R])
+    self.p_xy = K.GemmPlan([(x[j], self.y[j], tmp[j], False, False) for j in R])
+    self.p_zy = K.GemmPlan([(z[j], self.y[j], tmp[j], False, False) for j in R])
+
+  def orthonormalize(self):
+    b = self.x.shape[2]
+    self.p_gram_x.launch()
+    if _use_cholqr(b):
+      _K().chol_rinv_batched(self.gram, 1e-10, out=self.m)
+    else:
+      lam, u = _small_eigh_desc(self.gram)
+      keep = lam > 1e-10 * lam[:, :1].clamp_min(1e-30)
+      scale = torch.where(keep, lam.clamp_min(1e-30).rsqrt(), torch.zeros_like(lam))
+      self.m.copy_(u * scale[:, None, :])
+    self.p_xm.launch()
+    self.p_gram_t.launch()
+    torch.add(self.eye * 1.5, self.gram, alpha=-0.5, out=self.polish)
+    self.p_pol.launch()
+    return self.x
+
+  def rayleigh_ritz(self):
+    self.p_cx.launch()
+    self.p_xtz.launch()
+    theta, y = _small_eigh_desc(self.t)
+    self.y.copy_(y)
+    self.p_xy.launch()
+    self.x.copy_(self.tmp)
+    self.p_zy.launch()
+    self.z.copy_(self.tmp)
+    res = torch.linalg.vector_norm(self.z - self.x * theta[:, None, :], dim=1)
+    return theta, res
+
+
 def _filter_precision(n: int) -> str:
   """Arithmetic of the Chebyshev filter's C @ Y products (the bulk of the work; the
   Rayleigh-Ritz products and residuals are always float32 MFMA):
@@ -163,8 +216,13 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   x = torch.randn((bsz, n, b), generator=gen, device=dev, dtype=torch.float32)
   z = torch.empty_like(x)
   tmp = torch.empty_like(x)
-  x = _orthonormalize(x, tmp)
-  theta, res = _rayleigh_ritz(c, x, z, tmp)
+  planned = _Planned(c, x, z, tmp) if os.environ.get("PS_FD_PLANS", "1") != "0" else None
+  if planned is not None:
+    x = planned.orthonormalize()
+    theta, res = planned.rayleigh_ritz()
+  else:
+    x = _orthonormalize(x, tmp)
+    theta, res = _rayleigh_ritz(c, x, z, tmp)
   gemms = 1
   converged = torch.zeros((bsz,), dtype=torch.bool, device=dev)
   outer = 0
@@ -260,8 +318,12 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
         y = torch.where(active, y_next, y)
         sigma = torch.where(active, sigma_new, sigma)
       x.copy_(y)
-    x = _orthonormalize(x, tmp)
-    theta, res = _rayleigh_ritz(c, x, z, tmp)
+    if planned is not None:
+      x = planned.orthonormalize()
+      theta, res = planned.rayleigh_ritz()
+    else:
+      x = _orthonormalize(x, tmp)
+      theta, res = _rayleigh_ritz(c, x, z, tmp)
     gemms += 1
   else:
     top = theta[:, :1].clamp_min(1e-30)

@@ -6,6 +6,7 @@ import torch
 import bench
 dev = torch.device("cuda", 0)
 for mode in ("0", "1"):
+  os.environ["PS_FD_PLANS"] = mode
   os.environ["PS_FD_ROUND_CALL"] = mode
   for factors in (8, 1):
     r = bench.fd_cfg5(dev, factors=factors, updates=4)
