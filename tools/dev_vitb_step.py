@@ -6,6 +6,8 @@ import bench
 dev = torch.device("cuda:0")
 w = bench.VitBWorkload(0, 1, dev, None)
 w.step(); torch.cuda.synchronize()
+w.refresh_hint()   # last recompute's iteration counts (what the optimizer passes: ps_options.iters_hint)
+w.step(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(3):
   w.step()
