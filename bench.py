@@ -493,6 +493,11 @@ def profile_stage_kernel(work):
   everything else the call enqueues."""
   from precondition_amd import _lib
   L = _lib.lib()
+  # two untimed calls first: the pass may follow seconds of host-only work (the oracle of the parity
+  # sample), after which the GPU is in a low power state and the first launches run at ramping clocks
+  for _ in range(2):
+    work.compute()
+  _sync()
   L.ps_profile_reset()
   L.ps_profile_enable(1)
   try:

@@ -126,13 +126,17 @@ const char* ps_error_string(int code);
  *     PS_PRODUCTS_BF16X3  (Precision.DEFAULT) two-way split, three partial products, ~2^-16
  *                         relative; exact float32 once max|M - I| < 3e-2.
  *   The bf16 modes apply to exactly symmetric blocks; other blocks run float32 in the same call.
- * accumulation — how a float32 product sums over k (PS_PRODUCTS_F32 only):
- *     PS_ACCUM_SEGMENTED  (default) the M-side products (the powering chain and M' = Mi^p M) of
- *                         blocks NOT marked fast by iters_hint are summed in segments of 128
- *                         (blocked summation): on ill-conditioned blocks the root is then closer
- *                         to the float64 root than NumPy/OpenBLAS's float32 evaluation of the same
- *                         iteration (0.75x its error; one chain: 1.3x).
- *     PS_ACCUM_CHAIN      one fmaf chain over the whole k range everywhere (rounds 1-3).
+ * accumulation — how a float32 product sums over k (PS_PRODUCTS_F32 only; the call's, not a
+ *   block's: a block's bits never depend on what else is in the call):
+ *     PS_ACCUM_SEGMENTED  (default) every product of the Newton iteration is summed in segments
+ *                         of 128 values of k (blocked summation: the fp32 MFMA is one fmaf chain
+ *                         per output element, whose rounding grows like sqrt(K)).  On
+ *                         ill-conditioned blocks (cond ~5e3, p = 4: where two float32 evaluations of
+ *                         the iteration differ by more than 1e-4) the root is then closer to the
+ *                         float64 root than NumPy/OpenBLAS's float32 evaluation of the same
+ *                         iteration: 0.55-0.65 x its error (one chain: 1.3-1.6 x).  Same MFMA
+ *                         work; +0 % time at 512^2, +3 % at 1024^2.
+ *     PS_ACCUM_CHAIN      one fmaf chain over the whole k range (rounds 1-3).
  * averaged_steps — leading Newton steps of a try whose M update is computed in full and averaged
  *   with its transpose instead of being mirrored (section "symmetry" below); -1 = default (4).
  * iters_hint / iters_hint_stride / fast_max_iters — HOST pointer to one float per block (block b
@@ -140,12 +144,11 @@ const char* ps_error_string(int code);
  *   recompute (a host copy of column PS_M_ITERS of that call's metrics, stride PS_METRICS_STRIDE;
  *   the optimizer reads that table on the host anyway for the failure select of DS:2936-2950 and
  *   its state carries it, DS:338-351).  A block whose hint is in [1, fast_max_iters] (default 8:
- *   condition number below ~1e2) is well conditioned: it takes 0 averaged steps and plain chains,
- *   which is exact to 1e-6 there and ~4 % faster; a call whose blocks are all fast runs the
- *   two-register-set product kernel, any other call the CAREFUL instantiation (one register set,
- *   the other set's registers hold the segment totals).  NULL, 0 or NaN = no hint = the careful
- *   path.  Statistics move slowly (beta2 ~ 0.999), so last recompute's count is a sound predictor;
- *   a block that turns out slower than its hint is only less accurate, never wrong.
+ *   condition number below ~1e2) is well conditioned: it takes 0 averaged steps -- mirrored M
+ *   updates are exact to 1e-6 there -- which saves the 6 extra tile products of an averaged step
+ *   (-7 % at 256 x 512^2, -9 % at 64 x 1024^2).  NULL, 0 or NaN = no hint = the careful path.
+ *   Statistics move slowly (beta2 ~ 0.999), so last recompute's count is a sound predictor; a
+ *   block that turns out slower than its hint is only less accurate (mirror noise ~ cond * eps).
  * execution — PS_EXEC_STAGED (default: one launch per product stage, one host event wait per
  *   Newton step, one step behind the GPU) or PS_EXEC_PERSISTENT (one dataflow kernel, no host wait).
  * power_iteration — PS_PI_AUTO (resident when the chip is free, else streaming), PS_PI_STREAMING,

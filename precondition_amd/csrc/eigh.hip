@@ -1480,9 +1480,18 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       }
       const bool two = nstreams >= 2 && !pl.cj_pair[1].empty();
       hipStream_t gs[2] = {st, two ? side : st};
+      // Whatever way this scope is left (the error returns inside the sweep loop included), the side
+      // stream is joined back into the caller's stream: the call stays stream-ordered as a whole.
+      struct SideJoin {
+        hipStream_t st, side; hipEvent_t ev; bool forked;
+        ~SideJoin() {
+          if (forked && hipEventRecord(ev, side) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+        }
+      } side_join{st, side, side_ev[2], false};
       if (two) {   // everything queued so far on the caller's stream happens before the side stream starts
         PS_HIP(hipEventRecord(side_ev[2], st));
         PS_HIP(hipStreamWaitEvent(side, side_ev[2], 0));
+        side_join.forked = true;
       }
       const int first_gen = gen;
       bool done[2] = {pl.cj_pair[0].empty(), pl.cj_pair[1].empty()};
@@ -1531,6 +1540,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
         }
       }
       if (two) {
+        side_join.forked = false;
         PS_HIP(hipEventRecord(side_ev[2], side));
         PS_HIP(hipStreamWaitEvent(st, side_ev[2], 0));
       }

@@ -652,7 +652,8 @@ __global__ __launch_bounds__(256) void newton_control_kernel(
       st->ratio = 1.f;
       st->it = 0;
       st->asym_bits = 0; st->xmax_bits = 0;
-      st->avg_on = newton_avg_next(0, st->navg, st->err, avg_thr) ? 1 : 0;
+      // (blocks on the general path run full products: nothing to average, nothing counted)
+      st->avg_on = (st->general == 0 && newton_avg_next(0, st->navg, st->err, avg_thr)) ? 1 : 0;
       const bool cont = st->it < num_iters && st->err > tol && st->ratio < 1.2f;
       if (cont) st->phase = PH_ACTIVE; else finish_try(st);
     } else if (mode == 1 && st->phase == PH_ACTIVE) {
@@ -889,7 +890,7 @@ __device__ inline void p_control_init(const PArgs& pa, const NewtonBlock* nb, Ne
   ast(&st->it, 0);
   ast(&st->asym_bits, 0u);
   ast(&st->xmax_bits, 0u);
-  const int avg0 = newton_avg_next(0, ald(&st->navg), ald(&st->err), pa.avg_thr) ? 1 : 0;
+  const int avg0 = (ald(&st->general) == 0 && newton_avg_next(0, ald(&st->navg), ald(&st->err), pa.avg_thr)) ? 1 : 0;
   ast(&st->avg_on, avg0);
   const bool cont = 0 < pa.num_iters && err > pa.tol;
   if (cont) { ast(&st->phase, (int)PH_ACTIVE); p_start_step(pa, nb, b, cur, avg0); }
