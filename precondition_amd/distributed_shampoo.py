@@ -381,6 +381,21 @@ def distributed_shampoo(
                                 generate_fd_metrics, device=dev))
 
     stats = pytree.tree_map(_init, params)
+    if frequent_directions and _backend_for_testing is None:
+      # init-time preparation of the sketch-update path (kernel loading + allocator pool) for
+      # every (dimension, count) of compressed factors on the GPU: low_rank.prepare_fd
+      from . import low_rank as _lr
+      census = {}
+      _, treedef_ = pytree.tree_flatten(params)
+      for st_ in treedef_.flatten_up_to(stats):
+        if isinstance(st_, ParameterStats):
+          for pc_ in st_.preconditioners:
+            if (isinstance(pc_, torch.Tensor) and pc_.is_cuda and pc_.dim() == 2 and
+                pc_.shape[1] < pc_.shape[0]):
+              key = (int(pc_.shape[0]), pc_.device)
+              census[key] = census.get(key, 0) + 1
+      for (d_, dev_), cnt in census.items():
+        _lr.prepare_fd(d_, compression_rank, cnt, dev_)
     if shard_stats:
       params_flat, treedef = pytree.tree_flatten(params)
       st_flat = treedef.flatten_up_to(stats)

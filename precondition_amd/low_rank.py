@@ -244,6 +244,31 @@ def _fd_update_root(new_grad: torch.Tensor, p: int, rank: int = 0,
       generate_fd_metrics=generate_fd_metrics, new_grad_is_gram=new_grad_is_gram)])[0]
 
 
+def prepare_fd(d: int, rank: int, factors: int, device, p: int = 4, reps: int = 2) -> None:
+  """Init-time preparation of the Frequent-Directions branch for `factors` factors of dimension
+  `d` and sketch rank `rank` on `device`: `reps` throw-away sketch updates of random covariances
+  of those shapes.  The first update of a process otherwise pays for loading the code objects of
+  ~20 kernels and for growing the caching allocator's pool to the working set of an update (2 GB
+  for 8 x 4096^2; each growth step is a hipMalloc that synchronises the device): 650 ms for 8 x
+  4096^2 / rank 64, then 80 ms for the second one (a different allocation pattern once the sketch
+  is non-zero), 26 ms from the third on.  The optimizer calls this from init_fn (outside any step);
+  bench.py calls it before its timed FD updates.  Only sizes that take the block subspace path
+  (d >= SUBSPACE_MIN_N on the GPU) need it."""
+  if d < SUBSPACE_MIN_N or rank <= 0 or factors <= 0 or not torch.device(device).type == "cuda":
+    return
+  gen = torch.Generator(device=device).manual_seed(d + rank)
+  prevs = [torch.zeros((d, rank + 2), dtype=torch.float32, device=device) for _ in range(factors)]
+  for _ in range(max(1, reps)):
+    calls = []
+    for f in range(factors):
+      g = torch.randn((d, d), generator=gen, device=device, dtype=torch.float32)
+      calls.append(dict(new_grad=gram_of_block(g, 0), p=p, rank=rank, ridge_epsilon=1e-6, decay=0.999,
+                        padding_start=d, prev=prevs[f], new_grad_is_gram=True))
+      del g
+    prevs = [r[0] for r in _fd_update_root_batched(calls)]
+  torch.cuda.synchronize(device)
+
+
 def _fd_group_key(kw):
   """Calls that can share the stacked fast path of _fd_update_root_group: no padding, no
   diagnostics, the block method applies, and identical scalars."""
