@@ -1495,13 +1495,22 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       }
       const int first_gen = gen;
       bool done[2] = {pl.cj_pair[0].empty(), pl.cj_pair[1].empty()};
+      // Gram arithmetic per group and sweep: bf16x3 while the last KNOWN largest scaled entry of
+      // the group (one sweep behind the GPU) is above cj_x3_above; float32 afterwards, and always
+      // for the sweep that may stop (cj_gram_x3_kernel's comment)
+      const float cj_x3_above = opt.eigh_gram_x3_above;
+      float known_off[2] = {1.f, 1.f};
       for (int s = 0; s < cj_max_sweeps; ++s) {
         for (int r = 0; r < pl.max_nb - 1; ++r)
           for (int g = 0; g < 2; ++g) {
             if (done[g]) continue;
             const int np_g = (int)pl.cj_pair[g].size(), nr_g = (int)pl.cj_row[g].size();
-            hipLaunchKernelGGL(cj_gram_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks, lo.cj_pair[g],
-                               np_g, r);
+            if (cj_x3_above > 0.f && known_off[g] > cj_x3_above)
+              hipLaunchKernelGGL(cj_gram_x3_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks,
+                                 lo.cj_pair[g], np_g, r);
+            else
+              hipLaunchKernelGGL(cj_gram_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks, lo.cj_pair[g],
+                                 np_g, r);
             hipLaunchKernelGGL(cj_pivot_kernel, dim3(np_g), dim3(SE_T), piv_lds, gs[g], lo.blocks,
                                lo.cj_pair[g], r, cj_tol, cj_inner, cj_done * cj_done, cj_sort,
                                cj_stationary, cj_one_below, cj_x6);
@@ -1534,6 +1543,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
             if (opt.eigh_trace)
               fprintf(stderr, "eigh cj sweep %d group %d: max scaled Gram entry %.3e, %d block(s) still sweeping\n",
                       gen - 2 - first_gen, g, prev->max_off, prev->active);
+            known_off[g] = prev->max_off;
             if (prev->active == 0) done[g] = true;
           }
           if (done[0] && done[1]) break;

@@ -308,6 +308,119 @@ __global__ __launch_bounds__(256, 2) void cj_gram_kernel(EighBlock* blocks, cons
   }
 }
 
+// ---- the same Gram matrix on the bf16 MFMA for the sweeps that are far from convergence: the panel
+// is split into bf16 hi / lo pairs (x = hi + lo) and P = hi^T hi + hi^T lo + lo^T hi accumulates in
+// float32 -- ~2^-17 relative to |g_i||g_j| per entry, i.e. scaled entries good to ~1e-5, which is
+// all a rotation needs while the largest scaled entry of the sweep is above 1e-3 (the pivot's Q is
+// orthogonal whatever P it was computed from, so G G^T = D is untouched; the STOP decision only
+// ever comes from a float32 sweep: the noise floor of this kernel is above the sweep tolerance, so
+// a block can never converge on it).  3 / 16 of the float32 MFMA time: the kernel is HBM-bound (it
+// streams the pair's panel once).  K-tile = 32 rows of the panel; every thread loads a 4 x 4
+// patch (4 rows x 16 bytes), converts and writes it TRANSPOSED -- [column][k], k-contiguous,
+// 4 x ds_write_b64 per plane -- so that an MFMA fragment (8 consecutive k of one column) is one
+// 16-byte LDS read; rows of 40 bf16 (80 bytes) keep those reads conflict-free.
+template <int W>
+__device__ __forceinline__ void cj_gram_x3_mfma(const uint16_t* sh, const uint16_t* sl, int lane,
+                                                f32x16 (&acc)[3]) {
+  using T = GramTiles<W>;
+  const int i = lane & 31, h8 = 8 * (lane >> 5);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    xbf16x8 fh[4], fl[4];   // fragments of column block b (unused blocks fold away)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      fh[b] = *reinterpret_cast<const xbf16x8*>(sh + (b * 32 + i) * XLD + ks * 16 + h8);
+      fl[b] = *reinterpret_cast<const xbf16x8*>(sl + (b * 32 + i) * XLD + ks * 16 + h8);
+    }
+#pragma unroll
+    for (int t = 0; t < T::N; ++t) {
+      f32x16 c = acc[t];
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[T::TI[t]], fh[T::TJ[t]], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[T::TI[t]], fl[T::TJ[t]], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[T::TI[t]], fh[T::TJ[t]], c, 0, 0, 0);
+      acc[t] = c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void cj_gram_x3_kernel(EighBlock* blocks, const ETile* tiles,
+                                                            int ntiles, int round) {
+  // two stages x two planes x [128 columns][40] bf16 = 40,960 bytes
+  __shared__ __align__(16) uint16_t simg[2][2][JP * XLD];
+  const ETile te = tiles[xcd_remap(blockIdx.x, ntiles)];
+  EighBlock* eb = &blocks[te.block];
+  if (!eb->cj_active || round >= eb->nb - 1) return;
+  int I, J;
+  rr_pair(eb->nb, round, te.k, I, J);
+  const int ld = eb->npad, tid = threadIdx.x;
+  const float* G = eb->X;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // thread -> a 4-row x 4-column patch of a K-tile: rows 4 * (tid >> 5) .., columns 4 * (tid & 31) ..
+  const int rg = tid >> 5, c4 = (tid & 31) * 4;
+  const int gc = c4 < JB ? I * JB + c4 : J * JB + (c4 - JB);
+  const float* gp = G + (int64_t)(4 * rg) * ld + gc;
+  const int nk = ld / 32;
+  f32x4 r[4];
+  auto load = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = gload4(gp + (int64_t)(kt * 32 + q) * ld);
+  };
+  auto store = [&](int stage) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // column c4 + e: its 4 consecutive k as one 8-byte write per plane
+      xbf16x4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = r[q][e];
+        const __bf16 hb = (__bf16)x;
+        hi[q] = hb;
+        lo[q] = (__bf16)(x - (float)hb);
+      }
+      *reinterpret_cast<xbf16x4*>(&simg[stage][0][(c4 + e) * XLD + 4 * rg]) = hi;
+      *reinterpret_cast<xbf16x4*>(&simg[stage][1][(c4 + e) * XLD + 4 * rg]) = lo;
+    }
+  };
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  load(0);
+  store(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) load(kt + 1);
+    switch (wave) {
+      case 0: cj_gram_x3_mfma<0>(simg[cur][0], simg[cur][1], lane, acc); break;
+      case 1: cj_gram_x3_mfma<1>(simg[cur][0], simg[cur][1], lane, acc); break;
+      case 2: cj_gram_x3_mfma<2>(simg[cur][0], simg[cur][1], lane, acc); break;
+      default: cj_gram_x3_mfma<3>(simg[cur][0], simg[cur][1], lane, acc); break;
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+  }
+  float* P = eb->V + (int64_t)te.k * JP * JP;
+  const int i = lane & 31, h = lane >> 5;
+  auto put = [&](auto tag) {
+    using T = decltype(tag);
+#pragma unroll
+    for (int t = 0; t < T::N; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = T::TI[t] * 32 + (q & 3) + 8 * (q >> 2) + 4 * h, col = T::TJ[t] * 32 + i;
+        gstore1(P + row * JP + col, acc[t][q]);
+      }
+  };
+  switch (wave) {
+    case 0: put(GramTiles<0>{}); break;
+    case 1: put(GramTiles<1>{}); break;
+    case 2: put(GramTiles<2>{}); break;
+    default: put(GramTiles<3>{}); break;
+  }
+}
+
 // ---- all inner sweeps of the one-sided Jacobi on a 128-column problem with ONE column of every
 // pair kept in registers.  A sweep is a recursive-halving tournament: for block sizes s = 128,
 // 64, ..., 2 the first half of every block of s columns stays put ("stationary": its G and V
