@@ -1497,7 +1497,13 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       bool done[2] = {pl.cj_pair[0].empty(), pl.cj_pair[1].empty()};
       // Gram arithmetic per group and sweep: bf16x3 while the last KNOWN largest scaled entry of
       // the group (one sweep behind the GPU) is above cj_x3_above; float32 afterwards, and always
-      // for the sweep that may stop (cj_gram_x3_kernel's comment)
+      // for the sweep that may stop (cj_gram_x3_kernel's comment).  The threshold is conservative
+      // (5e-2: the first 3-4 of ~10 sweeps, -1 % time): with 3e-3 / 1e-3 the step is 4-7 % faster
+      // (472 / 460 vs 495 ms for 64 x 2048^2) but the root ends 2 x further from float64 (7.6e-6
+      // vs 4.2e-6; 1000^2: 5.9e-6 vs 2.7e-6) -- the float32 sweeps that follow a noisy phase start
+      // from 1e-5-level entries, and with the clustered eigenvalues of these spectra ONE sweep
+      // takes them just under the 2e-6 stop tolerance instead of far below it as the gradual
+      // float32 descent does.
       const float cj_x3_above = opt.eigh_gram_x3_above;
       float known_off[2] = {1.f, 1.f};
       for (int s = 0; s < cj_max_sweeps; ++s) {
@@ -1505,14 +1511,17 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
           for (int g = 0; g < 2; ++g) {
             if (done[g]) continue;
             const int np_g = (int)pl.cj_pair[g].size(), nr_g = (int)pl.cj_row[g].size();
-            if (cj_x3_above > 0.f && known_off[g] > cj_x3_above)
+            const bool x3 = cj_x3_above > 0.f && known_off[g] > cj_x3_above;
+            if (x3)
               hipLaunchKernelGGL(cj_gram_x3_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks,
                                  lo.cj_pair[g], np_g, r);
             else
               hipLaunchKernelGGL(cj_gram_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks, lo.cj_pair[g],
                                  np_g, r);
+            // on a bf16 Gram matrix entries below its noise floor (~1e-5 scaled) are not rotated:
+            // a rotation by noise would undo what the pair has already converged to
             hipLaunchKernelGGL(cj_pivot_kernel, dim3(np_g), dim3(SE_T), piv_lds, gs[g], lo.blocks,
-                               lo.cj_pair[g], r, cj_tol, cj_inner, cj_done * cj_done, cj_sort,
+                               lo.cj_pair[g], r, x3 ? fmaxf(cj_tol, opt.eigh_gram_x3_skip) : cj_tol, cj_inner, cj_done * cj_done, cj_sort,
                                cj_stationary, cj_one_below, cj_x6);
             if (cj_x6)
               hipLaunchKernelGGL(cj_update_x6_kernel, dim3(nr_g), blk, x6_lds, gs[g], lo.blocks,
