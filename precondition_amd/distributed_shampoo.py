@@ -755,7 +755,10 @@ def distributed_shampoo(
         for i, (g, sk) in enumerate(zip(grads_flat, plan.skipped)):
           if not sk:
             out[i] = torch.empty_like(g)
-        plan.apply_preconditioners(grads_flat, precs_flat, out)
+        # (dequantized int16 preconditioners are column-scaled, not exactly symmetric: they keep
+        # the reference's operand orientation)
+        plan.apply_preconditioners(grads_flat, precs_flat, out,
+                                   symmetric_precs=not quantize_second_moment)
         return out
     stage_a, stage_b, keep = [], [], []
     precs = [st.preconditioners for st in states]

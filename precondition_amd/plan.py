@@ -16,6 +16,7 @@ optimizer keeps its general per-block path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -50,7 +51,7 @@ class TreePlan:
     pl = TreePlan()
     pl.n_params = len(shapes)
     pl.skipped = list(skipped)
-    st_rows, a_rows, b_rows = [], [], []
+    st_rows, a_rows, b_rows, sa_rows, sb_rows = [], [], [], [], []
     stat_base = 0
     x_off = 0
     for i, (shape, pc) in enumerate(zip(shapes, pcs)):
@@ -90,6 +91,10 @@ class TreePlan:
           # stage A: X [n, m] = g^T P_L (transa);  stage B: Y [m, n] = X^T P_R into the result
           a_rows.append((i, off, stat_base + k, n, m, m, row_ld, m, m, False, x_off * 4))
           b_rows.append((i, stat_base + k + 1, x_off * 4, off, m, n, n, m, n, row_ld))
+          # symmetric preconditioners (apply_preconditioners): X^T [m, n] = P_L g, Y = X^T P_R
+          # (param, goff, stat, m, n, k, lda, ldb, ldc, xoff) / (param, stat, xoff, coff, m, n, k, lda, ldb, ldc)
+          sa_rows.append((i, off, stat_base + k, m, n, m, m, row_ld, n, x_off * 4))
+          sb_rows.append((i, stat_base + k + 1, x_off * 4, off, m, n, n, n, n, row_ld))
           x_off += m * n
           k += 2
       pl.n_stats_of.append(k)
@@ -141,6 +146,30 @@ class TreePlan:
       t["ldb"] = [r[8] for r in b_rows]
       t["ldc"] = [r[9] for r in b_rows]
       t["transa"], t["transb"] = 1, 0
+    # ---- the same application for bitwise symmetric preconditioners: P_L g instead of g^T P_L.
+    # Element (i, j) of P_L g sums P[i][k] g[k][j] over k, element (j, i) of g^T P_L sums
+    # g[k][j] P[k][i]: the same products in the same order when P[i][k] == P[k][i] bit for bit, so
+    # X^T comes out bit-identical -- but the left operand is now k-contiguous (16-byte LDS
+    # fragment reads instead of four 4-byte ones) and the stage-B product reads X^T the same way:
+    # 0.72-0.77 -> 0.80-0.83 of the fp32 MFMA peak on uniform batches of ViT-B's block shapes
+    # (tools/dev_r4_apply_layouts.py).  One-row products stay in the streaming mat-vec form.
+    pl.sa_tbl = gemm_tbl(sa_rows)
+    pl.sb_tbl = gemm_tbl(sb_rows)
+    if sa_rows:
+      pl.sa_param = np.array([r[0] for r in sa_rows], np.int64)
+      pl.sa_goff = np.array([r[1] for r in sa_rows], np.uint64)
+      pl.sa_stat = np.array([r[2] for r in sa_rows], np.int64)
+      pl.sa_xoff = np.array([r[9] for r in sa_rows], np.uint64)
+      t = pl.sa_tbl
+      for col, idx in (("m", 3), ("n", 4), ("k", 5), ("lda", 6), ("ldb", 7), ("ldc", 8)):
+        t[col] = [r[idx] for r in sa_rows]
+      t["transa"], t["transb"] = 0, 0
+      t = pl.sb_tbl
+      for col, idx in (("m", 4), ("n", 5), ("k", 6), ("lda", 7), ("ldb", 8), ("ldc", 9)):
+        t[col] = [r[idx] for r in sb_rows]
+      t["transa"], t["transb"] = 0, 0
+      # one-row products of the 1-D blocks: the rows of a_tbl whose result goes straight to the output
+      pl.a_vec_rows = np.nonzero(pl.a_c_is_res)[0] if a_rows else np.zeros(0, np.int64)
     return pl
 
   # ---------------------------------------------------------------------------
@@ -179,10 +208,12 @@ class TreePlan:
                                          ws.data_ptr(), ws.numel())
     check(rc, "ps_stats_update_grouped_f32")
 
-  def apply_preconditioners(self, grads_flat, precs_flat, results):
+  def apply_preconditioners(self, grads_flat, precs_flat, results, symmetric_precs=False):
     """Preconditioner.preconditioned_grad (DS:1645-1708) for every planned parameter:
     two grouped launches.  precs_flat: preconditioners in plan order; results[i]: contiguous
-    output of parameter i (None for skipped parameters)."""
+    output of parameter i (None for skipped parameters).  symmetric_precs: the preconditioners
+    are bitwise symmetric (roots of the symmetric Newton / eigh paths, identities): the products
+    are issued as X^T = P_L g, Y = X^T P_R (bit-identical, faster operand layout; see build)."""
     if len(self.a_tbl) == 0:
       return
     dev = self.check_dense(grads_flat, "preconditioned_grad")
@@ -198,13 +229,25 @@ class TreePlan:
     ta["a"] = gp[self.a_param] + self.a_goff
     ta["b"] = pp[self.a_stat]
     ta["c"] = np.where(self.a_c_is_res, rp[self.a_param], xp) + self.a_coff
+    sym = (symmetric_precs and len(getattr(self, "sa_tbl", ())) > 0 and
+           os.environ.get("PS_APPLY_SYM", "1") != "0")
+    if sym:
+      vec = ta[self.a_vec_rows]
+      sa = self.sa_tbl.copy()
+      sa["a"] = pp[self.sa_stat]
+      sa["b"] = gp[self.sa_param] + self.sa_goff
+      sa["c"] = xp + self.sa_xoff
+      ta = np.concatenate([sa, vec]) if len(vec) else sa
     L = lib()
     with torch.cuda.device(dev):
       for tbl in (ta, None):
         if tbl is None:
           if len(self.b_tbl) == 0:
             break
-          tbl = self.b_tbl.copy()
+          if sym:
+            tbl = self.sb_tbl.copy()
+          else:
+            tbl = self.b_tbl.copy()
           tbl["a"] = xp + self.b_xoff
           tbl["b"] = pp[self.b_stat]
           tbl["c"] = rp[self.b_param] + self.b_coff
