@@ -208,7 +208,13 @@ def sharded_inverse_pth_roots(
     seen[r] += elems[i]
 
   # Offsets of every statistic inside its owner's flat buffer of its phase; all
-  # ranks derive the same tables from shapes alone (no communication).
+  # ranks derive the same tables from shapes alone (no communication).  Every result starts on
+  # a 4 KB boundary: the per-statistic preconditioners are VIEWS into the gathered buffer and are
+  # read by every step's application products, whose 16-byte loads need aligned bases -- packed
+  # back to back, one 197 x 197 statistic (155,236 bytes) left every later preconditioner of the
+  # ViT-B tree 4 bytes off and the whole application on its guarded scalar-load path: 3.4 instead
+  # of 2.5 ms per step (tools/dev_r4_apply_real.py).
+  ALIGN = 1024   # float32 words
   offsets = [0] * n_stats
   slot = [0] * n_stats
   fill = [[0] * world for _ in range(n_phases)]
@@ -216,7 +222,7 @@ def sharded_inverse_pth_roots(
   for i in range(n_stats):
     r, ph = owner[i], phase_of[i]
     offsets[i] = fill[ph][r]
-    fill[ph][r] += elems[i]
+    fill[ph][r] += -(-elems[i] // ALIGN) * ALIGN
     slot[i] = count[ph][r]
     count[ph][r] += 1
 
