@@ -1497,8 +1497,10 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       bool done[2] = {pl.cj_pair[0].empty(), pl.cj_pair[1].empty()};
       // Gram arithmetic per group and sweep: bf16x3 while the last KNOWN largest scaled entry of
       // the group (one sweep behind the GPU) is above cj_x3_above; float32 afterwards, and always
-      // for the sweep that may stop (cj_gram_x3_kernel's comment).  The threshold is conservative
-      // (5e-2: the first 3-4 of ~10 sweeps, -1 % time): with 3e-3 / 1e-3 the step is 4-7 % faster
+      // for the sweep that may stop (cj_gram_x3_kernel's comment).  OFF by default (threshold 0): a
+      // conservative 5e-2 (the first 3-4 of ~10 sweeps) buys 1 % and still costs accuracy on small
+      // blocks whose few sweeps outrun the one-sweep lag of `known_off` (200^2 Wishart: 3.7e-6 vs
+      // 1.5e-6 from float64); with 3e-3 / 1e-3 the step is 4-7 % faster
       // (472 / 460 vs 495 ms for 64 x 2048^2) but the root ends 2 x further from float64 (7.6e-6
       // vs 4.2e-6; 1000^2: 5.9e-6 vs 2.7e-6) -- the float32 sweeps that follow a noisy phase start
       // from 1e-5-level entries, and with the clustered eigenvalues of these spectra ONE sweep

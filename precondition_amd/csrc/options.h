@@ -48,7 +48,7 @@ struct Options {
   float eigh_cj_one_below = 0.1f;  // PS_EIGH_CJ_ONE_BELOW
   int eigh_cj_sort = 1;            // PS_EIGH_CJ_SORT
   int eigh_cj_ubk = 8;             // PS_EIGH_CJ_UBK
-  float eigh_gram_x3_above = 5e-2f;  // PS_EIGH_GRAM_X3: bf16x3 Gram while the known scaled entry is above (0 = never)
+  float eigh_gram_x3_above = 0.f;    // PS_EIGH_GRAM_X3: bf16x3 Gram while the known scaled entry is above (0 = never: the default)
   float eigh_gram_x3_skip = 3e-5f;   // PS_EIGH_GRAM_X3_SKIP: pairs below this scaled entry are not rotated in bf16 sweeps
   int eigh_update_bf16x6 = 1;      // PS_EIGH_UPDATE_X6: update products on the bf16 MFMA (3-way split)
   int eigh_f64_reproject = 1;      // PS_EIGH_F64_REPROJECT
