@@ -1,5 +1,6 @@
 """Dev: error of the p=4 roots of the ViT-B sample blocks against the float64 closed form,
 and the cfg2 / headline step time, as a function of PS_NEWTON_AVG_STEPS."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench

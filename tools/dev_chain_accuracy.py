@@ -10,6 +10,7 @@ OpenBLAS (the oracle's arithmetic) blocks K (a few hundred) and sums the blocks.
   f64         every product accumulated in float64, rounded once
   <a>:<b>     arithmetic <a> for the M-side products (Mi^2, Mi^4, Mi^4 M), <b> for H Mi
 Usage: python tools/dev_chain_accuracy.py [n] [variants...]"""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import sys
 import numpy as np
 import torch

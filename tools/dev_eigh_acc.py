@@ -1,5 +1,6 @@
 """Dev: accuracy of the eigh root on the cases of test_eigh_root_accuracy_on_graded_spectra_near_lapack
 (and larger ones) for combinations of the Cholesky-Jacobi switches."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

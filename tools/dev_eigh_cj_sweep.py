@@ -1,4 +1,5 @@
 """Dev: cfg3 step time of the Cholesky-Jacobi eigh path over its tuning switches."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench

@@ -1,5 +1,6 @@
 """Dev: which reference cycles does one update() leave behind (they delay freeing device memory
 until the cyclic collector runs)."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, gc, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

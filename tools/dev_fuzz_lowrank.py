@@ -1,5 +1,6 @@
 """Dev: seeded fuzz of the low-rank root (DS:1033-1120) and the Frequent-Directions update
 (DS:1123-1290) against the oracle: random sizes, ranks (top and bottom), spectra, padding."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,4 +1,5 @@
 """Dev: random sizes / exponents / paddings / spectra, HIP batched root vs the oracle."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

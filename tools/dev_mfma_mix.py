@@ -1,4 +1,5 @@
 """Dev: what VALU work between fp32 MFMAs costs the MFMA pipe (ps_diag_mfma_mix)."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,5 @@
 """Dev: HBM roofline of the quantize / dequantize kernels on the ViT-B state (cfg4)."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

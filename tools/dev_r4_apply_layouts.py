@@ -1,6 +1,7 @@
 """dev (GPU): the two products of the preconditioner application on ViT-B-like blocks in the four
 operand layouts of gemm_grouped (transa, transb), as uniform batches: is the MC x MC form
 (g^T P as the optimizer issues it) the slow one?"""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch

@@ -1,6 +1,7 @@
 """dev (GPU, under rocprofv3 --kernel-trace): update() steps on the ViT-B tree, then the SAME application
 launches (real gradients, real preconditioners) repeated back to back: does the application kernel take
 longer inside a step than alone?"""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """dev (GPU): cfg5 FD update time, 8 factors and 1 factor per GPU, with the per-step Python loop
 (PS_FD_ROUND_CALL=0) and with the whole filter in one library call (default)."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch

@@ -1,5 +1,6 @@
 """dev (GPU): what the first FD update of a process pays for: kernel loading (small dummy update first)
 vs allocation of the big buffers (full-size dummy first)."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch

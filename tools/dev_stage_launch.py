@@ -1,4 +1,5 @@
 """Dev: one cfg2 / headline root call for per-launch kernel timing under rocprofv3."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench

@@ -1,6 +1,7 @@
 """Dev: per-workgroup timeline of the Newton product kernel (PS_NEWTON_TRACE): phase lengths of
 every tile (prologue = start -> first LDS fill, K loop, epilogue) and how the two workgroups of a
 CU overlap."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench

@@ -1,5 +1,6 @@
 """Dev: A/B of the Newton stage-kernel variants (PS_NEWTON_BK / PS_NEWTON_DEEP are read once per
 process, so each variant runs in a child process)."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, subprocess, sys
 CHILD = r'''
 import sys; sys.path.insert(0, ".")

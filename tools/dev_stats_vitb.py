@@ -1,5 +1,6 @@
 """Dev: time the grouped statistics launch on the ViT-B tree (bench.py's VitBWorkload).
 Under rocprofv3 --kernel-trace the dispatches are told apart by their grid sizes."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -3,6 +3,7 @@ affects the accuracy of the coupled Newton iteration at cond ~ 7e3, p = 4.
 variants: full (reference), mirror (upper triangle copied to lower, what the symmetric
 HIP mode did in round 1), mirror_squares_only, avg (mixed products fully computed then
 (X + X^T)/2, squares mirrored), avg_all."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import numpy as np
 F32 = np.float32
 rng = np.random.default_rng(0)

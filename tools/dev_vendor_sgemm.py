@@ -1,6 +1,7 @@
 """Dev yardstick: the vendor float32 GEMM (torch.bmm / torch.mm -> rocBLAS / hipBLASLt, float32
 'highest' precision = the fp32 MFMA path) on the product shapes of the bench workloads, next to
 this library's exact-f32 core (ps_gemm via K.gemm) on the same shapes."""
+import os; os.environ.setdefault("PS_DEV_ENV", "1")   # developer switches (PS_*) are read only under PS_DEV_ENV=1
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

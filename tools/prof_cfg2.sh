@@ -3,7 +3,7 @@
 # Separate rocprofv3 passes (kernel trace + one PMC group each) of the cfg2 bench.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && export PS_DEV_ENV=1
 B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-headline --no-extras --steps 3 --warmup 2 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/bench_trace.json 2> $OUT/trace.err
 for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do

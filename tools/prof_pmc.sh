@@ -4,7 +4,7 @@
 # other trace domains) of an arbitrary dev script; summarize with tools/summarize_pmc2.py.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 rm -rf $OUT; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && export PS_DEV_ENV=1
 B="python3 $GRAFT_REPO_ROOT/$@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/run.log 2> $OUT/trace.err
 for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do

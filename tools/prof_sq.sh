@@ -4,7 +4,7 @@
 # combined with other trace domains): where a wavefront's cycles go.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 rm -rf $OUT; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && export PS_DEV_ENV=1
 B="python3 $GRAFT_REPO_ROOT/$@"
 rocprofv3 --list-avail > $OUT/avail.txt 2>&1
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \

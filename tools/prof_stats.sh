@@ -2,7 +2,7 @@
 # Dev: rocprofv3 kernel stats of the ViT-B statistics launch (run on the GPU box).
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_stats
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && export PS_DEV_ENV=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/dev_stats_vitb.py > $OUT/run.log 2> $OUT/run.err
 cd $GRAFT_REPO_ROOT
 python - <<PY

@@ -2,7 +2,7 @@
 # Dev: rocprofv3 kernel stats of update() steps on the ViT-B tree (run on the GPU box).
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_update
 rm -rf $OUT; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && export PS_DEV_ENV=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/dev_update_step.py > $OUT/run.log 2> $OUT/run.err
 cd $GRAFT_REPO_ROOT
 grep -E "update ms|unsynchronised" $OUT/run.log
