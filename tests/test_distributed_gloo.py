@@ -551,3 +551,25 @@ def test_cost_model_uses_iteration_counts():
   assert load == [40, 40], (owner, load)
   flat = comm.ownership_table(sizes, exps, 2, "lpt")
   assert sorted(flat.count(r) for r in (0, 1)) == [4, 4]
+
+
+def test_gathered_results_start_on_aligned_boundaries():
+  """The per-statistic results are views into the gathered buffer and feed 16-byte vector loads of
+  every later step (preconditioner application): each must start on a 4 KB boundary whatever the
+  sizes before it (a 197 x 197 statistic once left the rest of a ViT-B tree 4 bytes off and its
+  application on the scalar-load path)."""
+  import torch
+  from precondition_amd import comm
+  sizes = [197, 768, 5, 1000, 33, 1024]
+  stats = [torch.full((n, n), float(i)) for i, n in enumerate(sizes)]
+
+  def root_fn(mats, ps, pads, out=None, **kw):
+    for m, o in zip(mats, out):
+      o.copy_(m + 0.5)
+    return out, torch.zeros((len(mats), 8))
+
+  roots, _ = comm.sharded_inverse_pth_roots(stats, [4] * len(sizes), group=None, root_fn=root_fn)
+  for i, (r, n) in enumerate(zip(roots, sizes)):
+    assert tuple(r.shape) == (n, n) and float(r[0, 0]) == i + 0.5
+    assert r.storage_offset() % 1024 == 0 and r.data_ptr() % 16 == 0, (i, r.storage_offset())
+    assert r.is_contiguous()
