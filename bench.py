@@ -508,15 +508,19 @@ def profile_stage_kernel(work):
   everything else the call enqueues."""
   from precondition_amd import _lib
   L = _lib.lib()
-  # two untimed calls first: the pass may follow seconds of host-only work (the oracle of the parity
-  # sample), after which the GPU is in a low power state and the first launches run at ramping clocks
-  for _ in range(2):
+  # untimed calls first: the pass may follow seconds of host-only work (the oracle of the parity
+  # sample), after which the GPU is in a low power state and the first launches run at ramping
+  # clocks (one run read 0.485 ms per launch where the timed loop and rocprofv3 say 0.44)
+  t_end = time.perf_counter() + 0.3
+  while time.perf_counter() < t_end:
     work.compute()
-  _sync()
+    _sync()
+  reps = 3
   L.ps_profile_reset()
   L.ps_profile_enable(1)
   try:
-    work.compute()  # rank-local: no collective, so only rank 0 needs to run it
+    for _ in range(reps):   # rank-local: no collective, so only rank 0 needs to run it
+      work.compute()
     _sync()
   finally:
     L.ps_profile_enable(0)
@@ -524,7 +528,7 @@ def profile_stage_kernel(work):
   launches = C.c_int64()
   L.ps_profile_get(C.addressof(stage_ms), C.addressof(launches), C.addressof(pi_ms),
                    C.addressof(other_ms))
-  return stage_ms.value, launches.value, pi_ms.value, other_ms.value
+  return stage_ms.value / reps, launches.value // reps, pi_ms.value / reps, other_ms.value / reps
 
 
 def executed_fraction(n, p=4, iters=8.0, avg_steps=None):
