@@ -425,15 +425,21 @@ int ps_gemm_grouped_plan_destroy(ps_gemm_plan* plan);
  * transpose = 2 writes the tile-blocked layout of a left operand (a_tiled): tile (i, j) of 128
  * rows x 32 columns is contiguous at ((i * (cols / 32) + j) * 4096) elements, so that a product
  * streams whole DRAM pages of it (cols % 32 == 0; the destination holds ceil(rows/128)*128*cols
- * elements, ldd is ignored). */
+ * elements, ldd is ignored); transpose = 3 writes the FRAGMENT-MAJOR layout of ps_fd_cy_step_f32
+ * (rows % 64 == 0, cols % 64 == 0, rows * cols elements, ldd ignored): element (r, k) at
+ * (((r / 64) * (cols / 16) + k / 16) * 2 + (r % 64) / 32) * 512 + (32 * ((k % 16) / 8) + r % 32) * 8
+ * + k % 8, i.e. the 64 lanes x 16 bytes one v_mfma_f32_32x32x16_bf16 consumes are one contiguous
+ * kilobyte and a 64-row panel is one sequential stream over k. */
 typedef struct {
   const void* a_hi; const void* a_lo;   /* bf16 [m][k], leading dimension lda (elements) */
   const void* b_hi; const void* b_lo;   /* bf16 [n][k], leading dimension ldb */
   float* c;                             /* float32 [m][n], leading dimension ldc */
   int32_t m, n, k;
   int64_t lda, ldb, ldc;
-  int32_t a_tiled;   /* != 0: the A planes are tile-blocked (ps_convert_f32_to_bf16, transpose = 2):
-                        [ceil(m/128)][k/32][128][32], rows past m zero; lda is ignored */
+  int32_t a_tiled;   /* 1: the A planes are tile-blocked (ps_convert_f32_to_bf16, transpose = 2):
+                        [ceil(m/128)][k/32][128][32], rows past m zero; lda is ignored.
+                        2: fragment-major planes (transpose = 3) -- accepted by
+                        ps_fd_filter_round_f32 only (ps_gemm_bf16_grouped: PS_EUNSUPPORTED) */
   int32_t reserved;  /* 0 */
 } ps_gemm_bf16_desc;
 
@@ -550,8 +556,11 @@ const char* ps_comm_last_error(void);
  *     sigma_m = 1 / (2 / sigma1 - sigma_{m-1}); a factor with degree < step keeps y.  When
  *     yt_hi is given the new iterate is also written transposed as bf16 (hi, and lo = the bf16
  *     of the remainder when yt_lo is given) at yt[c][j * n + r], leading dimension ldt: the
- *     operand layout of ps_gemm_bf16_grouped for the next C @ Y product.  y_next must not alias
- *     z, y or y_prev.
+ *     operand layout of ps_gemm_bf16_grouped for the next C @ Y product; ldt = 0 selects the
+ *     fragment-major planes of ps_fd_cy_step_f32 instead (n % 64 == 0, b % 32 == 0; factor j at
+ *     j * n * b elements: element (k = row r of the iterate, column c) at
+ *     ((r / 16) * (b / 32) + c / 32) * 512 + (32 * ((r % 16) / 8) + c % 32) * 8 + r % 8).
+ *     y_next must not alias z, y or y_prev.
  *   ps_chol_rinv_batched_f32: out[j] = R^-1 for the Cholesky factor G_j = R^T R of `batch`
  *     symmetric b x b matrices stacked contiguously (float64 arithmetic, b <= ps_chol_rinv_max_n());
  *     a pivot <= drop_rel * max diag(G_j) drops its direction (zero row and column of out[j]). */
@@ -566,6 +575,19 @@ int ps_fd_filter_step_f32(void* stream, const float* z, const float* y, const fl
  * current), y1 and y2 are scratch of the same shape; *result_index (host) receives 0, 1 or 2: the
  * buffer that holds the filtered block.  The product's task tables are built and uploaded once per
  * call.  workspace: ps_gemm_bf16_grouped_workspace_bytes(desc, batch). */
+/* ps_fd_cy_step_f32: step >= 2 of the same recurrence with its product in ONE launch:
+ * z = C_j y (bf16 hi/lo planes, three products, float32 accumulation), y_next = (z - ctr y) 2 sigma_k / e
+ * - sigma_{k-1} sigma_k y_prev, and (nt_hi, nt_lo given) y_next as the fragment-major bf16 planes the
+ * next step reads.  c_hi / c_lo: HOST arrays of `batch` <= 16 device pointers to the fragment-major
+ * covariances (ps_convert_f32_to_bf16, transpose = 3); yt_hi / yt_lo: the planes of y (written by
+ * ps_fd_filter_step_f32 with ldt = 0 or by the previous call; nt_* must be other buffers).
+ * n % 128 == 0, b in {32, 64, 96}; PS_EUNSUPPORTED otherwise.  A factor with degree < step: y_next = y.
+ * ps_fd_filter_round_f32 uses it when every desc[j].a_tiled == 2: yt_hi / yt_lo must then hold TWO
+ * copies of the planes (2 * batch * n * b elements each); desc[j].b_*, c and ldt are ignored. */
+int ps_fd_cy_step_f32(void* stream, const void* const* c_hi, const void* const* c_lo, int batch,
+                      const void* yt_hi, const void* yt_lo, const float* y, const float* y_prev,
+                      float* y_next, void* nt_hi, void* nt_lo, const float* params, int step,
+                      int64_t n, int64_t b);
 int ps_fd_filter_round_f32(void* stream, const ps_gemm_bf16_desc* desc, int batch, float* z,
                            float* y0, float* y1, float* y2, void* yt_hi, void* yt_lo,
                            const float* params, int max_degree, int64_t n, int64_t b, int64_t ldt,

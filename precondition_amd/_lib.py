@@ -262,6 +262,10 @@ _SIGNATURES = {
     "ps_fd_filter_step_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "ps_fd_cy_step_f32":
+        (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_int, C.c_int64, C.c_int64]),
     "ps_fd_filter_round_f32":
         (C.c_int, [C.c_void_p, C.POINTER(GemmBf16Desc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64,

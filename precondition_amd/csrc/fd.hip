@@ -62,6 +62,26 @@ __global__ __launch_bounds__(256) void fd_filter_step_kernel(
   }
   if (hi == nullptr) return;
   __syncthreads();
+  if (ldt == 0) {
+    // fragment-major planes of the fused step (gemm_bf16.hip fd_cy_step_kernel; n % 64 == 0,
+    // b % 32 == 0): per factor [n / 16][b / 32][lane = 32 (k / 8 % 2) + col % 32][8 k]
+    const int cbs = b >> 5;
+    for (int it = tid; it < 4 * 2 * 64; it += 256) {
+      const int ln = it & 63, cbl = (it >> 6) & 1, kk = it >> 7;
+      const int c = c0 + cbl * 32 + (ln & 31);
+      if (c >= b) continue;
+      const int rb = kk * 16 + (ln >> 5) * 8;
+      const int64_t o = base + ((int64_t)((r0 >> 4) + kk) * cbs + (c >> 5)) * 512 + ln * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = t[rb + i][c - c0];
+        const __bf16 h = (__bf16)x;
+        hi[o + i] = __builtin_bit_cast(uint16_t, h);
+        if (lo != nullptr) lo[o + i] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+      }
+    }
+    return;
+  }
   for (int el = tid; el < 64 * 64; el += 256) {
     const int c = el >> 6, r = el & 63;    // output row = column c of the iterate
     if (r0 + r >= n || c0 + c >= b) continue;
@@ -205,8 +225,9 @@ extern "C" int ps_fd_filter_step_f32(void* stream, const float* z, const float* 
                                      int64_t n, int64_t b, int64_t ldt) {
   PS_DEVICE_CHECK();
   if (!z || !y || !y_next || !params || batch < 1 || n < 1 || b < 1 || step < 1 ||
-      (step > 1 && !y_prev) || (yt_hi && ldt < (int64_t)batch * n) || (!yt_hi && yt_lo))
+      (step > 1 && !y_prev) || (yt_hi && ldt != 0 && ldt < (int64_t)batch * n) || (!yt_hi && yt_lo))
     return PS_EINVAL;
+  if (yt_hi && ldt == 0 && (n % 64 != 0 || b % 32 != 0)) return PS_EUNSUPPORTED;
   const int64_t tr = (n + 63) / 64, tc = (b + 63) / 64;
   if (tr * tc * batch > 0x7fffffff) return PS_EUNSUPPORTED;
   hipLaunchKernelGGL(fd_filter_step_kernel, dim3((unsigned)(tr * tc * batch)), dim3(256), 0,

@@ -58,6 +58,9 @@ struct HTask {
 struct HTile { int task; short tm, tn; int ks; };
 
 __device__ inline u32x4 gload16(const uint16_t* p) { return *(const u32x4 PS_GLOBAL*)(p); }
+__device__ inline u32x4 gload16_nt(const uint16_t* p) {
+  return __builtin_nontemporal_load((const u32x4 PS_GLOBAL*)(p));
+}
 
 // 128 rows x HBK k of one operand array -> registers (HV x 16 bytes per thread)
 constexpr int HV = TILE * HBK / 8 / 256;   // 16-byte chunks per thread
@@ -227,6 +230,19 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* src, uint16_
     t[r][c] = (r0 + r < rows && c0 + c < cols) ? gload1(src + (int64_t)(r0 + r) * lds + c0 + c) : 0.f;
   }
   __syncthreads();
+  if (transpose == 3) {
+    // fragment-major left operand of fd_cy_step_kernel: the 64 x 64 tile is ONE contiguous run of
+    // 4096 elements, [k block of 16][row half of 32][lane = 32 (k / 8 % 2) + row % 32][8 k]
+    const int64_t base = ((int64_t)tr * (cols / 16) + c0 / 16) * 1024;
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int kk = e >> 10, sub = (e >> 9) & 1, ln = (e >> 3) & 63, ki = e & 7;
+      const float x = t[sub * 32 + (ln & 31)][kk * 16 + (ln >> 5) * 8 + ki];
+      const __bf16 h = (__bf16)x;
+      hi[base + e] = __builtin_bit_cast(uint16_t, h);
+      if (lo != nullptr) lo[base + e] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+    }
+    return;
+  }
   for (int e = tid; e < 64 * 64; e += 256) {
     const int a = e >> 6, b = e & 63;          // output tile coordinates (row a, col b)
     const int r = transpose == 1 ? b : a, c = transpose == 1 ? a : b;
@@ -246,7 +262,181 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* src, uint16_
   }
 }
 
+
+// ---- one whole step of the Chebyshev filter of the FD branch in ONE launch ---------------------
+//   z = C y (bf16 hi/lo operands, three products, float32 accumulation)
+//   y' = (z - ctr y) 2 sigma' / e - sigma sigma' y_prev          (ps_fd_filter_step_f32, step >= 2)
+//   y' also as the bf16 hi/lo operand of the next step
+// The product is a stream over C (4 bytes per element, read once) against a block of b <= 96
+// columns: nothing of C is reused, so it does not go through LDS.  Both operands are stored
+// FRAGMENT-MAJOR -- the 64 x 16 bytes a wavefront feeds to one v_mfma_f32_32x32x16_bf16 are one
+// contiguous kilobyte (lane l: row or column l % 32, k = 8 (l / 32) .. + 7):
+//   C   [n / 64][n / 16][2][64][8]   (ps_convert_f32_to_bf16, transpose = 3)
+//   Y^T [n / 16][b / 32][64][8]      per factor (written by the previous step)
+// One workgroup = 64 rows of one factor; its four wavefronts take the 16-wide k blocks round robin
+// (kk = w, w + 4, ...: together they walk C's rows as one sequential stream of 8 KB per round),
+// keep 2 x (b / 32) accumulator tiles each, and add them through LDS in a fixed order at the end.  No barrier and no LDS traffic inside the K loop; two register sets of loads in flight.
+// The iterate planes are read from L2 (all 64 workgroups of a factor run on one XCD, xcd_remap).
+struct FdCyArgs {
+  const uint16_t* a_hi[16]; const uint16_t* a_lo[16];
+  const uint16_t* bt_hi; const uint16_t* bt_lo;
+  const float* y; const float* y_prev; float* y_next;
+  uint16_t* nt_hi; uint16_t* nt_lo;
+  const float* params;
+  int step, n, nwg;
+};
+
+template <int CB>
+__global__ __launch_bounds__(256, 2) void fd_cy_step_kernel(const FdCyArgs a) {
+  constexpr int B = CB * 32, ZLD = B + 1, NQ = 64 * B / 4 / 256;
+  __shared__ float zt[2][64 * ZLD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = a.n >> 6;
+  const int t = xcd_remap(blockIdx.x, a.nwg);
+  const int j = t / per, rb = t % per, r0 = rb * 64;
+  const float ctr = a.params[4 * j + 0], e = a.params[4 * j + 1], sigma1 = a.params[4 * j + 2];
+  const int deg = (int)a.params[4 * j + 3];
+  const int64_t fb = (int64_t)j * a.n * B;            // factor base (elements) in y* and the planes
+  const int64_t blk = fb + (int64_t)r0 * B;           // this workgroup's 64 x B block: contiguous
+  if (a.step > deg) {                                 // the factor's filter is finished: y' = y
+    for (int q = tid; q < 64 * B / 4; q += 256)
+      *(f32x4 PS_GLOBAL*)(a.y_next + blk + 4 * q) = gload4(a.y + blk + 4 * q);
+    return;
+  }
+  float sigma = sigma1;
+  for (int m = 2; m < a.step; ++m) sigma = 1.f / (2.f / sigma1 - sigma);
+  const float sn = 1.f / (2.f / sigma1 - sigma);
+  const float c1 = 2.f * sn / e, c2 = sigma * sn;
+
+  const int nkk = a.n >> 4, cnt = nkk >> 2;           // k blocks of 16; per wavefront (n % 128 == 0)
+  const uint16_t* pah = a.a_hi[j] + ((int64_t)rb * nkk * 128 + lane) * 8;
+  const uint16_t* pal = a.a_lo[j] + ((int64_t)rb * nkk * 128 + lane) * 8;
+  const uint16_t* pbh = a.bt_hi + fb + lane * 8;
+  const uint16_t* pbl = a.bt_lo + fb + lane * 8;
+  // this block of y and y_prev (the recurrence's other inputs): requested now, used after the K loop
+  f32x4 yy[NQ], yp[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    yy[q] = gload4(a.y + blk + 4 * (tid + 256 * q));
+    yp[q] = gload4(a.y_prev + blk + 4 * (tid + 256 * q));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 ra[2][4], rb_[2][2 * CB];
+  auto load_set = [&](int s, int i) {
+    const int kk = w + 4 * i;
+    const uint16_t* qh = pah + (int64_t)kk * 1024;
+    const uint16_t* ql = pal + (int64_t)kk * 1024;
+    // C is read once: non-temporal, so that it does not push the iterate planes (re-read by every
+    // workgroup of the factor) out of the XCD's L2 (137 -> 126 us per step at 8 x 4096^2)
+    ra[s][0] = gload16_nt(qh); ra[s][1] = gload16_nt(qh + 512);
+    ra[s][2] = gload16_nt(ql); ra[s][3] = gload16_nt(ql + 512);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      rb_[s][cb] = gload16(pbh + (int64_t)(kk * CB + cb) * 512);
+      rb_[s][CB + cb] = gload16(pbl + (int64_t)(kk * CB + cb) * 512);
+    }
+  };
+  f32x16 acc[2][CB];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[sub][cb][r] = 0.f;
+  auto compute = [&](int s) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, ra[s][sub]);
+      const bf16x8 al = __builtin_bit_cast(bf16x8, ra[s][2 + sub]);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, rb_[s][cb]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, rb_[s][CB + cb]);
+        // small terms first: lo*hi + hi*lo, then hi*hi (lo*lo ~ 2^-18 relative is dropped)
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sub][cb], 0, 0, 0);
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sub][cb], 0, 0, 0);
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sub][cb], 0, 0, 0);
+      }
+    }
+  };
+  load_set(0, 0);
+  __builtin_amdgcn_sched_barrier(0);   // set 0 must be requested first: the loop's waits count loads in order
+  load_set(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  // sched_barrier: without it the scheduler sinks every load to just before its use (fewer live
+  // registers, but a vmcnt(0) wait after each handful of loads: nothing stays in flight)
+  for (int i = 0; i < cnt - 2; i += 2) {              // cnt is even and >= 2
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_set(0, i + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_set(1, i + 3);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  compute(0);
+  compute(1);
+  // z tile = (w0 + w2) + (w1 + w3) of the four wavefronts' accumulators (fixed order): wavefronts
+  // 0 / 1 store into the two LDS tiles, 2 / 3 add theirs
+  for (int p = 0; p < 2; ++p) {
+    if ((w >> 1) == p) {
+      float* zw = zt[w & 1];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float* q = zw + row * ZLD + cb * 32 + (lane & 31);
+            *q = p == 0 ? acc[sub][cb][r] : *q + acc[sub][cb][r];
+          }
+    }
+    __syncthreads();
+  }
+  // recurrence on the 64 x B block (contiguous in y, y_prev, y_next)
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int q = tid + 256 * qi;
+    const int r = (q * 4) / B, c = (q * 4) % B;
+    float* zr = zt[0] + r * ZLD + c;
+    const float* zs = zt[1] + r * ZLD + c;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {      // the arithmetic of fd_filter_step_kernel, element for element
+      float x = ((zr[i] + zs[i]) - ctr * yy[qi][i]) * c1;
+      x -= c2 * yp[qi][i];
+      v[i] = x;
+      zr[i] = x;
+    }
+    *(f32x4 PS_GLOBAL*)(a.y_next + blk + 4 * q) = v;
+  }
+  if (a.nt_hi == nullptr) return;
+  __syncthreads();
+  // the new iterate as the next step's fragment-major bf16 operand: this block's 64 rows are k
+  // blocks r0 / 16 .. + 3 of the factor's planes = one contiguous run of 4 * CB kilobytes per plane
+  for (int it = tid; it < 4 * CB * 64; it += 256) {
+    const int ln = it & 63, cb = (it >> 6) % CB, kk = (it >> 6) / CB;
+    const float* col = zt[0] + (kk * 16 + (ln >> 5) * 8) * ZLD + cb * 32 + (ln & 31);
+    u32x4 h4, l4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x0 = col[(2 * i) * ZLD], x1 = col[(2 * i + 1) * ZLD];
+      const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+      const __bf16 l0 = (__bf16)(x0 - (float)h0), l1 = (__bf16)(x1 - (float)h1);
+      h4[i] = (unsigned)__builtin_bit_cast(uint16_t, h0) | ((unsigned)__builtin_bit_cast(uint16_t, h1) << 16);
+      l4[i] = (unsigned)__builtin_bit_cast(uint16_t, l0) | ((unsigned)__builtin_bit_cast(uint16_t, l1) << 16);
+    }
+    const int64_t o = fb + ((int64_t)((r0 >> 4) + kk) * CB + cb) * 512 + ln * 8;
+    *(u32x4 PS_GLOBAL*)(a.nt_hi + o) = h4;
+    *(u32x4 PS_GLOBAL*)(a.nt_lo + o) = l4;
+  }
+}
+
 }  // namespace psk
+
 
 using namespace psk;
 
@@ -254,9 +444,10 @@ extern "C" int ps_convert_f32_to_bf16(void* stream, const float* src, void* dst_
                                       void* dst_lo, int64_t rows, int64_t cols, int64_t lds,
                                       int64_t ldd, int transpose) {
   PS_DEVICE_CHECK();
-  if (!src || !dst_hi || rows < 1 || cols < 1 || lds < cols || transpose < 0 || transpose > 2 ||
-      (transpose != 2 && ldd < (transpose ? rows : cols)))
+  if (!src || !dst_hi || rows < 1 || cols < 1 || lds < cols || transpose < 0 || transpose > 3 ||
+      (transpose < 2 && ldd < (transpose ? rows : cols)))
     return PS_EINVAL;
+  if (transpose == 3 && (rows % 64 != 0 || cols % 64 != 0)) return PS_EUNSUPPORTED;
   if (transpose == 2) {
     // tile-blocked operand of ps_gemm_bf16_grouped (a_tiled): the destination holds
     // ceil(rows / 128) * 128 * cols elements; rows past `rows` must read as zero
@@ -327,6 +518,7 @@ static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count,
   const size_t total_tiles = htiles(desc, count);
   for (int i = 0; i < count; ++i) {
     const ps_gemm_bf16_desc& d = desc[i];
+    if (d.a_tiled == 2) return PS_EUNSUPPORTED;   // fragment-major planes: ps_fd_cy_step_f32 only
     if (!d.a_hi || !d.b_hi || !d.c || d.m < 1 || d.n < 1 || d.k < 1 ||
         (!d.a_tiled && d.lda < d.k) || d.ldb < d.k || d.ldc < d.n)
       return PS_EINVAL;
@@ -409,6 +601,41 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
   return hplan_launch((hipStream_t)stream, pl);
 }
 
+extern "C" int ps_fd_cy_step_f32(void* stream, const void* const* c_hi, const void* const* c_lo,
+                                 int batch, const void* yt_hi, const void* yt_lo, const float* y,
+                                 const float* y_prev, float* y_next, void* nt_hi, void* nt_lo,
+                                 const float* params, int step, int64_t n, int64_t b) {
+  PS_DEVICE_CHECK();
+  if (!c_hi || !c_lo || batch < 1 || !yt_hi || !yt_lo || !y || !y_prev || !y_next || !params ||
+      step < 2 || (nt_hi == nullptr) != (nt_lo == nullptr) || nt_hi == yt_hi || nt_lo == yt_lo)
+    return PS_EINVAL;
+  if (batch > 16 || n < 128 || n % 128 != 0 || b % 32 != 0 || b < 32 || b > 96 ||
+      (int64_t)batch * (n / 64) > 0x7fffffff)
+    return PS_EUNSUPPORTED;
+  FdCyArgs a{};
+  for (int j = 0; j < batch; ++j) {
+    if (!c_hi[j] || !c_lo[j] || ((uintptr_t)c_hi[j] % 16) != 0 || ((uintptr_t)c_lo[j] % 16) != 0)
+      return PS_EINVAL;
+    a.a_hi[j] = (const uint16_t*)c_hi[j];
+    a.a_lo[j] = (const uint16_t*)c_lo[j];
+  }
+  if (((uintptr_t)yt_hi % 16) != 0 || ((uintptr_t)yt_lo % 16) != 0 || ((uintptr_t)y % 16) != 0 ||
+      ((uintptr_t)y_prev % 16) != 0 || ((uintptr_t)y_next % 16) != 0 ||
+      (nt_hi && (((uintptr_t)nt_hi % 16) != 0 || ((uintptr_t)nt_lo % 16) != 0)))
+    return PS_EUNSUPPORTED;
+  a.bt_hi = (const uint16_t*)yt_hi; a.bt_lo = (const uint16_t*)yt_lo;
+  a.y = y; a.y_prev = y_prev; a.y_next = y_next;
+  a.nt_hi = (uint16_t*)nt_hi; a.nt_lo = (uint16_t*)nt_lo;
+  a.params = params; a.step = step; a.n = (int)n;
+  a.nwg = (int)(batch * (n / 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (b == 96) hipLaunchKernelGGL((fd_cy_step_kernel<3>), dim3(a.nwg), dim3(256), 0, st, a);
+  else if (b == 64) hipLaunchKernelGGL((fd_cy_step_kernel<2>), dim3(a.nwg), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((fd_cy_step_kernel<1>), dim3(a.nwg), dim3(256), 0, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 // One whole Chebyshev filter of the subspace iteration (precondition_amd/subspace.py) in one call:
 //   step 1:            y1 = recurrence(z, y0)                           (z = C y0 is given)
 //   step s = 2..deg:   z = C y_{s-1}  (grouped bf16 product, plan built once)
@@ -429,6 +656,38 @@ extern "C" int ps_fd_filter_round_f32(void* stream, const ps_gemm_bf16_desc* des
     return PS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bool more = max_degree >= 2;
+  int frag = 0;
+  for (int j = 0; j < batch; ++j) frag += desc[j].a_tiled == 2;
+  if (frag != 0) {
+    // Fragment-major covariances: every step after the first is ONE launch (fd_cy_step_kernel:
+    // product + recurrence + the next operand); yt_hi / yt_lo hold TWO copies of the iterate
+    // planes (2 * batch * n * b elements each), written and read alternately.
+    if (frag != batch) return PS_EINVAL;
+    if (more && !yt_lo) return PS_EUNSUPPORTED;
+    const void* ch[16]; const void* cl[16];
+    if (batch > 16) return PS_EUNSUPPORTED;
+    for (int j = 0; j < batch; ++j) {
+      if (desc[j].m != n || desc[j].k != n || desc[j].n != b) return PS_EINVAL;
+      ch[j] = desc[j].a_hi; cl[j] = desc[j].a_lo;
+    }
+    const int64_t plane = (int64_t)batch * n * b;
+    uint16_t* th[2] = {(uint16_t*)yt_hi, (uint16_t*)yt_hi + plane};
+    uint16_t* tl[2] = {(uint16_t*)yt_lo, (uint16_t*)yt_lo + plane};
+    PS_RC(ps_fd_filter_step_f32(stream, z, y0, nullptr, y1, more ? th[0] : nullptr,
+                                more ? tl[0] : nullptr, params, 1, batch, n, b, 0));
+    float* bufs[3] = {y0, y1, y2};
+    int ip = 0, iy = 1, in = 2, cur = 0;
+    for (int step = 2; step <= max_degree; ++step) {
+      const bool again = step < max_degree;
+      PS_RC(ps_fd_cy_step_f32(stream, ch, cl, batch, th[cur], tl[cur], bufs[iy], bufs[ip], bufs[in],
+                              again ? th[cur ^ 1] : nullptr, again ? tl[cur ^ 1] : nullptr, params,
+                              step, n, b));
+      const int t = ip; ip = iy; iy = in; in = t;
+      cur ^= 1;
+    }
+    *result_index = iy;
+    return PS_OK;
+  }
   PS_RC(ps_fd_filter_step_f32(stream, z, y0, nullptr, y1, more ? yt_hi : nullptr,
                               more ? yt_lo : nullptr, params, 1, batch, n, b, ldt));
   float* bufs[3] = {y0, y1, y2};

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GTask* ta
 // partial products, each in its own workgroup, summed by gemm_splitk_reduce_kernel.
 // Calls with enough tiles (the per-step application of the preconditioners) are unchanged.
 static int splitk_for(int total_tiles, int k) {
-  if (total_tiles >= 256 || k < 512) return 1;
+  // one workgroup per CU with a long contraction (the float32 C @ X of the Rayleigh-Ritz step of the
+  // FD branch: 256 tiles, k = 4096) leaves the CU waiting on every K-tile: two per CU from k = 2048
+  if (total_tiles >= 512 || k < 512 || (total_tiles >= 256 && k < 2048)) return 1;
   int s = (512 + total_tiles - 1) / total_tiles;   // aim at ~2 workgroups per CU
   s = std::min(s, k / 256);                        // at least 256 k per split
   return std::max(1, std::min(s, 64));

@@ -509,11 +509,13 @@ def _gemm_desc_table(items):
 
 
 class TiledBf16:
-  """Left operand of gemm_bf16_grouped in the tile-blocked layout (to_bf16(..., tiled=True)):
-  `hi` / `lo` are flat bfloat16 buffers of ceil(rows / 128) * 128 * cols elements."""
+  """Left operand of the bf16 products in a blocked layout (to_bf16(..., tiled=True | "frag")):
+  `hi` / `lo` are flat bfloat16 buffers.  layout 1: 128 x 32 tiles contiguous (gemm_bf16_grouped,
+  ceil(rows / 128) * 128 * cols elements); layout 2: fragment-major (fd_filter_round / fd_cy_step:
+  the kilobyte one MFMA consumes is contiguous; rows * cols elements, both multiples of 64)."""
 
-  def __init__(self, hi, lo, rows, cols):
-    self.hi, self.lo, self.rows, self.cols = hi, lo, rows, cols
+  def __init__(self, hi, lo, rows, cols, layout=1):
+    self.hi, self.lo, self.rows, self.cols, self.layout = hi, lo, rows, cols, layout
 
 
 @_device_guarded
@@ -526,6 +528,15 @@ def to_bf16(x: torch.Tensor, split: bool = False, transpose: bool = False, tiled
   if x.dim() != 2:
     raise ValueError("to_bf16 expects a 2-D tensor")
   r, c = int(x.shape[0]), int(x.shape[1])
+  if tiled == "frag":
+    if transpose or c % 64 != 0 or r % 64 != 0:
+      raise ValueError("fragment-major bf16 operands: no transpose, rows and columns multiples of 64")
+    hi = torch.empty((r * c,), dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty((r * c,), dtype=torch.bfloat16, device=x.device) if split else None
+    rc = lib().ps_convert_f32_to_bf16(_stream(), x.data_ptr(), hi.data_ptr(),
+                                      lo.data_ptr() if split else None, r, c, _as_2d_ld(x), c, 3)
+    check(rc, "ps_convert_f32_to_bf16")
+    return TiledBf16(hi, lo, r, c, layout=2)
   if tiled:
     if transpose or c % 32 != 0:
       raise ValueError("tiled bf16 operands: no transpose, columns a multiple of 32")
@@ -558,6 +569,8 @@ def gemm_bf16_grouped(items):
   dev = items[0][2].device
   for d, (a, (b_hi, b_lo), c) in zip(descs, items):
     if isinstance(a, TiledBf16):   # tile-blocked left operand (to_bf16(..., tiled=True))
+      if a.layout != 1:
+        raise ValueError("gemm_bf16_grouped: fragment-major operands belong to fd_filter_round")
       _require_gpu(c, "gemm_bf16_grouped")
       m, k, n = a.rows, a.cols, int(b_hi.shape[0])
       need = ((m + 127) // 128) * 128 * k
@@ -600,12 +613,13 @@ def gemm_bf16_grouped(items):
 
 
 @_device_guarded
-def fd_filter_step(z, y, y_prev, y_next, params, step, want_bf16=True, split=True):
+def fd_filter_step(z, y, y_prev, y_next, params, step, want_bf16=True, split=True, frag=False):
   """One step of the scaled Chebyshev recurrence for the stacked iterates [B, n, b] of a
   subspace-iteration call (include/ps_api.h: ps_fd_filter_step_f32), fused with the bf16
   hi / lo split + transposition of the new iterate.  `params` = device [B, 4] float32
   {ctr, e, sigma1, degree}.  Returns (yt_hi, yt_lo) [b, B * n] bfloat16 (None, None without
-  `want_bf16`; yt_lo None without `split`)."""
+  `want_bf16`; yt_lo None without `split`); frag: flat fragment-major planes of B * n * b elements
+  instead (the operand layout of fd_cy_step)."""
   for t in (z, y, y_next, params):
     _require_gpu(t, "fd_filter_step")
   bsz, n, b = (int(v) for v in y.shape)
@@ -616,13 +630,14 @@ def fd_filter_step(z, y, y_prev, y_next, params, step, want_bf16=True, split=Tru
     raise ValueError("fd_filter_step: params must be a contiguous float32 [B, 4] tensor")
   hi = lo = None
   if want_bf16:
-    hi = torch.empty((b, bsz * n), dtype=torch.bfloat16, device=y.device)
-    lo = torch.empty((b, bsz * n), dtype=torch.bfloat16, device=y.device) if split else None
+    shape = (bsz * n * b,) if frag else (b, bsz * n)
+    hi = torch.empty(shape, dtype=torch.bfloat16, device=y.device)
+    lo = torch.empty(shape, dtype=torch.bfloat16, device=y.device) if split else None
   rc = lib().ps_fd_filter_step_f32(
       _stream(), z.data_ptr(), y.data_ptr(), y_prev.data_ptr() if y_prev is not None else None,
       y_next.data_ptr(), hi.data_ptr() if hi is not None else None,
       lo.data_ptr() if lo is not None else None, params.data_ptr(), int(step), bsz, n, b,
-      bsz * n)
+      0 if frag else bsz * n)
   check(rc, "ps_fd_filter_step_f32")
   return hi, lo
 
@@ -645,8 +660,13 @@ def fd_filter_round(c16, z, bufs, params, max_degree, plain=False):
     raise ValueError("fd_filter_round: shape mismatch")
   dev = z.device
   ldt = bsz * n
-  yt_hi = torch.empty((b, ldt), dtype=torch.bfloat16, device=dev)
-  yt_lo = None if plain else torch.empty((b, ldt), dtype=torch.bfloat16, device=dev)
+  frag = isinstance(c16[0], TiledBf16) and c16[0].layout == 2
+  if frag and (plain or any(not isinstance(a, TiledBf16) or a.layout != 2 or a.lo is None for a in c16)):
+    raise ValueError("fd_filter_round: fragment-major covariances need hi/lo pairs for every factor")
+  # fragment-major: two copies of the iterate planes, written and read alternately by the fused steps
+  yt_shape = (2, bsz * n * b) if frag else (b, ldt)
+  yt_hi = torch.empty(yt_shape, dtype=torch.bfloat16, device=dev)
+  yt_lo = None if plain else torch.empty(yt_shape, dtype=torch.bfloat16, device=dev)
   descs = (GemmBf16Desc * bsz)()
   for j, d in enumerate(descs):
     a = c16[j]
@@ -654,7 +674,7 @@ def fd_filter_round(c16, z, bufs, params, max_degree, plain=False):
       if a.rows != n or a.cols != n:
         raise ValueError("fd_filter_round: covariance shape mismatch")
       d.a_hi, d.a_lo = a.hi.data_ptr(), (None if (plain or a.lo is None) else a.lo.data_ptr())
-      d.lda, d.a_tiled = n, 1
+      d.lda, d.a_tiled = n, a.layout
     else:
       a_hi, a_lo = a
       if tuple(a_hi.shape) != (n, n):
@@ -667,7 +687,7 @@ def fd_filter_round(c16, z, bufs, params, max_degree, plain=False):
     d.m, d.n, d.k = n, b, n
     d.ldb, d.ldc = ldt, b
   L = lib()
-  ws = _workspace(L.ps_gemm_bf16_grouped_workspace_bytes(descs, bsz), dev)
+  ws = _workspace(1024 if frag else L.ps_gemm_bf16_grouped_workspace_bytes(descs, bsz), dev)
   which = C.c_int32(-1)
   rc = L.ps_fd_filter_round_f32(
       _stream(), descs, bsz, z.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(),
@@ -675,6 +695,42 @@ def fd_filter_round(c16, z, bufs, params, max_degree, plain=False):
       ldt, ws.data_ptr(), ws.numel(), C.addressof(which))
   check(rc, "ps_fd_filter_round_f32")
   return bufs[which.value]
+
+
+def fd_frag_supported(bsz: int, n: int, b: int) -> bool:
+  """Shapes the fused filter step (ps_fd_cy_step_f32) takes."""
+  return bsz <= 16 and n >= 128 and n % 128 == 0 and b in (32, 64, 96)
+
+
+@_device_guarded
+def fd_cy_step(c16, yt, y, y_prev, y_next, nt, params, step):
+  """One fused step (>= 2) of the Chebyshev filter (ps_fd_cy_step_f32): y_next = recurrence(C y, y,
+  y_prev) and, with nt = (hi, lo) buffers, y_next as fragment-major bf16 planes.  c16: fragment-major
+  covariances (to_bf16(..., tiled="frag")); yt = (hi, lo): the planes of y, each bsz * n * b
+  bfloat16 (fd_filter_step(..., frag=True) or the previous call's nt)."""
+  bsz, n, b = (int(v) for v in y.shape)
+  for t in (y, y_prev, y_next, params):
+    _require_gpu(t, "fd_cy_step")
+    if not t.is_contiguous() or t.dtype != torch.float32:
+      raise ValueError("fd_cy_step expects contiguous float32 tensors")
+  if tuple(y_prev.shape) != (bsz, n, b) or tuple(y_next.shape) != (bsz, n, b) or tuple(params.shape) != (bsz, 4):
+    raise ValueError("fd_cy_step: shape mismatch")
+  planes = [yt[0], yt[1]] + ([nt[0], nt[1]] if nt is not None else [])
+  for t in planes:
+    if t.dtype != torch.bfloat16 or not t.is_cuda or not t.is_contiguous() or t.numel() != bsz * n * b:
+      raise ValueError("fd_cy_step: iterate planes must be contiguous bfloat16 of bsz * n * b elements")
+  ch, cl = (C.c_void_p * bsz)(), (C.c_void_p * bsz)()
+  for j, a in enumerate(c16):
+    if not isinstance(a, TiledBf16) or a.layout != 2 or a.lo is None or a.rows != n or a.cols != n:
+      raise ValueError("fd_cy_step: covariances must be fragment-major hi/lo pairs of shape [n, n]")
+    ch[j], cl[j] = a.hi.data_ptr(), a.lo.data_ptr()
+  rc = lib().ps_fd_cy_step_f32(_stream(), ch, cl, bsz, yt[0].data_ptr(), yt[1].data_ptr(), y.data_ptr(),
+                               y_prev.data_ptr(), y_next.data_ptr(),
+                               nt[0].data_ptr() if nt is not None else None,
+                               nt[1].data_ptr() if nt is not None else None, params.data_ptr(),
+                               int(step), n, b)
+  check(rc, "ps_fd_cy_step_f32")
+  return y_next
 
 
 @_device_guarded

@@ -196,6 +196,11 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   if mode != "f32":  # the covariance is converted ONCE per call (hi/lo pair)
     # tile-blocked (128 x 32 tiles contiguous): the product streams whole DRAM pages of C
     tiled = n % 32 == 0 and os.environ.get("PS_FD_TILED", "1") != "0"
+    # fragment-major (the kilobyte one MFMA consumes is contiguous): every filter step after the
+    # first is then ONE launch -- product, recurrence and the next bf16 operand (ps_fd_cy_step_f32)
+    if (tiled and mode == "bf16x3" and _fused_filter() and _K().fd_frag_supported(bsz, n, b) and
+        os.environ.get("PS_FD_ROUND_CALL", "1") != "0" and os.environ.get("PS_FD_FRAG", "1") != "0"):
+      tiled = "frag"
     c16 = [_K().to_bf16(m, split=True, tiled=tiled) for m in c]
 
   def filter_product(y, z, plain):

@@ -207,3 +207,111 @@ def test_stacked_batch_form_bit_identical_to_list_form(device):
   out = torch.empty((5, 200, 200), device=device)
   r_v, m_v = K().matrix_inverse_pth_root_batched(big[:, :200, :200], [4, 2, 4, 8, 1], out=out)
   assert r_v is out and torch.equal(m_v, m_st) and torch.equal(out, r_st)
+
+
+# ---------------------------------------------------------------------------
+# Fused filter step of the FD branch (ps_fd_cy_step_f32) and its fragment-major operands
+def _frag_index_a(n, k):
+  r = torch.arange(n)[:, None]
+  c = torch.arange(k)[None, :]
+  return ((((r // 64) * (k // 16) + c // 16) * 2 + (r % 64) // 32) * 512 + (32 * ((c % 16) // 8) + r % 32) * 8 + c % 8)
+
+
+def _frag_index_y(n, b):
+  r = torch.arange(n)[:, None]          # row of the iterate = k of the next product
+  c = torch.arange(b)[None, :]
+  return ((r // 16) * (b // 32) + c // 32) * 512 + (32 * ((r % 16) // 8) + c % 32) * 8 + r % 8
+
+
+def test_fragment_major_conversion_is_a_permutation_of_the_plain_one(device):
+  x = torch.randn((256, 192), device=device) * 3.0
+  hi, lo = K().to_bf16(x, split=True)
+  f = K().to_bf16(x, split=True, tiled="frag")
+  idx = _frag_index_a(256, 192).to(device)
+  assert torch.equal(f.hi[idx.reshape(-1)].view(256, 192), hi)
+  assert torch.equal(f.lo[idx.reshape(-1)].view(256, 192), lo)
+  assert sorted(idx.reshape(-1).tolist()) == list(range(256 * 192))
+  with pytest.raises(ValueError):
+    K().to_bf16(torch.randn((100, 64), device=device), split=True, tiled="frag")
+
+
+@pytest.mark.parametrize("bsz,n,b", [(3, 256, 96), (2, 384, 64), (1, 128, 32), (8, 1024, 96)])
+def test_fused_filter_step_matches_product_plus_recurrence(bsz, n, b, device):
+  """ps_fd_cy_step_f32 against its two-launch form (gemm_bf16_grouped on the same hi/lo operands, then
+  ps_fd_filter_step_f32): same arithmetic per element, another order of the k sum -> agreement to
+  float32 rounding of the sum; the bf16 planes it writes are exactly the split of ITS y_next; a factor
+  whose degree is below the step keeps its iterate bit for bit."""
+  gen = torch.Generator(device=device).manual_seed(11)
+  cs = []
+  for j in range(bsz):
+    g = torch.randn((n, n // 2), generator=gen, device=device)
+    cs.append((g @ g.T) / n)
+  y = torch.randn((bsz, n, b), generator=gen, device=device)
+  y_prev = torch.randn((bsz, n, b), generator=gen, device=device)
+  params = torch.tensor([[0.4, 0.5, 0.3, 12.0]] * bsz, device=device)
+  params[-1, 3] = 2.0 if bsz > 1 else 12.0          # last factor: degree 2 < step 3 (bsz > 1)
+  step = 3
+  # reference: plain layouts
+  c_t = [K().to_bf16(c, split=True, tiled=True) for c in cs]
+  yt_hi, yt_lo = K().to_bf16(y.view(bsz * n, b), split=True, transpose=True)
+  z = torch.empty_like(y)
+  K().gemm_bf16_grouped([(c_t[j], (yt_hi[:, j * n:(j + 1) * n], yt_lo[:, j * n:(j + 1) * n]), z[j])
+                         for j in range(bsz)])
+  want = torch.empty_like(y)
+  K().fd_filter_step(z, y, y_prev, want, params, step, want_bf16=False)
+  # fused: fragment-major layouts
+  c_f = [K().to_bf16(c, split=True, tiled="frag") for c in cs]
+  idx = _frag_index_y(n, b).to(device).reshape(-1)
+  y_hi, y_lo = K().to_bf16(y.view(bsz * n, b), split=True)
+  pl_hi = torch.empty((bsz * n * b,), dtype=torch.bfloat16, device=device)
+  pl_lo = torch.empty_like(pl_hi)
+  for j in range(bsz):
+    pl_hi[j * n * b + idx] = y_hi[j * n:(j + 1) * n].reshape(-1)
+    pl_lo[j * n * b + idx] = y_lo[j * n:(j + 1) * n].reshape(-1)
+  got = torch.empty_like(y)
+  nt = (torch.zeros_like(pl_hi), torch.zeros_like(pl_lo))
+  K().fd_cy_step(c_f, (pl_hi, pl_lo), y, y_prev, got, nt, params, step)
+  torch.cuda.synchronize()
+  scale = float(want.abs().max())
+  assert float((got - want).abs().max()) <= 2e-6 * scale, float((got - want).abs().max()) / scale
+  if bsz > 1:
+    assert torch.equal(got[-1], y[-1])
+  g_hi, g_lo = K().to_bf16(got.view(bsz * n, b), split=True)
+  for j in range(bsz - 1 if bsz > 1 else 1):
+    assert torch.equal(nt[0][j * n * b + idx].view(n, b), g_hi[j * n:(j + 1) * n])
+    assert torch.equal(nt[1][j * n * b + idx].view(n, b), g_lo[j * n:(j + 1) * n])
+  # the first-step kernel writes the same planes (ldt = 0)
+  t_hi, t_lo = K().fd_filter_step(z, y, None, want, params, 1, frag=True)
+  w_hi, w_lo = K().to_bf16(want.view(bsz * n, b), split=True)
+  for j in range(bsz):
+    assert torch.equal(t_hi[j * n * b + idx].view(n, b), w_hi[j * n:(j + 1) * n])
+    assert torch.equal(t_lo[j * n * b + idx].view(n, b), w_lo[j * n:(j + 1) * n])
+  # shapes the fused step does not take are refused, not mangled
+  from precondition_amd import _lib
+  with pytest.raises((_lib.PsError, ValueError)):
+    K().fd_cy_step(c_f, (pl_hi, pl_lo), y, y_prev, got, (pl_hi, pl_lo), params, step)
+
+
+def test_filter_round_fragment_major_equals_tile_blocked_round(device):
+  """ps_fd_filter_round_f32 with fragment-major covariances (one launch per step) against the same
+  round on tile-blocked ones (product + reduce + recurrence launches): 12 steps, three factors with
+  different degrees."""
+  bsz, n, b = 3, 512, 96
+  gen = torch.Generator(device=device).manual_seed(5)
+  cs = []
+  for j in range(bsz):
+    g = torch.randn((n, n // 4), generator=gen, device=device)
+    cs.append((g @ g.T) / n)
+  x = torch.linalg.qr(torch.randn((bsz, n, b), generator=gen, device=device))[0].contiguous()
+  z = torch.stack([cs[j] @ x[j] for j in range(bsz)]).contiguous()
+  top = [float(torch.linalg.eigvalsh(c)[-1]) for c in cs]
+  params = torch.tensor([[0.05 * t, 0.05 * t, 0.05 / 0.95, d] for t, d in zip(top, (12.0, 7.0, 3.0))], device=device)
+  outs = []
+  for layout in (True, "frag"):
+    c16 = [K().to_bf16(c, split=True, tiled=layout) for c in cs]
+    bufs = [x.clone(), torch.empty_like(x), torch.empty_like(x)]
+    outs.append(K().fd_filter_round(c16, z.clone(), bufs, params, 12).clone())
+  torch.cuda.synchronize()
+  for j in range(bsz):
+    a, b_ = outs[0][j], outs[1][j]
+    assert float((a - b_).norm() / a.norm()) < 5e-6, (j, float((a - b_).norm() / a.norm()))
