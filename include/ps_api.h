@@ -600,6 +600,12 @@ int ps_fd_filter_round_f32(void* stream, const ps_gemm_bf16_desc* desc, int batc
 int ps_fd_round_control_f32(void* stream, const float* theta, const float* res, int batch, int b,
                             int k, int n, float tol, int degree, float* params,
                             int32_t* converged, int32_t* summary);
+/* ps_fd_cov_update_f32: c[j] <- 0.5 ((decay c[j] + gram[j]) + (decay c[j] + gram[j])^T) in place for
+ * `batch` stacked n x n matrices c (contiguous) and the HOST array gram of device pointers to
+ * contiguous n x n matrices: the covariance decay * W W^T + R R^T of DS:1174-1193, symmetrised, in
+ * one pass (the result is bitwise symmetric). */
+int ps_fd_cov_update_f32(void* stream, float* c, const float* const* gram, int batch, int64_t n,
+                         float decay);
 int ps_chol_rinv_max_n(void);
 int ps_chol_rinv_batched_f32(void* stream, const float* gram, float* out, int b, int batch,
                              float drop_rel);

@@ -273,6 +273,8 @@ _SIGNATURES = {
     "ps_fd_round_control_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                    C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ps_fd_cov_update_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_float]),
     "ps_chol_rinv_max_n": (C.c_int, []),
     "ps_chol_rinv_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]),

@@ -97,19 +97,29 @@ __global__ __launch_bounds__(256) void fd_filter_step_kernel(
 // or below drop_rel * max diag(G) drops its direction (row and column of the result zero: the
 // column of X it belongs to becomes zero, like the eigen-based orthonormalisation drops the
 // directions of a rank-deficient block).  out = R^-1 = (L^-1)^T, float32, row-major [b][b].
+//
+// Both halves are right-looking rank-1 sweeps over LDS with ONE barrier per column and no
+// dependent FMA chain (thread = row r x column parity h; the value every lane multiplies by is one
+// broadcast LDS read).  The left-looking / column-per-thread form before it spent its time in
+// chains of float64 FMAs that each waited for two LDS reads: 0.22 ms for 8 x 96^2.
+//   factor:  for c: p = S[c][c];  L[r][c] = S[r][c] / sqrt(p) (kept in a second array, so that the
+//            unscaled column stays readable);  S[r][j] -= S[r][c] S[j][c] / p   (c < j <= r)
+//   invert:  X = I;  for k: X[k][:] /= L[k][k] (folded into the multiplier);
+//            X[r][c] -= (L[r][k] / L[k][k]) X[k][c]   (r > k, c <= k)
 constexpr int CQ_MAX = 96;
 __global__ __launch_bounds__(256) void chol_rinv_kernel(const float* gram, float* out, int b,
                                                         float drop_rel) {
   extern __shared__ double cq[];
-  double* S = cq;                       // [b][b + 1]
-  double* X = cq + CQ_MAX * (CQ_MAX + 1);
-  __shared__ double s_d, s_max;
+  double* S = cq;                       // [b][b + 1]: the trailing matrix, then X = L^-1
+  double* Lm = cq + CQ_MAX * (CQ_MAX + 1);   // [b][b + 1]: L
+  __shared__ double s_max;
   __shared__ int s_drop[CQ_MAX];
   const int tid = threadIdx.x, ldS = b + 1;
+  const int r = tid & 127, h = tid >> 7;
   const float* g = gram + (int64_t)blockIdx.x * b * b;
   for (int e = tid; e < b * b; e += 256) {
-    const int r = e / b, c = e % b;
-    S[r * ldS + c] = 0.5 * ((double)g[r * b + c] + (double)g[c * b + r]);
+    const int rr = e / b, c = e % b;
+    S[rr * ldS + c] = 0.5 * ((double)g[rr * b + c] + (double)g[c * b + rr]);
   }
   __syncthreads();
   if (tid == 0) {
@@ -119,57 +129,117 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const float* gram, float
   }
   __syncthreads();
   const double thresh = (double)drop_rel * s_max;
-  // Left-looking factorisation, one thread per row: column c of L needs only the finished
-  // columns k < c, so every row forms its dot product sum_k L[r][k] L[c][k] before the pivot is
-  // known (row c's own partner values are one broadcast LDS read per term); two barriers per
-  // column and one LDS write per element (the right-looking form updated the whole trailing
-  // block per column with an integer division per element: 0.35 ms for 8 x 96^2).
-  const int r = tid;
   for (int c = 0; c < b; ++c) {
-    double acc = 0.0;
+    const double p = S[c * ldS + c];
+    const bool ok = p > thresh && p > 0.0 && p < 1.0e300;
+    // 1 / sqrt(p) from the hardware seed + two Newton steps (a float64 division or square root is a
+    // ~50-instruction sequence, and every wavefront would run three of them per column)
+    double rs = __builtin_amdgcn_rsq(ok ? p : 1.0);
+    rs = rs * fma(-0.5 * (ok ? p : 1.0) * rs, rs, 1.5);
+    rs = rs * fma(-0.5 * (ok ? p : 1.0) * rs, rs, 1.5);
     if (r >= c && r < b) {
-      acc = S[r * ldS + c];
-      for (int k = 0; k < c; ++k) acc = fma(-S[r * ldS + k], S[c * ldS + k], acc);
-    }
-    if (r == c) {
-      const bool ok = acc > thresh && acc > 0.0 && acc < 1.0e300;
-      s_drop[c] = ok ? 0 : 1;
-      s_d = ok ? sqrt(acc) : 1.0;
-    }
-    __syncthreads();
-    if (r >= c && r < b) {
-      const double d = s_d;
-      const bool dropped = s_drop[c] != 0;
-      S[r * ldS + c] = r == c ? d : (dropped ? 0.0 : acc / d);
-    }
-    __syncthreads();
-  }
-  // X = L^-1 (lower), one column per thread; dropped directions: zero row and column
-  if (tid < b) {
-    const int c = tid;
-    for (int r = 0; r < c; ++r) X[r * ldS + c] = 0.0;
-    if (s_drop[c]) {
-      for (int r = c; r < b; ++r) X[r * ldS + c] = 0.0;
-    } else {
-      X[c * ldS + c] = 1.0 / S[c * ldS + c];
-      for (int r = c + 1; r < b; ++r) {
-        double s = 0.0;
-        if (!s_drop[r]) {
-          for (int k = c; k < r; ++k) s = fma(S[r * ldS + k], X[k * ldS + c], s);
-          s = -s / S[r * ldS + r];
+      double* sr = S + r * ldS;
+      const double src = sr[c];
+      if (h == 0) {
+        Lm[r * ldS + c] = r == c ? (ok ? p * rs : 1.0) : (ok ? src * rs : 0.0);
+        if (r == c) s_drop[c] = ok ? 0 : 1;
+      }
+      if (ok && r > c) {
+        const double m = -(src * rs) * rs;         // - S[r][c] / p
+        const double* sc = S + c;
+        int j = c + 1 + h;
+        // four independent element updates per trip: the loads of a trip are in flight together
+        for (; j + 6 <= r; j += 8) {
+          const double a0 = sr[j], a1 = sr[j + 2], a2 = sr[j + 4], a3 = sr[j + 6];
+          const double b0 = sc[j * ldS], b1 = sc[(j + 2) * ldS], b2 = sc[(j + 4) * ldS],
+                       b3 = sc[(j + 6) * ldS];
+          sr[j] = fma(m, b0, a0);
+          sr[j + 2] = fma(m, b1, a1);
+          sr[j + 4] = fma(m, b2, a2);
+          sr[j + 6] = fma(m, b3, a3);
         }
-        X[r * ldS + c] = s;
+        for (; j <= r; j += 2) sr[j] = fma(m, sc[j * ldS], sr[j]);
       }
     }
+    __syncthreads();
+  }
+  // X = L^-1 in S (lower); dropped directions: zero row and column
+  for (int e = tid; e < b * b; e += 256) {
+    const int rr = e / b, c = e % b;
+    S[rr * ldS + c] = (rr == c && !s_drop[c]) ? 1.0 : 0.0;
   }
   __syncthreads();
+  // 1 / L[k][k] once per row (the diagonal of Lm becomes its reciprocal)
+  if (tid < b) Lm[tid * ldS + tid] = 1.0 / Lm[tid * ldS + tid];
+  __syncthreads();
+  for (int k = 0; k < b; ++k) {
+    // row k of X is final up to its 1 / L[k][k]; rows below subtract their multiple of it
+    if (r > k && r < b && !s_drop[r] && !s_drop[k]) {
+      const double m = -Lm[r * ldS + k] * Lm[k * ldS + k];
+      double* sr = S + r * ldS;
+      const double* sk = S + k * ldS;
+      int c = h;
+      for (; c + 6 <= k; c += 8) {
+        const double a0 = sr[c], a1 = sr[c + 2], a2 = sr[c + 4], a3 = sr[c + 6];
+        const double b0 = sk[c], b1 = sk[c + 2], b2 = sk[c + 4], b3 = sk[c + 6];
+        sr[c] = fma(m, b0, a0);
+        sr[c + 2] = fma(m, b1, a1);
+        sr[c + 4] = fma(m, b2, a2);
+        sr[c + 6] = fma(m, b3, a3);
+      }
+      for (; c <= k; c += 2) sr[c] = fma(m, sk[c], sr[c]);
+    }
+    __syncthreads();
+  }
   float* o = out + (int64_t)blockIdx.x * b * b;
   for (int e = tid; e < b * b; e += 256) {
-    const int r = e / b, c = e % b;       // out[r][c] = R^-1[r][c] = L^-1[c][r]
-    o[e] = (float)X[c * ldS + r];
+    const int rr = e / b, c = e % b;      // out[rr][c] = R^-1[rr][c] = L^-1[c][rr] / L[c][c]
+    o[e] = (float)(S[c * ldS + rr] * Lm[c * ldS + c]);
   }
 }
 
+
+// C_j <- 0.5 ((decay C_j + G_j) + (decay C_j + G_j)^T) in place, for the stacked covariances of a
+// group of factors (DS:1174-1193's operand: decay * W W^T + R R^T, symmetrised): one pass over C and
+// G (12 bytes per element) instead of an axpy per factor, a strided transposed add and a scaling
+// pass over the whole stack (~5 x the traffic).  One workgroup owns the tile pair (ti, tj), (tj, ti).
+struct CovArgs { const float* g[16]; float* c; int n, tiles, pairs; float decay; };
+__global__ __launch_bounds__(256) void fd_cov_update_kernel(const CovArgs a) {
+  __shared__ float sa[64][65], sb[64][65];
+  const int j = blockIdx.x / a.pairs;
+  int rem = blockIdx.x % a.pairs, ti = 0;
+  while (rem >= a.tiles - ti) { rem -= a.tiles - ti; ++ti; }   // pair index -> (ti, tj >= ti)
+  const int tj = ti + rem, tid = threadIdx.x, n = a.n;
+  float* c = a.c + (int64_t)j * n * n;
+  const float* g = a.g[j];
+  const int r0 = ti * 64, c0 = tj * 64;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, q = e & 63;
+    float u = 0.f, v = 0.f;
+    if (r0 + r < n && c0 + q < n) {
+      const int64_t o = (int64_t)(r0 + r) * n + c0 + q;
+      const float t = a.decay * gload1(c + o);
+      u = t + gload1(g + o);
+    }
+    if (ti != tj && c0 + r < n && r0 + q < n) {
+      const int64_t o = (int64_t)(c0 + r) * n + r0 + q;
+      const float t = a.decay * gload1(c + o);
+      v = t + gload1(g + o);
+    }
+    sa[r][q] = u;
+    sb[r][q] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, q = e & 63;
+    if (ti == tj) {
+      if (r0 + r < n && c0 + q < n) gstore1(c + (int64_t)(r0 + r) * n + c0 + q, 0.5f * (sa[r][q] + sa[q][r]));
+    } else {
+      if (r0 + r < n && c0 + q < n) gstore1(c + (int64_t)(r0 + r) * n + c0 + q, 0.5f * (sa[r][q] + sb[q][r]));
+      if (c0 + r < n && r0 + q < n) gstore1(c + (int64_t)(c0 + r) * n + r0 + q, 0.5f * (sa[q][r] + sb[r][q]));
+    }
+  }
+}
 
 // Per-round control of the subspace iteration (precondition_amd/subspace.py), one thread per
 // factor: convergence of the k wanted Ritz pairs, the scaled Chebyshev filter's interval and
@@ -234,6 +304,28 @@ extern "C" int ps_fd_filter_step_f32(void* stream, const float* z, const float* 
                      (hipStream_t)stream, z, y, y_prev, y_next, (uint16_t*)yt_hi,
                      (uint16_t*)yt_lo, params, step, (int)n, (int)b, ldt, (int)tr, (int)tc);
   PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_fd_cov_update_f32(void* stream, float* c, const float* const* gram, int batch,
+                                    int64_t n, float decay) {
+  PS_DEVICE_CHECK();
+  if (!c || !gram || batch < 1 || n < 1) return PS_EINVAL;
+  const int64_t tiles = (n + 63) / 64, pairs = tiles * (tiles + 1) / 2;
+  if (tiles > 32767 || pairs * 16 > 0x7fffffff) return PS_EUNSUPPORTED;
+  for (int j0 = 0; j0 < batch; j0 += 16) {
+    CovArgs a{};
+    const int nb = batch - j0 < 16 ? batch - j0 : 16;
+    for (int j = 0; j < nb; ++j) {
+      if (!gram[j0 + j]) return PS_EINVAL;
+      a.g[j] = gram[j0 + j];
+    }
+    a.c = c + (int64_t)j0 * n * n;
+    a.n = (int)n; a.tiles = (int)tiles; a.pairs = (int)pairs; a.decay = decay;
+    hipLaunchKernelGGL(fd_cov_update_kernel, dim3((unsigned)(pairs * nb)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    PS_LAUNCH_CHECK();
+  }
   return PS_OK;
 }
 

@@ -697,6 +697,25 @@ def fd_filter_round(c16, z, bufs, params, max_degree, plain=False):
   return bufs[which.value]
 
 
+@_device_guarded
+def fd_cov_update(c: torch.Tensor, grams, decay: float) -> torch.Tensor:
+  """c[j] <- sym(decay * c[j] + grams[j]) in place for the stacked covariances [B, n, n] of a group of
+  FD factors (ps_fd_cov_update_f32: one pass; the result is bitwise symmetric)."""
+  _require_gpu(c, "fd_cov_update")
+  bsz, n = int(c.shape[0]), int(c.shape[1])
+  if c.dim() != 3 or c.shape[2] != n or not c.is_contiguous() or c.dtype != torch.float32 or len(grams) != bsz:
+    raise ValueError("fd_cov_update expects a contiguous float32 [B, n, n] stack and B Gram matrices")
+  ptrs = (C.c_void_p * bsz)()
+  for j, g in enumerate(grams):
+    _require_gpu(g, "fd_cov_update")
+    if tuple(g.shape) != (n, n) or not g.is_contiguous() or g.dtype != torch.float32:
+      raise ValueError("fd_cov_update: Gram matrices must be contiguous float32 [n, n]")
+    ptrs[j] = g.data_ptr()
+  check(lib().ps_fd_cov_update_f32(_stream(), c.data_ptr(), ptrs, bsz, n, float(decay)),
+        "ps_fd_cov_update_f32")
+  return c
+
+
 def fd_frag_supported(bsz: int, n: int, b: int) -> bool:
   """Shapes the fused filter step (ps_fd_cy_step_f32) takes."""
   return bsz <= 16 and n >= 128 and n % 128 == 0 and b in (32, 64, 96)

@@ -305,11 +305,11 @@ def _fd_update_root_group(calls, key):
   # C = decay * W W^T + R R^T (the SVD's u, s^2)
   c = torch.empty((bsz, d, d), dtype=torch.float32, device=dev)
   kernels.gemm_grouped([(weighted[j], weighted[j], c[j], False, True) for j in range(bsz)])
-  for j, kw in enumerate(calls):
-    g = kw["new_grad"]
-    gram = g if is_gram else kernels.matmul(g.contiguous(), g.contiguous(), transb=True)
-    torch.add(gram, c[j], alpha=decay, out=c[j])
-  c = (c + c.transpose(1, 2)).mul_(0.5)
+  grams = []
+  for kw in calls:
+    g = kw["new_grad"].contiguous()
+    grams.append(g if is_gram else kernels.matmul(g, g, transb=True))
+  kernels.fd_cov_update(c, grams, decay)      # c <- sym(decay * W W^T + gram), one pass
   e, u, conv, _ = subspace.top_eigenpairs_batched(list(c.unbind(0)), r + 1)   # e [B, r+1] desc
   # ---- _fd_finish, stacked ----
   noise = d * 1.2e-7 * torch.clamp(e.max(dim=1, keepdim=True).values, min=0.0)

@@ -315,3 +315,50 @@ def test_filter_round_fragment_major_equals_tile_blocked_round(device):
   for j in range(bsz):
     a, b_ = outs[0][j], outs[1][j]
     assert float((a - b_).norm() / a.norm()) < 5e-6, (j, float((a - b_).norm() / a.norm()))
+
+
+@pytest.mark.parametrize("b", [96, 64, 33, 5])
+def test_chol_rinv_against_float64_cholesky(b, device):
+  """ps_chol_rinv_batched_f32 (the CholeskyQR step of the FD branch's orthonormalisation): R^-1 of
+  G = R^T R against numpy's float64 factorisation on well and badly conditioned Gram matrices, and
+  the dropped directions of a rank-deficient one (zero row and column; the kept block still
+  whitens G)."""
+  rng = np.random.default_rng(b)
+  mats = []
+  for cond in (1.0, 1e3, 1e6):
+    x = rng.standard_normal((4 * b, b)) * np.logspace(0, -np.log10(cond) / 2, b)[None, :]
+    mats.append((x.T @ x).astype(np.float32))
+  g = torch.tensor(np.stack(mats), device=device)
+  out = K().chol_rinv_batched(g, 1e-10).cpu().numpy().astype(np.float64)
+  for m, o in zip(mats, out):
+    m64 = 0.5 * (m.astype(np.float64) + m.astype(np.float64).T)
+    want = np.linalg.inv(np.linalg.cholesky(m64)).T          # R^-1, upper triangular
+    assert np.allclose(o, np.triu(o)), "R^-1 must be upper triangular"
+    assert np.abs(o - want).max() <= 2e-6 * np.abs(want).max()
+    assert np.abs(o.T @ m64 @ o - np.eye(b)).max() < 5e-5 * np.sqrt(np.linalg.cond(m64))
+  if b >= 33:
+    x = rng.standard_normal((4 * b, b))
+    x[:, 7] = 0.0                      # a zero column: its pivot is exactly 0
+    x[:, 20] = x[:, 3]                 # a duplicate: its pivot is at rounding level
+    m = (x.T @ x).astype(np.float32)
+    o = K().chol_rinv_batched(torch.tensor(m[None], device=device), 1e-6).cpu().numpy()[0].astype(np.float64)
+    for d in (7, 20):
+      assert not o[d].any() and not o[:, d].any(), d
+    keep = [i for i in range(b) if i not in (7, 20)]
+    w = o.T @ m.astype(np.float64) @ o
+    assert np.abs(w[np.ix_(keep, keep)] - np.eye(len(keep))).max() < 1e-4
+
+
+@pytest.mark.parametrize("bsz,n", [(3, 256), (2, 200), (1, 65)])
+def test_fd_cov_update_one_pass_equals_torch_form(bsz, n, device):
+  """ps_fd_cov_update_f32: c <- 0.5 ((decay c + g) + (decay c + g)^T) in one pass, against the three
+  torch passes it replaces (low_rank._fd_update_root_group); exactly symmetric result, also on
+  inputs that are not symmetric."""
+  gen = torch.Generator(device=device).manual_seed(n)
+  c = torch.randn((bsz, n, n), generator=gen, device=device)
+  grams = [torch.randn((n, n), generator=gen, device=device) for _ in range(bsz)]
+  want = torch.stack([0.999 * c[j] + grams[j] for j in range(bsz)])
+  want = (want + want.transpose(1, 2)) * 0.5
+  got = K().fd_cov_update(c.clone(), grams, 0.999)
+  assert torch.equal(got, got.transpose(1, 2))
+  assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
