@@ -440,7 +440,9 @@ typedef struct {
                         [ceil(m/128)][k/32][128][32], rows past m zero; lda is ignored.
                         2: fragment-major planes (transpose = 3) -- accepted by
                         ps_fd_filter_round_f32 only (ps_gemm_bf16_grouped: PS_EUNSUPPORTED) */
-  int32_t reserved;  /* 0 */
+  int32_t symmetric; /* != 0: c = a a^T (b_* == a_*, ldb == lda, m == n, a_tiled == 0): only the
+                        upper tile triangle is multiplied, every tile is also stored as its mirror
+                        image; the result is bitwise symmetric */
 } ps_gemm_bf16_desc;
 
 int ps_convert_f32_to_bf16(void* stream, const float* src, void* dst_hi, void* dst_lo,

@@ -52,7 +52,7 @@ class GemmBf16Desc(C.Structure):
   _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("b_hi", C.c_void_p),
               ("b_lo", C.c_void_p), ("c", C.c_void_p), ("m", C.c_int32), ("n", C.c_int32),
               ("k", C.c_int32), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
-              ("a_tiled", C.c_int32), ("reserved", C.c_int32)]
+              ("a_tiled", C.c_int32), ("symmetric", C.c_int32)]
 
 
 class TransformDesc(C.Structure):

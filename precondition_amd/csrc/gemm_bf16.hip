@@ -54,8 +54,12 @@ struct HTask {
   int ksplit, kchunk;   // split-K (deterministic two-pass), as in ps_gemm_grouped_f32
   float* partial;       // [ksplit][m][n] when ksplit > 1
   int a_tiled;          // A planes in the tile-blocked layout (ps_convert_f32_to_bf16 mode 2)
+  int sym;              // c = a a^T: only tiles tm <= tn are computed, every tile also stores its mirror
+  float* ptile;         // sym: [slot][nks][128][128] partial tiles of the few K-split tail tiles
 };
-struct HTile { int task; short tm, tn; int ks; };
+// kchunk / nks / pslot: a tile of a symmetric product that is cut along k on its own (pslot >= 0)
+struct HTile { int task; short tm, tn; int ks; int kchunk, nks, pslot; };
+constexpr int SYM_TLD = TILE + 1;   // row stride of the LDS staging tile of a mirror store
 
 __device__ inline u32x4 gload16(const uint16_t* p) { return *(const u32x4 PS_GLOBAL*)(p); }
 __device__ inline u32x4 gload16_nt(const uint16_t* p) {
@@ -106,8 +110,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int row0 = te.tm * TILE, col0 = te.tn * TILE;
-  const int kbeg = te.ks * tk.kchunk;                 // k % 32 == 0 and kchunk % 32 == 0
-  const int nk = (min(tk.kchunk, tk.k - kbeg) + HBK - 1) / HBK;   // (checked on the host)
+  const int kchunk = te.pslot >= 0 ? te.kchunk : tk.kchunk;
+  const int kbeg = te.ks * kchunk;                    // k % 32 == 0 and kchunk % 32 == 0
+  const int nk = (min(kchunk, tk.k - kbeg) + HBK - 1) / HBK;      // (checked on the host)
   f32x16 acc[2][2];
   zero_acc(acc);
   u32x4 ra[HSETS][SA][HV], rb[HSETS][SB][HV];
@@ -183,8 +188,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
       __syncthreads();
     }
   }
+  if (te.pslot >= 0) {
+    // K-split tail tile of a symmetric product: the whole 128 x 128 partial tile, compact
+    float* pt = tk.ptile + ((int64_t)te.pslot * te.nks + te.ks) * (TILE * TILE);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          gstore1(pt + acc_row(wm, i, r, lane) * TILE + acc_col(wn, j, lane), acc[i][j][r]);
+    return;
+  }
   float* out = tk.ksplit > 1 ? tk.partial + (int64_t)te.ks * tk.m * tk.n : tk.c;
   const int64_t ldo = tk.ksplit > 1 ? tk.n : tk.ldc;
+  const bool diag = tk.sym && te.tm == te.tn;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -193,8 +211,69 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + acc_row(wm, i, r, lane);
         const int col = col0 + acc_col(wn, j, lane);
-        if (row < tk.m && col < tk.n) gstore1(out + (int64_t)row * ldo + col, acc[i][j][r]);
+        if (row < tk.m && col < tk.n && (!diag || row <= col)) {
+          gstore1(out + (int64_t)row * ldo + col, acc[i][j][r]);
+          // a diagonal tile keeps its upper triangle and mirrors it: hi*lo and lo*hi enter the
+          // accumulation chain in a fixed order, so (i, j) and (j, i) differ in the last bits
+          if (diag && row < col) gstore1(out + (int64_t)col * ldo + row, acc[i][j][r]);
+        }
       }
+  if (!tk.sym || diag) return;
+  // mirror tile (tn, tm): through LDS, so that the global stores run along rows
+  float* st = reinterpret_cast<float*>(hs);
+  __syncthreads();                               // the K loop's last fragment reads are done
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        st[acc_row(wm, i, r, lane) * SYM_TLD + acc_col(wn, j, lane)] = acc[i][j][r];
+  __syncthreads();
+  for (int e = tid; e < TILE * TILE; e += 256) {
+    const int c = e >> 7, r = e & (TILE - 1);     // mirror row = col0 + c, mirror column = row0 + r
+    if (col0 + c < tk.n && row0 + r < tk.m)
+      gstore1(tk.c + (int64_t)(col0 + c) * tk.ldc + row0 + r, st[r * SYM_TLD + c]);
+  }
+}
+
+// K-split tail tiles of a symmetric product: sum of the nks partial tiles in split order, stored as
+// the tile and as its mirror.
+struct HSymSlot { int task; short tm, tn; int nks, local; };   // local: index among its task's slots
+__global__ __launch_bounds__(256) void gemm_bf16_symtile_reduce_kernel(const HTask* tasks,
+                                                                      const HSymSlot* slots) {
+  __shared__ float st[64 * (TILE + 1)];
+  const HSymSlot sl = slots[blockIdx.x];
+  const HTask tk = tasks[sl.task];
+  const float* pt = tk.ptile + (int64_t)sl.local * sl.nks * (TILE * TILE);
+  const int row0 = sl.tm * TILE, col0 = sl.tn * TILE, tid = threadIdx.x;
+  const bool diag = sl.tm == sl.tn;
+  for (int half = 0; half < 2; ++half) {           // 64 tile rows at a time (33 KB of LDS)
+    for (int e = tid; e < 64 * TILE; e += 256) {
+      const int r = half * 64 + (e >> 7), c = e & (TILE - 1);
+      float v = 0.f;
+      int q = 0;
+      for (; q + 4 <= sl.nks; q += 4) {
+        const float p0 = pt[(int64_t)(q + 0) * TILE * TILE + r * TILE + c],
+                    p1 = pt[(int64_t)(q + 1) * TILE * TILE + r * TILE + c],
+                    p2 = pt[(int64_t)(q + 2) * TILE * TILE + r * TILE + c],
+                    p3 = pt[(int64_t)(q + 3) * TILE * TILE + r * TILE + c];
+        v = (((v + p0) + p1) + p2) + p3;
+      }
+      for (; q < sl.nks; ++q) v += pt[(int64_t)q * TILE * TILE + r * TILE + c];
+      // a diagonal tile keeps its upper triangle and mirrors it (see gemm_bf16_grouped_kernel)
+      if (row0 + r < tk.m && col0 + c < tk.n && (!diag || r <= c))
+        gstore1(tk.c + (int64_t)(row0 + r) * tk.ldc + col0 + c, v);
+      st[(e >> 7) * (TILE + 1) + c] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * TILE; e += 256) {
+      const int c = e >> 6, r = e & 63;             // mirror row = col0 + c, column = row0 + half * 64 + r
+      if (col0 + c < tk.n && row0 + half * 64 + r < tk.m && (!diag || half * 64 + r < c))
+        gstore1(tk.c + (int64_t)(col0 + c) * tk.ldc + row0 + half * 64 + r, st[r * (TILE + 1) + c]);
+    }
+    __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(256) void gemm_bf16_splitk_reduce_kernel(const HTask* tasks) {
@@ -481,13 +560,46 @@ static size_t htiles(const ps_gemm_bf16_desc* d, int count) {
   return tiles;
 }
 
+// Symmetric products (c = a a^T): the tiles with tm <= tn, diagonal ones first.  With T (T + 1) / 2
+// equal tiles on a chip that holds SYM_SLOTS of them at a time the last partial round would take as
+// long as a full one (528 tiles of a 4096^2 Gram matrix: 512 + 16), so the tiles of that round
+// -- when they are few -- are cut along k into pieces (compact partial tiles, summed and mirrored
+// by gemm_bf16_symtile_reduce_kernel): the round then takes 1 / 32 of a tile.  A product with fewer
+// tiles than slots is cut in the same way as a whole (36 tiles of a 1024^2 Gram matrix: 15 pieces each).
+constexpr int SYM_SLOTS = 512, SYM_TAIL_MAX = 64, SYM_NKS = 32;
+struct SymPlan { int64_t tiles; int tail, kc, nks; };   // the last `tail` tiles in nks pieces of kc
+static SymPlan sym_plan(int m, int k) {
+  const int T = (m + TILE - 1) / TILE;
+  SymPlan p{(int64_t)T * (T + 1) / 2, 0, k, 1};
+  int want = 1;
+  if (p.tiles < SYM_SLOTS) {
+    p.tail = (int)p.tiles;
+    want = std::min<int64_t>(SYM_NKS, (SYM_SLOTS + p.tiles - 1) / p.tiles);
+  } else if (p.tiles % SYM_SLOTS != 0 && p.tiles % SYM_SLOTS <= SYM_TAIL_MAX) {
+    p.tail = (int)(p.tiles % SYM_SLOTS);
+    want = SYM_NKS;
+  }
+  // k per piece: a multiple of HBK, at least 4 K-tiles; nks = the number of NON-EMPTY pieces
+  p.kc = std::max(4 * HBK, (int)psh::round_up((k + want - 1) / want, HBK));
+  p.nks = (k + p.kc - 1) / p.kc;
+  if (p.nks <= 1) { p.tail = 0; p.nks = 1; p.kc = k; }
+  return p;
+}
+
 static size_t hbytes(const ps_gemm_bf16_desc* d, int count) {
   const size_t tiles = htiles(d, count);
   size_t split_tiles = 0, partial = 0;
   for (int i = 0; i < count; ++i) {
-    const int s = hsplit_for(tiles, d[i].k);
-    split_tiles += (size_t)s * ((d[i].m + TILE - 1) / TILE) * ((d[i].n + TILE - 1) / TILE);
+    const int s = d[i].symmetric ? 1 : hsplit_for(tiles, d[i].k);
+    const size_t t = (size_t)((d[i].m + TILE - 1) / TILE) * ((d[i].n + TILE - 1) / TILE);
+    split_tiles += (size_t)s * t;
     if (s > 1) partial += psh::align_up((size_t)s * d[i].m * d[i].n * sizeof(float), 256) + 256;
+    if (d[i].symmetric) {
+      const SymPlan sp = sym_plan(d[i].m, d[i].k);
+      split_tiles += (size_t)sp.tail * sp.nks;
+      partial += psh::align_up((size_t)sp.tail * sp.nks * TILE * TILE * sizeof(float), 256) + 256 +
+                 4 * (psh::align_up(sizeof(HSymSlot) * sp.tail, 256) + 256);
+    }
   }
   return 4 * (psh::align_up(sizeof(HTask) * count, 256) + 256) +
          4 * (psh::align_up(sizeof(HTile) * split_tiles, 256) + 256) + partial + 1024;
@@ -503,7 +615,10 @@ extern "C" size_t ps_gemm_bf16_grouped_workspace_bytes(const ps_gemm_bf16_desc* 
 // the Chebyshev filter of the FD branch multiplies the same covariances by an iterate that is
 // rewritten in place ~12 times per round (ps_fd_filter_round_f32).
 struct HPlan {
-  struct Group { HTask* dt = nullptr; HTile* dl = nullptr; int nt = 0, ntasks = 0; bool any_split = false; };
+  struct Group {
+    HTask* dt = nullptr; HTile* dl = nullptr; int nt = 0, ntasks = 0; bool any_split = false;
+    HSymSlot* ds = nullptr; int nslots = 0; bool any_sym = false;
+  };
   Group g[4];
 };
 
@@ -514,6 +629,7 @@ static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count,
   // groups by (split of A, split of B)
   std::vector<HTask> tasks[4];
   std::vector<HTile> tiles[4];
+  std::vector<HSymSlot> slots[4];
   psh::Arena ar(workspace, workspace_bytes);
   const size_t total_tiles = htiles(desc, count);
   for (int i = 0; i < count; ++i) {
@@ -531,7 +647,34 @@ static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count,
     const int tid = (int)tasks[g].size();
     HTask t{(const uint16_t*)d.a_hi, (const uint16_t*)d.a_lo, (const uint16_t*)d.b_hi,
             (const uint16_t*)d.b_lo, d.c, d.m, d.n, d.k, d.lda, d.ldb, d.ldc, 1, d.k, nullptr,
-            d.a_tiled ? 1 : 0};
+            d.a_tiled ? 1 : 0, d.symmetric ? 1 : 0, nullptr};
+    if (d.symmetric) {
+      // c = a a^T: same planes on both sides, square output
+      if (d.m != d.n || d.a_tiled || d.b_hi != d.a_hi || d.b_lo != d.a_lo || d.ldb != d.lda)
+        return PS_EINVAL;
+      const int T = (d.m + TILE - 1) / TILE;
+      const SymPlan sp = sym_plan(d.m, d.k);
+      const int64_t nt = sp.tiles;
+      const int tail = sp.tail, kc = sp.kc, nks = sp.nks;
+      if (tail > 0) t.ptile = ar.take<float>((size_t)tail * nks * TILE * TILE);
+      tasks[g].push_back(t);
+      int64_t idx = 0;
+      const int slot0 = (int)slots[g].size();
+      auto emit = [&](int tm, int tn) {
+        if (idx >= nt - tail) {                       // the last `tail` tiles: cut along k
+          const int slot = (int)slots[g].size() - slot0;
+          slots[g].push_back({tid, (short)tm, (short)tn, nks, slot});
+          for (int ks = 0; ks < nks; ++ks) tiles[g].push_back({tid, (short)tm, (short)tn, ks, kc, nks, slot});
+        } else {
+          tiles[g].push_back({tid, (short)tm, (short)tn, 0, 0, 1, -1});
+        }
+        ++idx;
+      };
+      for (int tm = 0; tm < T; ++tm) emit(tm, tm);    // diagonal tiles first: never in the tail
+      for (int tm = 0; tm < T; ++tm)
+        for (int tn = tm + 1; tn < T; ++tn) emit(tm, tn);
+      continue;
+    }
     const int sp = hsplit_for(total_tiles, d.k);
     if (sp > 1) {
       t.kchunk = psh::round_up((d.k + sp - 1) / sp, HBK);
@@ -542,7 +685,7 @@ static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count,
     tasks[g].push_back(t);
     for (int tm = 0; tm < (d.m + TILE - 1) / TILE; ++tm)
       for (int tn = 0; tn < (d.n + TILE - 1) / TILE; ++tn)
-        for (int ks = 0; ks < t.ksplit; ++ks) tiles[g].push_back({tid, (short)tm, (short)tn, ks});
+        for (int ks = 0; ks < t.ksplit; ++ks) tiles[g].push_back({tid, (short)tm, (short)tn, ks, 0, 1, -1});
   }
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
@@ -566,7 +709,13 @@ static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count,
     PS_RC(psh::upload_async(st, gr.dl, tiles[g].data(), sizeof(HTile) * tiles[g].size()));
     gr.nt = (int)tiles[g].size();
     gr.ntasks = (int)tasks[g].size();
-    for (auto& t : tasks[g]) gr.any_split |= t.ksplit > 1;
+    for (auto& t : tasks[g]) { gr.any_split |= t.ksplit > 1; gr.any_sym |= t.sym != 0; }
+    if (!slots[g].empty()) {
+      gr.ds = ar.take<HSymSlot>(slots[g].size());
+      if (ar.overflow) return PS_EWORKSPACE;
+      PS_RC(psh::upload_async(st, gr.ds, slots[g].data(), sizeof(HSymSlot) * slots[g].size()));
+      gr.nslots = (int)slots[g].size();
+    }
   }
   return PS_OK;
 }
@@ -576,7 +725,8 @@ static int hplan_launch(hipStream_t st, const HPlan& pl) {
     const HPlan::Group& gr = pl.g[g];
     if (gr.nt == 0) continue;
     const int sa = (g & 2) ? 2 : 1, sb = (g & 1) ? 2 : 1;
-    const size_t lds = (size_t)2 * (sa + sb) * HOP * sizeof(uint16_t);  // 40 .. 80 KiB
+    size_t lds = (size_t)2 * (sa + sb) * HOP * sizeof(uint16_t);  // 40 .. 80 KiB
+    if (gr.any_sym) lds = std::max(lds, (size_t)TILE * SYM_TLD * sizeof(float));   // mirror staging
     if (g == 0)
       hipLaunchKernelGGL((gemm_bf16_grouped_kernel<1, 1>), dim3(gr.nt), dim3(256), lds, st, gr.dt, gr.dl, gr.nt);
     else if (g == 1)
@@ -588,6 +738,9 @@ static int hplan_launch(hipStream_t st, const HPlan& pl) {
     if (gr.any_split)
       hipLaunchKernelGGL(gemm_bf16_splitk_reduce_kernel, dim3((unsigned)gr.ntasks, 256), dim3(256), 0,
                          st, gr.dt);
+    if (gr.nslots > 0)
+      hipLaunchKernelGGL(gemm_bf16_symtile_reduce_kernel, dim3((unsigned)gr.nslots), dim3(256), 0, st,
+                         gr.dt, gr.ds);
     PS_LAUNCH_CHECK();
   }
   return PS_OK;

@@ -558,10 +558,11 @@ def to_bf16(x: torch.Tensor, split: bool = False, transpose: bool = False, tiled
 
 
 @_device_guarded
-def gemm_bf16_grouped(items):
+def gemm_bf16_grouped(items, symmetric=False):
   """items: list of ((a_hi, a_lo | None), (bt_hi, bt_lo | None), c): c [m, n] float32 =
   a [m, k] @ bt [n, k]^T on the bf16 MFMA with float32 accumulation (hi/lo pairs: three
-  accumulated products).  Operands are contiguous bfloat16 tensors from to_bf16."""
+  accumulated products).  Operands are contiguous bfloat16 tensors from to_bf16.  symmetric: every
+  item is c = a a^T (bt must BE a): half of the tiles are multiplied, c is bitwise symmetric."""
   if not items:
     return
   from ._lib import GemmBf16Desc
@@ -606,6 +607,10 @@ def gemm_bf16_grouped(items):
     d.b_hi, d.b_lo = b_hi.data_ptr(), (b_lo.data_ptr() if b_lo is not None else None)
     d.c, d.m, d.n, d.k = c.data_ptr(), m, n, k
     d.lda, d.ldb, d.ldc = _as_2d_ld(a_hi), _as_2d_ld(b_hi), _as_2d_ld(c)
+    if symmetric:
+      if b_hi is not a_hi or b_lo is not a_lo:
+        raise ValueError("gemm_bf16_grouped(symmetric=True): both operands must be the same tensors")
+      d.symmetric = 1
   L = lib()
   ws = _workspace(L.ps_gemm_bf16_grouped_workspace_bytes(descs, len(items)), dev)
   check(L.ps_gemm_bf16_grouped(_stream(), descs, len(items), ws.data_ptr(), ws.numel()),

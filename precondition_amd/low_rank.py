@@ -197,10 +197,11 @@ def gram_of_block(g: torch.Tensor, axis: int) -> torch.Tensor:
     gt = g if axis == 0 else g.t()
     hi, lo = kernels.to_bf16(gt.contiguous() if not gt.is_contiguous() else gt, split=True)
     out = torch.empty((d, d), dtype=torch.float32, device=g.device)
-    kernels.gemm_bf16_grouped([((hi, lo), (hi, lo), out)])
-    # hi*lo and lo*hi enter the float32 accumulation chain in a fixed order, so out is symmetric
-    # only up to rounding: its consumers (the eigensolvers) want exact symmetry
-    return torch.add(out, out.t()).mul_(0.5)
+    # the upper tile triangle only, every tile stored with its mirror image (hi*lo and lo*hi enter the
+    # float32 accumulation chain in a fixed order, so a full product would be symmetric only up to
+    # rounding: its consumers, the eigensolvers, want exact symmetry)
+    kernels.gemm_bf16_grouped([((hi, lo), (hi, lo), out)], symmetric=True)
+    return out
   zero = torch.zeros((d, d), dtype=torch.float32, device=g.device)
   out = torch.empty_like(zero)
   kernels.stats_update_grouped([(g, axis, zero, out)], 0.0, 1.0)

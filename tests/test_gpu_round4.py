@@ -362,3 +362,34 @@ def test_fd_cov_update_one_pass_equals_torch_form(bsz, n, device):
   got = K().fd_cov_update(c.clone(), grams, 0.999)
   assert torch.equal(got, got.transpose(1, 2))
   assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("d,k", [(4096, 4096), (4224, 1056), (1024, 2048), (2048, 512), (200, 64)])
+def test_symmetric_bf16_product_equals_full_product(d, k, device):
+  """gemm_bf16_grouped(symmetric=True) -- the Gram matrix of an FD gradient block -- against the full
+  product on the same hi/lo operands: the same three products per element, k summed in pieces whose
+  boundaries differ (the K-split tail round at 4096 / 4224, every tile below 512 tiles) -> float32
+  rounding of the sum; bitwise symmetric; two products in one call."""
+  gen = torch.Generator(device=device).manual_seed(d)
+  g = torch.randn((d, k), generator=gen, device=device)
+  hi, lo = K().to_bf16(g, split=True)
+  full = torch.empty((d, d), device=device)
+  K().gemm_bf16_grouped([((hi, lo), (hi, lo), full)])
+  sym = torch.full((d, d), float("nan"), device=device)
+  K().gemm_bf16_grouped([((hi, lo), (hi, lo), sym)], symmetric=True)
+  torch.cuda.synchronize()
+  assert torch.equal(sym, sym.t())
+  iu = torch.triu(torch.ones((d, d), dtype=torch.bool, device=device))
+  diff = (sym - full).abs()[iu]
+  # tiles of the K-split tail sum their k pieces in another order: float32 rounding of the sum
+  assert float(diff.max()) <= 2e-6 * float(full.abs().max()), float(diff.max())
+  ref = g.double() @ g.double().t()
+  assert float((sym.double() - ref).norm() / ref.norm()) < 2e-5
+  if d <= 2048:   # two symmetric products in ONE grouped call (each has its own partial tiles)
+    g2 = torch.randn((d, k), generator=gen, device=device)
+    hi2, lo2 = K().to_bf16(g2, split=True)
+    s1, s2 = torch.empty_like(sym), torch.empty_like(sym)
+    K().gemm_bf16_grouped([((hi, lo), (hi, lo), s1), ((hi2, lo2), (hi2, lo2), s2)], symmetric=True)
+    alone = torch.empty_like(sym)
+    K().gemm_bf16_grouped([((hi2, lo2), (hi2, lo2), alone)], symmetric=True)
+    assert torch.equal(s1, sym) and torch.equal(s2, alone)
