@@ -237,42 +237,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const HTask* 
   }
 }
 
-// K-split tail tiles of a symmetric product: sum of the nks partial tiles in split order, stored as
-// the tile and as its mirror.
+// K-split tiles of a symmetric product: sum of the nks partial tiles in split order, stored as the
+// tile and as its mirror.  SYM_RED workgroups per tile (16 tile rows each: with one workgroup per
+// tile the 16 tail tiles of a 4096^2 Gram matrix took 160 us, as long as half the product).
 struct HSymSlot { int task; short tm, tn; int nks, local; };   // local: index among its task's slots
+constexpr int SYM_RED = 8, SYM_RR = TILE / SYM_RED;
 __global__ __launch_bounds__(256) void gemm_bf16_symtile_reduce_kernel(const HTask* tasks,
                                                                       const HSymSlot* slots) {
-  __shared__ float st[64 * (TILE + 1)];
-  const HSymSlot sl = slots[blockIdx.x];
+  __shared__ float st[SYM_RR * (TILE + 1)];
+  const HSymSlot sl = slots[blockIdx.x / SYM_RED];
+  const int part = blockIdx.x % SYM_RED;
   const HTask tk = tasks[sl.task];
   const float* pt = tk.ptile + (int64_t)sl.local * sl.nks * (TILE * TILE);
   const int row0 = sl.tm * TILE, col0 = sl.tn * TILE, tid = threadIdx.x;
   const bool diag = sl.tm == sl.tn;
-  for (int half = 0; half < 2; ++half) {           // 64 tile rows at a time (33 KB of LDS)
-    for (int e = tid; e < 64 * TILE; e += 256) {
-      const int r = half * 64 + (e >> 7), c = e & (TILE - 1);
-      float v = 0.f;
-      int q = 0;
-      for (; q + 4 <= sl.nks; q += 4) {
-        const float p0 = pt[(int64_t)(q + 0) * TILE * TILE + r * TILE + c],
-                    p1 = pt[(int64_t)(q + 1) * TILE * TILE + r * TILE + c],
-                    p2 = pt[(int64_t)(q + 2) * TILE * TILE + r * TILE + c],
-                    p3 = pt[(int64_t)(q + 3) * TILE * TILE + r * TILE + c];
-        v = (((v + p0) + p1) + p2) + p3;
-      }
-      for (; q < sl.nks; ++q) v += pt[(int64_t)q * TILE * TILE + r * TILE + c];
-      // a diagonal tile keeps its upper triangle and mirrors it (see gemm_bf16_grouped_kernel)
-      if (row0 + r < tk.m && col0 + c < tk.n && (!diag || r <= c))
-        gstore1(tk.c + (int64_t)(row0 + r) * tk.ldc + col0 + c, v);
-      st[(e >> 7) * (TILE + 1) + c] = v;
+  for (int e = tid; e < SYM_RR * TILE; e += 256) {
+    const int lr = e >> 7, r = part * SYM_RR + lr, c = e & (TILE - 1);
+    const float* q0 = pt + r * TILE + c;
+    float v = 0.f;
+    int q = 0;
+    for (; q + 4 <= sl.nks; q += 4) {     // four partials in flight, summed in split order
+      const float p0 = gload1(q0 + (int64_t)(q + 0) * TILE * TILE), p1 = gload1(q0 + (int64_t)(q + 1) * TILE * TILE),
+                  p2 = gload1(q0 + (int64_t)(q + 2) * TILE * TILE), p3 = gload1(q0 + (int64_t)(q + 3) * TILE * TILE);
+      v = (((v + p0) + p1) + p2) + p3;
     }
-    __syncthreads();
-    for (int e = tid; e < 64 * TILE; e += 256) {
-      const int c = e >> 6, r = e & 63;             // mirror row = col0 + c, column = row0 + half * 64 + r
-      if (col0 + c < tk.n && row0 + half * 64 + r < tk.m && (!diag || half * 64 + r < c))
-        gstore1(tk.c + (int64_t)(col0 + c) * tk.ldc + row0 + half * 64 + r, st[r * (TILE + 1) + c]);
-    }
-    __syncthreads();
+    for (; q < sl.nks; ++q) v += gload1(q0 + (int64_t)q * TILE * TILE);
+    // a diagonal tile keeps its upper triangle and mirrors it (see gemm_bf16_grouped_kernel)
+    if (row0 + r < tk.m && col0 + c < tk.n && (!diag || r <= c))
+      gstore1(tk.c + (int64_t)(row0 + r) * tk.ldc + col0 + c, v);
+    st[lr * (TILE + 1) + c] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < SYM_RR * TILE; e += 256) {
+    const int c = e / SYM_RR, lr = e % SYM_RR, r = part * SYM_RR + lr;   // mirror row col0 + c, column row0 + r
+    if (col0 + c < tk.n && row0 + r < tk.m && (!diag || r < c))
+      gstore1(tk.c + (int64_t)(col0 + c) * tk.ldc + row0 + r, st[lr * (TILE + 1) + c]);
   }
 }
 
@@ -628,7 +627,7 @@ static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count,
   if (workspace_bytes < hbytes(desc, count)) return PS_EWORKSPACE;
   // groups by (split of A, split of B)
   std::vector<HTask> tasks[4];
-  std::vector<HTile> tiles[4];
+  std::vector<HTile> tiles[4], pieces[4];     // pieces: the K-split tiles of symmetric products
   std::vector<HSymSlot> slots[4];
   psh::Arena ar(workspace, workspace_bytes);
   const size_t total_tiles = htiles(desc, count);
@@ -664,7 +663,7 @@ static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count,
         if (idx >= nt - tail) {                       // the last `tail` tiles: cut along k
           const int slot = (int)slots[g].size() - slot0;
           slots[g].push_back({tid, (short)tm, (short)tn, nks, slot});
-          for (int ks = 0; ks < nks; ++ks) tiles[g].push_back({tid, (short)tm, (short)tn, ks, kc, nks, slot});
+          for (int ks = 0; ks < nks; ++ks) pieces[g].push_back({tid, (short)tm, (short)tn, ks, kc, nks, slot});
         } else {
           tiles[g].push_back({tid, (short)tm, (short)tn, 0, 0, 1, -1});
         }
@@ -701,6 +700,21 @@ static int hplan_build(hipStream_t st, const ps_gemm_bf16_desc* desc, int count,
   });
   for (int g = 0; g < 4; ++g) {
     if (tasks[g].empty()) continue;
+    if (!pieces[g].empty()) {
+      // xcd_remap hands list chunk x (sizes q + 1, ..., q) to XCD x in order: every chunk gets its
+      // contiguous share of the whole tiles first, then its share of the pieces, so that all XCDs
+      // finish their whole tiles together and the pieces fill the last round everywhere
+      const size_t F = tiles[g].size(), n = F + pieces[g].size();
+      std::vector<HTile> all;
+      all.reserve(n);
+      size_t fi = 0, pi = 0;
+      for (size_t x = 0; x < (size_t)psh::NXCD; ++x) {
+        const size_t sx = n / psh::NXCD + (x < n % psh::NXCD), fx = F / psh::NXCD + (x < F % psh::NXCD);
+        for (size_t i = 0; i < fx; ++i) all.push_back(tiles[g][fi++]);
+        for (size_t i = fx; i < sx; ++i) all.push_back(pieces[g][pi++]);
+      }
+      tiles[g].swap(all);
+    }
     HPlan::Group& gr = pl.g[g];
     gr.dt = ar.take<HTask>(tasks[g].size());
     gr.dl = ar.take<HTile>(tiles[g].size());
@@ -739,8 +753,8 @@ static int hplan_launch(hipStream_t st, const HPlan& pl) {
       hipLaunchKernelGGL(gemm_bf16_splitk_reduce_kernel, dim3((unsigned)gr.ntasks, 256), dim3(256), 0,
                          st, gr.dt);
     if (gr.nslots > 0)
-      hipLaunchKernelGGL(gemm_bf16_symtile_reduce_kernel, dim3((unsigned)gr.nslots), dim3(256), 0, st,
-                         gr.dt, gr.ds);
+      hipLaunchKernelGGL(gemm_bf16_symtile_reduce_kernel, dim3((unsigned)gr.nslots * SYM_RED), dim3(256),
+                         0, st, gr.dt, gr.ds);
     PS_LAUNCH_CHECK();
   }
   return PS_OK;
