@@ -386,34 +386,43 @@ def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
   tails = [float(p[1, -1]) for p in prevs]
   roof = None
   if subspace._filter_precision(d) != "f32" and not SELFTEST:
-    # the dominant kernel: one C @ Y product of the filter for all factors (HBM-bound: the
-    # covariance is read once as a bf16 hi/lo pair = 4 bytes per element, for b = 96 columns)
+    # the dominant kernel: one step of the Chebyshev filter for all factors in ONE launch
+    # (ps_fd_cy_step_f32: z = C y on bf16 hi/lo operands, the recurrence, the next bf16 operand).
+    # HBM-bound: the covariance is read once as a hi/lo pair = 4 bytes per element, for b = 96
+    # columns; y, y_prev, y_next (float32) and the iterate planes in and out are 20 bytes per
+    # element of the [d, b] block
     from precondition_amd import kernels as K
     b = 96
-    cs = [torch.randn((d, d), generator=gen, device=dev) for _ in range(factors)]
-    tiled = os.environ.get("PS_FD_TILED", "1") != "0"   # the layout subspace.py uses
-    c16 = [K.to_bf16(c, split=True, tiled=tiled) for c in cs]
-    y = torch.randn((factors * d, b), generator=gen, device=dev)
-    z = torch.empty((factors, d, b), device=dev)
-    yt = K.to_bf16(y, split=True, transpose=True)
-    items = [(c16[j] if tiled else (c16[j][0], c16[j][1]),
-              (yt[0][:, j * d:(j + 1) * d], yt[1][:, j * d:(j + 1) * d]),
-              z[j]) for j in range(factors)]
-    K.gemm_bf16_grouped(items); _sync()
+    c16 = []
+    for _ in range(factors):
+      c = torch.randn((d, d), generator=gen, device=dev)
+      c16.append(K.to_bf16(c, split=True, tiled="frag"))
+      del c
+    y = torch.randn((factors, d, b), generator=gen, device=dev)
+    y_prev = torch.randn((factors, d, b), generator=gen, device=dev)
+    z = torch.randn((factors, d, b), generator=gen, device=dev)
+    y1, out = torch.empty_like(y), torch.empty_like(y)
+    params = torch.tensor([[0.4, 0.5, 0.3, 12.0]] * factors, device=dev)
+    yt = K.fd_filter_step(z, y, None, y1, params, 1, frag=True)
+    nt = (torch.empty_like(yt[0]), torch.empty_like(yt[1]))
+    for _ in range(3):
+      K.fd_cy_step(c16, yt, y, y_prev, out, nt, params, 3)
+    _sync()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-      K.gemm_bf16_grouped(items)
+      K.fd_cy_step(c16, yt, y, y_prev, out, nt, params, 3)
     e1.record(); _sync()
     ms = e0.elapsed_time(e1) / 10
-    nbytes = factors * (4.0 * d * d + 4.0 * d * b + 4.0 * d * b)   # C (hi+lo), Y^T (hi+lo), Z
-    roof = {"kernel": "gemm_bf16_grouped_kernel (+ split-K reduce): Z = C @ Y, hi/lo operands",
+    nbytes = factors * (4.0 * d * d + 20.0 * d * b)
+    roof = {"kernel": "fd_cy_step_kernel: one filter step (z = C y on hi/lo bf16 operands + recurrence "
+                      "+ next operand) for all factors in one launch",
             "bound": "hbm", "peak": 8000, "unit": "GB/s",
             "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
             "frac": round(nbytes / (ms * 1e-3) / 1e9 / 8000, 4),
-            "ms_per_product_all_factors": round(ms, 4),
+            "ms_per_step_all_factors": round(ms, 4),
             "equiv_bf16x3_tflops": round(factors * 3 * 2.0 * d * d * b / (ms * 1e-3) / 1e12, 1)}
-    del cs, c16, y, z, yt, items
+    del c16, y, y_prev, z, y1, out, yt, nt
   return {"workload": f"{factors} factors of dim {d}, rank {rank}, {updates} FD updates from a "
                       "zero sketch, grad blocks ~N(0,1) [4096x4096], fp32",
           "products": subspace._filter_precision(d),

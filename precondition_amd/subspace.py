@@ -189,6 +189,7 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   bsz = len(mats)
   n = int(mats[0].shape[0])
   dev = mats[0].device
+  degree = int(os.environ.get("PS_FD_DEGREE", degree))   # dev: cap of the per-factor filter degree
   b = min(n, ((k + oversample + 31) // 32) * 32)
   c = [m if m.is_contiguous() else m.contiguous() for m in mats]
   mode = _filter_precision(n)
