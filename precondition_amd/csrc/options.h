@@ -34,6 +34,7 @@ struct Options {
   int wg_per_cu = 0;               // PS_NEWTON_WG_PER_CU
   bool newton_prof = false;        // PS_NEWTON_PROF
   const char* newton_trace = nullptr;  // PS_NEWTON_TRACE=<file>
+  int stagger = -1;                // PS_NEWTON_STAGGER: -1 = auto (25 us when every tile of a launch has K >= 1024), 0 = off, else (mode << 16) | microseconds (dev)
   int avg_lpt = 0;                 // PS_NEWTON_AVG_LPT: two-pass tiles first in averaged launches (measured: +1 % time)
   int eigh_small = 1;              // PS_EIGH_SMALL
   int eigh_small_refresh = 1;      // PS_EIGH_SMALL_REFRESH

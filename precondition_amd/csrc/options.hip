@@ -37,6 +37,7 @@ void ps_dev_env_overrides(Options& o) {
   geti("PS_NEWTON_GRID", o.grid_cap);
   geti("PS_NEWTON_WG_PER_CU", o.wg_per_cu);
   geti("PS_NEWTON_AVG_LPT", o.avg_lpt);
+  geti("PS_NEWTON_STAGGER", o.stagger);
   o.newton_prof = getenv("PS_NEWTON_PROF") != nullptr;
   o.newton_trace = getenv("PS_NEWTON_TRACE");
   geti("PS_EIGH_SMALL", o.eigh_small);
