@@ -590,6 +590,17 @@ int ps_fd_cy_step_f32(void* stream, const void* const* c_hi, const void* const* 
                       const void* yt_hi, const void* yt_lo, const float* y, const float* y_prev,
                       float* y_next, void* nt_hi, void* nt_lo, const float* params, int step,
                       int64_t n, int64_t b);
+/* ps_fd_cx6_f32: z_j = C_j x_j to float32 accuracy on the bf16 MFMA (the Rayleigh-Ritz product of the
+ * subspace iteration): both operands as THREE bf16 planes (v = p0 + p1 + p2) and the six products above
+ * 2^-24, float32 accumulation.  c0 / c1 / c2: HOST arrays of `batch` <= 16 device pointers to the
+ * fragment-major planes of the covariances (ps_convert_f32_to_bf16x3_frag; p0 / p1 are the hi / lo planes
+ * of ps_convert_f32_to_bf16 mode 3); x, z: [batch][n][b] float32; xt0..2: scratch of batch * n * b bf16
+ * each (the planes of x, written by the call).  n % 128 == 0, b in {32, 64, 96}. */
+int ps_convert_f32_to_bf16x3_frag(void* stream, const float* src, void* p0, void* p1, void* p2,
+                                  int64_t rows, int64_t cols, int64_t lds);
+int ps_fd_cx6_f32(void* stream, const void* const* c0, const void* const* c1, const void* const* c2,
+                  int batch, const float* x, float* z, void* xt0, void* xt1, void* xt2, int64_t n,
+                  int64_t b);
 int ps_fd_filter_round_f32(void* stream, const ps_gemm_bf16_desc* desc, int batch, float* z,
                            float* y0, float* y1, float* y2, void* yt_hi, void* yt_lo,
                            const float* params, int max_degree, int64_t n, int64_t b, int64_t ldt,

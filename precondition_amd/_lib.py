@@ -266,6 +266,11 @@ _SIGNATURES = {
         (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_int, C.c_int64, C.c_int64]),
+    "ps_convert_f32_to_bf16x3_frag":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "ps_fd_cx6_f32":
+        (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "ps_fd_filter_round_f32":
         (C.c_int, [C.c_void_p, C.POINTER(GemmBf16Desc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64,

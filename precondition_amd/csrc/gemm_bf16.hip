@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_splitk_reduce_kernel(const HTas
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* src, uint16_t* hi,
                                                        uint16_t* lo, int rows, int cols,
                                                        int64_t lds, int64_t ldd, int transpose,
-                                                       int tiles_c) {
+                                                       int tiles_c, uint16_t* lo2 = nullptr) {
   __shared__ float t[64][65];
   const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
   const int r0 = tr * 64, c0 = tc * 64, tid = threadIdx.x;
@@ -317,7 +317,12 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* src, uint16_
       const float x = t[sub * 32 + (ln & 31)][kk * 16 + (ln >> 5) * 8 + ki];
       const __bf16 h = (__bf16)x;
       hi[base + e] = __builtin_bit_cast(uint16_t, h);
-      if (lo != nullptr) lo[base + e] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+      if (lo != nullptr) {
+        const __bf16 l = (__bf16)(x - (float)h);
+        lo[base + e] = __builtin_bit_cast(uint16_t, l);
+        // third plane of the six-product form (ps_fd_cx6_f32): x = hi + lo + lo2 to float32 accuracy
+        if (lo2 != nullptr) lo2[base + e] = __builtin_bit_cast(uint16_t, (__bf16)((x - (float)h) - (float)l));
+      }
     }
     return;
   }
@@ -513,7 +518,166 @@ __global__ __launch_bounds__(256, 2) void fd_cy_step_kernel(const FdCyArgs a) {
   }
 }
 
+
+// ---- Z = C X to float32 accuracy on the bf16 MFMA (the Rayleigh-Ritz product of the FD branch) -----
+// Both operands as THREE bf16 planes (x = p0 + p1 + p2, 8 + 8 + 8 mantissa bits) and the six products
+// whose weight is above 2^-24: p2 q0 + p1 q1 + p0 q2 + p1 q0 + p0 q1 + p0 q0 (smallest first), float32
+// accumulation -- the arithmetic of the Newton path's bf16x6 mode (gemm_bf16x.hip.h).  Same structure
+// as fd_cy_step_kernel (fragment-major planes, no LDS in the K loop): the float32 MFMA product it
+// replaces is bound by the float32 matrix rate (0.39 ms for 8 x 4096^2 @ 4096 x 96), this one by the
+// 6 bytes per element of C it streams.
+struct FdCx6Args {
+  const uint16_t* a[3][16];
+  const uint16_t* bt[3];
+  float* z;
+  int n, nwg;
+};
+
+// x [B][n][b] float32 -> three fragment-major planes (the Y^T layout of fd_cy_step_kernel)
+template <int CB>
+__global__ __launch_bounds__(256) void fd_split3_frag_kernel(const float* x, uint16_t* p0, uint16_t* p1,
+                                                             uint16_t* p2, int n) {
+  constexpr int B = CB * 32, ZLD = B + 1;
+  __shared__ float t[64 * ZLD];
+  const int per = n >> 6, j = blockIdx.x / per, rb = blockIdx.x % per, r0 = rb * 64, tid = threadIdx.x;
+  const int64_t fb = (int64_t)j * n * B, blk = fb + (int64_t)r0 * B;
+  for (int q = tid; q < 64 * B / 4; q += 256) {
+    const f32x4 v = gload4(x + blk + 4 * q);
+    float* d = t + ((q * 4) / B) * ZLD + (q * 4) % B;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  __syncthreads();
+  for (int it = tid; it < 4 * CB * 64; it += 256) {
+    const int ln = it & 63, cb = (it >> 6) % CB, kk = (it >> 6) / CB;
+    const float* col = t + (kk * 16 + (ln >> 5) * 8) * ZLD + cb * 32 + (ln & 31);
+    u32x4 w0, w1, w2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned u0 = 0, u1 = 0, u2 = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float v = col[(2 * i + h) * ZLD];
+        const __bf16 a = (__bf16)v;
+        const __bf16 bb = (__bf16)(v - (float)a);
+        const __bf16 c = (__bf16)((v - (float)a) - (float)bb);
+        u0 |= (unsigned)__builtin_bit_cast(uint16_t, a) << (16 * h);
+        u1 |= (unsigned)__builtin_bit_cast(uint16_t, bb) << (16 * h);
+        u2 |= (unsigned)__builtin_bit_cast(uint16_t, c) << (16 * h);
+      }
+      w0[i] = u0; w1[i] = u1; w2[i] = u2;
+    }
+    const int64_t o = fb + ((int64_t)((r0 >> 4) + kk) * CB + cb) * 512 + ln * 8;
+    *(u32x4 PS_GLOBAL*)(p0 + o) = w0;
+    *(u32x4 PS_GLOBAL*)(p1 + o) = w1;
+    *(u32x4 PS_GLOBAL*)(p2 + o) = w2;
+  }
+}
+
+template <int CB>
+__global__ __launch_bounds__(256, 2) void fd_cx6_kernel(const FdCx6Args a) {
+  constexpr int B = CB * 32, ZLD = B + 1, NQ = 64 * B / 4 / 256;
+  __shared__ float zt[2][64 * ZLD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = a.n >> 6;
+  const int t = xcd_remap(blockIdx.x, a.nwg);
+  const int j = t / per, rb = t % per, r0 = rb * 64;
+  const int64_t fb = (int64_t)j * a.n * B, blk = fb + (int64_t)r0 * B;
+  const int nkk = a.n >> 4, cnt = nkk >> 2;
+  const uint16_t* pa[3];
+  const uint16_t* pb[3];
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    pa[pl] = a.a[pl][j] + ((int64_t)rb * nkk * 128 + lane) * 8;
+    pb[pl] = a.bt[pl] + fb + lane * 8;
+  }
+  u32x4 ra[2][3][2], rb_[2][3][CB];
+  auto load_set = [&](int s, int i) {
+    const int kk = w + 4 * i;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      ra[s][pl][0] = gload16_nt(pa[pl] + (int64_t)kk * 1024);
+      ra[s][pl][1] = gload16_nt(pa[pl] + (int64_t)kk * 1024 + 512);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) rb_[s][pl][cb] = gload16(pb[pl] + (int64_t)(kk * CB + cb) * 512);
+  };
+  f32x16 acc[2][CB];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[sub][cb][r] = 0.f;
+  auto compute = [&](int s) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const bf16x8 a0 = __builtin_bit_cast(bf16x8, ra[s][0][sub]);
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, ra[s][1][sub]);
+      const bf16x8 a2 = __builtin_bit_cast(bf16x8, ra[s][2][sub]);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, rb_[s][0][cb]);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, rb_[s][1][cb]);
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, rb_[s][2][cb]);
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[sub][cb], 0, 0, 0);
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[sub][cb], 0, 0, 0);
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[sub][cb], 0, 0, 0);
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[sub][cb], 0, 0, 0);
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[sub][cb], 0, 0, 0);
+        acc[sub][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[sub][cb], 0, 0, 0);
+      }
+    }
+  };
+  load_set(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_set(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < cnt - 2; i += 2) {
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_set(0, i + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_set(1, i + 3);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  compute(0);
+  compute(1);
+  for (int p = 0; p < 2; ++p) {
+    if ((w >> 1) == p) {
+      float* zw = zt[w & 1];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float* q = zw + row * ZLD + cb * 32 + (lane & 31);
+            *q = p == 0 ? acc[sub][cb][r] : *q + acc[sub][cb][r];
+          }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int q = tid + 256 * qi;
+    const int r = (q * 4) / B, c = (q * 4) % B;
+    const float* zr = zt[0] + r * ZLD + c;
+    const float* zs = zt[1] + r * ZLD + c;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = zr[i] + zs[i];
+    *(f32x4 PS_GLOBAL*)(a.z + blk + 4 * q) = v;
+  }
+}
+
 }  // namespace psk
+
 
 
 using namespace psk;
@@ -799,6 +963,57 @@ extern "C" int ps_fd_cy_step_f32(void* stream, const void* const* c_hi, const vo
   if (b == 96) hipLaunchKernelGGL((fd_cy_step_kernel<3>), dim3(a.nwg), dim3(256), 0, st, a);
   else if (b == 64) hipLaunchKernelGGL((fd_cy_step_kernel<2>), dim3(a.nwg), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((fd_cy_step_kernel<1>), dim3(a.nwg), dim3(256), 0, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_convert_f32_to_bf16x3_frag(void* stream, const float* src, void* p0, void* p1, void* p2,
+                                             int64_t rows, int64_t cols, int64_t lds) {
+  PS_DEVICE_CHECK();
+  if (!src || !p0 || !p1 || !p2 || rows < 1 || cols < 1 || lds < cols) return PS_EINVAL;
+  if (rows % 64 != 0 || cols % 64 != 0) return PS_EUNSUPPORTED;
+  const int64_t tr = rows / 64, tc = cols / 64;
+  if (tr * tc > 0x7fffffff) return PS_EUNSUPPORTED;
+  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)(tr * tc)), dim3(256), 0, (hipStream_t)stream, src,
+                     (uint16_t*)p0, (uint16_t*)p1, (int)rows, (int)cols, lds, cols, 3, (int)tc,
+                     (uint16_t*)p2);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_fd_cx6_f32(void* stream, const void* const* c0, const void* const* c1,
+                             const void* const* c2, int batch, const float* x, float* z, void* xt0,
+                             void* xt1, void* xt2, int64_t n, int64_t b) {
+  PS_DEVICE_CHECK();
+  if (!c0 || !c1 || !c2 || batch < 1 || !x || !z || !xt0 || !xt1 || !xt2 || x == z) return PS_EINVAL;
+  if (batch > 16 || n < 128 || n % 128 != 0 || b % 32 != 0 || b < 32 || b > 96 ||
+      (int64_t)batch * (n / 64) > 0x7fffffff)
+    return PS_EUNSUPPORTED;
+  FdCx6Args a{};
+  for (int j = 0; j < batch; ++j) {
+    const void* p[3] = {c0[j], c1[j], c2[j]};
+    for (int pl = 0; pl < 3; ++pl) {
+      if (!p[pl] || ((uintptr_t)p[pl] % 16) != 0) return PS_EINVAL;
+      a.a[pl][j] = (const uint16_t*)p[pl];
+    }
+  }
+  if (((uintptr_t)x % 16) != 0 || ((uintptr_t)z % 16) != 0 || ((uintptr_t)xt0 % 16) != 0 ||
+      ((uintptr_t)xt1 % 16) != 0 || ((uintptr_t)xt2 % 16) != 0)
+    return PS_EUNSUPPORTED;
+  a.bt[0] = (const uint16_t*)xt0; a.bt[1] = (const uint16_t*)xt1; a.bt[2] = (const uint16_t*)xt2;
+  a.z = z; a.n = (int)n; a.nwg = (int)(batch * (n / 64));
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(a.nwg), blk(256);
+  if (b == 96) {
+    hipLaunchKernelGGL((fd_split3_frag_kernel<3>), grid, blk, 0, st, x, (uint16_t*)xt0, (uint16_t*)xt1, (uint16_t*)xt2, (int)n);
+    hipLaunchKernelGGL((fd_cx6_kernel<3>), grid, blk, 0, st, a);
+  } else if (b == 64) {
+    hipLaunchKernelGGL((fd_split3_frag_kernel<2>), grid, blk, 0, st, x, (uint16_t*)xt0, (uint16_t*)xt1, (uint16_t*)xt2, (int)n);
+    hipLaunchKernelGGL((fd_cx6_kernel<2>), grid, blk, 0, st, a);
+  } else {
+    hipLaunchKernelGGL((fd_split3_frag_kernel<1>), grid, blk, 0, st, x, (uint16_t*)xt0, (uint16_t*)xt1, (uint16_t*)xt2, (int)n);
+    hipLaunchKernelGGL((fd_cx6_kernel<1>), grid, blk, 0, st, a);
+  }
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -514,8 +514,9 @@ class TiledBf16:
   ceil(rows / 128) * 128 * cols elements); layout 2: fragment-major (fd_filter_round / fd_cy_step:
   the kilobyte one MFMA consumes is contiguous; rows * cols elements, both multiples of 64)."""
 
-  def __init__(self, hi, lo, rows, cols, layout=1):
+  def __init__(self, hi, lo, rows, cols, layout=1, lo2=None):
     self.hi, self.lo, self.rows, self.cols, self.layout = hi, lo, rows, cols, layout
+    self.lo2 = lo2      # third plane (x = hi + lo + lo2 to float32 accuracy): to_bf16(..., tiled="frag3")
 
 
 @_device_guarded
@@ -528,6 +529,14 @@ def to_bf16(x: torch.Tensor, split: bool = False, transpose: bool = False, tiled
   if x.dim() != 2:
     raise ValueError("to_bf16 expects a 2-D tensor")
   r, c = int(x.shape[0]), int(x.shape[1])
+  if tiled == "frag3":   # fragment-major hi / lo / lo2 (the six-product form of fd_cx6)
+    if transpose or not split or c % 64 != 0 or r % 64 != 0:
+      raise ValueError("fragment-major bf16 operands: split, no transpose, rows and columns multiples of 64")
+    p = [torch.empty((r * c,), dtype=torch.bfloat16, device=x.device) for _ in range(3)]
+    rc = lib().ps_convert_f32_to_bf16x3_frag(_stream(), x.data_ptr(), p[0].data_ptr(), p[1].data_ptr(),
+                                             p[2].data_ptr(), r, c, _as_2d_ld(x))
+    check(rc, "ps_convert_f32_to_bf16x3_frag")
+    return TiledBf16(p[0], p[1], r, c, layout=2, lo2=p[2])
   if tiled == "frag":
     if transpose or c % 64 != 0 or r % 64 != 0:
       raise ValueError("fragment-major bf16 operands: no transpose, rows and columns multiples of 64")
@@ -755,6 +764,29 @@ def fd_cy_step(c16, yt, y, y_prev, y_next, nt, params, step):
                                int(step), n, b)
   check(rc, "ps_fd_cy_step_f32")
   return y_next
+
+
+@_device_guarded
+def fd_cx6(c16, x, z, scratch=None):
+  """z[j] = C_j @ x[j] to float32 accuracy on the bf16 MFMA (ps_fd_cx6_f32: three bf16 planes per
+  operand, six products).  c16: covariances from to_bf16(..., tiled="frag3"); x, z: [B, n, b] float32;
+  scratch: optional 3 reusable bfloat16 buffers of B * n * b elements."""
+  bsz, n, b = (int(v) for v in x.shape)
+  for t in (x, z):
+    _require_gpu(t, "fd_cx6")
+    if tuple(t.shape) != (bsz, n, b) or not t.is_contiguous() or t.dtype != torch.float32:
+      raise ValueError("fd_cx6 expects contiguous float32 [B, n, b] tensors")
+  if scratch is None:
+    scratch = [torch.empty((bsz * n * b,), dtype=torch.bfloat16, device=x.device) for _ in range(3)]
+  p0, p1, p2 = ((C.c_void_p * bsz)() for _ in range(3))
+  for j, a in enumerate(c16):
+    if not isinstance(a, TiledBf16) or a.layout != 2 or a.lo is None or a.lo2 is None or a.rows != n or a.cols != n:
+      raise ValueError("fd_cx6: covariances must be fragment-major three-plane operands of shape [n, n]")
+    p0[j], p1[j], p2[j] = a.hi.data_ptr(), a.lo.data_ptr(), a.lo2.data_ptr()
+  rc = lib().ps_fd_cx6_f32(_stream(), p0, p1, p2, bsz, x.data_ptr(), z.data_ptr(), scratch[0].data_ptr(),
+                           scratch[1].data_ptr(), scratch[2].data_ptr(), n, b)
+  check(rc, "ps_fd_cx6_f32")
+  return z
 
 
 @_device_guarded

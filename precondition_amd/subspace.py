@@ -105,11 +105,15 @@ class _Planned:
   and launched ~6 times (PS_FD_PLANS=0 restores the per-product table building).  Same kernels,
   same operands, same order: bit-identical results."""
 
-  def __init__(self, c, x, z, tmp):
+  def __init__(self, c, x, z, tmp, c16x6=None):
     K = _K()
     bsz, n, b = x.shape
     dev = x.device
     self.c, self.x, self.z, self.tmp = c, x, z, tmp
+    self.c16x6 = c16x6      # three-plane fragment-major covariances: C x of Rayleigh-Ritz by fd_cx6
+    self.x6_scratch = None
+    if c16x6 is not None:
+      self.x6_scratch = [torch.empty((bsz * n * b,), dtype=torch.bfloat16, device=dev) for _ in range(3)]
     mk = lambda: torch.empty((bsz, b, b), dtype=torch.float32, device=dev)
     self.gram, self.m, self.polish, self.t, self.y = mk(), mk(), mk(), mk(), mk()
     self.eye = torch.eye(b, dtype=torch.float32, device=dev)
@@ -140,7 +144,10 @@ class _Planned:
     return self.x
 
   def rayleigh_ritz(self):
-    self.p_cx.launch()
+    if self.c16x6 is not None:   # z = C x on the bf16 MFMA, three planes per operand: float32 accuracy
+      _K().fd_cx6(self.c16x6, self.x, self.z, self.x6_scratch)
+    else:
+      self.p_cx.launch()
     self.p_xtz.launch()
     theta, y = _small_eigh_desc(self.t)
     self.y.copy_(y)
@@ -201,7 +208,8 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
     # first is then ONE launch -- product, recurrence and the next bf16 operand (ps_fd_cy_step_f32)
     if (tiled and mode == "bf16x3" and _fused_filter() and _K().fd_frag_supported(bsz, n, b) and
         os.environ.get("PS_FD_ROUND_CALL", "1") != "0" and os.environ.get("PS_FD_FRAG", "1") != "0"):
-      tiled = "frag"
+      # + a third plane: the float32-accurate C x of Rayleigh-Ritz runs on the bf16 MFMA as well
+      tiled = "frag3" if os.environ.get("PS_FD_RR_X6", "1") != "0" else "frag"
     c16 = [_K().to_bf16(m, split=True, tiled=tiled) for m in c]
 
   def filter_product(y, z, plain):
@@ -222,7 +230,8 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   x = torch.randn((bsz, n, b), generator=gen, device=dev, dtype=torch.float32)
   z = torch.empty_like(x)
   tmp = torch.empty_like(x)
-  planned = _Planned(c, x, z, tmp) if os.environ.get("PS_FD_PLANS", "1") != "0" else None
+  x6 = c16 if (c16 is not None and tiled == "frag3") else None
+  planned = _Planned(c, x, z, tmp, c16x6=x6) if os.environ.get("PS_FD_PLANS", "1") != "0" else None
   if planned is not None:
     x = planned.orthonormalize()
     theta, res = planned.rayleigh_ritz()

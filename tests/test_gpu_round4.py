@@ -393,3 +393,30 @@ def test_symmetric_bf16_product_equals_full_product(d, k, device):
     alone = torch.empty_like(sym)
     K().gemm_bf16_grouped([((hi2, lo2), (hi2, lo2), alone)], symmetric=True)
     assert torch.equal(s1, sym) and torch.equal(s2, alone)
+
+
+@pytest.mark.parametrize("bsz,n,b", [(2, 512, 96), (1, 256, 64), (8, 1024, 96)])
+def test_six_product_cx_has_float32_accuracy(bsz, n, b, device):
+  """ps_fd_cx6_f32 (C x of the Rayleigh-Ritz step on three bf16 planes per operand) against float64:
+  as close as the float32 MFMA product it replaces, and the hi / lo planes of the three-plane
+  conversion are those of the two-plane one."""
+  gen = torch.Generator(device=device).manual_seed(7 * n)
+  cs = []
+  for j in range(bsz):
+    g = torch.randn((n, n // 2), generator=gen, device=device)
+    cs.append((g @ g.T) / n)
+  x = torch.randn((bsz, n, b), generator=gen, device=device)
+  c3 = [K().to_bf16(c, split=True, tiled="frag3") for c in cs]
+  c2 = K().to_bf16(cs[0], split=True, tiled="frag")
+  assert torch.equal(c3[0].hi, c2.hi) and torch.equal(c3[0].lo, c2.lo)
+  rec = c3[0].hi.float() + c3[0].lo.float() + c3[0].lo2.float()
+  idx = _frag_index_a(n, n).to(device).reshape(-1)
+  assert float((rec[idx].view(n, n) - cs[0]).abs().max()) <= 2.0 ** -22 * float(cs[0].abs().max())
+  z = torch.empty_like(x)
+  K().fd_cx6(c3, x, z)
+  z32 = torch.stack([cs[j] @ x[j] for j in range(bsz)])
+  ref = torch.stack([cs[j].double() @ x[j].double() for j in range(bsz)])
+  e6 = float((z.double() - ref).norm() / ref.norm())
+  e32 = float((z32.double() - ref).norm() / ref.norm())
+  print(f"n={n}: six-product {e6:.2e}  float32 {e32:.2e}")
+  assert e6 <= 3e-7 and e6 <= 3.0 * e32 + 1e-7
