@@ -619,6 +619,33 @@ int ps_fd_round_control_f32(void* stream, const float* theta, const float* res, 
  * one pass (the result is bitwise symmetric). */
 int ps_fd_cov_update_f32(void* stream, float* c, const float* const* gram, int batch, int64_t n,
                          float decay);
+/* ps_fd_round_f32: everything of one outer round of the subspace iteration that is not the filter,
+ * in ONE call (precondition_amd/subspace.py _Planned; ~35 launches that the Python host issued one by
+ * one):  [orthonormalize != 0:  G = X^T X;  M = R^-1 (ps_chol_rinv_batched_f32, drop 1e-10);  T = X M;
+ * G = T^T T;  P = 1.5 I - 0.5 G;  X = T P]   Z = C X (c0 given: ps_fd_cx6_f32, else the plan cx);
+ * T = X^T Z;  (theta, Y) = eigenpairs of (T + T^T) / 2, descending;  X <- X Y;  Z <- Z Y;
+ * res[j][i] = || z_i - theta_i x_i ||;  ps_fd_round_control_f32(theta, res).
+ * The eight products are plans of ps_gemm_grouped_plan_create on exactly these buffers:
+ *   gram_x: gram = x^T x    xm: tmp = x m     gram_t: gram = tmp^T tmp    pol: x = tmp polish
+ *   cx: z = C x             xtz: t = x^T z    xy: tmp = x y               zy: tmp = z y
+ * b <= ps_chol_rinv_max_n().  sym, evals, evecs: scratch of batch*b*b, batch*b, batch*b*b floats;
+ * eigh_workspace: ps_eigh_root_workspace_bytes(batch, {b, ...}).  Only enqueues. */
+typedef struct {
+  const ps_gemm_plan* gram_x; const ps_gemm_plan* xm; const ps_gemm_plan* gram_t; const ps_gemm_plan* pol;
+  const ps_gemm_plan* cx; const ps_gemm_plan* xtz; const ps_gemm_plan* xy; const ps_gemm_plan* zy;
+  const void* const* c0; const void* const* c1; const void* const* c2;   /* HOST arrays, or all NULL */
+  void* xt0; void* xt1; void* xt2;                                       /* scratch of ps_fd_cx6_f32 */
+  float* x; float* z; float* tmp;                                        /* [batch][n][b] */
+  float* gram; float* m; float* polish; float* t; float* y; float* sym;  /* [batch][b][b] */
+  float* evals; float* evecs;                                            /* [batch][b], [batch][b][b] */
+  float* theta; float* res;                                              /* [batch][b] */
+  void* eigh_workspace; size_t eigh_workspace_bytes;
+  float* params; int32_t* converged; int32_t* summary;                   /* ps_fd_round_control_f32 */
+  int32_t batch, n, b, k, degree, orthonormalize;
+  float tol;
+  int32_t reserved;
+} ps_fd_round_desc;
+int ps_fd_round_f32(void* stream, const ps_fd_round_desc* d);
 int ps_chol_rinv_max_n(void);
 int ps_chol_rinv_batched_f32(void* stream, const float* gram, float* out, int b, int batch,
                              float drop_rel);

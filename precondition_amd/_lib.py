@@ -55,6 +55,18 @@ class GemmBf16Desc(C.Structure):
               ("a_tiled", C.c_int32), ("symmetric", C.c_int32)]
 
 
+class FdRoundDesc(C.Structure):
+  """Mirror of ps_fd_round_desc."""
+  _fields_ = ([(n, C.c_void_p) for n in ("gram_x", "xm", "gram_t", "pol", "cx", "xtz", "xy", "zy",
+                                          "c0", "c1", "c2", "xt0", "xt1", "xt2", "x", "z", "tmp",
+                                          "gram", "m", "polish", "t", "y", "sym", "evals", "evecs",
+                                          "theta", "res", "eigh_workspace")] +
+              [("eigh_workspace_bytes", C.c_size_t)] +
+              [(n, C.c_void_p) for n in ("params", "converged", "summary")] +
+              [(n, C.c_int32) for n in ("batch", "n", "b", "k", "degree", "orthonormalize")] +
+              [("tol", C.c_float), ("reserved", C.c_int32)])
+
+
 class TransformDesc(C.Structure):
   """Mirror of ps_transform_desc."""
   _fields_ = [(n, C.c_void_p) for n in ("grad", "pgrad", "param", "diag_in", "diag_out",
@@ -280,6 +292,7 @@ _SIGNATURES = {
                    C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ps_fd_cov_update_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_float]),
+    "ps_fd_round_f32": (C.c_int, [C.c_void_p, C.POINTER(FdRoundDesc)]),
     "ps_chol_rinv_max_n": (C.c_int, []),
     "ps_chol_rinv_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]),

@@ -241,6 +241,63 @@ __global__ __launch_bounds__(256) void fd_cov_update_kernel(const CovArgs a) {
   }
 }
 
+// ---- small kernels of ps_fd_round_f32 (the b x b / n x b glue of one outer round) ----------------
+// one thread per element of the [batch][b][b] arrays (grid = batch * ceil(b * b / 256))
+// which 0: polish = 1.5 I - 0.5 gram;  1: sym = (t + t^T) / 2;
+// 2: eigenpairs ascending (eigh_small_kernel) -> descending: theta[i] = evals[b-1-i], y[:, i] = evecs[:, b-1-i]
+__global__ __launch_bounds__(256) void fd_bb_kernel(const float* in, const float* in2, float* out,
+                                                    float* out2, int b, int which, int per) {
+  const int j = blockIdx.x / per, e = (blockIdx.x % per) * 256 + threadIdx.x;
+  if (e >= b * b) return;
+  const int64_t base = (int64_t)j * b * b;
+  const int r = e / b, c = e % b;
+  if (which == 0) {
+    const float h = -0.5f * in[base + e];
+    out[base + e] = (r == c ? 1.5f : 0.f) + h;
+  } else if (which == 1) {
+    out[base + e] = 0.5f * (in[base + e] + in[base + (int64_t)c * b + r]);
+  } else {
+    out[base + e] = in[base + (int64_t)r * b + (b - 1 - c)];
+    if (r == 0) out2[(int64_t)j * b + c] = in2[(int64_t)j * b + (b - 1 - c)];
+  }
+}
+// res[j][c] = || z[j][:, c] - theta[j][c] x[j][:, c] ||_2 in two launches: partial sums of squares over
+// FD_RCH row chunks (one workgroup per factor, 32 columns and chunk), then the chunks in order
+constexpr int FD_RCH = 32;
+__global__ __launch_bounds__(256) void fd_resnorm_part_kernel(const float* x, const float* z,
+                                                              const float* theta, float* part, int n,
+                                                              int b) {
+  __shared__ float sh[8][33];
+  const int cbs = (b + 31) / 32;
+  const int ch = blockIdx.x % FD_RCH, cb = (blockIdx.x / FD_RCH) % cbs, j = blockIdx.x / (FD_RCH * cbs);
+  const int c = cb * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  const int rows = (n + FD_RCH - 1) / FD_RCH, r0 = ch * rows, r1 = min(n, r0 + rows);
+  const int64_t base = (int64_t)j * n * b;
+  float acc = 0.f;
+  if (c < b) {
+    const float th = theta[(int64_t)j * b + c];
+    for (int r = r0 + rg; r < r1; r += 8) {
+      const float dlt = gload1(z + base + (int64_t)r * b + c) - gload1(x + base + (int64_t)r * b + c) * th;
+      acc += dlt * dlt;
+    }
+  }
+  sh[rg][threadIdx.x & 31] = acc;
+  __syncthreads();
+  if (rg == 0 && c < b) {
+    float s0 = 0.f;
+    for (int g = 0; g < 8; ++g) s0 += sh[g][threadIdx.x & 31];
+    part[((int64_t)j * FD_RCH + ch) * b + c] = s0;
+  }
+}
+__global__ __launch_bounds__(256) void fd_resnorm_sum_kernel(const float* part, float* res, int b, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = e / b, c = e % b;
+  float s0 = 0.f;
+  for (int ch = 0; ch < FD_RCH; ++ch) s0 += part[((int64_t)j * FD_RCH + ch) * b + c];
+  res[e] = sqrtf(s0);
+}
+
 // Per-round control of the subspace iteration (precondition_amd/subspace.py), one thread per
 // factor: convergence of the k wanted Ritz pairs, the scaled Chebyshev filter's interval and
 // per-factor degree (theta_1 may be amplified over theta_k by at most ~1e2 = exp(4.6)), written
@@ -327,6 +384,59 @@ extern "C" int ps_fd_cov_update_f32(void* stream, float* c, const float* const* 
     PS_LAUNCH_CHECK();
   }
   return PS_OK;
+}
+
+extern "C" int ps_fd_round_f32(void* stream, const ps_fd_round_desc* d) {
+  PS_DEVICE_CHECK();
+  if (!d || d->batch < 1 || d->n < 1 || d->b < 1 || d->k < 1 || d->k > d->b || !d->x || !d->z || !d->tmp ||
+      !d->gram || !d->m || !d->polish || !d->t || !d->y || !d->sym || !d->evals || !d->evecs || !d->theta ||
+      !d->res || !d->eigh_workspace || !d->params || !d->converged || !d->summary || !d->xtz || !d->xy ||
+      !d->zy || (d->orthonormalize && (!d->gram_x || !d->xm || !d->gram_t || !d->pol)))
+    return PS_EINVAL;
+  const bool x6 = d->c0 != nullptr;
+  if (x6 ? (!d->c1 || !d->c2 || !d->xt0 || !d->xt1 || !d->xt2) : !d->cx) return PS_EINVAL;
+  // the eigenpairs must come back sorted (the LDS-resident solver of b <= 128 sorts them)
+  if (d->b > CQ_MAX || d->b > ps_eigh_sorted_max_n()) return PS_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = d->batch, b = d->b, per = (b * b + 255) / 256;
+  if (b < FD_RCH) return PS_EUNSUPPORTED;   // the residual partials are kept in `sym`
+  const size_t blk_bytes = (size_t)B * d->n * b * sizeof(float);
+  if (d->orthonormalize) {
+    PS_RC(ps_gemm_grouped_plan_launch(stream, d->gram_x));
+    PS_RC(ps_chol_rinv_batched_f32(stream, d->gram, d->m, b, B, 1e-10f));
+    PS_RC(ps_gemm_grouped_plan_launch(stream, d->xm));
+    PS_RC(ps_gemm_grouped_plan_launch(stream, d->gram_t));
+    hipLaunchKernelGGL(fd_bb_kernel, dim3(B * per), dim3(256), 0, st, d->gram, nullptr, d->polish, nullptr, b, 0, per);
+    PS_RC(ps_gemm_grouped_plan_launch(stream, d->pol));
+  }
+  if (x6) PS_RC(ps_fd_cx6_f32(stream, d->c0, d->c1, d->c2, B, d->x, d->z, d->xt0, d->xt1, d->xt2, d->n, b));
+  else PS_RC(ps_gemm_grouped_plan_launch(stream, d->cx));
+  PS_RC(ps_gemm_grouped_plan_launch(stream, d->xtz));
+  hipLaunchKernelGGL(fd_bb_kernel, dim3(B * per), dim3(256), 0, st, d->t, nullptr, d->sym, nullptr, b, 1, per);
+  {
+    std::vector<const float*> a(B);
+    std::vector<float*> ev(B), vv(B);
+    std::vector<int32_t> nn(B, b);
+    for (int j = 0; j < B; ++j) {
+      a[j] = d->sym + (size_t)j * b * b;
+      ev[j] = d->evals + (size_t)j * b;
+      vv[j] = d->evecs + (size_t)j * b * b;
+    }
+    PS_RC(ps_eigh_batched_f32(stream, a.data(), nn.data(), nn.data(), B, ev.data(), vv.data(), nn.data(),
+                              d->eigh_workspace, d->eigh_workspace_bytes));
+  }
+  hipLaunchKernelGGL(fd_bb_kernel, dim3(B * per), dim3(256), 0, st, d->evecs, d->evals, d->y, d->theta, b, 2, per);
+  PS_RC(ps_gemm_grouped_plan_launch(stream, d->xy));
+  PS_HIP(hipMemcpyAsync(d->x, d->tmp, blk_bytes, hipMemcpyDeviceToDevice, st));
+  PS_RC(ps_gemm_grouped_plan_launch(stream, d->zy));
+  PS_HIP(hipMemcpyAsync(d->z, d->tmp, blk_bytes, hipMemcpyDeviceToDevice, st));
+  // the partial sums live in `sym` (free after the eigensolver): batch * 32 * b <= batch * b * b floats
+  hipLaunchKernelGGL(fd_resnorm_part_kernel, dim3(B * ((b + 31) / 32) * FD_RCH), dim3(256), 0, st, d->x, d->z,
+                     d->theta, d->sym, d->n, b);
+  hipLaunchKernelGGL(fd_resnorm_sum_kernel, dim3((B * b + 255) / 256), dim3(256), 0, st, d->sym, d->res, b, B * b);
+  PS_LAUNCH_CHECK();
+  return ps_fd_round_control_f32(stream, d->theta, d->res, B, b, d->k, d->n, d->tol, d->degree, d->params,
+                                 d->converged, d->summary);
 }
 
 extern "C" int ps_chol_rinv_max_n(void) { return CQ_MAX; }

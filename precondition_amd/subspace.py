@@ -18,6 +18,7 @@ The caller falls back to the full eigendecomposition if this does not converge.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import List, Sequence, Tuple
 
@@ -110,6 +111,7 @@ class _Planned:
     bsz, n, b = x.shape
     dev = x.device
     self.c, self.x, self.z, self.tmp = c, x, z, tmp
+    self._rd = None
     self.c16x6 = c16x6      # three-plane fragment-major covariances: C x of Rayleigh-Ritz by fd_cx6
     self.x6_scratch = None
     if c16x6 is not None:
@@ -126,6 +128,49 @@ class _Planned:
     self.p_xtz = K.GemmPlan([(x[j], z[j], self.t[j], True, False) for j in R])
     self.p_xy = K.GemmPlan([(x[j], self.y[j], tmp[j], False, False) for j in R])
     self.p_zy = K.GemmPlan([(z[j], self.y[j], tmp[j], False, False) for j in R])
+
+  def round_call(self, k, tol, degree, orthonormalize=True):
+    """orthonormalize (optional) + Rayleigh-Ritz + the per-round control in ONE library call
+    (ps_fd_round_f32: the ~35 launches of these steps issued from C++ instead of one by one from
+    Python -- the host was the limit of a round with few factors).  Returns (theta, res, params,
+    converged, summary) as persistent device tensors, or None where the call does not apply."""
+    from . import _lib
+    L = _lib.lib()
+    bsz, n, b = (int(v) for v in self.x.shape)
+    if not _use_cholqr(b) or b > L.ps_eigh_sorted_max_n() or os.environ.get("PS_FD_ROUND_LIB", "1") == "0":
+      return None
+    if self._rd is None:
+      dev = self.x.device
+      d = _lib.FdRoundDesc()
+      f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+      keep = dict(sym=f32(bsz, b, b), evals=f32(bsz, b), evecs=f32(bsz, b, b), theta=f32(bsz, b), res=f32(bsz, b),
+                  params=f32(bsz, 4), converged=torch.empty((bsz,), dtype=torch.int32, device=dev),
+                  summary=torch.empty((4,), dtype=torch.int32, device=dev))
+      nn = (C.c_int32 * bsz)(*([b] * bsz))
+      keep["ews"] = torch.empty((max(int(L.ps_eigh_root_workspace_bytes(bsz, nn)), 256),), dtype=torch.uint8, device=dev)
+      for name, plan in (("gram_x", self.p_gram_x), ("xm", self.p_xm), ("gram_t", self.p_gram_t), ("pol", self.p_pol),
+                         ("cx", self.p_cx), ("xtz", self.p_xtz), ("xy", self.p_xy), ("zy", self.p_zy)):
+        setattr(d, name, plan._h.value)
+      if self.c16x6 is not None:
+        ptrs = [(C.c_void_p * bsz)() for _ in range(3)]
+        for j, a in enumerate(self.c16x6):
+          ptrs[0][j], ptrs[1][j], ptrs[2][j] = a.hi.data_ptr(), a.lo.data_ptr(), a.lo2.data_ptr()
+        keep["ptrs"] = ptrs
+        d.c0, d.c1, d.c2 = (C.cast(p, C.c_void_p).value for p in ptrs)
+        d.xt0, d.xt1, d.xt2 = (t.data_ptr() for t in self.x6_scratch)
+      for name, t in (("x", self.x), ("z", self.z), ("tmp", self.tmp), ("gram", self.gram), ("m", self.m),
+                      ("polish", self.polish), ("t", self.t), ("y", self.y)):
+        setattr(d, name, t.data_ptr())
+      for name in ("sym", "evals", "evecs", "theta", "res", "params", "converged", "summary"):
+        setattr(d, name, keep[name].data_ptr())
+      d.eigh_workspace, d.eigh_workspace_bytes = keep["ews"].data_ptr(), keep["ews"].numel()
+      d.batch, d.n, d.b = bsz, n, b
+      self._rd, self._rd_keep = d, keep
+    d, keep = self._rd, self._rd_keep
+    d.k, d.degree, d.tol, d.orthonormalize = int(k), int(degree), float(tol), 1 if orthonormalize else 0
+    with torch.cuda.device(self.x.device):
+      _lib.check(L.ps_fd_round_f32(torch.cuda.current_stream().cuda_stream, C.byref(d)), "ps_fd_round_f32")
+    return keep["theta"], keep["res"], keep["params"], keep["converged"], keep["summary"]
 
   def orthonormalize(self):
     b = self.x.shape[2]
@@ -232,7 +277,13 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
   tmp = torch.empty_like(x)
   x6 = c16 if (c16 is not None and tiled == "frag3") else None
   planned = _Planned(c, x, z, tmp, c16x6=x6) if os.environ.get("PS_FD_PLANS", "1") != "0" else None
-  if planned is not None:
+  # orthonormalisation + Rayleigh-Ritz + the control of the next round in one library call where it applies
+  rc = planned.round_call(k, tol, degree) if (planned is not None and _fused_filter()) else None
+  lib_round = rc is not None
+  params = conv_i = summ = None
+  if lib_round:
+    theta, res, params, conv_i, summ = rc
+  elif planned is not None:
     x = planned.orthonormalize()
     theta, res = planned.rayleigh_ritz()
   else:
@@ -247,7 +298,8 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
     if fused:
       # convergence test + filter interval + per-factor degree in ONE small launch and one host
       # read (csrc/fd.hip fd_round_control_kernel; the torch form below is the same arithmetic)
-      params, conv_i, summ = _K().fd_round_control(theta, res, k, n, tol, degree)
+      if not lib_round:
+        params, conv_i, summ = _K().fd_round_control(theta, res, k, n, tol, degree)
       all_conv, max_deg, min_deg, plain_ok = summ.tolist()
       converged = conv_i.bool()
       if all_conv:
@@ -333,7 +385,9 @@ def top_eigenpairs_batched(mats: Sequence[torch.Tensor], k: int, tol: float = 1e
         y = torch.where(active, y_next, y)
         sigma = torch.where(active, sigma_new, sigma)
       x.copy_(y)
-    if planned is not None:
+    if lib_round:
+      theta, res, params, conv_i, summ = planned.round_call(k, tol, degree)
+    elif planned is not None:
       x = planned.orthonormalize()
       theta, res = planned.rayleigh_ritz()
     else:

@@ -420,3 +420,42 @@ def test_six_product_cx_has_float32_accuracy(bsz, n, b, device):
   e32 = float((z32.double() - ref).norm() / ref.norm())
   print(f"n={n}: six-product {e6:.2e}  float32 {e32:.2e}")
   assert e6 <= 3e-7 and e6 <= 3.0 * e32 + 1e-7
+
+
+@pytest.mark.parametrize("bsz,n,b", [(3, 512, 96), (1, 256, 64)])
+def test_library_round_equals_python_issued_round(bsz, n, b, device):
+  """ps_fd_round_f32 (orthonormalisation + Rayleigh-Ritz + control in one call) against the same steps
+  issued one by one from Python (subspace._Planned.orthonormalize / rayleigh_ritz + fd_round_control):
+  same kernels for the products and solvers; the glue (polish, symmetrisation, flip, residual norms)
+  has its own kernels, so Ritz values agree to float32 rounding and the control decisions exactly."""
+  from precondition_amd import subspace
+  gen = torch.Generator(device=device).manual_seed(3 * n)
+  cs = []
+  for j in range(bsz):
+    g = torch.randn((n, n // 4), generator=gen, device=device)
+    cs.append(((g @ g.T) / n).contiguous())
+  x0 = torch.randn((bsz, n, b), generator=gen, device=device)
+  k = b - 31
+  outs = []
+  for lib_round in (False, True):
+    x = x0.clone(); z = torch.empty_like(x); tmp = torch.empty_like(x)
+    c16 = [K().to_bf16(c, split=True, tiled="frag3") for c in cs]
+    pl = subspace._Planned(cs, x, z, tmp, c16x6=c16)
+    if lib_round:
+      theta, res, params, conv, summ = pl.round_call(k, 1e-5, 12)
+    else:
+      pl.orthonormalize()
+      theta, res = pl.rayleigh_ritz()
+      params, conv, summ = K().fd_round_control(theta, res, k, n, 1e-5, 12)
+    torch.cuda.synchronize()
+    outs.append([t.clone() for t in (theta, res, params, conv, summ, x, z)])
+  a, c_ = outs
+  top = float(a[0].abs().max())
+  assert float((a[0] - c_[0]).abs().max()) <= 2e-6 * top                     # Ritz values
+  assert float((a[1] - c_[1]).abs().max()) <= 1e-5 * top                     # residual norms
+  assert torch.equal(a[3], c_[3]) and torch.equal(a[4][:3], c_[4][:3])       # converged flags, degrees
+  assert float((a[2] - c_[2]).abs().max()) <= 1e-5 * max(float(a[2].abs().max()), 1e-30)
+  # the Ritz vectors span the same space: compare the projectors on the leading k
+  for j in range(bsz):
+    pa, pb = a[5][j][:, :k], c_[5][j][:, :k]
+    assert float((pa @ (pa.T @ pb) - pb).norm() / pb.norm()) < 1e-3
