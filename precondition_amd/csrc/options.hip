@@ -95,6 +95,8 @@ Options resolve(const ps_options* u, bool* bad) {
     if (c.pi_timeout_ms >= 0) o.pi_timeout_ms = (double)c.pi_timeout_ms;
     if (c.eigh_sweep_tol > 0.f) o.eigh_sweep_tol = c.eigh_sweep_tol;
     if (c.eigh_streams > 0) o.eigh_streams = c.eigh_streams;
+    if (c.eigh_solver == PS_EIGH_TWO_SIDED) o.eigh_cj = 0;
+    else if (c.eigh_solver != PS_EIGH_ONE_SIDED && bad) *bad = true;
   }
   ps_dev_env_overrides(o);
   return o;

@@ -137,7 +137,8 @@ class _Planned:
     from . import _lib
     L = _lib.lib()
     bsz, n, b = (int(v) for v in self.x.shape)
-    if not _use_cholqr(b) or b > L.ps_eigh_sorted_max_n() or os.environ.get("PS_FD_ROUND_LIB", "1") == "0":
+    if (b < 32 or not _use_cholqr(b) or b > L.ps_eigh_sorted_max_n() or
+        os.environ.get("PS_FD_ROUND_LIB", "1") == "0"):
       return None
     if self._rd is None:
       dev = self.x.device
