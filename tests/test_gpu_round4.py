@@ -485,3 +485,42 @@ def test_eigh_solver_option_two_sided_reproduces_lapack_on_rank_deficient_input(
   assert e2 <= 1.1 * e_o and e1 <= 4.0 * e_o
   with pytest.raises(Exception):
     K().matrix_inverse_pth_root_batched([t], [p], [n], eigh=True, options={"eigh_solver": 7})
+
+
+def test_fd_entry_points_refuse_what_they_do_not_support(device):
+  """Shapes and argument combinations outside the fused FD kernels' domain are refused with a status
+  (PS_EUNSUPPORTED / PS_EINVAL), never computed wrongly."""
+  from precondition_amd import _lib
+  n, b = 256, 96
+  c = torch.randn((n, n), device=device)
+  c = (c @ c.T).contiguous()
+  y = torch.randn((1, n, b), device=device)
+  params = torch.tensor([[0.1, 0.2, 0.3, 4.0]], device=device)
+  frag = K().to_bf16(c, split=True, tiled="frag")
+  planes = K().fd_filter_step(y, y, None, torch.empty_like(y), params, 1, frag=True)
+  # a tile-blocked covariance is not a fragment-major one
+  with pytest.raises(ValueError):
+    K().fd_cy_step([K().to_bf16(c, split=True, tiled=True)], planes, y, y, torch.empty_like(y), None, params, 2)
+  # step 1 has no product: the fused step starts at 2
+  with pytest.raises(_lib.PsError):
+    K().fd_cy_step([frag], planes, y, y, torch.empty_like(y), None, params, 1)
+  # n must be a multiple of 128 for the fused step; the conversion itself needs multiples of 64
+  c2 = torch.randn((192, 192), device=device)
+  f2 = K().to_bf16(c2, split=True, tiled="frag")
+  y2 = torch.randn((1, 192, 32), device=device)
+  p2 = K().fd_filter_step(y2, y2, None, torch.empty_like(y2), params, 1, frag=True)
+  with pytest.raises(_lib.PsError, match="-3"):
+    K().fd_cy_step([f2], p2, y2, y2, torch.empty_like(y2), None, params, 2)
+  with pytest.raises(ValueError):
+    K().to_bf16(torch.randn((100, 128), device=device), split=True, tiled="frag3")
+  # the six-product C x needs the third plane
+  with pytest.raises(ValueError):
+    K().fd_cx6([frag], y, torch.empty_like(y))
+  # a symmetric product of two different operands is a caller error
+  hi, lo = K().to_bf16(c, split=True)
+  hi2, lo2 = K().to_bf16(c + 1.0, split=True)
+  with pytest.raises(ValueError):
+    K().gemm_bf16_grouped([((hi, lo), (hi2, lo2), torch.empty((n, n), device=device))], symmetric=True)
+  # covariance update: shapes must match
+  with pytest.raises(ValueError):
+    K().fd_cov_update(torch.zeros((2, n, n), device=device), [c], 0.9)
