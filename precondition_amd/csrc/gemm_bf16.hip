@@ -369,21 +369,23 @@ struct FdCyArgs {
   int step, n, nwg;
 };
 
-template <int CB>
+// SUB = 32-row halves per workgroup: 2 (64 rows) when the factors fill the chip, 1 for one or two factors
+// (twice the workgroups: a single 4096-dim factor is only 64 blocks of 64 rows).
+template <int CB, int SUB = 2>
 __global__ __launch_bounds__(256, 2) void fd_cy_step_kernel(const FdCyArgs a) {
-  constexpr int B = CB * 32, ZLD = B + 1, NQ = 64 * B / 4 / 256;
-  __shared__ float zt[2][64 * ZLD];
+  constexpr int B = CB * 32, ZLD = B + 1, ROWS = 32 * SUB, NQ = ROWS * B / 4 / 256;
+  __shared__ float zt[2][ROWS * ZLD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int per = a.n >> 6;
+  const int per = a.n / ROWS;
   const int t = xcd_remap(blockIdx.x, a.nwg);
-  const int j = t / per, rb = t % per, r0 = rb * 64;
+  const int j = t / per, rb = t % per, r0 = rb * ROWS;
   const float ctr = a.params[4 * j + 0], e = a.params[4 * j + 1], sigma1 = a.params[4 * j + 2];
   const int deg = (int)a.params[4 * j + 3];
   const int64_t fb = (int64_t)j * a.n * B;            // factor base (elements) in y* and the planes
-  const int64_t blk = fb + (int64_t)r0 * B;           // this workgroup's 64 x B block: contiguous
+  const int64_t blk = fb + (int64_t)r0 * B;           // this workgroup's ROWS x B block: contiguous
   if (a.step > deg) {                                 // the factor's filter is finished: y' = y
-    for (int q = tid; q < 64 * B / 4; q += 256)
+    for (int q = tid; q < ROWS * B / 4; q += 256)
       *(f32x4 PS_GLOBAL*)(a.y_next + blk + 4 * q) = gload4(a.y + blk + 4 * q);
     return;
   }
@@ -393,8 +395,10 @@ __global__ __launch_bounds__(256, 2) void fd_cy_step_kernel(const FdCyArgs a) {
   const float c1 = 2.f * sn / e, c2 = sigma * sn;
 
   const int nkk = a.n >> 4, cnt = nkk >> 2;           // k blocks of 16; per wavefront (n % 128 == 0)
-  const uint16_t* pah = a.a_hi[j] + ((int64_t)rb * nkk * 128 + lane) * 8;
-  const uint16_t* pal = a.a_lo[j] + ((int64_t)rb * nkk * 128 + lane) * 8;
+  // C planes: [n / 64][n / 16][2 halves][64 lanes][8]; a 32-row workgroup reads one half of every kilobyte pair
+  const int64_t a0 = (((int64_t)(r0 >> 6) * nkk * 2 + ((r0 >> 5) & 1)) * 64 + lane) * 8;
+  const uint16_t* pah = a.a_hi[j] + a0;
+  const uint16_t* pal = a.a_lo[j] + a0;
   const uint16_t* pbh = a.bt_hi + fb + lane * 8;
   const uint16_t* pbl = a.bt_lo + fb + lane * 8;
   // this block of y and y_prev (the recurrence's other inputs): requested now, used after the K loop
@@ -405,33 +409,36 @@ __global__ __launch_bounds__(256, 2) void fd_cy_step_kernel(const FdCyArgs a) {
     yp[q] = gload4(a.y_prev + blk + 4 * (tid + 256 * q));
   }
   __builtin_amdgcn_sched_barrier(0);
-  u32x4 ra[2][4], rb_[2][2 * CB];
+  u32x4 ra[2][2 * SUB], rb_[2][2 * CB];
   auto load_set = [&](int s, int i) {
     const int kk = w + 4 * i;
     const uint16_t* qh = pah + (int64_t)kk * 1024;
     const uint16_t* ql = pal + (int64_t)kk * 1024;
     // C is read once: non-temporal, so that it does not push the iterate planes (re-read by every
     // workgroup of the factor) out of the XCD's L2 (137 -> 126 us per step at 8 x 4096^2)
-    ra[s][0] = gload16_nt(qh); ra[s][1] = gload16_nt(qh + 512);
-    ra[s][2] = gload16_nt(ql); ra[s][3] = gload16_nt(ql + 512);
+#pragma unroll
+    for (int sub = 0; sub < SUB; ++sub) {
+      ra[s][sub] = gload16_nt(qh + 512 * sub);
+      ra[s][SUB + sub] = gload16_nt(ql + 512 * sub);
+    }
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
       rb_[s][cb] = gload16(pbh + (int64_t)(kk * CB + cb) * 512);
       rb_[s][CB + cb] = gload16(pbl + (int64_t)(kk * CB + cb) * 512);
     }
   };
-  f32x16 acc[2][CB];
+  f32x16 acc[SUB][CB];
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub)
+  for (int sub = 0; sub < SUB; ++sub)
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[sub][cb][r] = 0.f;
   auto compute = [&](int s) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < SUB; ++sub) {
       const bf16x8 ah = __builtin_bit_cast(bf16x8, ra[s][sub]);
-      const bf16x8 al = __builtin_bit_cast(bf16x8, ra[s][2 + sub]);
+      const bf16x8 al = __builtin_bit_cast(bf16x8, ra[s][SUB + sub]);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         const bf16x8 bh = __builtin_bit_cast(bf16x8, rb_[s][cb]);
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void fd_cy_step_kernel(const FdCyArgs a) {
     if ((w >> 1) == p) {
       float* zw = zt[w & 1];
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+      for (int sub = 0; sub < SUB; ++sub)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void fd_cy_step_kernel(const FdCyArgs a) {
     }
     __syncthreads();
   }
-  // recurrence on the 64 x B block (contiguous in y, y_prev, y_next)
+  // recurrence on the ROWS x B block (contiguous in y, y_prev, y_next)
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
     const int q = tid + 256 * qi;
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void fd_cy_step_kernel(const FdCyArgs a) {
   __syncthreads();
   // the new iterate as the next step's fragment-major bf16 operand: this block's 64 rows are k
   // blocks r0 / 16 .. + 3 of the factor's planes = one contiguous run of 4 * CB kilobytes per plane
-  for (int it = tid; it < 4 * CB * 64; it += 256) {
+  for (int it = tid; it < (ROWS / 16) * CB * 64; it += 256) {
     const int ln = it & 63, cb = (it >> 6) % CB, kk = (it >> 6) / CB;
     const float* col = zt[0] + (kk * 16 + (ln >> 5) * 8) * ZLD + cb * 32 + (ln & 31);
     u32x4 h4, l4;
@@ -573,47 +580,47 @@ __global__ __launch_bounds__(256) void fd_split3_frag_kernel(const float* x, uin
   }
 }
 
-template <int CB>
+template <int CB, int SUB = 2>
 __global__ __launch_bounds__(256, 2) void fd_cx6_kernel(const FdCx6Args a) {
-  constexpr int B = CB * 32, ZLD = B + 1, NQ = 64 * B / 4 / 256;
-  __shared__ float zt[2][64 * ZLD];
+  constexpr int B = CB * 32, ZLD = B + 1, ROWS = 32 * SUB, NQ = ROWS * B / 4 / 256;
+  __shared__ float zt[2][ROWS * ZLD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int per = a.n >> 6;
+  const int per = a.n / ROWS;
   const int t = xcd_remap(blockIdx.x, a.nwg);
-  const int j = t / per, rb = t % per, r0 = rb * 64;
+  const int j = t / per, rb = t % per, r0 = rb * ROWS;
   const int64_t fb = (int64_t)j * a.n * B, blk = fb + (int64_t)r0 * B;
   const int nkk = a.n >> 4, cnt = nkk >> 2;
   const uint16_t* pa[3];
   const uint16_t* pb[3];
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
-    pa[pl] = a.a[pl][j] + ((int64_t)rb * nkk * 128 + lane) * 8;
+    pa[pl] = a.a[pl][j] + (((int64_t)(r0 >> 6) * nkk * 2 + ((r0 >> 5) & 1)) * 64 + lane) * 8;
     pb[pl] = a.bt[pl] + fb + lane * 8;
   }
-  u32x4 ra[2][3][2], rb_[2][3][CB];
+  u32x4 ra[2][3][SUB], rb_[2][3][CB];
   auto load_set = [&](int s, int i) {
     const int kk = w + 4 * i;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      ra[s][pl][0] = gload16_nt(pa[pl] + (int64_t)kk * 1024);
-      ra[s][pl][1] = gload16_nt(pa[pl] + (int64_t)kk * 1024 + 512);
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) ra[s][pl][sub] = gload16_nt(pa[pl] + (int64_t)kk * 1024 + 512 * sub);
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) rb_[s][pl][cb] = gload16(pb[pl] + (int64_t)(kk * CB + cb) * 512);
   };
-  f32x16 acc[2][CB];
+  f32x16 acc[SUB][CB];
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub)
+  for (int sub = 0; sub < SUB; ++sub)
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[sub][cb][r] = 0.f;
   auto compute = [&](int s) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < SUB; ++sub) {
       const bf16x8 a0 = __builtin_bit_cast(bf16x8, ra[s][0][sub]);
       const bf16x8 a1 = __builtin_bit_cast(bf16x8, ra[s][1][sub]);
       const bf16x8 a2 = __builtin_bit_cast(bf16x8, ra[s][2][sub]);
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void fd_cx6_kernel(const FdCx6Args a) {
     if ((w >> 1) == p) {
       float* zw = zt[w & 1];
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+      for (int sub = 0; sub < SUB; ++sub)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -932,6 +939,9 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
   return hplan_launch((hipStream_t)stream, pl);
 }
 
+// Fewer than 256 blocks of 64 rows (one 4096-dim factor is 64): the fused kernels run on 32-row blocks
+static bool fd_half_blocks(int batch, int64_t n) { return (int64_t)batch * (n / 64) < 256; }
+
 extern "C" int ps_fd_cy_step_f32(void* stream, const void* const* c_hi, const void* const* c_lo,
                                  int batch, const void* yt_hi, const void* yt_lo, const float* y,
                                  const float* y_prev, float* y_next, void* nt_hi, void* nt_lo,
@@ -958,11 +968,18 @@ extern "C" int ps_fd_cy_step_f32(void* stream, const void* const* c_hi, const vo
   a.y = y; a.y_prev = y_prev; a.y_next = y_next;
   a.nt_hi = (uint16_t*)nt_hi; a.nt_lo = (uint16_t*)nt_lo;
   a.params = params; a.step = step; a.n = (int)n;
-  a.nwg = (int)(batch * (n / 64));
   hipStream_t st = (hipStream_t)stream;
-  if (b == 96) hipLaunchKernelGGL((fd_cy_step_kernel<3>), dim3(a.nwg), dim3(256), 0, st, a);
-  else if (b == 64) hipLaunchKernelGGL((fd_cy_step_kernel<2>), dim3(a.nwg), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((fd_cy_step_kernel<1>), dim3(a.nwg), dim3(256), 0, st, a);
+  if (fd_half_blocks(batch, n)) {   // one or two factors: 32-row workgroups, twice as many
+    a.nwg = (int)(batch * (n / 32));
+    if (b == 96) hipLaunchKernelGGL((fd_cy_step_kernel<3, 1>), dim3(a.nwg), dim3(256), 0, st, a);
+    else if (b == 64) hipLaunchKernelGGL((fd_cy_step_kernel<2, 1>), dim3(a.nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((fd_cy_step_kernel<1, 1>), dim3(a.nwg), dim3(256), 0, st, a);
+  } else {
+    a.nwg = (int)(batch * (n / 64));
+    if (b == 96) hipLaunchKernelGGL((fd_cy_step_kernel<3>), dim3(a.nwg), dim3(256), 0, st, a);
+    else if (b == 64) hipLaunchKernelGGL((fd_cy_step_kernel<2>), dim3(a.nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((fd_cy_step_kernel<1>), dim3(a.nwg), dim3(256), 0, st, a);
+  }
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -1001,19 +1018,22 @@ extern "C" int ps_fd_cx6_f32(void* stream, const void* const* c0, const void* co
       ((uintptr_t)xt1 % 16) != 0 || ((uintptr_t)xt2 % 16) != 0)
     return PS_EUNSUPPORTED;
   a.bt[0] = (const uint16_t*)xt0; a.bt[1] = (const uint16_t*)xt1; a.bt[2] = (const uint16_t*)xt2;
-  a.z = z; a.n = (int)n; a.nwg = (int)(batch * (n / 64));
+  a.z = z; a.n = (int)n;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(a.nwg), blk(256);
-  if (b == 96) {
-    hipLaunchKernelGGL((fd_split3_frag_kernel<3>), grid, blk, 0, st, x, (uint16_t*)xt0, (uint16_t*)xt1, (uint16_t*)xt2, (int)n);
-    hipLaunchKernelGGL((fd_cx6_kernel<3>), grid, blk, 0, st, a);
-  } else if (b == 64) {
-    hipLaunchKernelGGL((fd_split3_frag_kernel<2>), grid, blk, 0, st, x, (uint16_t*)xt0, (uint16_t*)xt1, (uint16_t*)xt2, (int)n);
-    hipLaunchKernelGGL((fd_cx6_kernel<2>), grid, blk, 0, st, a);
-  } else {
-    hipLaunchKernelGGL((fd_split3_frag_kernel<1>), grid, blk, 0, st, x, (uint16_t*)xt0, (uint16_t*)xt1, (uint16_t*)xt2, (int)n);
-    hipLaunchKernelGGL((fd_cx6_kernel<1>), grid, blk, 0, st, a);
-  }
+  const bool half = fd_half_blocks(batch, n);
+  a.nwg = (int)(batch * (n / (half ? 32 : 64)));
+  const dim3 sgrid((unsigned)(batch * (n / 64))), grid(a.nwg), blk(256);
+#define PS_CX6(CBV)                                                                                         \
+  do {                                                                                                      \
+    hipLaunchKernelGGL((fd_split3_frag_kernel<CBV>), sgrid, blk, 0, st, x, (uint16_t*)xt0, (uint16_t*)xt1,  \
+                       (uint16_t*)xt2, (int)n);                                                             \
+    if (half) hipLaunchKernelGGL((fd_cx6_kernel<CBV, 1>), grid, blk, 0, st, a);                             \
+    else hipLaunchKernelGGL((fd_cx6_kernel<CBV, 2>), grid, blk, 0, st, a);                                  \
+  } while (0)
+  if (b == 96) PS_CX6(3);
+  else if (b == 64) PS_CX6(2);
+  else PS_CX6(1);
+#undef PS_CX6
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -235,9 +235,10 @@ def test_fragment_major_conversion_is_a_permutation_of_the_plain_one(device):
     K().to_bf16(torch.randn((100, 64), device=device), split=True, tiled="frag")
 
 
-@pytest.mark.parametrize("bsz,n,b", [(3, 256, 96), (2, 384, 64), (1, 128, 32), (8, 1024, 96)])
+@pytest.mark.parametrize("bsz,n,b", [(3, 256, 96), (2, 384, 64), (1, 128, 32), (8, 1024, 96), (16, 1024, 96)])
 def test_fused_filter_step_matches_product_plus_recurrence(bsz, n, b, device):
-  """ps_fd_cy_step_f32 against its two-launch form (gemm_bf16_grouped on the same hi/lo operands, then
+  """(fewer than 256 blocks of 64 rows run on 32-row workgroups: the last case is the 64-row form)
+  ps_fd_cy_step_f32 against its two-launch form (gemm_bf16_grouped on the same hi/lo operands, then
   ps_fd_filter_step_f32): same arithmetic per element, another order of the k sum -> agreement to
   float32 rounding of the sum; the bf16 planes it writes are exactly the split of ITS y_next; a factor
   whose degree is below the step keeps its iterate bit for bit."""
@@ -395,7 +396,7 @@ def test_symmetric_bf16_product_equals_full_product(d, k, device):
     assert torch.equal(s1, sym) and torch.equal(s2, alone)
 
 
-@pytest.mark.parametrize("bsz,n,b", [(2, 512, 96), (1, 256, 64), (8, 1024, 96)])
+@pytest.mark.parametrize("bsz,n,b", [(2, 512, 96), (1, 256, 64), (8, 1024, 96), (16, 1024, 64)])
 def test_six_product_cx_has_float32_accuracy(bsz, n, b, device):
   """ps_fd_cx6_f32 (C x of the Rayleigh-Ritz step on three bf16 planes per operand) against float64:
   as close as the float32 MFMA product it replaces, and the hi / lo planes of the three-plane
