@@ -940,7 +940,10 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
 }
 
 // Fewer than 256 blocks of 64 rows (one 4096-dim factor is 64): the fused kernels run on 32-row blocks
-static bool fd_half_blocks(int batch, int64_t n) { return (int64_t)batch * (n / 64) < 256; }
+#ifndef PS_FD_HALF_BELOW
+#define PS_FD_HALF_BELOW 256
+#endif
+static bool fd_half_blocks(int batch, int64_t n) { return (int64_t)batch * (n / 64) < PS_FD_HALF_BELOW; }
 
 extern "C" int ps_fd_cy_step_f32(void* stream, const void* const* c_hi, const void* const* c_lo,
                                  int batch, const void* yt_hi, const void* yt_lo, const float* y,
