@@ -939,9 +939,10 @@ extern "C" int ps_gemm_bf16_grouped(void* stream, const ps_gemm_bf16_desc* desc,
   return hplan_launch((hipStream_t)stream, pl);
 }
 
-// Fewer than 256 blocks of 64 rows (one 4096-dim factor is 64): the fused kernels run on 32-row blocks
+// At most 128 blocks of 64 rows (one 4096-dim factor is 64): the fused kernels run on 32-row blocks, i.e.
+// on at most one workgroup per CU
 #ifndef PS_FD_HALF_BELOW
-#define PS_FD_HALF_BELOW 256
+#define PS_FD_HALF_BELOW 129   // measured at n = 4096, b = 96: 1 / 2 factors 35 / 40 us (64-row: 48 / 51), 3 factors 73 (56)
 #endif
 static bool fd_half_blocks(int batch, int64_t n) { return (int64_t)batch * (n / 64) < PS_FD_HALF_BELOW; }
 

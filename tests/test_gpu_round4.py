@@ -237,7 +237,7 @@ def test_fragment_major_conversion_is_a_permutation_of_the_plain_one(device):
 
 @pytest.mark.parametrize("bsz,n,b", [(3, 256, 96), (2, 384, 64), (1, 128, 32), (8, 1024, 96), (16, 1024, 96)])
 def test_fused_filter_step_matches_product_plus_recurrence(bsz, n, b, device):
-  """(fewer than 256 blocks of 64 rows run on 32-row workgroups: the last case is the 64-row form)
+  """(at most 128 blocks of 64 rows run on 32-row workgroups: the last case is the 64-row form)
   ps_fd_cy_step_f32 against its two-launch form (gemm_bf16_grouped on the same hi/lo operands, then
   ps_fd_filter_step_f32): same arithmetic per element, another order of the k sum -> agreement to
   float32 rounding of the sum; the bf16 planes it writes are exactly the split of ITS y_next; a factor
