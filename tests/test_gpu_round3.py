@@ -91,13 +91,15 @@ def test_resident_power_iteration_beside_a_kernel_holding_most_cus(device, monke
   torch.cuda.synchronize()
   assert torch.equal(lam, lam_ref) and torch.equal(it, it_ref)
   assert health()[0] == 0
-  # half of the CUs held: no delay at all
+  # half of the CUs held: usually no delay at all (the free slots hold a prefix of the teams), but
+  # since round 4 a team lives inside ONE XCD, and when the filler's workgroups fill whole XCDs
+  # the teams dealt to those wait for it: bounded by the filler, never an expired wait
   hold_half_of_the_cus(side, 150.0, cus=128)
   time.sleep(0.01)
   t0 = time.perf_counter()
   lam, it = K().power_iteration_batched(mats)
   torch.cuda.current_stream().synchronize()
-  assert time.perf_counter() - t0 < 0.05
+  assert time.perf_counter() - t0 < 1.0
   torch.cuda.synchronize()
   assert torch.equal(lam, lam_ref) and health()[0] == 0
 
