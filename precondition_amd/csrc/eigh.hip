@@ -1515,7 +1515,10 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
             const int np_g = (int)pl.cj_pair[g].size(), nr_g = (int)pl.cj_row[g].size();
             const bool x3 = cj_x3_above > 0.f && known_off[g] > cj_x3_above;
             if (x3)
-              hipLaunchKernelGGL(cj_gram_x3_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks,
+              hipLaunchKernelGGL(cj_gram_x3_kernel<2>, dim3(np_g), blk, 0, gs[g], lo.blocks,
+                                 lo.cj_pair[g], np_g, r);
+            else if (opt.eigh_gram_bf16x6)
+              hipLaunchKernelGGL(cj_gram_x3_kernel<3>, dim3(np_g), blk, 0, gs[g], lo.blocks,
                                  lo.cj_pair[g], np_g, r);
             else
               hipLaunchKernelGGL(cj_gram_kernel, dim3(np_g), blk, 0, gs[g], lo.blocks, lo.cj_pair[g],

@@ -319,22 +319,28 @@ __global__ __launch_bounds__(256, 2) void cj_gram_kernel(EighBlock* blocks, cons
 // patch (4 rows x 16 bytes), converts and writes it TRANSPOSED -- [column][k], k-contiguous,
 // 4 x ds_write_b64 per plane -- so that an MFMA fragment (8 consecutive k of one column) is one
 // 16-byte LDS read; rows of 40 bf16 (80 bytes) keep those reads conflict-free.
-template <int W>
-__device__ __forceinline__ void cj_gram_x3_mfma(const uint16_t* sh, const uint16_t* sl, int lane,
-                                                f32x16 (&acc)[3]) {
+template <int W, int PLANES>
+__device__ __forceinline__ void cj_gram_x3_mfma(const uint16_t* sh, const uint16_t* sl, const uint16_t* s2,
+                                                int lane, f32x16 (&acc)[3]) {
   using T = GramTiles<W>;
   const int i = lane & 31, h8 = 8 * (lane >> 5);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    xbf16x8 fh[4], fl[4];   // fragments of column block b (unused blocks fold away)
+    xbf16x8 fh[4], fl[4], f2[4];   // fragments of column block b (unused blocks fold away)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       fh[b] = *reinterpret_cast<const xbf16x8*>(sh + (b * 32 + i) * XLD + ks * 16 + h8);
       fl[b] = *reinterpret_cast<const xbf16x8*>(sl + (b * 32 + i) * XLD + ks * 16 + h8);
+      if (PLANES == 3) f2[b] = *reinterpret_cast<const xbf16x8*>(s2 + (b * 32 + i) * XLD + ks * 16 + h8);
     }
 #pragma unroll
     for (int t = 0; t < T::N; ++t) {
       f32x16 c = acc[t];
+      if (PLANES == 3) {   // the three terms of weight 2^-16: x = h + l + l2, products above 2^-24 kept
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[T::TI[t]], fh[T::TJ[t]], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[T::TI[t]], fl[T::TJ[t]], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[T::TI[t]], f2[T::TJ[t]], c, 0, 0, 0);
+      }
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[T::TI[t]], fh[T::TJ[t]], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[T::TI[t]], fl[T::TJ[t]], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[T::TI[t]], fh[T::TJ[t]], c, 0, 0, 0);
@@ -343,10 +349,14 @@ __device__ __forceinline__ void cj_gram_x3_mfma(const uint16_t* sh, const uint16
   }
 }
 
+// PLANES = 3: three bf16 planes per operand and six products -- float32-level accuracy (the
+// arithmetic of cj_update_x6_kernel), still HBM-bound: the float32 MFMA form of the Gram kernel
+// shares its FMA lanes with the pivots of the other stream group, this one does not.
+template <int PLANES>
 __global__ __launch_bounds__(256, 2) void cj_gram_x3_kernel(EighBlock* blocks, const ETile* tiles,
                                                             int ntiles, int round) {
-  // two stages x two planes x [128 columns][40] bf16 = 40,960 bytes
-  __shared__ __align__(16) uint16_t simg[2][2][JP * XLD];
+  // two stages x PLANES planes x [128 columns][40] bf16 = 40,960 (61,440) bytes
+  __shared__ __align__(16) uint16_t simg[2][PLANES][JP * XLD];
   const ETile te = tiles[xcd_remap(blockIdx.x, ntiles)];
   EighBlock* eb = &blocks[te.block];
   if (!eb->cj_active || round >= eb->nb - 1) return;
@@ -368,16 +378,19 @@ __global__ __launch_bounds__(256, 2) void cj_gram_x3_kernel(EighBlock* blocks, c
   auto store = [&](int stage) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {   // column c4 + e: its 4 consecutive k as one 8-byte write per plane
-      xbf16x4 hi, lo;
+      xbf16x4 hi, lo, l2;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float x = r[q][e];
         const __bf16 hb = (__bf16)x;
+        const __bf16 lb = (__bf16)(x - (float)hb);
         hi[q] = hb;
-        lo[q] = (__bf16)(x - (float)hb);
+        lo[q] = lb;
+        l2[q] = (__bf16)((x - (float)hb) - (float)lb);
       }
       *reinterpret_cast<xbf16x4*>(&simg[stage][0][(c4 + e) * XLD + 4 * rg]) = hi;
       *reinterpret_cast<xbf16x4*>(&simg[stage][1][(c4 + e) * XLD + 4 * rg]) = lo;
+      if (PLANES == 3) *reinterpret_cast<xbf16x4*>(&simg[stage][2][(c4 + e) * XLD + 4 * rg]) = l2;
     }
   };
   f32x16 acc[3];
@@ -393,10 +406,10 @@ __global__ __launch_bounds__(256, 2) void cj_gram_x3_kernel(EighBlock* blocks, c
     const bool more = kt + 1 < nk;
     if (more) load(kt + 1);
     switch (wave) {
-      case 0: cj_gram_x3_mfma<0>(simg[cur][0], simg[cur][1], lane, acc); break;
-      case 1: cj_gram_x3_mfma<1>(simg[cur][0], simg[cur][1], lane, acc); break;
-      case 2: cj_gram_x3_mfma<2>(simg[cur][0], simg[cur][1], lane, acc); break;
-      default: cj_gram_x3_mfma<3>(simg[cur][0], simg[cur][1], lane, acc); break;
+      case 0: cj_gram_x3_mfma<0, PLANES>(simg[cur][0], simg[cur][1], simg[cur][PLANES - 1], lane, acc); break;
+      case 1: cj_gram_x3_mfma<1, PLANES>(simg[cur][0], simg[cur][1], simg[cur][PLANES - 1], lane, acc); break;
+      case 2: cj_gram_x3_mfma<2, PLANES>(simg[cur][0], simg[cur][1], simg[cur][PLANES - 1], lane, acc); break;
+      default: cj_gram_x3_mfma<3, PLANES>(simg[cur][0], simg[cur][1], simg[cur][PLANES - 1], lane, acc); break;
     }
     if (more) store(cur ^ 1);
     __syncthreads();

@@ -52,6 +52,7 @@ struct Options {
   float eigh_gram_x3_above = 0.f;    // PS_EIGH_GRAM_X3: bf16x3 Gram while the known scaled entry is above (0 = never: the default)
   float eigh_gram_x3_skip = 3e-5f;   // PS_EIGH_GRAM_X3_SKIP: pairs below this scaled entry are not rotated in bf16 sweeps
   int eigh_update_bf16x6 = 1;      // PS_EIGH_UPDATE_X6: update products on the bf16 MFMA (3-way split)
+  int eigh_gram_bf16x6 = 1;        // PS_EIGH_GRAM_X6: Gram products on the bf16 MFMA, three planes, six products (float32-level)
   int eigh_f64_reproject = 1;      // PS_EIGH_F64_REPROJECT
   float eigh_scaled_tol = 1e-5f;   // PS_EIGH_SCALED_TOL
   int eigh_extra_sweeps = 4;       // PS_EIGH_EXTRA_SWEEPS

@@ -56,6 +56,7 @@ void ps_dev_env_overrides(Options& o) {
   geti("PS_EIGH_CJ_STREAMS", o.eigh_streams);
   geti("PS_EIGH_CJ_UBK", o.eigh_cj_ubk);
   geti("PS_EIGH_UPDATE_X6", o.eigh_update_bf16x6);
+  geti("PS_EIGH_GRAM_X6", o.eigh_gram_bf16x6);
   getf("PS_EIGH_GRAM_X3", o.eigh_gram_x3_above);
   getf("PS_EIGH_GRAM_X3_SKIP", o.eigh_gram_x3_skip);
   geti("PS_EIGH_F64_REPROJECT", o.eigh_f64_reproject);
