@@ -1460,7 +1460,11 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       // everything on the caller's stream).  The host stays one sweep ahead of the GPU (it waits
       // for the status of sweep s - 1 only after sweep s is queued), so the streams never
       // drain; converged blocks' workgroups exit at once.
-      const int nstreams = opt.eigh_streams;
+      // Two stream groups by default.  With the x6 update and x6 Gram kernels (61 KB of LDS each: neither
+      // fits beside a 134 KB pivot workgroup) one stream is within +-3 % of two at 64 x 2048^2, faster on
+      // one box (466 vs 476 ms) and slower on the next (500 vs 483); smaller problems gain from two
+      // (64 x 1024^2: 72 vs 80 ms, 256 x 512^2: 50 vs 54 ms).
+      const int nstreams = opt.eigh_streams > 0 ? opt.eigh_streams : 2;
       static thread_local hipStream_t side = nullptr;
       static thread_local hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
       if (!side) PS_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));

@@ -23,7 +23,7 @@ struct Options {
   int power_iteration = PS_PI_AUTO;
   double pi_timeout_ms = 5000.0;
   float eigh_sweep_tol = 2e-6f;
-  int eigh_streams = 2;
+  int eigh_streams = 0;            // 0 = by size (eigh.hip), 1 | 2
   // ---- dev (environment, PS_DEV_ENV=1 only) -----------------------------------------------------
   bool force_general = false;      // PS_NEWTON_SYMMETRIC=0: full products for every block
   int stage_bk = 32;               // PS_NEWTON_BK = 16 | 32
