@@ -156,9 +156,13 @@ const char* ps_error_string(int code);
  *   launch's waits, < 0 = default 5000, 0 = every wait counts as expired (tests).
  * eigh_* — ps_eigh_root_batched_opt_f32: eigh_sweep_tol (<= 0: default 2e-6) is the scaled
  *   off-diagonal bound that ends the one-sided Jacobi sweeps; eigh_streams (0: default 2);
- *   eigh_solver: PS_EIGH_ONE_SIDED (default: Hestenes block Jacobi on the float64-accumulated
- *   Cholesky factor, 2.7 x faster at 64 x 2048^2) or PS_EIGH_TWO_SIDED (blocked two-sided Jacobi on
- *   the matrix itself + float64 re-projection).  Both are at LAPACK-float32's distance from the
+ *   eigh_solver: PS_EIGH_AUTO (default) = PS_EIGH_TRIDIAGONAL for matrices of 129 ... 4096 rows:
+ *   Householder tridiagonalisation + float64 divide and conquer + compact-WY back-transformation
+ *   (csrc/eigh_td.hip.h; the algorithm class of LAPACK's ssyevd, which the reference's
+ *   jnp.linalg.eigh runs, DS:1007), with the Jacobi solvers as the fallback when an iteration cap is
+ *   hit; PS_EIGH_ONE_SIDED (rounds 3-4: Hestenes block Jacobi on the float64-accumulated Cholesky
+ *   factor) or PS_EIGH_TWO_SIDED (blocked two-sided Jacobi on the matrix itself + float64
+ *   re-projection).  The Jacobi solvers are at LAPACK-float32's distance from the
  *   float64 root on well-conditioned and graded inputs.  On RANK-DEFICIENT + ridge inputs (a noise
  *   cluster of eigenvalues around the ridge, where max(e, ridge)^(-1/p) has its kink) every float32
  *   solver is 5e-4 ... 5e-3 from float64; the two-sided solver then reproduces LAPACK's result to
@@ -171,7 +175,7 @@ enum { PS_PRODUCTS_F32 = 0, PS_PRODUCTS_BF16X6 = 1, PS_PRODUCTS_BF16X3 = 2 };
 enum { PS_ACCUM_SEGMENTED = 0, PS_ACCUM_CHAIN = 1 };
 enum { PS_EXEC_STAGED = 0, PS_EXEC_PERSISTENT = 1 };
 enum { PS_PI_AUTO = 0, PS_PI_STREAMING = 1, PS_PI_RESIDENT = 2 };
-enum { PS_EIGH_ONE_SIDED = 0, PS_EIGH_TWO_SIDED = 1 };
+enum { PS_EIGH_AUTO = 0, PS_EIGH_TWO_SIDED = 1, PS_EIGH_ONE_SIDED = 2, PS_EIGH_TRIDIAGONAL = 3 };
 typedef struct {
   uint32_t struct_size;        /* sizeof(ps_options) of the caller's build */
   int32_t products;            /* PS_PRODUCTS_* */
@@ -186,7 +190,7 @@ typedef struct {
   int32_t pi_timeout_ms;       /* < 0 = default */
   float eigh_sweep_tol;        /* <= 0 = default */
   int32_t eigh_streams;        /* 0 = default */
-  int32_t eigh_solver;         /* PS_EIGH_ONE_SIDED (0, default) | PS_EIGH_TWO_SIDED */
+  int32_t eigh_solver;         /* PS_EIGH_AUTO (0, default) | PS_EIGH_TWO_SIDED | PS_EIGH_ONE_SIDED | PS_EIGH_TRIDIAGONAL */
   int32_t reserved[5];         /* 0 */
 } ps_options;
 /* Fills *opt with the defaults (struct_size = sizeof(ps_options)). */

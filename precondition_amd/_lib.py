@@ -140,7 +140,7 @@ def make_options(options=None):
   accumulation ('segmented' | 'chain'), averaged_steps, iters_hint (host float array, one per
   block: last recompute's inverse_pth_root_iters), fast_max_iters, averaged_err_threshold,
   execution ('staged' | 'persistent'), power_iteration ('auto' | 'streaming' | 'resident'),
-  pi_timeout_ms, eigh_sweep_tol, eigh_streams, eigh_solver ('one_sided' | 'two_sided').  Unknown keys
+  pi_timeout_ms, eigh_sweep_tol, eigh_streams, eigh_solver ('auto' | 'tridiagonal' | 'one_sided' | 'two_sided').  Unknown keys
   raise."""
   import numpy as np
   o = PsOptions()
@@ -162,7 +162,7 @@ def make_options(options=None):
   enum("accumulation", PS_ACCUM)
   enum("execution", PS_EXEC)
   enum("power_iteration", PS_PI)
-  enum("eigh_solver", {"one_sided": 0, "two_sided": 1})
+  enum("eigh_solver", {"auto": 0, "two_sided": 1, "one_sided": 2, "tridiagonal": 3})
   for key in ("averaged_steps", "fast_max_iters", "pi_timeout_ms", "eigh_streams"):
     if opts.get(key) is not None:
       setattr(o, key, int(opts[key]))

@@ -77,6 +77,7 @@ struct EighBlock {
   int cj_active;   // ... and is still sweeping
   int chol_fail;   // the factorisation met a non-positive pivot: two-sided fallback
   int cj_group;    // which of the two interleaved streams sweeps this block
+  int td_done;     // eigh_td.hip.h solved this block (its result stands; the Jacobi solvers skip it)
 };
 
 struct ETile {
@@ -117,10 +118,11 @@ __device__ inline void rr_pair_raw(int m, int r, int k, int& a, int& b) {
 
 // ---- init: D = A_in masked + ridge I, A = D, V = I; ||D||_F partials -------------
 __global__ __launch_bounds__(256) void eigh_init_kernel(EighBlock* blocks,
-                                                        const ETile* tiles) {
+                                                        const ETile* tiles, int skip_td_done) {
   __shared__ float red[4];
   const ETile te = tiles[blockIdx.x];
   EighBlock* eb = &blocks[te.block];
+  if (skip_td_done && eb->td_done) return;   // second start of the blocks eigh_td.hip.h handed back
   const int n = eb->n, ld = eb->npad, tid = threadIdx.x;
   const int tpr = ld / TILE;
   const float ridge = eb->ridge;
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(256) void eigh_control_kernel(EighBlock* blocks, in
       const float so = __uint_as_float(eb->soff_bits);
       eb->soff_bits = 0;
       eb->off_rel = so;
-      eb->active = (!eb->small && so > tol) ? 1 : 0;
+      eb->active = (!eb->small && !eb->td_done && so > tol) ? 1 : 0;
     } else if (eb->active) {
       const int cnt = eb->npairs * (eb->nb - 1);
       float off = 0.f;
@@ -745,7 +747,7 @@ __global__ void eigh_set_active_kernel(EighBlock* blocks, int nblocks, int swap_
   if (b >= nblocks) return;
   EighBlock* eb = &blocks[b];
   if (eb->n == 0) return;
-  eb->active = (eb->small || eb->cj) ? 0 : 1;
+  eb->active = (eb->small || eb->cj || eb->td_done) ? 0 : 1;
   if (swap_vw) { float* t = eb->V; eb->V = eb->W; eb->W = t; }
 }
 
@@ -1098,6 +1100,8 @@ __global__ __launch_bounds__(256) void eigh_zero_out_kernel(EighBlock* blocks) {
 
 }  // namespace psk
 
+#include "eigh_td.hip.h"
+
 // =============================================================================
 using namespace psk;
 using psh::Arena;
@@ -1122,9 +1126,26 @@ struct EPlan {
   std::vector<int> cj_group_of;              // per entry of big_ids
   int cj_swept = 0;
   PiPlan pip;
+  TdPlan td;                      // blocks of more than 128 rows: tridiagonalisation + divide and conquer
 };
 
-void finish_eplan(EPlan& pl) { pl.pip.build(pl.batch, pl.n_eff); }
+// sizing = true (ps_eigh_root_workspace_bytes: the caller's padding_start values are not known yet):
+// the tridiagonalisation workspace is carved for every block of more than 128 rows at
+// min(n, TD_MAXN), an upper bound of what any padding_start can make the call need.
+void finish_eplan(EPlan& pl, bool sizing = false) {
+  pl.pip.build(pl.batch, pl.n_eff);
+  if (sizing) {
+    std::vector<int> ids, nn = pl.n_eff;
+    for (int b : pl.big_ids)
+      if (pl.n_eff[b] > SE_MAXN) { ids.push_back(b); nn[b] = std::min(nn[b], TD_MAXN); }
+    if (!ids.empty()) td_make_plan(pl.td, ids, nn, pl.npad);
+    return;
+  }
+  bool td_ok = !pl.big_ids.empty();
+  for (int b : pl.big_ids)
+    if (pl.n_eff[b] <= SE_MAXN || pl.n_eff[b] > TD_MAXN) td_ok = false;
+  if (td_ok) td_make_plan(pl.td, pl.big_ids, pl.n_eff, pl.npad);
+}
 
 void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_start) {
   pl.batch = batch;
@@ -1169,6 +1190,7 @@ struct ELayout {
   ETile *sq, *pair, *row, *col, *rq, *chol, *cj_pair[2], *cj_row[2];
   int* big_ids;
   std::vector<float*> mat[5], Q, offp, ssq, evals;
+  TdLayout td;
 };
 
 size_t ecarve(EPlan& pl, Arena& ar, ELayout* lo) {
@@ -1202,6 +1224,7 @@ size_t ecarve(EPlan& pl, Arena& ar, ELayout* lo) {
     if (lo) { lo->Q.push_back(q); lo->offp.push_back(op); lo->ssq.push_back(ss);
               lo->evals.push_back(ev); }
   }
+  td_carve(pl.td, ar, lo ? &lo->td : nullptr);
   return ar.off;
 }
 
@@ -1220,7 +1243,7 @@ extern "C" size_t ps_eigh_root_workspace_bytes(int batch, const int32_t* n) {
   if (batch <= 0 || !n) return 0;
   EPlan pl;
   make_eplan(pl, batch, n, nullptr);
-  finish_eplan(pl);
+  finish_eplan(pl, true);
   Arena ar(nullptr, 0);
   return ecarve(pl, ar, nullptr) + 256;
 }
@@ -1320,7 +1343,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   // Power iteration (tol = error_tolerance, DS:996-1001) -> ridge -> D = A + ridge I.  Queued
   // again (on the streaming power iteration) if the resident one reports an expired wait at the
   // first host wait of the call (PiPlan::health).
-  const unsigned pi_expired_before = PiPlan::expired_total();
+  unsigned pi_expired_before = PiPlan::expired_total();
   auto enqueue_front = [&]() -> int {
     int rc2;
     if ((rc2 = up(lo.blocks, hb.data(), sizeof(EighBlock) * batch))) return rc2;
@@ -1334,7 +1357,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
                        pl.pip.d_blocks, batch, mode == 0 ? ridge_epsilon : 0.f, error_tolerance,
                        relative_matrix_epsilon);
     if (nsq > 0) {
-      hipLaunchKernelGGL(eigh_init_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
+      hipLaunchKernelGGL(eigh_init_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq, 0);
       hipLaunchKernelGGL(eigh_control_kernel, dim3(1), blk, 0, st, lo.blocks, batch, 0, 0.f, 0,
                          (EStatus*)nullptr);
     }
@@ -1404,7 +1427,48 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     // values are 20-30 % closer to float64 on rank-deficient-plus-ridge inputs.
     const int cj_refine = opt.eigh_cj_refine;
     const int cj_polish = opt.eigh_cj_polish;
-    if (cj_on && mode == 0 && any_big) {
+    // Blocks of 129 ... 4096 rows: tridiagonalisation + divide and conquer (eigh_td.hip.h).  One host
+    // wait at its end tells whether any block hit an iteration cap (or the resident power iteration
+    // expired); such a call starts over on the Jacobi solvers below.
+    // Blocks it keeps (all of them in mode 1; in root mode those whose spectrum spans less than
+    // eigh_td_max_cond: a float32 tridiagonalisation leaves eps * ||D|| of unstructured error, which
+    // the root function amplifies by ||D|| / lambda) are marked td_done and skipped by everything
+    // between here and the common finish; the others start over on the Jacobi solvers.
+    bool td_all = false;   // every block of more than 128 rows is done
+    bool td_any = false;
+    if (opt.eigh_td && any_big && !pl.td.empty()) {
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = td_run(st, pl.td, lo.td, lo.blocks, hb, opt.eigh_td_defl_eps, opt.eigh_td_stage,
+                         mode == 0 ? opt.eigh_td_max_cond : 0.f)))
+          return rc;
+        EStatus* slot = &status[63];
+        slot->gen = -1;
+        hipLaunchKernelGGL(td_status_kernel, dim3(1), dim3(1), 0, st, lo.td.nfail, slot);
+        PS_LAUNCH_CHECK();
+        PS_HIP(hipStreamSynchronize(st));
+        if (slot->gen != 0) return PS_EINTERNAL;
+        if (attempt == 0 && PiPlan::expired_total() != pi_expired_before) {
+          if ((rc = enqueue_front())) return rc;   // ridge of some blocks is NaN: streaming power iteration now
+          if ((rc = enqueue_small())) return rc;
+          pi_expired_before = PiPlan::expired_total();   // handled here: the Jacobi path below must not start over
+          continue;
+        }
+        const int redo = slot->active, nbig = (int)pl.big_ids.size();
+        if (opt.eigh_trace)
+          fprintf(stderr, "eigh td: %d of %d block(s) handed to the Jacobi solvers (%d for an iteration cap / "
+                          "non-finite input, the rest for their condition number)\n", redo, nbig, slot->pad_);
+        td_all = redo == 0;
+        td_any = redo < nbig;
+        if (!td_all) {   // those blocks start over: A = D, V = I
+          hipLaunchKernelGGL(eigh_init_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq, 1);
+          PS_LAUNCH_CHECK();
+        }
+        break;
+      }
+    }
+    const bool td_done = td_all;
+    if (td_done) run_two_sided = false;
+    if (cj_on && mode == 0 && any_big && !td_done) {
       const float cj_tol = opt.eigh_sweep_tol;
       const int cj_inner = opt.eigh_cj_inner;
       const float cj_done = opt.eigh_cj_done;   // inner iteration: stop after a sweep below this cosine
@@ -1643,8 +1707,12 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     // on the float64 MFMA as a float32 hi/lo pair; the Rayleigh quotients, and the error metric's
     // product U^T (D U), are taken from it (39 + 8.6 ms of float64 VALU dot products and a float32
     // D U product become 20 ms).
-    const bool cj_only = cj_on && mode == 0 && any_big && !run_two_sided && pl.small_ids.empty() &&
-                         cj_refine;
+    if (td_any) {   // the finish of the one-sided path (Rayleigh quotients from D V) applies to them
+      hipLaunchKernelGGL(td_mark_cj_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks, batch);
+      PS_LAUNCH_CHECK();
+    }
+    const bool cj_only = (cj_on || td_done) && mode == 0 && any_big && !run_two_sided &&
+                         pl.small_ids.empty() && cj_refine;
     if (cj_only) {
       hipLaunchKernelGGL(eigh_reproject_f64_kernel<0>, dim3(4 * nsq), blk, 0, st, lo.blocks, lo.sq);
       hipLaunchKernelGGL(cj_rayleigh_from_dv_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);

@@ -204,7 +204,7 @@ __global__ void cj_select_kernel(EighBlock* blocks, int nblocks) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblocks) return;
   EighBlock* eb = &blocks[b];
-  const int on = (eb->n > 0 && !eb->small && eb->npad >= 2 * TILE) ? 1 : 0;
+  const int on = (eb->n > 0 && !eb->small && eb->npad >= 2 * TILE && !eb->td_done) ? 1 : 0;
   eb->cj = on;
   eb->cj_active = on;
   eb->chol_fail = 0;

@@ -24,6 +24,7 @@ struct Options {
   double pi_timeout_ms = 5000.0;
   float eigh_sweep_tol = 2e-6f;
   int eigh_streams = 0;            // 0 = by size (eigh.hip), 1 | 2
+  int eigh_td = 1;                 // eigh_solver AUTO / TRIDIAGONAL: eigh_td.hip.h for 129 ... 4096 rows (PS_EIGH_TD)
   // ---- dev (environment, PS_DEV_ENV=1 only) -----------------------------------------------------
   bool force_general = false;      // PS_NEWTON_SYMMETRIC=0: full products for every block
   int stage_bk = 32;               // PS_NEWTON_BK = 16 | 32
@@ -58,6 +59,10 @@ struct Options {
   int eigh_extra_sweeps = 4;       // PS_EIGH_EXTRA_SWEEPS
   int eigh_final_polish = 1;       // PS_EIGH_FINAL_POLISH
   int eigh_refine = 1;             // PS_EIGH_REFINE
+  int eigh_td_stage = 0;           // PS_EIGH_TD_STAGE: 1 = stop after the reduction (Z_T = I; tests of the stages)
+  float eigh_td_defl_eps = 1e-8f;  // PS_EIGH_TD_DEFL_EPS: deflation tolerance of the divide and conquer (x 8 ||T||)
+  int eigh_td_streams = 1;         // PS_EIGH_TD_STREAMS: stream groups of the reduction
+  float eigh_td_max_cond = 1e3f;   // PS_EIGH_TD_MAX_COND: root mode keeps a block's result if lambda_max / lambda_min is below
 };
 
 // PS_EINVAL-style validation is the caller's: resolve() clamps what it does not understand to the

@@ -64,6 +64,11 @@ void ps_dev_env_overrides(Options& o) {
   geti("PS_EIGH_EXTRA_SWEEPS", o.eigh_extra_sweeps);
   geti("PS_EIGH_FINAL_POLISH", o.eigh_final_polish);
   geti("PS_EIGH_REFINE", o.eigh_refine);
+  geti("PS_EIGH_TD", o.eigh_td);
+  geti("PS_EIGH_TD_STAGE", o.eigh_td_stage);
+  getf("PS_EIGH_TD_DEFL_EPS", o.eigh_td_defl_eps);
+  geti("PS_EIGH_TD_STREAMS", o.eigh_td_streams);
+  getf("PS_EIGH_TD_MAX_COND", o.eigh_td_max_cond);
 }
 
 }  // namespace
@@ -96,8 +101,9 @@ Options resolve(const ps_options* u, bool* bad) {
     if (c.pi_timeout_ms >= 0) o.pi_timeout_ms = (double)c.pi_timeout_ms;
     if (c.eigh_sweep_tol > 0.f) o.eigh_sweep_tol = c.eigh_sweep_tol;
     if (c.eigh_streams > 0) o.eigh_streams = c.eigh_streams;
-    if (c.eigh_solver == PS_EIGH_TWO_SIDED) o.eigh_cj = 0;
-    else if (c.eigh_solver != PS_EIGH_ONE_SIDED && bad) *bad = true;
+    if (c.eigh_solver == PS_EIGH_TWO_SIDED) { o.eigh_cj = 0; o.eigh_td = 0; }
+    else if (c.eigh_solver == PS_EIGH_ONE_SIDED) o.eigh_td = 0;
+    else if (c.eigh_solver != PS_EIGH_AUTO && c.eigh_solver != PS_EIGH_TRIDIAGONAL && bad) *bad = true;
   }
   ps_dev_env_overrides(o);
   return o;
