@@ -436,6 +436,61 @@ def fd_cfg5(dev, factors=8, d=4096, rank=64, updates=3):
                   "b x b problems in the LDS-resident eigensolver, fp32 Rayleigh-Ritz"}
 
 
+def fd_parity_literal(dev, d=4096, rank=64, updates=2, p=4):
+  """BASELINE configs[4] on its LITERAL input (grad blocks ~N(0,1), no spiked rows): the HIP
+  Frequent-Directions update against oracle.fd_update_root (DS:1123-1290: LAPACK SVD of
+  [sqrt(decay) W | R]) for `updates` chained updates of one factor, each chain on its own
+  previous state.  The leading 64 singular values of a square Gaussian block sit in the edge
+  cluster of the spectrum, so individual eigenvectors are not comparable; what the optimizer
+  uses is: rho / tail, const = tail^(-1/p), the deflated and inverted eigenvalues, and the
+  operator P = const (I - U U^T) + U diag(inverted) U^T (DS:1690-1705)."""
+  from oracle import shampoo_oracle as orc
+  from precondition_amd import low_rank
+  gen = torch.Generator(device=dev).manual_seed(64)
+  prev_g = torch.zeros((d, rank + 2), dtype=torch.float32, device=dev)
+  prev_r = np.zeros((d, rank + 2), np.float32)
+  rows = []
+  for u in range(updates):
+    g = torch.randn((d, d), generator=gen, device=dev, dtype=torch.float32)
+    new, _ = low_rank._fd_update_root(
+        low_rank.gram_of_block(g, 0), p, rank=rank, ridge_epsilon=1e-6, error_tolerance=0.0,
+        relative_matrix_epsilon=True, decay=0.999, padding_start=d, prev=prev_g,
+        new_grad_is_gram=True)
+    _sync()
+    ref = orc.fd_update_root(g.cpu().numpy(), p, rank, ridge_epsilon=1e-6, error_tolerance=0.0,
+                             relative_matrix_epsilon=True, decay=0.999, padding_start=d, prev=prev_r)
+    got = new.cpu().numpy().astype(np.float64)
+    rf = ref.astype(np.float64)
+    r = rank
+    def op(pc):
+      c = pc[0, -1]
+      return c * np.eye(d) + (pc[:, :r] * (pc[:r, -2] - c)) @ pc[:, :r].T
+    def low(pc):
+      return (pc[:, :r] * pc[-r:, -1]) @ pc[:, :r].T
+    pg, pr = op(got), op(rf)
+    lg, lr = low(got), low(rf)
+    rho = float(rf[1, -1])
+    rows.append({
+        "update": u + 1,
+        "tail": float(got[1, -1]), "tail_ref": rho,
+        "tail_rel": abs(float(got[1, -1]) - rho) / rho,
+        "const_rel": abs(float(got[0, -1]) - float(rf[0, -1])) / float(rf[0, -1]),
+        "deflated_max_abs_over_tail": float(np.abs(got[-r:, -1] - rf[-r:, -1]).max() / rho),
+        "inverted_max_rel": float((np.abs(got[:r, -2] - rf[:r, -2]) / np.abs(rf[:r, -2])).max()),
+        "operator_rel_fro": float(np.linalg.norm(pg - pr) / np.linalg.norm(pr)),
+        "lowrank_part_rel_fro": float(np.linalg.norm(lg - lr) / max(np.linalg.norm(lr), 1e-300)),
+        "has_zeros_equal": bool(got[-1, -2] == rf[-1, -2]),
+    })
+    prev_g, prev_r = new, ref
+    del g, pg, pr, lg, lr
+  return {"input": f"one factor of dim {d}, rank {rank}, grad blocks ~N(0,1) (the literal BASELINE input), "
+                   f"{updates} chained updates, p={p}",
+          "oracle": "oracle.fd_update_root (numpy.linalg.svd of [sqrt(decay) W | R])",
+          "updates": rows,
+          "operator_rel_fro_max": max(x["operator_rel_fro"] for x in rows),
+          "tail_rel_max": max(x["tail_rel"] for x in rows)}
+
+
 def quant_f3(dev):
   """int16 quantize / dequantize of the ViT-B statistics (395 matrices,
   282.8 M elements, diagonal extracted) and int8 of its rank > 1 momentum buffers; HBM
@@ -647,10 +702,20 @@ def parity_sample_vit_b(vw, roots, metrics, per_class=1):
     h64 = (v * (np.maximum(w, 0) + ridge) ** (-1.0 / p)) @ v.T
     eq = bool(m[i, 1] == mm["inverse_pth_root_iters"] and m[i, 4] == mm["total_retries"])
     iters_equal &= eq
-    rows.append({"n": key[0], "p": key[1], "iters": float(m[i, 1]),
-                 "rel_fro_vs_oracle": _rel_fro(got, h_ref),
-                 "build_vs_f64": _rel_fro(got, h64), "oracle_vs_f64": _rel_fro(h_ref, h64)})
-  return {"classes": rows, "rel_fro_max": max(r["rel_fro_vs_oracle"] for r in rows),
+    row = {"n": key[0], "p": key[1], "iters": float(m[i, 1]),
+           "rel_fro_vs_oracle": _rel_fro(got, h_ref),
+           "build_vs_f64": _rel_fro(got, h64), "oracle_vs_f64": _rel_fro(h_ref, h64)}
+    # the criterion, per class: where the oracle's own float32 evaluation is within the bar of the
+    # float64 root, the build must be within the bar of the ORACLE; where it is not (two float32
+    # evaluations of an ill-conditioned root differ by more than the bar), the build must be at
+    # least as close to float64 as the oracle is
+    row["passes"] = bool(row["rel_fro_vs_oracle"] <= 1e-4 if row["oracle_vs_f64"] <= 1e-4
+                         else row["build_vs_f64"] <= row["oracle_vs_f64"])
+    rows.append(row)
+  return {"classes": rows, "passes": all(r["passes"] for r in rows),
+          "criterion": "per class: rel_fro_vs_oracle <= 1e-4 where oracle_vs_f64 <= 1e-4, "
+                       "else build_vs_f64 <= oracle_vs_f64",
+          "rel_fro_max": max(r["rel_fro_vs_oracle"] for r in rows),
           "rel_fro_median": float(np.median([r["rel_fro_vs_oracle"] for r in rows])),
           "max_build_over_oracle_error_vs_f64": max(r["build_vs_f64"] / r["oracle_vs_f64"] for r in rows),
           "iteration_and_retry_counts_equal": iters_equal, "bar": 1e-4,
@@ -792,6 +857,17 @@ def main():
 
   work = Workload(args.workload, rank, world, dev, multi)
   sec, flops = timed(work, args.steps, args.warmup, multi)
+  # The same step WITHOUT last recompute's iteration counts (ps_options.iters_hint): the first
+  # recompute of a run, or a caller that keeps no metrics.  Every block then takes the careful
+  # path (averaged M updates); reported beside the hinted number, never instead of it.
+  sec_no_hint = None
+  if not args.workload.startswith("eigh"):
+    kept, work.hint = work.hint, None
+    _refresh, work.refresh_hint = work.refresh_hint, (lambda: None)
+    sec_no_hint, _ = timed(work, max(2, args.steps // 2), 1, multi)
+    work.refresh_hint = _refresh
+    work.hint = kept
+    work.step(); work.refresh_hint()   # metrics / hint of the state the later legs expect
   nb, n, _, p, _ = WORKLOADS[args.workload]
   iters = work.metrics[:, 1].cpu().numpy()
   errs = work.metrics[:, 0].cpu().numpy()
@@ -815,6 +891,7 @@ def main():
                       f"A=GG^T with G~N(0,1) [{n}x{WORKLOADS[args.workload][2]}], "
                       "ridge 1e-6 relative, Newton",
           "blocks_per_gpu": nb, "n": n, "p": p,
+          "ms_per_step_no_hint": (round(sec_no_hint * 1e3, 3) if sec_no_hint else None),
           "parallelism": f"blocks partitioned over {world} GPU(s)" +
                          (", %s all-gather of roots in the timed region" % (
                              "RCCL" if (multi and not SELFTEST and
@@ -920,11 +997,18 @@ def main():
     torch.cuda.empty_cache()
     hw = Workload("headline_64x1024_p4", rank, world, dev, multi)
     hsec, hflops = timed(hw, max(2, args.steps // 2), 1, multi)
+    kept, hw.hint = hw.hint, None
+    _refresh, hw.refresh_hint = hw.refresh_hint, (lambda: None)
+    hsec_no_hint, _ = timed(hw, 2, 1, multi)
+    hw.refresh_hint = _refresh
+    hw.hint = kept
+    hw.step(); hw.refresh_hint()
     hex_ = executed_fraction(1024, 4, float(hw.metrics[:, 5].double().mean().item()),
                              float(hw.metrics[:, 7].double().mean().item()))
     head = {"workload": "64 blocks/GPU of 1024x1024 fp32, p=4",
             "value": round(hflops / hsec / 1e9, 1), "unit": "GFLOP/s (algorithmic, SURVEY 8d)",
             "ms_per_step": round(hsec * 1e3, 3),
+            "ms_per_step_no_hint": round(hsec_no_hint * 1e3, 3),
             "executed_fraction_of_algorithmic_flops": round(hex_, 4),
             # north_star bar: >= 40 % MFMA peak on this set; whole step, EXECUTED flops
             "executed_frac_of_f32_mfma_peak": round(
@@ -954,11 +1038,12 @@ def main():
     line["headline_1024"] = head
     # north_star's bar (>= 40 % of the fp32 MFMA peak on batched 1024^2, <= 1e-4 vs reference)
     # where the driver's record keeps it: the top-level `config`
-    line["config"]["headline_1024"] = {
-        "ms_per_step": head["ms_per_step"],
-        "kernel_frac": (head.get("roofline") or {}).get("frac"),
-        "step_executed_frac": head["executed_frac_of_f32_mfma_peak"],
-        "rel_fro_max": (head.get("parity_vs_oracle") or {}).get("rel_fro_max")}
+    # FLAT scalars: the driver's record keeps the scalars of `config` and drops nested objects
+    line["config"]["headline_1024_ms"] = head["ms_per_step"]
+    line["config"]["headline_1024_ms_no_hint"] = head["ms_per_step_no_hint"]
+    line["config"]["headline_1024_kernel_frac"] = (head.get("roofline") or {}).get("frac")
+    line["config"]["headline_1024_step_executed_frac"] = head["executed_frac_of_f32_mfma_peak"]
+    line["config"]["headline_1024_rel_fro"] = (head.get("parity_vs_oracle") or {}).get("rel_fro_max")
     del hw
 
   if not args.no_extras:
@@ -1096,8 +1181,10 @@ def main():
         edt = time.perf_counter() - t0
         conv = (6 + 2.0 / 3 + 4) * 2048.0 ** 3 * 64
         return {
-            "workload": "64 blocks of 2048x2048 fp32, p=2, eigh path (float64-accumulated "
-                        "Cholesky + one-sided block Jacobi on the factor, csrc/eigh_cj.hip.h)",
+            "workload": "64 blocks of 2048x2048 fp32, p=2, eigh path (Householder tridiagonalisation + "
+                        "float64 divide and conquer + compact-WY back-transformation, "
+                        "csrc/eigh_td.hip.h; blocks with lambda_max / lambda_min > 1e3 take the "
+                        "one-sided block Jacobi of csrc/eigh_cj.hip.h instead)",
             "ms_per_step": round(edt * 1e3, 1),
             "jacobi_sweeps": float(ew.metrics[:, 5].max()),
             "error_metric_max": float(ew.metrics[:, 0].max()),
@@ -1107,10 +1194,9 @@ def main():
                          "achieved": round(conv / edt / 1e12, 2),
                          "frac": round(conv / edt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                          "convention": "SURVEY.md 8d: (6 2/3 + 4) n^3 per block incl. the error "
-                                       "metric (what a tridiagonalisation-based eigh would "
-                                       "execute); the one-sided block Jacobi executes ~6 n^3 "
-                                       "per sweep x ~10 sweeps, its kernel split and MFMA-busy "
-                                       "share are in profiles/r03_eigh_*"},
+                                       "metric; the reduction's symmetric mat-vec is HBM-bound "
+                                       "(n^3 / 6 * 4 bytes per block: kernel split in "
+                                       "profiles/r05_eigh_*)"},
         }
 
       def fd_f32():
@@ -1132,8 +1218,17 @@ def main():
                 "note": "BASELINE configs[4] over 8 GPUs = one 4096-dim factor per rank; no exchange "
                         "step inside an FD update"}
 
+      def fd_main():
+        r = fd_cfg5(dev)
+        if not args.no_cpu_baseline:
+          try:
+            r["parity_vs_oracle"] = fd_parity_literal(dev)
+          except Exception as e:  # pylint: disable=broad-except
+            r["parity_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        return r
+
       for key, fn in (("newton_bf16x6", lambda: newton_bf16x6_leg(dev, clock)),
-                      ("fd_cfg5", lambda: fd_cfg5(dev)), ("fd_cfg5_f32_products", fd_f32),
+                      ("fd_cfg5", fd_main), ("fd_cfg5_f32_products", fd_f32),
                       ("fd_cfg5_rank_share", fd_one),
                       ("quant_f3", lambda: quant_f3(dev)), ("eigh_cfg3", eigh_cfg3)):
         torch.cuda.empty_cache()
@@ -1143,12 +1238,23 @@ def main():
           line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
   if rank == 0:
+    cfg = line["config"]   # flat scalars only (the driver's record drops lists and objects)
     if isinstance(line.get("eigh_cfg3"), dict) and "ms_per_step" in line["eigh_cfg3"]:
-      line["config"]["eigh_cfg3_ms"] = line["eigh_cfg3"]["ms_per_step"]
+      cfg["eigh_cfg3_ms"] = line["eigh_cfg3"]["ms_per_step"]
+      cfg["eigh_cfg3_rel_fro"] = (line["eigh_cfg3"].get("parity_vs_oracle") or {}).get("rel_fro_max")
+      cfg["eigh_cfg3_frac_of_f32_mfma_peak"] = (line["eigh_cfg3"].get("roofline") or {}).get("frac")
     if isinstance(line.get("fd_cfg5"), dict) and "ms_per_factor_update" in line["fd_cfg5"]:
-      line["config"]["fd_cfg5_ms"] = line["fd_cfg5"]["ms_per_factor_update"]
+      cfg["fd_cfg5_ms_per_factor"] = float(np.median(line["fd_cfg5"]["ms_per_factor_update"]))
+      par = line["fd_cfg5"].get("parity_vs_oracle") or {}
+      cfg["fd_cfg5_operator_rel_fro"] = par.get("operator_rel_fro_max")
+      cfg["fd_cfg5_tail_rel"] = par.get("tail_rel_max")
+    if isinstance(line.get("fd_cfg5_rank_share"), dict) and "ms_per_factor_update" in line["fd_cfg5_rank_share"]:
+      cfg["fd_cfg5_one_factor_per_gpu_ms"] = float(np.median(line["fd_cfg5_rank_share"]["ms_per_factor_update"]))
     if isinstance(line.get("vit_b_cfg4"), dict):
-      line["config"]["vit_b_cfg4_ms"] = line["vit_b_cfg4"].get("ms_per_step")
+      cfg["vit_b_cfg4_ms"] = line["vit_b_cfg4"].get("ms_per_step")
+      vpar = line["vit_b_cfg4"].get("parity_vs_oracle") or {}
+      if vpar:
+        cfg["vit_b_cfg4_parity_passes"] = vpar.get("passes")
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     line["cpu_baseline"] = cpu_baseline(args.workload)
   if rank == 0:

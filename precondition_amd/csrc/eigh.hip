@@ -1439,7 +1439,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     if (opt.eigh_td && any_big && !pl.td.empty()) {
       for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = td_run(st, pl.td, lo.td, lo.blocks, hb, opt.eigh_td_defl_eps, opt.eigh_td_stage,
-                         mode == 0 ? opt.eigh_td_max_cond : 0.f)))
+                         mode == 0 ? opt.eigh_td_max_cond : 0.f, opt.eigh_td_streams)))
           return rc;
         EStatus* slot = &status[63];
         slot->gen = -1;

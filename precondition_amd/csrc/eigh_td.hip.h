@@ -91,31 +91,57 @@ __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, in
   const int X = jbase / TILE + blockIdx.x;
   if (X >= nt) return;
   const int c = X * TILE + tid;
-  float wfin = 0.f, gamma = 0.f;
   const bool do_f = jf >= 0 && jf <= n - 2;
+  const bool do_r = jr >= 0 && jr <= n - 1;
+  const int i = do_r ? jr % TD_NB : 0, p = jr - i;
+  // every load of the kernel is issued before the first use (one memory round trip)
+  float pd[32];
+  float tauf = 0.f, wpc = 0.f, vfc = 0.f, wpj = 0.f, vfj = 0.f;
+  if (do_f) {
+    const int x0 = (jf + 1) / TILE;
+#pragma unroll
+    for (int x = 0; x < 32; ++x) pd[x] = (x >= x0 && x < nt) ? tb->part_dot[x] : 0.f;
+    tauf = tb->tau[jf];
+    wpc = tb->wp[c];
+    vfc = tb->VHt[(int64_t)jf * ld + c];
+    if (do_r) { wpj = tb->wp[jr]; vfj = tb->VHt[(int64_t)jf * ld + jr]; }
+  }
+  float vj = 0.f, wj = 0.f, u = 0.f;
+  float wrow[TD_NB], vrow[TD_NB];
+  if (do_r) {
+    if (tid < i) {
+      vj = tb->VHt[(int64_t)(p + tid) * ld + jr];
+      wj = tb->Wt[(int64_t)tid * ld + jr];
+    }
+    u = tb->A[(int64_t)jr * ld + c];
+#pragma unroll
+    for (int ip = 0; ip < TD_NB; ++ip) {
+      wrow[ip] = ip < i ? tb->Wt[(int64_t)ip * ld + c] : 0.f;
+      vrow[ip] = ip < i ? tb->VHt[(int64_t)(p + ip) * ld + c] : 0.f;
+    }
+  }
+  float wfin = 0.f, gamma = 0.f;
   if (do_f) {
     float s = 0.f;
-    for (int x = (jf + 1) / TILE; x < nt; ++x) s += tb->part_dot[x];
-    gamma = 0.5f * tb->tau[jf] * s;
-    const int i_f = jf % TD_NB;
-    wfin = tb->wp[c] - gamma * tb->VHt[(int64_t)jf * ld + c];
-    tb->Wt[(int64_t)i_f * ld + c] = wfin;
+#pragma unroll
+    for (int x = 0; x < 32; ++x) s += pd[x];
+    gamma = 0.5f * tauf * s;
+    wfin = wpc - gamma * vfc;
+    tb->Wt[(int64_t)(jf % TD_NB) * ld + c] = wfin;
   }
-  if (jr < 0 || jr > n - 1) return;
-  const int i = jr % TD_NB, p = jr - i;
+  if (!do_r) return;
   if (tid < i) {
-    sVj[tid] = tb->VHt[(int64_t)(p + tid) * ld + jr];
-    float wj = tb->Wt[(int64_t)tid * ld + jr];
-    if (do_f && tid == i - 1)   // being finalised by another workgroup of this launch: recompute
-      wj = tb->wp[jr] - gamma * tb->VHt[(int64_t)jf * ld + jr];
+    if (do_f && tid == i - 1) wj = wpj - gamma * vfj;   // being finalised by another workgroup: recompute
+    sVj[tid] = vj;
     sWj[tid] = wj;
   }
   __syncthreads();
-  float u = tb->A[(int64_t)jr * ld + c];
-  for (int ip = 0; ip < i; ++ip) {
-    const float wc = (do_f && ip == i - 1) ? wfin : tb->Wt[(int64_t)ip * ld + c];
-    const float vc = tb->VHt[(int64_t)(p + ip) * ld + c];
-    u -= sVj[ip] * wc + sWj[ip] * vc;
+#pragma unroll
+  for (int ip = 0; ip < TD_NB; ++ip) {
+    if (ip < i) {
+      const float wc = (do_f && ip == i - 1) ? wfin : wrow[ip];
+      u -= sVj[ip] * wc + sWj[ip] * vrow[ip];
+    }
   }
   if (c >= n) u = 0.f;
   if (c == jr) tb->dT[jr] = u;
@@ -156,6 +182,12 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
   while (q >= Tmax - Ip) { q -= Tmax - Ip; ++Ip; }
   const int I = I0 + Ip, J = I + q;
   if (J >= nt) return;
+  // the tile: thread -> rows (tid >> 5) + 8 k, columns 4 (tid & 31) .. ; its loads go out first
+  const int r0 = tid >> 5, c4 = (tid & 31) * 4;
+  const float* src = tb->A + (int64_t)(I * TILE + r0) * ld + J * TILE + c4;
+  f32x4 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = gload4(src + (int64_t)(8 * k) * ld);
   float beta, tau, scale, v1;
   td_house(tb, j, beta, tau, scale, v1);
   if (tid < TILE) {
@@ -163,12 +195,6 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
     svI[tid] = cI == j + 1 ? v1 : (cI > j + 1 && cI < n ? tb->ubuf[cI] * scale : 0.f);
     svJ[tid] = cJ == j + 1 ? v1 : (cJ > j + 1 && cJ < n ? tb->ubuf[cJ] * scale : 0.f);
   }
-  // the tile: thread -> rows (tid >> 5) + 8 k, columns 4 (tid & 31) ..
-  const int r0 = tid >> 5, c4 = (tid & 31) * 4;
-  const float* src = tb->A + (int64_t)(I * TILE + r0) * ld + J * TILE + c4;
-  f32x4 a[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = gload4(src + (int64_t)(8 * k) * ld);
   __syncthreads();
   const f32x4 vj = *reinterpret_cast<const f32x4*>(&svJ[c4]);
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -221,8 +247,8 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
 #pragma unroll
     for (int off = 4; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
     if (sub == 0 && ip < i) {
-      tb->part_ab[(I * 2 + 0) * TD_NB + ip] = sa;
-      tb->part_ab[(I * 2 + 1) * TD_NB + ip] = sb;
+      tb->part_ab[(0 * TD_NB + ip) * 32 + I] = sa;   // [which][ip][tile row]: the reader's run is contiguous
+      tb->part_ab[(1 * TD_NB + ip) * 32 + I] = sb;
     }
   }
 }
@@ -238,23 +264,44 @@ __global__ __launch_bounds__(128) void td_w_kernel(TdBlock* blocks, int j) {
   const int I0 = (j + 1) / TILE, X = I0 + blockIdx.x;
   if (X >= nt) return;
   const int i = j % TD_NB, p = j - i;
+  const int c = X * TILE + tid;
+  // every load of the kernel is issued before the first use
+  float pab[32];
   if (tid < 2 * TD_NB) {
-    const int which = tid / TD_NB, ip = tid % TD_NB;
+    const float* src = tb->part_ab + (int64_t)tid * 32;   // tid = which * TD_NB + ip
+#pragma unroll
+    for (int x4 = 0; x4 < 8; ++x4) {
+      const f32x4 v = gload4(src + 4 * x4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pab[4 * x4 + e] = v[e];
+    }
+  }
+  float ys[32], wrow[TD_NB], vrow[TD_NB];
+#pragma unroll
+  for (int Y = 0; Y < 32; ++Y)
+    ys[Y] = (Y >= I0 && Y < nt) ? tb->slab[((int64_t)X * nt + Y) * TILE + tid] : 0.f;
+#pragma unroll
+  for (int ip = 0; ip < TD_NB; ++ip) {
+    vrow[ip] = ip < i ? tb->VHt[(int64_t)(p + ip) * ld + c] : 0.f;
+    wrow[ip] = ip < i ? tb->Wt[(int64_t)ip * ld + c] : 0.f;
+  }
+  const float tau = tb->tau[j];
+  const float vc = tb->VHt[(int64_t)j * ld + c];
+  if (tid < 2 * TD_NB) {
     float s = 0.f;
-    if (ip < i)
-      for (int x = I0; x < nt; ++x) s += tb->part_ab[(x * 2 + which) * TD_NB + ip];
-    sab[which][ip] = s;
+#pragma unroll
+    for (int x = 0; x < 32; ++x) s += (x >= I0 && x < nt) ? pab[x] : 0.f;
+    sab[tid / TD_NB][tid % TD_NB] = (tid % TD_NB) < i ? s : 0.f;
   }
   __syncthreads();
-  const int c = X * TILE + tid;
   float y = 0.f;
-  for (int Y = I0; Y < nt; ++Y) y += tb->slab[((int64_t)X * nt + Y) * TILE + tid];
-  for (int ip = 0; ip < i; ++ip)
-    y -= tb->VHt[(int64_t)(p + ip) * ld + c] * sab[0][ip] + tb->Wt[(int64_t)ip * ld + c] * sab[1][ip];
-  const float tau = tb->tau[j];
+#pragma unroll
+  for (int Y = 0; Y < 32; ++Y) y += ys[Y];
+#pragma unroll
+  for (int ip = 0; ip < TD_NB; ++ip) y -= vrow[ip] * sab[0][ip] + wrow[ip] * sab[1][ip];
   const float w = (c > j && c < n) ? tau * y : 0.f;
   tb->wp[c] = w;
-  const float dot = td_wg_sum128(w * tb->VHt[(int64_t)j * ld + c], red);
+  const float dot = td_wg_sum128(w * vc, red);
   if (tid == 0) tb->part_dot[X] = dot;
 }
 
@@ -897,7 +944,7 @@ inline void td_carve(const TdPlan& pl, psh::Arena& ar, TdLayout* lo) {
     tb.slab = ar.take<float>(nt * nt * TILE);
     tb.part_ss = ar.take<float>(nt);
     tb.part_dot = ar.take<float>(nt);
-    tb.part_ab = ar.take<float>(nt * 2 * TD_NB);
+    tb.part_ab = ar.take<float>(2 * TD_NB * 32);
     tb.dT = ar.take<float>(ld); tb.eT = ar.take<float>(ld); tb.tau = ar.take<float>(ld);
     tb.evals = ar.take<float>(ld);
     double** f64s[] = {&tb.d64, &tb.e64, &tb.Dc[0], &tb.Dc[1], &tb.z, &tb.dl, &tb.w, &tb.mu,
@@ -914,7 +961,8 @@ inline void td_carve(const TdPlan& pl, psh::Arena& ar, TdLayout* lo) {
 // Enqueues the whole solver on `st` for the blocks of the plan.  stage 1 (developer): stop after
 // the reduction (Z_T = I: the output vectors are Q, the values diag(T)).
 inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_ebs,
-                  const std::vector<EighBlock>& hb, float eps_defl, int stage, float max_cond) {
+                  const std::vector<EighBlock>& hb, float eps_defl, int stage, float max_cond,
+                  int stream_groups) {
   const int B = (int)pl.ids.size();
   for (int k = 0; k < B; ++k) {
     TdBlock& tb = lo.host[k];
@@ -947,22 +995,54 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
   const dim3 b256(256), b128(128);
   const int nmax = pl.nmax, ntmax = pl.ntmax;
   // ---- reduction to tridiagonal form ----
+  // The blocks are dealt to `stream_groups` (1 | 2) groups that reduce on two streams: a column costs
+  // three dependent launches, of which only the mat-vec is HBM-bound; one group's short vector kernels
+  // run beside the other group's mat-vec.
+  static thread_local hipStream_t side = nullptr;
+  static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const bool two = stream_groups >= 2 && B >= 2;
+  if (two && !side) {
+    PS_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    PS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
   hipLaunchKernelGGL(td_zero_kernel, dim3(256, B), b256, 0, st, lo.blocks, 0);
   hipLaunchKernelGGL(td_zero_kernel, dim3(8, B), b256, 0, st, lo.blocks, 1);
+  const int ngroups = two ? 2 : 1;
+  const int gfirst[3] = {0, two ? (B + 1) / 2 : B, B};
+  hipStream_t gs[2] = {st, two ? side : st};
+  struct SideJoin {   // however this scope is left, the side stream is joined back into the caller's
+    hipStream_t st, side; hipEvent_t ev; bool forked;
+    ~SideJoin() { if (forked && hipEventRecord(ev, side) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0); }
+  } join{st, side, ev_join, false};
+  if (two) {
+    PS_HIP(hipEventRecord(ev_fork, st));
+    PS_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    join.forked = true;
+  }
   for (int j = 0; j < nmax; ++j) {
     const int i = j % TD_NB;
-    hipLaunchKernelGGL(td_row_kernel, dim3(ntmax - j / TILE, B), b128, 0, st, lo.blocks,
-                       i > 0 ? j - 1 : -1, j);
-    if (j <= nmax - 2) {
-      const int T = ntmax - (j + 1) / TILE;
-      hipLaunchKernelGGL(td_symv_kernel, dim3(T * (T + 1) / 2, B), b256, 0, st, lo.blocks, j, T);
-      hipLaunchKernelGGL(td_w_kernel, dim3(T, B), b128, 0, st, lo.blocks, j);
+    for (int g = 0; g < ngroups; ++g) {
+      TdBlock* gb = lo.blocks + gfirst[g];
+      const int Bg = gfirst[g + 1] - gfirst[g];
+      hipLaunchKernelGGL(td_row_kernel, dim3(ntmax - j / TILE, Bg), b128, 0, gs[g], gb,
+                         i > 0 ? j - 1 : -1, j);
+      if (j <= nmax - 2) {
+        const int T = ntmax - (j + 1) / TILE;
+        hipLaunchKernelGGL(td_symv_kernel, dim3(T * (T + 1) / 2, Bg), b256, 0, gs[g], gb, j, T);
+        hipLaunchKernelGGL(td_w_kernel, dim3(T, Bg), b128, 0, gs[g], gb, j);
+      }
+      if (i == TD_NB - 1 && j + 1 <= nmax - 1) {   // row j + 1 (even if it is the last: d[n - 1]) reads the updated matrix
+        const int p = j - i, T = ntmax - (p + TD_NB) / TILE;
+        hipLaunchKernelGGL(td_row_kernel, dim3(ntmax - (j + 1) / TILE, Bg), b128, 0, gs[g], gb, j, -1);
+        hipLaunchKernelGGL(td_syr2k_kernel, dim3(T * (T + 1) / 2, Bg), b256, 0, gs[g], gb, p, T);
+      }
     }
-    if (i == TD_NB - 1 && j + 1 <= nmax - 1) {   // row j + 1 (even if it is the last: d[n - 1]) reads the updated matrix
-      const int p = j - i, T = ntmax - (p + TD_NB) / TILE;
-      hipLaunchKernelGGL(td_row_kernel, dim3(ntmax - (j + 1) / TILE, B), b128, 0, st, lo.blocks, j, -1);
-      hipLaunchKernelGGL(td_syr2k_kernel, dim3(T * (T + 1) / 2, B), b256, 0, st, lo.blocks, p, T);
-    }
+  }
+  if (two) {
+    join.forked = false;
+    PS_HIP(hipEventRecord(ev_join, side));
+    PS_HIP(hipStreamWaitEvent(st, ev_join, 0));
   }
   PS_LAUNCH_CHECK();
   // ---- divide and conquer ----

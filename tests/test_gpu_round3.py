@@ -156,7 +156,8 @@ def test_eigh_root_cholesky_jacobi_vs_oracle(n, k, p, device):
   1e-4 on the root (north_star's bar), error metric of the same size as LAPACK's."""
   a = wishart(n, k, n + p)
   h_ref, m_ref = orc.matrix_inverse_pth_root_eigh(a, p)
-  roots, met = K().matrix_inverse_pth_root_batched([torch.tensor(a, device=device)], [p], eigh=True)
+  roots, met = K().matrix_inverse_pth_root_batched([torch.tensor(a, device=device)], [p], eigh=True,
+                                                   options={"eigh_solver": "one_sided"})
   h = roots[0].cpu().numpy()
   met = met.cpu().numpy()
   assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 1e-4
@@ -177,24 +178,28 @@ def test_eigh_root_two_sided_fallback_for_indefinite_input(device, monkeypatch):
   good = wishart(256, 1024, 3)
   mats = [torch.tensor(good, device=device), torch.tensor(bad, device=device),
           torch.tensor(wishart(300, 900, 4), device=device)]
-  roots, met = K().matrix_inverse_pth_root_batched(mats, [2, 2, 2], eigh=True)
-  for m, h in zip(mats, roots):
-    h_ref, _ = orc.matrix_inverse_pth_root_eigh(m.cpu().numpy(), 2)
-    rel = np.linalg.norm(h.cpu().numpy() - h_ref) / np.linalg.norm(h_ref)
-    assert rel < 2e-4, rel
+  # default solver (round 5): the tridiagonalisation path keeps the two positive definite blocks and
+  # hands the indefinite one to the Jacobi solvers (Cholesky breakdown -> two-sided) inside the call
+  for opts in (None, {"eigh_solver": "one_sided"}):
+    roots, met = K().matrix_inverse_pth_root_batched(mats, [2, 2, 2], eigh=True, options=opts)
+    for m, h in zip(mats, roots):
+      h_ref, _ = orc.matrix_inverse_pth_root_eigh(m.cpu().numpy(), 2)
+      rel = np.linalg.norm(h.cpu().numpy() - h_ref) / np.linalg.norm(h_ref)
+      assert rel < 2e-4, (opts, rel)
   # the same batch on the two-sided solver alone
-  monkeypatch.setenv("PS_EIGH_CJ", "0")
-  roots2, _ = K().matrix_inverse_pth_root_batched(mats, [2, 2, 2], eigh=True)
+  roots2, _ = K().matrix_inverse_pth_root_batched(mats, [2, 2, 2], eigh=True,
+                                                  options={"eigh_solver": "two_sided"})
   assert torch.allclose(roots[1], roots2[1], rtol=0, atol=2e-4 * float(roots2[1].abs().max()))
 
 
 def test_eigh_root_one_stream_and_two_streams_agree(device, monkeypatch):
   """The two stream groups sweep disjoint blocks: results do not depend on the interleaving."""
   mats = [torch.tensor(wishart(256 + 128 * (i % 2), 1024, 40 + i), device=device) for i in range(5)]
+  one = {"eigh_solver": "one_sided"}
   monkeypatch.setenv("PS_EIGH_CJ_STREAMS", "1")
-  r1, m1 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True)
+  r1, m1 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True, options=one)
   monkeypatch.setenv("PS_EIGH_CJ_STREAMS", "2")
-  r2, m2 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True)
+  r2, m2 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True, options=one)
   for a, b in zip(r1, r2):
     assert torch.equal(a, b)
   assert torch.equal(m1, m2)

@@ -1,0 +1,156 @@
+"""Round-5 GPU tests (through the C-ABI):
+
+* the tridiagonalisation + divide-and-conquer eigensolver (csrc/eigh_td.hip.h; the algorithm class of
+  the reference's jnp.linalg.eigh -> LAPACK ssyevd, DS:1007) behind matrix_inverse_pth_root_eigh
+  (DS:943-1030) and behind plain eigh: roots against the oracle, eigenpairs against NumPy float64,
+  sizes that cross every panel / tile / leaf boundary of the reduction, mixed batches;
+* blocks whose spectrum spans more than 1e3 are handed to the Jacobi solvers inside the same call
+  and come out bit-identical to a call pinned to that solver;
+* the two stream groups of the reduction do not change a bit;
+* BASELINE configs[4] on its literal input against the oracle's LAPACK-SVD update.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shampoo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def K():
+  from precondition_amd import kernels
+  return kernels
+
+
+def wishart(n, k, seed):
+  g = np.random.default_rng(seed).standard_normal((n, k)).astype(np.float32)
+  return (g @ g.T).astype(np.float32)
+
+
+# 129, 161: the last row is the first of a 32-column panel; 257, 385: first of a 128-row tile;
+# 1000: odd splits at every level of the partition tree; 2048: the size of BASELINE configs[2]
+@pytest.mark.parametrize("n,k,p", [(129, 600, 2), (161, 700, 4), (200, 800, 2), (257, 1100, 2),
+                                   (384, 768, 4), (385, 1500, 2), (1000, 2000, 2), (2048, 4096, 2)])
+def test_eigh_root_tridiagonal_path_vs_oracle(n, k, p, device):
+  a = wishart(n, k, n + p)
+  h_ref, m_ref = orc.matrix_inverse_pth_root_eigh(a, p)
+  roots, met = K().matrix_inverse_pth_root_batched([torch.tensor(a, device=device)], [p], eigh=True)
+  h = roots[0].cpu().numpy()
+  met = met.cpu().numpy()
+  assert met[0, 5] == 0, "no Jacobi sweep: the block stayed on the tridiagonalisation path"
+  assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 2e-5
+  assert np.abs(h - h.T).max() <= 1e-5 * np.abs(h).max()
+  lam = float(np.linalg.eigvalsh(a.astype(np.float64)).max())
+  assert met[0, 0] < 1e-5 * lam and met[0, 0] < 0.1, met[0]     # DS:1017-1021, failure threshold 0.1
+  assert (met[0, 1:5] == 0).all()                                 # DS:1022: only the error field
+  # float64 closed form
+  w, v = np.linalg.eigh(a.astype(np.float64))
+  _, lam_pi, _ = orc.power_iteration(a, 100, 1e-6)
+  eps = 1e-6 * max(float(lam_pi), 1e-6)
+  ref64 = (v * np.maximum(w + eps, eps) ** (-1.0 / p)) @ v.T
+  e_hip = np.linalg.norm(h - ref64) / np.linalg.norm(ref64)
+  cond = float(w.max() + eps) / float(max(w.min(), 0.0) + eps)
+  assert e_hip < max(2e-6, 1e-7 * cond), (e_hip, cond)
+
+
+def test_eigh_root_tridiagonal_path_padding_and_mixed_batch(device):
+  """padding_start < n (DS:985-1010: the trailing rows / columns are masked, the root is zero
+  there), blocks of different sizes in one call, a block of <= 128 rows beside them."""
+  sizes = [(300, 260), (640, 640), (130, 129), (96, 96), (1024, 1000)]
+  mats, pads = [], []
+  for i, (n, ps) in enumerate(sizes):
+    a = wishart(n, 3 * n, 900 + i)
+    a[ps:, :] = 0; a[:, ps:] = 0
+    mats.append(a); pads.append(ps)
+  roots, met = K().matrix_inverse_pth_root_batched([torch.tensor(a, device=device) for a in mats],
+                                                   [2, 4, 2, 4, 2], pads, eigh=True)
+  for a, ps, p, h in zip(mats, pads, [2, 4, 2, 4, 2], roots):
+    h_ref, _ = orc.matrix_inverse_pth_root_eigh(a, p, padding_start=ps)
+    h = h.cpu().numpy()
+    assert np.linalg.norm(h - h_ref) / np.linalg.norm(h_ref) < 2e-5, (a.shape, ps)
+    assert not h[ps:, :].any() and not h[:, ps:].any()
+
+
+def test_eigh_plain_eigenpairs_tridiagonal_path(device):
+  """ps_eigh_batched_f32 (jnp.linalg.eigh, DS:1071 / subspace problems): indefinite input too."""
+  rng = np.random.default_rng(3)
+  mats = []
+  for n in (129, 200, 333, 512, 1000):
+    g = rng.standard_normal((n, n))
+    mats.append(((g + g.T) / 2).astype(np.float32))
+  mats.append(wishart(600, 100, 8) + np.float32(1e-3) * np.eye(600, dtype=np.float32))   # rank-deficient cluster
+  es, vs = K().eigh_batched([torch.tensor(m, device=device) for m in mats])
+  for a, e, v in zip(mats, es, vs):
+    w = np.linalg.eigvalsh(a.astype(np.float64))
+    nrm = np.abs(w).max()
+    e, v = e.cpu().numpy().astype(np.float64), v.cpu().numpy().astype(np.float64)
+    assert np.abs(e - w).max() <= 2e-6 * nrm
+    assert np.abs(v.T @ v - np.eye(len(w))).max() < 5e-6
+    assert np.abs(a.astype(np.float64) @ v - v * e).max() <= 5e-6 * nrm
+
+
+def test_eigh_ill_conditioned_blocks_take_the_jacobi_solver_in_the_same_call(device):
+  """A float32 tridiagonalisation leaves eps * ||D|| of unstructured error, which lambda^(-1/p)
+  amplifies by ||D|| / lambda: blocks with lambda_max / lambda_min > 1e3 (ps_options default) are
+  handed to the one-sided block Jacobi on the Cholesky factor (relative accuracy on small
+  eigenvalues) inside the call.  Their roots are bit-identical to a call pinned to that solver;
+  the well-conditioned blocks of the same call stay on the fast path."""
+  rng = np.random.default_rng(12)
+  q, _ = np.linalg.qr(rng.standard_normal((384, 384)))
+  graded = (q * 10.0 ** rng.uniform(-4, 2, 384)) @ q.T
+  graded = ((graded + graded.T) / 2).astype(np.float32)
+  g = rng.standard_normal((512, 128)); lowrank = (g @ g.T).astype(np.float32)
+  mats = [wishart(512, 2048, 1), graded, wishart(300, 1200, 2), lowrank]
+  ts = [torch.tensor(m, device=device) for m in mats]
+  ps = [2, 4, 2, 2]
+  r_auto, m_auto = K().matrix_inverse_pth_root_batched(ts, ps, eigh=True)
+  r_jac, m_jac = K().matrix_inverse_pth_root_batched(ts, ps, eigh=True, options={"eigh_solver": "one_sided"})
+  m_auto, m_jac = m_auto.cpu().numpy(), m_jac.cpu().numpy()
+  assert m_auto[0, 5] == 0 and m_auto[2, 5] == 0          # no Jacobi sweeps on the Wishart blocks
+  assert m_auto[1, 5] >= 3 and m_auto[3, 5] >= 3          # the graded / rank-deficient ones swept
+  for i in (1, 3):
+    assert torch.equal(r_auto[i], r_jac[i]) and np.array_equal(m_auto[i], m_jac[i])
+  for i in (0, 2):   # two solvers, one answer (to float32 accuracy)
+    d = (r_auto[i] - r_jac[i]).norm() / r_jac[i].norm()
+    assert float(d) < 1e-5
+  for a, p, h in zip(mats, ps, r_auto):
+    h_ref, _ = orc.matrix_inverse_pth_root_eigh(a, p)
+    w, v = np.linalg.eigh(a.astype(np.float64))
+    _, lam_pi, _ = orc.power_iteration(a, 100, 1e-6)
+    eps = 1e-6 * max(float(lam_pi), 1e-6)
+    ref64 = (v * np.maximum(w + eps, eps) ** (-1.0 / p)) @ v.T
+    e_hip = np.linalg.norm(h.cpu().numpy() - ref64) / np.linalg.norm(ref64)
+    e_ref = np.linalg.norm(h_ref - ref64) / np.linalg.norm(ref64)
+    assert e_hip < 6 * e_ref + 2e-4
+
+
+def test_eigh_tridiagonal_path_stream_groups_do_not_change_a_bit(device, monkeypatch):
+  mats = [torch.tensor(wishart(256 + 128 * (i % 3), 1600, 60 + i), device=device) for i in range(5)]
+  monkeypatch.setenv("PS_EIGH_TD_STREAMS", "1")
+  r1, m1 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True)
+  monkeypatch.setenv("PS_EIGH_TD_STREAMS", "2")
+  r2, m2 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True)
+  r3, m3 = K().matrix_inverse_pth_root_batched(mats, [2] * 5, eigh=True)
+  for a, b, c in zip(r1, r2, r3):
+    assert torch.equal(a, b) and torch.equal(b, c)
+  assert torch.equal(m1, m2) and torch.equal(m2, m3)
+
+
+def test_fd_cfg5_literal_input_vs_oracle(device):
+  """BASELINE configs[4] on its literal input (grad blocks ~N(0,1), d = 4096, rank 64): two chained
+  Frequent-Directions updates against oracle.fd_update_root (DS:1123-1290, LAPACK SVD).  The 64
+  leading singular values sit in the edge cluster of the spectrum, so the comparison is on what the
+  optimizer uses: rho / tail, const, the deflated and inverted eigenvalues and the preconditioning
+  operator const (I - U U^T) + U diag(inverted) U^T (DS:1690-1705)."""
+  import bench
+  par = bench.fd_parity_literal(device, updates=2)
+  for row in par["updates"]:
+    assert row["has_zeros_equal"]
+    assert row["tail_rel"] < 2e-3, row
+    assert row["const_rel"] < 1e-3, row
+    assert row["deflated_max_abs_over_tail"] < 5e-3, row
+    assert row["inverted_max_rel"] < 2e-3, row
+    assert row["operator_rel_fro"] < 1e-3, row
