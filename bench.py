@@ -918,7 +918,9 @@ def main():
     ex = executed_fraction(n, p, float(iters.mean()), float(work.metrics[:, 7].mean()))
     alg = fl1 / (stage_ms * 1e-3) / 1e12 if stage_ms > 0 else 0.0
     ach = alg * ex
-    persistent = os.environ.get("PS_NEWTON_PERSISTENT", "0") != "0"
+    # (the library reads PS_* only under PS_DEV_ENV=1: label the execution that actually ran)
+    dev_env = os.environ.get("PS_DEV_ENV", "0") not in ("", "0")
+    persistent = dev_env and os.environ.get("PS_NEWTON_PERSISTENT", "0") != "0"
     line["roofline"] = {
         "kernel": "newton_persistent_kernel" if persistent else "newton_stage_kernel",
         "bound": "mfma",
@@ -956,11 +958,11 @@ def main():
         # registers for all passes, HBM is read once; a pass is bound by the tile mat-vecs on
         # the VALU and two hand-off latencies, so the bandwidth figures are "equivalent" ones.
         "power_iteration": {
-            "execution": "streaming" if os.environ.get("PS_PI_RESIDENT", "1") == "0"
+            "execution": "streaming" if (dev_env and os.environ.get("PS_PI_RESIDENT", "1") == "0")
                          else "resident (matrices in registers, one launch per co-resident pass)",
             "ms": round(pi_ms, 3),
             "us_per_step": round(pi_ms * 10.0, 2),
-            "bound": "hbm" if os.environ.get("PS_PI_RESIDENT", "1") == "0" else "valu+latency",
+            "bound": "hbm" if (dev_env and os.environ.get("PS_PI_RESIDENT", "1") == "0") else "valu+latency",
             "hbm_peak_GBps": 8000,
             "algorithmic_equiv_GBps": round(nb * n * n * 4 * 100 / max(pi_ms, 1e-9) / 1e6, 1),
             "upper_triangle_equiv_GBps": round(nb * n * n * 4 * 100 * ex / max(pi_ms, 1e-9) / 1e6,
@@ -1017,7 +1019,8 @@ def main():
       sm, ln, pm, om = profile_stage_kernel(hw)
       f1 = hw.flops()
       head["roofline"] = {
-          "kernel": "newton_persistent_kernel" if os.environ.get("PS_NEWTON_PERSISTENT", "0") != "0"
+          "kernel": "newton_persistent_kernel" if (os.environ.get("PS_DEV_ENV", "0") not in ("", "0") and
+                                                   os.environ.get("PS_NEWTON_PERSISTENT", "0") != "0")
                     else "newton_stage_kernel",
           "bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
           "achieved": round(f1 * hex_ / (sm * 1e-3) / 1e12, 2) if sm > 0 else None,

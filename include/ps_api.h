@@ -191,9 +191,15 @@ typedef struct {
   float eigh_sweep_tol;        /* <= 0 = default */
   int32_t eigh_streams;        /* 0 = default */
   int32_t eigh_solver;         /* PS_EIGH_AUTO (0, default) | PS_EIGH_TWO_SIDED | PS_EIGH_ONE_SIDED | PS_EIGH_TRIDIAGONAL */
-  int32_t reserved[5];         /* 0 */
+  int32_t reserved[5];         /* reserved[0] = PS_OPTIONS_MAGIC (written by ps_options_init), the rest 0 */
 } ps_options;
-/* Fills *opt with the defaults (struct_size = sizeof(ps_options)). */
+/* Fills *opt with the defaults (struct_size = sizeof(ps_options), reserved[0] = PS_OPTIONS_MAGIC).
+ * EVERY ps_options must start from this call: a zero-initialised struct is NOT the defaults
+ * (pi_timeout_ms = 0 would mean "every resident wait expires", averaged_steps = 0 "no averaged
+ * updates"), so a full-size struct without the marker is refused with PS_EINVAL instead of
+ * silently changing the numerics. */
+#define PS_OPTIONS_MAGIC 0x5053
+
 void ps_options_init(ps_options* opt);
 
 /* v0 of power_iteration: first n values of

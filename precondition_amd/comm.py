@@ -292,6 +292,10 @@ def sharded_inverse_pth_roots(
 
           _, m = _root()
           if pi_expired_before is not None:
+            if (options or {}).get("execution") == "persistent" and statistics[0].is_cuda:
+              # the persistent execution only enqueues: the resident power iteration (queued before
+              # it) may still be running, and its expiry counter with it
+              torch.cuda.current_stream(statistics[0].device).synchronize()
             if _expired_waits() != pi_expired_before:
               lam = _power_iteration()     # streaming execution now (ps_power_iteration_health)
               _, m = _root()

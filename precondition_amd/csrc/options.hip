@@ -1,6 +1,7 @@
 // options.hip — ps_options -> psh::Options, and the library's only reader of the environment.
 #include "options.h"
 
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -85,6 +86,13 @@ Options resolve(const ps_options* u, bool* bad) {
     size_t sz = u->struct_size;
     if (sz < sizeof(uint32_t) || sz > sizeof(ps_options)) { if (bad) *bad = true; sz = sizeof(uint32_t); }
     memcpy(&c, u, sz);
+    // a struct that reaches the marker field must carry it (ps_options_init): `ps_options o = {0}` is
+    // not the defaults
+    if (sz >= offsetof(ps_options, reserved) + sizeof(int32_t) && c.reserved[0] != PS_OPTIONS_MAGIC) {
+      if (bad) *bad = true;
+      ps_dev_env_overrides(o);
+      return o;
+    }
     if (c.products >= PS_PRODUCTS_F32 && c.products <= PS_PRODUCTS_BF16X3) o.products = c.products;
     else if (bad) *bad = true;
     if (c.accumulation == PS_ACCUM_SEGMENTED || c.accumulation == PS_ACCUM_CHAIN) o.accumulation = c.accumulation;
@@ -120,4 +128,5 @@ extern "C" void ps_options_init(ps_options* opt) {
   opt->averaged_steps = -1;
   opt->iters_hint_stride = 1;
   opt->pi_timeout_ms = -1;
+  opt->reserved[0] = PS_OPTIONS_MAGIC;
 }

@@ -147,6 +147,18 @@ def distributed_shampoo(
     # stay replicated (every rank applies them to its full gradient).  The optimizer
     # state is then rank-local: checkpoint every rank (or gather) to save it.
     shard_statistics: bool = False,
+    # eigh=True only: which eigensolver roots the blocks of more than 128 rows (ps_options.eigh_solver).
+    # "auto" = tridiagonalisation + divide and conquer (the class of the reference's LAPACK ssyevd);
+    # blocks whose spectrum spans more than 1e3 -- rank-deficient statistics + ridge among them -- are
+    # handed to the one-sided Jacobi solver inside the call; "two_sided" reproduces LAPACK's result on
+    # such blocks to three digits at 2.7 x the time (include/ps_api.h).
+    eigh_solver: str = "auto",
+    # Newton branch: the previous recompute's iteration counts (state.training_metrics) steer the
+    # per-block accuracy policy of the next root call (ps_options.iters_hint: blocks that took <= 8
+    # iterations skip the averaged M updates) and weight the "lpt" ownership.  An explicit option
+    # of this build (it needs generate_training_metrics=True to have the counts in the state, but is
+    # not implied by it): False = every block takes the careful path on every recompute.
+    iteration_count_hint: bool = True,
     _backend_for_testing: Any = None,
 ):
   """Returns GradientTransformation(init_fn, update_fn); see module docstring."""
@@ -158,6 +170,10 @@ def distributed_shampoo(
   # (None, the reference's default there, means "highest the backend has").
   from .kernels import products_for_precision
   root_options = {"products": products_for_precision(precision)}
+  if eigh_solver not in ("auto", "tridiagonal", "one_sided", "two_sided"):
+    raise ValueError(f"eigh_solver must be auto | tridiagonal | one_sided | two_sided, found {eigh_solver!r}")
+  if eigh and eigh_solver != "auto":
+    root_options["eigh_solver"] = eigh_solver
   products_for_precision(tensordot_precision)
   del tensordot_precision
   # (the partition specs describe XLA shardings; here the stacked statistics are always
@@ -624,7 +640,7 @@ def distributed_shampoo(
     # the first one = no hint): they steer the per-block accuracy policy of the root call
     # (ps_options.iters_hint) and weight the "lpt" ownership.  One small D2H per recompute.
     iters_hint = None
-    if (generate_training_metrics and not eigh and compression_rank == 0 and
+    if (iteration_count_hint and generate_training_metrics and not eigh and compression_rank == 0 and
         not lobpcg_topk_precondition):
       its = [st_.training_metrics.inverse_pth_root_iters for st_, num in zip(states, counts)
              if num > 0]
@@ -692,7 +708,7 @@ def distributed_shampoo(
         compute_fn=compute_fn, payload_elems=payload_elems, sizes=sizes,
         pi_first=(_backend_for_testing is None and not lobpcg_topk_precondition),
         metrics_cols=metrics_cols if compute_fn is not None else comm.METRICS_STRIDE,
-        iters_hint=iters_hint, hint_in_ownership=not shard_statistics,
+        iters_hint=iters_hint, hint_in_ownership=not shard_stats,
         options=(root_options if (compute_fn is None and not lobpcg_topk_precondition) else None))
     errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
     if quantize_second_moment:
@@ -757,8 +773,16 @@ def distributed_shampoo(
             out[i] = torch.empty_like(g)
         # (dequantized int16 preconditioners are column-scaled, not exactly symmetric: they keep
         # the reference's operand orientation)
+        # Precondition of the symmetric operand layout (P_L g applied as P_L^T g): float32 roots of
+        # this library's Newton / eigh kernels on statistics of its own Gram kernel are bitwise
+        # symmetric (mirrored tiles; W W^T).  The LOBPCG-deflated roots add a rank-k correction
+        # outside those kernels and keep the reference's orientation.  A state imported from another
+        # implementation may hold statistics / preconditioners that are symmetric only to rounding:
+        # P_L^T g then differs from the reference's g^T P orientation by that rounding (PS_APPLY_SYM=0
+        # under PS_DEV_ENV=1 restores the reference's orientation for such a run).
         plan.apply_preconditioners(grads_flat, precs_flat, out,
-                                   symmetric_precs=not quantize_second_moment)
+                                   symmetric_precs=(not quantize_second_moment and
+                                                    not lobpcg_topk_precondition))
         return out
     stage_a, stage_b, keep = [], [], []
     precs = [st.preconditioners for st in states]

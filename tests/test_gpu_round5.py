@@ -149,8 +149,11 @@ def test_fd_cfg5_literal_input_vs_oracle(device):
   par = bench.fd_parity_literal(device, updates=2)
   for row in par["updates"]:
     assert row["has_zeros_equal"]
-    assert row["tail_rel"] < 2e-3, row
-    assert row["const_rel"] < 1e-3, row
-    assert row["deflated_max_abs_over_tail"] < 5e-3, row
-    assert row["inverted_max_rel"] < 2e-3, row
-    assert row["operator_rel_fro"] < 1e-3, row
+    # measured (MI355X, round 5): tail 8e-7, const 2.5e-7, deflated 5e-7 of rho, inverted 3.4e-7,
+    # operator 2.5e-7, low-rank part U diag(deflated) U^T 1.1e-5
+    assert row["tail_rel"] < 1e-5, row
+    assert row["const_rel"] < 1e-5, row
+    assert row["deflated_max_abs_over_tail"] < 1e-5, row
+    assert row["inverted_max_rel"] < 1e-5, row
+    assert row["operator_rel_fro"] < 1e-5, row
+    assert row["lowrank_part_rel_fro"] < 1e-3, row

@@ -67,6 +67,9 @@ def test_options_defaults_validation_and_precision_mapping():
   o, keep = _lib.make_options(None)
   assert o.struct_size == ctypes.sizeof(_lib.PsOptions) and not keep
   assert (o.products, o.accumulation, o.averaged_steps, o.execution) == (0, 0, -1, 0)
+  # the marker a full-size struct must carry (a zero-initialised one is refused with PS_EINVAL)
+  assert o.reserved[0] == 0x5053 and "PS_OPTIONS_MAGIC 0x5053" in open(
+      os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ps_api.h")).read()
   assert _lib.lib().ps_newton_averaged_steps() == 4
   o, keep = _lib.make_options({"products": "bf16x6", "execution": "persistent",
                                "iters_hint": [8, 14, 0], "fast_max_iters": 9,
