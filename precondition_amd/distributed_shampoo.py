@@ -159,6 +159,14 @@ def distributed_shampoo(
     # of this build (it needs generate_training_metrics=True to have the counts in the state, but is
     # not implied by it): False = every block takes the careful path on every recompute.
     iteration_count_hint: bool = True,
+    # The counterpart of the reference's jit-compiled update_fn (DS:3627-3659: traced once, no
+    # per-step host work): update() takes ownership of the state it is given.  On the steps without
+    # a root recompute the statistics, diagonal statistics and momenta are updated IN PLACE, the
+    # returned state holds the same tensors, and the returned updates live in buffers the optimizer
+    # owns (valid until the next update call) -- no allocation, no descriptor rebuilt, the same
+    # seven launches (plan.DonatedStep).  The state passed in must not be used afterwards.  Applies
+    # to float32 dense states (the tree-plan path); anything else takes the functional path.
+    donate_state: bool = False,
     _backend_for_testing: Any = None,
 ):
   """Returns GradientTransformation(init_fn, update_fn); see module docstring."""
@@ -900,6 +908,58 @@ def distributed_shampoo(
                                state.training_metrics)
     return transformed, new_state
 
+  def _recompute_step(step):
+    """Does _compute_preconditioners root on this step (DS:3460-3474)?"""
+    steps_t = preconditioning_compute_steps
+    if (decay_preconditioning_compute_steps and end_preconditioning_compute_steps
+        and callable(learning_rate)):
+      steps_t = preconditioning_compute_steps_schedule(
+          learning_rate, preconditioning_compute_steps,
+          end_preconditioning_compute_steps, step)
+    return step % steps_t == 0
+
+  def _transform_cfg(step):
+    lr = learning_rate(step) if callable(learning_rate) else learning_rate
+    return dict(
+        graft_type=int(graft_type), nesterov=int(bool(nesterov)),
+        moving_average_for_momentum=int(bool(moving_average_for_momentum)),
+        decoupled_learning_rate=int(bool(decoupled_learning_rate)),
+        decoupled_weight_decay=int(bool(decoupled_weight_decay)),
+        run_shampoo=int(step >= start_preconditioning_step),
+        beta1=float(beta1), beta2_w1=float(beta2),
+        beta2_w2=float(beta2 if beta2 == 1.0 else 1.0 - beta2),
+        diagonal_epsilon=float(diagonal_epsilon), weight_decay=float(weight_decay),
+        lr=float(lr),
+        clip_by_scaled_gradient_norm=float(clip_by_scaled_gradient_norm or 0.0))
+
+  _donated = {}   # tree shapes -> plan.DonatedStep
+
+  def _donated_update(grads_flat, stats_flat, params_flat, step):
+    """update() on a donated state (steps without a root recompute): the updates, or None when
+    this step / state takes the functional path."""
+    if (_backend_for_testing is not None or quantize_second_moment or
+        best_effort_memory_usage_reduction or lobpcg_topk_precondition or _recompute_step(step)):
+      return None
+    plan = _tree_plan(params_flat)
+    if plan is None or not stats_flat:
+      return None
+    ds = _donated.get(id(plan))
+    if ds is None:
+      from .plan import DonatedStep
+      ds = _donated[id(plan)] = DonatedStep(plan, _graft_type_has_diagonal_statistics(),
+                                            weight_decay != 0)
+    if not ds.bound_to(stats_flat):
+      ok = (all(isinstance(st, ParameterStats) and
+                st.momentum.quantized_dtype == torch.float32 and
+                st.diagonal_momentum.quantized_dtype == torch.float32 and
+                isinstance(st.avg_grad, MaskedNode) for st in stats_flat) and
+            all(g.dtype == torch.float32 and g.is_contiguous() for g in grads_flat))
+      if not ok or not ds.bind(stats_flat, grads_flat, params_flat, symmetric_precs=True):
+        return None
+    do_stats = statistics_compute_steps <= 1 or step % statistics_compute_steps == 0
+    w2 = beta2 if beta2 == 1.0 else 1.0 - beta2
+    return ds.step(grads_flat, params_flat, _transform_cfg(step), do_stats, beta2, w2)
+
   def _transform_grads_fused(grads_flat, states, params_flat, pgs, step):
     """_transform_grad (DS:3496-3625) for the whole tree in three HIP launches."""
     lr = learning_rate(step) if callable(learning_rate) else learning_rate
@@ -949,6 +1009,10 @@ def distributed_shampoo(
     # them inside its float32 arithmetic; the kernels here take float32 only, so promote
     # at the door and hand the updates back in the gradient's dtype.
     grad_dtypes = [g.dtype for g in grads_flat]
+    if donate_state and all(dt == torch.float32 for dt in grad_dtypes):
+      upd = _donated_update(grads_flat, stats_flat, params_flat, step)
+      if upd is not None:   # state updated in place: the same objects go back
+        return (treedef.unflatten(upd), ShampooState(count=state.count + 1, stats=state.stats))
     grads_flat = [g if g.dtype == torch.float32 else g.to(torch.float32) for g in grads_flat]
     if any(p.dtype != torch.float32 for p in params_flat):
       params_flat = [p if p.dtype == torch.float32 else p.to(torch.float32)

@@ -257,3 +257,164 @@ class TreePlan:
         rc = L.ps_gemm_grouped_f32(kernels._stream(), descs, n, ws.data_ptr(), ws.numel())
         check(rc, "ps_gemm_grouped_f32")
     del x  # the caching allocator keeps it alive until the stream has consumed it
+
+
+class DonatedStep:
+  """The every-step calls of update() on a DONATED state (distributed_shampoo(donate_state=True)):
+  the counterpart of the reference's jit-compiled update_fn (DS:3627-3659), which does no per-step
+  host work beyond the dispatch.
+
+  The state tensors (statistics, diagonal statistics, both momenta) are updated IN PLACE, the
+  preconditioned gradients, the intermediate X of the two-sided application and the updates live
+  in buffers this object owns, so every pointer column of the four descriptor tables (Gram
+  update, application stage A and B, _transform_grad) is filled ONCE per binding; a step patches
+  only the gradient (and, with weight decay, parameter) columns when those pointers moved, and
+  issues the same seven launches as the functional path.  No torch.empty, no per-tensor Python
+  objects, no pytree rebuilt: the caller gets the same state objects back.
+
+  Bound to one list of ParameterStats objects (identity is checked each step: a state the caller
+  rebuilt, or the one a recompute step returned, is simply bound again)."""
+
+  def __init__(self, plan: TreePlan, has_diag: bool, use_params: bool):
+    self.plan = plan
+    self.has_diag = has_diag
+    self.use_params = use_params
+    self.objs = None
+    self.gp = None
+    self.pp_params = None
+
+  def bound_to(self, stats_flat) -> bool:
+    objs = self.objs
+    return (objs is not None and len(objs) == len(stats_flat) and
+            all(a is b for a, b in zip(objs, stats_flat)))
+
+  def bind(self, stats_flat, grads_flat, params_flat, symmetric_precs: bool):
+    pl = self.plan
+    dev = pl.check_dense(grads_flat, "update (donated state)")
+    stats = [s for st in stats_flat for s in st.statistics]
+    precs = [p for st in stats_flat for p in st.preconditioners]
+    moms = [st.momentum.quantized for st in stats_flat]
+    dmoms = [st.diagonal_momentum.quantized for st in stats_flat]
+    diags = [st.diagonal_statistics.quantized for st in stats_flat] if self.has_diag else []
+    if len(stats) != len(pl.stat_dims) or len(precs) != len(pl.stat_dims):
+      return False
+    pl.check_dense(stats + precs + moms + dmoms + diags, "update (donated state)")
+    n = pl.n_params
+    self.dev = dev
+    # buffers owned by the step (valid until the next update call)
+    if getattr(self, "upd", None) is None:
+      self.upd = [torch.empty_like(g) for g in grads_flat]
+      self.pg = [None if sk else torch.empty_like(g) for g, sk in zip(grads_flat, pl.skipped)]
+      self.x = torch.empty(max(pl.x_elems, 1), dtype=torch.float32, device=dev)
+    sp, prp = pl._ptrs(stats), pl._ptrs(precs)
+    rp = np.fromiter((0 if r is None else r.data_ptr() for r in self.pg), np.uint64, n)
+    xp = np.uint64(self.x.data_ptr())
+    # ---- Gram update, in place ----
+    st = pl.stats_tbl.copy()
+    st["stat_in"] = sp
+    st["stat_out"] = sp
+    self.st_tbl = st
+    # ---- application ----
+    ta = pl.a_tbl.copy()
+    ta["b"] = prp[pl.a_stat] if len(ta) else prp[:0]
+    ta["c"] = (np.where(pl.a_c_is_res, rp[pl.a_param], xp) + pl.a_coff) if len(ta) else prp[:0]
+    self.sym = bool(symmetric_precs and len(getattr(pl, "sa_tbl", ())) > 0 and
+                    os.environ.get("PS_APPLY_SYM", "1") != "0")
+    if self.sym:
+      vec = ta[pl.a_vec_rows]
+      sa = pl.sa_tbl.copy()
+      sa["a"] = prp[pl.sa_stat]
+      sa["c"] = xp + pl.sa_xoff
+      self.n_sa = len(sa)
+      self.ta = np.concatenate([sa, vec]) if len(vec) else sa
+      tb = pl.sb_tbl.copy()
+    else:
+      self.ta = ta
+      tb = pl.b_tbl.copy()
+    if len(tb):
+      tb["a"] = xp + pl.b_xoff
+      tb["b"] = prp[pl.b_stat]
+      tb["c"] = rp[pl.b_param] + pl.b_coff
+    self.tb = tb
+    # ---- _transform_grad, in place ----
+    tt = np.zeros(n, kernels._TDESC_DT)
+    tt["pgrad"] = rp
+    mp, dp = pl._ptrs(moms), pl._ptrs(dmoms)
+    tt["mom_in"] = mp; tt["mom_out"] = mp
+    tt["dmom_in"] = dp; tt["dmom_out"] = dp
+    if self.has_diag:
+      gp_ = pl._ptrs(diags)
+      tt["diag_in"] = gp_; tt["diag_out"] = gp_
+    tt["upd_out"] = pl._ptrs(self.upd)
+    tt["numel"] = pl.numel
+    self.tt = tt
+    L = lib()
+    with torch.cuda.device(dev):
+      def ws_for(nbytes):
+        return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+      self.ws_stats = ws_for(L.ps_stats_update_grouped_workspace_bytes(
+          C.cast(self.st_tbl.ctypes.data, C.POINTER(StatsDesc)), len(self.st_tbl))) if len(self.st_tbl) else None
+      self.ws_a = ws_for(L.ps_gemm_grouped_workspace_bytes(
+          C.cast(self.ta.ctypes.data, C.POINTER(GemmDesc)), len(self.ta))) if len(self.ta) else None
+      self.ws_b = ws_for(L.ps_gemm_grouped_workspace_bytes(
+          C.cast(self.tb.ctypes.data, C.POINTER(GemmDesc)), len(self.tb))) if len(self.tb) else None
+      tt_probe = self.tt.copy()
+      tt_probe["grad"] = tt_probe["upd_out"]   # sizes only
+      self.ws_t = ws_for(L.ps_transform_grads_workspace_bytes(
+          C.cast(tt_probe.ctypes.data, C.POINTER(kernels.TransformDesc)), n))
+    self.objs = list(stats_flat)
+    self.gp = None
+    self.pp_params = None
+    return True
+
+  def _patch_grads(self, grads_flat):
+    pl = self.plan
+    gp = pl._ptrs(grads_flat)
+    if self.gp is not None and np.array_equal(gp, self.gp):
+      return
+    for g, u in zip(grads_flat, self.upd):   # (only when the pointers moved)
+      if (g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous() or
+          g.device != self.dev or g.shape != u.shape):
+        kernels._require_gpu(g, "update (donated state)")
+        raise ValueError("update (donated state): contiguous float32 gradients of the bound shapes on one device")
+    self.gp = gp
+    if len(self.st_tbl):
+      self.st_tbl["g"] = gp[pl.st_param] + pl.st_goff
+    if self.sym:
+      self.ta["b"][:self.n_sa] = gp[pl.sa_param] + pl.sa_goff
+      if len(self.ta) > self.n_sa:
+        vr = pl.a_vec_rows
+        self.ta["a"][self.n_sa:] = gp[pl.a_param[vr]] + pl.a_goff[vr]
+    elif len(self.ta):
+      self.ta["a"] = gp[pl.a_param] + pl.a_goff
+    self.tt["grad"] = gp
+
+  def step(self, grads_flat, params_flat, cfg, do_stats: bool, w1: float, w2: float):
+    """Enqueues the step; returns the update tensors (owned by this object)."""
+    self._patch_grads(grads_flat)
+    if self.use_params:
+      pp = self.plan._ptrs(params_flat)
+      if self.pp_params is None or not np.array_equal(pp, self.pp_params):
+        self.plan.check_dense(params_flat, "update (donated state)")
+        self.pp_params = pp
+        self.tt["param"] = pp
+    L = lib()
+    stream = kernels._stream()
+    with torch.cuda.device(self.dev):
+      if do_stats and len(self.st_tbl):
+        rc = L.ps_stats_update_grouped_f32(stream, C.cast(self.st_tbl.ctypes.data, C.POINTER(StatsDesc)),
+                                           len(self.st_tbl), float(w1), float(w2),
+                                           self.ws_stats.data_ptr(), self.ws_stats.numel())
+        check(rc, "ps_stats_update_grouped_f32")
+      for tbl, ws in ((self.ta, self.ws_a), (self.tb, self.ws_b)):
+        if len(tbl):
+          rc = L.ps_gemm_grouped_f32(stream, C.cast(tbl.ctypes.data, C.POINTER(GemmDesc)), len(tbl),
+                                     ws.data_ptr(), ws.numel())
+          check(rc, "ps_gemm_grouped_f32")
+      c = kernels.TransformConfig()
+      for k, v in cfg.items():
+        setattr(c, k, v)
+      rc = L.ps_transform_grads_f32(stream, C.cast(self.tt.ctypes.data, C.POINTER(kernels.TransformDesc)),
+                                    self.plan.n_params, C.byref(c), self.ws_t.data_ptr(), self.ws_t.numel())
+      check(rc, "ps_transform_grads_f32")
+    return self.upd

@@ -7,7 +7,9 @@
 * blocks whose spectrum spans more than 1e3 are handed to the Jacobi solvers inside the same call
   and come out bit-identical to a call pinned to that solver;
 * the two stream groups of the reduction do not change a bit;
-* BASELINE configs[4] on its literal input against the oracle's LAPACK-SVD update.
+* BASELINE configs[4] on its literal input against the oracle's LAPACK-SVD update;
+* distributed_shampoo(donate_state=True): the in-place, allocation-free every-step path gives the
+  same bits as the functional one on the reference's end-to-end goldens and on a ViT-B-shaped tree.
 """
 import os
 
@@ -157,3 +159,69 @@ def test_fd_cfg5_literal_input_vs_oracle(device):
     assert row["inverted_max_rel"] < 1e-5, row
     assert row["operator_rel_fro"] < 1e-5, row
     assert row["lowrank_part_rel_fro"] < 1e-3, row
+
+
+# ---------------------------------------------------------------------------
+# donate_state=True (the jit-equivalent of update_fn, DS:3627-3659)
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _e2e_cases():
+  from tests.test_optimizer_host_logic import _index
+  return _index(GOLD) + _index(GOLD, "e2e_more_index.json")
+
+
+@pytest.mark.parametrize("case", _e2e_cases(), ids=lambda c: c["name"])
+def test_donated_state_bit_identical_to_functional_on_e2e_goldens(case, device):
+  """Every update of every step of the reference's end-to-end cases (DST:116-261, generated from the
+  reference's own update_fn): donate_state=True returns the same bits as the functional path, steps
+  with and without a root recompute alike, and the final state matches the golden one."""
+  from tests.test_optimizer_host_logic import check_final_state, run_e2e_case
+  name = "e2e.npz" if case in __import__("tests.test_optimizer_host_logic", fromlist=["_index"])._index(GOLD) else "e2e_more.npz"
+  z = np.load(os.path.join(GOLD, name))
+  skip = [i for i in range(case["n_params"]) if f"{case['name']}__upd{i}_t0" not in z.files]
+  u_fun, u_don = [], []
+  st_f, _ = run_e2e_case(case, z, device, None, skip_params=skip, updates_out=u_fun)
+  st_d, worst = run_e2e_case(case, z, device, None, skip_params=skip, updates_out=u_don,
+                             extra_kwargs={"donate_state": True})
+  for t, (a, b) in enumerate(zip(u_fun, u_don)):
+    for i, (x, y) in enumerate(zip(a, b)):
+      assert torch.equal(x, y), (case["name"], t, i)
+  import precondition_amd as pa
+  for x, y in zip(pa.pytree.tree_leaves(st_f), pa.pytree.tree_leaves(st_d)):
+    if isinstance(x, torch.Tensor):
+      assert torch.equal(x, y)
+
+
+def test_donated_state_vit_b_shaped_tree_no_allocation_and_same_bits(device):
+  """A transformer-shaped tree (2-D blocks over several 1024-blocks, vectors, a skipped scalar):
+  donate_state=True keeps the state tensors (same storage across steps), returns the optimizer's own
+  update buffers, and matches the functional path bit for bit over a recompute boundary."""
+  import precondition_amd as pa
+  rng = np.random.default_rng(0)
+  shapes = [(768, 3072), (3072,), (768, 12, 64), (12, 64), (1, 197, 768), (768, 1000), (1000,), ()]
+  params = [torch.from_numpy(np.asarray(rng.standard_normal(s) * 0.02, np.float32)).to(device) for s in shapes]
+  def grads_at(t):
+    r = np.random.default_rng(100 + t)
+    return [torch.from_numpy(np.asarray(r.standard_normal(s) * 0.02, np.float32)).to(device) for s in shapes]
+  outs = {}
+  for donate in (False, True):
+    opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=3, start_preconditioning_step=1,
+                                 graft_type=pa.GraftingType.RMSPROP_NORMALIZED, weight_decay=1e-3,
+                                 donate_state=donate)
+    st = opt.init(params)
+    ups, ptrs = [], []
+    for t in range(7):
+      upd, st = opt.update(grads_at(t), st, params)
+      ups.append([u.clone() for u in upd])
+      ptrs.append([x.data_ptr() for x in pa.pytree.tree_leaves(st) if isinstance(x, torch.Tensor) and x.is_cuda])
+    outs[donate] = (ups, st, ptrs)
+  for t, (a, b) in enumerate(zip(outs[False][0], outs[True][0])):
+    for x, y in zip(a, b):
+      assert torch.equal(x, y), t
+  for x, y in zip(pa.pytree.tree_leaves(outs[False][1]), pa.pytree.tree_leaves(outs[True][1])):
+    if isinstance(x, torch.Tensor):
+      assert torch.equal(x, y)
+  p = outs[True][2]
+  assert p[1] == p[2] and p[4] == p[5]      # steps 1 -> 2 and 4 -> 5: no recompute, same storage
+  assert outs[False][2][1] != outs[False][2][2]   # the functional path allocates a new state every step

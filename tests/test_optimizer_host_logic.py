@@ -33,9 +33,10 @@ def np_float(x):
   return x.cpu().numpy()
 
 
-def run_e2e_case(c, z, device, backend, skip_params=(), group=None):
+def run_e2e_case(c, z, device, backend, skip_params=(), group=None, extra_kwargs=None, updates_out=None):
   name, n = c["name"], c["n_params"]
   kw = dict(c["kwargs"])
+  kw.update(extra_kwargs or {})
   if "graft_type" in kw:
     kw["graft_type"] = pa.GraftingType(kw["graft_type"])
   if "precondtioner_type" in kw:
@@ -52,6 +53,8 @@ def run_e2e_case(c, z, device, backend, skip_params=(), group=None):
   for t in range(c["steps"]):
     grads = tuple(torch.tensor(z[f"{name}__grad{i}_t{t}"], device=device) for i in range(n))
     upd, st = opt.update(grads, st, params)
+    if updates_out is not None:   # (copies: a donated state's updates live in reused buffers)
+      updates_out.append([u.clone() for u in upd])
     for i in range(n):
       if i in skip_params:
         continue

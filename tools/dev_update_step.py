@@ -16,6 +16,8 @@ if "--quant" in sys.argv:  # int8 momentum + int16 statistics / preconditioners 
   dist.init_process_group("nccl", store=dist.FileStore(os.path.join(tempfile.mkdtemp(), "s"), 1),
                           rank=0, world_size=1)
   kw = dict(best_effort_memory_usage_reduction=True, batch_axis_name=dist.group.WORLD)
+if "--donate" in sys.argv:   # the in-place, allocation-free every-step path (plan.DonatedStep)
+  kw["donate_state"] = True
 opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=50, start_preconditioning_step=1, graft_type=pa.GraftingType.RMSPROP_NORMALIZED, **kw)
 st = opt.init(params)
 torch.cuda.synchronize()
@@ -32,7 +34,16 @@ for t in range(20):
   upd, st = opt.update(grads, st, params)
 t_host = (time.perf_counter() - t0) / 20
 torch.cuda.synchronize(); t_all = (time.perf_counter() - t0) / 20
-print(f"20 unsynchronised steps: host {t_host*1e3:.2f} ms/step, wall {t_all*1e3:.2f} ms/step")
+print(f"20 unsynchronised steps: host {t_host*1e3:.2f} ms/step (includes back-pressure of a full launch queue), wall {t_all*1e3:.2f} ms/step")
+# host cost proper: enqueue time of 2 steps into an EMPTY queue (the launches never block)
+hs = []
+for rep in range(5):
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  for t in range(2):
+    upd, st = opt.update(grads, st, params)
+  hs.append((time.perf_counter() - t0) / 2)
+torch.cuda.synchronize()
+print(f"host enqueue time, empty queue: {min(hs)*1e3:.2f} ms/step (median {sorted(hs)[2]*1e3:.2f})")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for t in range(3):
