@@ -507,8 +507,14 @@ def quant_f3(dev):
       g = torch.randn((s[0], 64), generator=gen, device=dev)
       stats.append(g @ g.T)
 
-  def t(fn, reps=5):
+  def t(fn, reps=20):
+    # sub-millisecond launches: keep the (untimed) warm-up going for 0.3 s, or the timed repetitions
+    # run at ramping clocks (measured: every kernel of this leg then looks like 2.5 TB/s)
     out = fn(); _sync()
+    t_warm = time.perf_counter()
+    while not SELFTEST and time.perf_counter() - t_warm < 0.3:
+      out = fn()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(reps):
       out = fn()
@@ -526,6 +532,14 @@ def quant_f3(dev):
   tq2, _ = t(lambda: K.quantize_grouped(stats, torch.int16, True, out=tr))
   fl = [torch.empty_like(x) for x in stats]
   td2, _ = t(lambda: K.dequantize_grouped(tr, out=fl))
+  # descriptors resident (kernels.QuantizePlan: table + workspace built once; what a state updated
+  # in place needs per step): one C-ABI call per launch
+  plan = K.QuantizePlan(stats, torch.int16, True, tr)
+  tq3, _ = t(lambda: plan.quantize())
+  plan_f = K.QuantizePlan(fl, torch.int16, True, tr)
+  td3, _ = t(lambda: plan_f.dequantize())
+  mplan = K.QuantizePlan(moms, torch.int8, False, mr)
+  mq3, _ = t(lambda: mplan.quantize())
   return {"workload": f"ViT-B state: {len(stats)} statistics ({ne / 1e6:.1f} M elements) as int16 + "
                       f"diagonal, {len(moms)} momentum buffers ({nm / 1e6:.1f} M elements) as int8; "
                       "wall clock of the grouped calls incl. host descriptor building",
@@ -536,6 +550,12 @@ def quant_f3(dev):
           "int16_quantize_preallocated_GBps": round(ne * 6 / tq2 / 1e9, 1),
           "int16_dequantize_preallocated_ms": round(td2 * 1e3, 3),
           "int16_dequantize_preallocated_GBps": round(ne * 6 / td2 / 1e9, 1),
+          "int16_quantize_plan_ms": round(tq3 * 1e3, 3),
+          "int16_quantize_plan_GBps": round(ne * 6 / tq3 / 1e9, 1),
+          "int16_quantize_plan_frac_of_hbm_peak": round(ne * 6 / tq3 / 8e12, 4),
+          "int16_dequantize_plan_ms": round(td3 * 1e3, 3),
+          "int16_dequantize_plan_GBps": round(ne * 6 / td3 / 1e9, 1),
+          "int8_quantize_plan_ms": round(mq3 * 1e3, 3), "int8_quantize_plan_GBps": round(nm * 5 / mq3 / 1e9, 1),
           "int8_quantize_ms": round(mq * 1e3, 3), "int8_quantize_GBps": round(nm * 5 / mq / 1e9, 1),
           "int8_dequantize_ms": round(md * 1e3, 3), "int8_dequantize_GBps": round(nm * 5 / md / 1e9, 1)}
 

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "common.h"
+#include "options.h"
 
 namespace psk {
 
@@ -39,16 +40,9 @@ struct QTensor {
   long long rows, cols, ld, ldq;
   int bits, extract, vec4;
   int chunk0, strips;
+  int flat;               // contiguous [rows, cols] float4-addressable tensor: the flat kernels take it
+  int fchunk0, fchunks;   // its chunks of QFLAT consecutive elements
 };
-
-__device__ inline const QTensor* find_tensor(const QTensor* ts, int count, int chunk) {
-  int lo = 0, hi = count - 1;
-  while (lo < hi) {  // last tensor with chunk0 <= chunk
-    const int mid = (lo + hi + 1) >> 1;
-    if (ts[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
-  }
-  return &ts[lo];
-}
 
 typedef float qf4 __attribute__((ext_vector_type(4)));
 struct F4 { float x, y, z, w; };
@@ -57,12 +51,29 @@ __device__ inline F4 ldg4(const float* p) {
   return {v[0], v[1], v[2], v[3]};
 }
 __device__ inline float ldg1(const float* p) { return *(const float PS_GLOBAL*)(p); }
+// (wave-uniform 64-bit base) + (one 32-bit byte offset per lane): the uniform part stays in SGPRs, so
+// sixteen loads in flight cost ONE address VGPR instead of a 64-bit pair each (with per-load 64-bit
+// addresses these kernels took 240-316 VGPRs: one wavefront per SIMD, slower than four loads in flight)
+__device__ inline F4 ldg4_so(const void* ubase, uint32_t lane_off) {
+  const qf4 v = *(const qf4 PS_GLOBAL*)((const char PS_GLOBAL*)ubase + (uint64_t)lane_off);
+  return {v[0], v[1], v[2], v[3]};
+}
+__device__ inline uint2 ldg2u_so(const void* ubase, uint32_t lane_off) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v v = *(const u2v PS_GLOBAL*)((const char PS_GLOBAL*)ubase + (uint64_t)lane_off);
+  return uint2{v[0], v[1]};
+}
+__device__ inline unsigned ldg1u_so(const void* ubase, uint32_t lane_off) {
+  return *(const unsigned PS_GLOBAL*)((const char PS_GLOBAL*)ubase + (uint64_t)lane_off);
+}
 
 // ---- pass 1: column maxima -------------------------------------------------------------
-__global__ __launch_bounds__(256) void quant_colmax_kernel(const QTensor* ts, int count) {
+__global__ __launch_bounds__(256) void quant_colmax_kernel(const QTensor* ts, const int* cmap, int chunk_base) {
   __shared__ unsigned red[4][QW];
-  const QTensor* t = find_tensor(ts, count, blockIdx.x);
-  const int local = blockIdx.x - t->chunk0;
+  const int chunk = blockIdx.x + chunk_base;
+  const QTensor* t = &ts[cmap[chunk]];
+  if (t->flat) return;   // quant_flat_kernel took it
+  const int local = chunk - t->chunk0;
   const int strip = local % t->strips, rc = local / t->strips;
   const int tid = threadIdx.x;
   const long long rows = t->rows, cols = t->cols, ld = t->ld;
@@ -73,16 +84,21 @@ __global__ __launch_bounds__(256) void quant_colmax_kernel(const QTensor* ts, in
     const long long col = (long long)strip * QW + lane * 4;
     unsigned m[4] = {0u, 0u, 0u, 0u};
     if (col < cols) {
-      // four rows in flight per lane (independent 16-byte loads) before the first use
-      for (long long rb = r0 + wave; rb < r1; rb += 16) {
-        F4 v[4];
+      // all 16 rows of the lane in flight (independent 16-byte loads) before the first use: with four
+      // the kernel ran at 3.7 TB/s (latency-bound), the same access shape streams at 6 TB/s
+      // (tools/bench_symv.hip v1)
+      uint32_t loff = (uint32_t)((wave * ld + lane * 4) * 4);
+      asm volatile("" : "+v"(loff));
+      for (long long rb = r0 + wave; rb == r0 + wave; rb += 64) {   // QR = 64 rows: one pass
+        F4 v[16];
+        const float* ub = t->fin + (rb - wave) * ld + (long long)strip * QW;   // wave-uniform
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 16; ++u) {
           const long long r = rb + 4 * u;
-          v[u] = r < r1 ? ldg4(t->fin + r * ld + col) : F4{0.f, 0.f, 0.f, 0.f};
+          v[u] = r < r1 ? ldg4_so(ub + (long long)(4 * u) * ld, loff) : F4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 16; ++u) {
           const long long r = rb + 4 * u;
           float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -117,14 +133,143 @@ __global__ __launch_bounds__(256) void quant_colmax_kernel(const QTensor* ts, in
   }
 }
 
+// ---- flat kernels (round 5): chunks of 16384 CONSECUTIVE elements ---------------------------------------
+// A contiguous [rows, cols] tensor is streamed in runs of 64 KB (whole rows, back to back) instead of
+// 64-row x 1 KB tiles: the 1 KB row pieces of a tile land in different DRAM pages (measured: the tile
+// form decodes at 2.5 TB/s).  Column of an element = its flat offset mod cols, tracked incrementally;
+// the column maxima of a chunk are merged in LDS (ds_max_u32) and flushed with one global atomicMax
+// per column.  Same arithmetic as the tile kernels, bit for bit.
+constexpr int QFLAT = 16384;      // elements per chunk (16 float4 per thread)
+constexpr int QFLAT_MAXC = 8192;  // columns kept in LDS by the column-max pass
+constexpr int QMAXT = 1 << 30;
+__device__ inline int encode1(float x, float bs_nonzero);
+
+template <int MODE>   // 0 = column maxima, 1 = encode, 2 = decode
+__global__ __launch_bounds__(256) void quant_flat_kernel(const QTensor* ts, const int* cmap) {
+  __shared__ unsigned s_max[MODE == 0 ? QFLAT_MAXC : 1];
+  // chunk -> tensor from a per-chunk table (one 4-byte load): a binary search over the tensor table
+  // costs nine dependent loads, a copy of its prefix column to LDS 50 KB of L2 reads per workgroup
+  const QTensor* t = &ts[cmap[blockIdx.x]];
+  const int local = blockIdx.x - t->fchunk0;
+  const int tid = threadIdx.x;
+  const long long cols = t->cols, total = t->rows * t->cols;
+  const long long base = (long long)local * QFLAT;
+  const int extract = t->extract;
+  const float nb = t->bits == 8 ? 127.f : 32767.f;
+  if (MODE == 0) {
+    for (int c = tid; c < cols; c += 256) s_max[c] = 0u;
+    __syncthreads();
+  }
+  // incremental (row, col) of the thread's float4s: offsets base + 4 tid + 1024 k
+  const long long off0 = base + 4 * tid;
+  long long row = off0 / cols;
+  int col = (int)(off0 - row * cols);
+  const int step_c = (int)(1024 % cols);
+  const long long step_r = 1024 / cols;
+  uint32_t loff = (uint32_t)(4 * tid * 4);
+  asm volatile("" : "+v"(loff));
+  F4 v[16];
+  uint2 pk16[16];
+  unsigned pk8[16];
+  const char* fbase = reinterpret_cast<const char*>(t->fin) + base * 4;
+  const int esz = t->bits == 16 ? 2 : 1;
+  const char* cbase = reinterpret_cast<const char*>(t->codes) + base * esz;
+  uint32_t coff = (uint32_t)(4 * tid * esz);
+  asm volatile("" : "+v"(coff));
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const bool in = off0 + 1024 * k < total;
+    if (MODE != 2) {
+      v[k] = in ? ldg4_so(fbase + (long long)k * 4096, loff) : F4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      pk16[k] = uint2{0u, 0u}; pk8[k] = 0u;
+      if (in) {
+        if (t->bits == 16) pk16[k] = ldg2u_so(cbase + (long long)k * 2048, coff);
+        else pk8[k] = ldg1u_so(cbase + (long long)k * 1024, coff);
+      }
+    }
+  }
+  if (MODE == 1 && local == 0) {   // bucket sizes (QU:86), once per tensor
+    for (int c = tid; c < cols; c += 256) t->bucket[c] = __fdiv_rn(__uint_as_float(t->colmax[c]), nb);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const bool in = off0 + 1024 * k < total;
+    if (in) {
+      if (MODE == 0) {
+        float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (extract && col + j == row) x[j] = 0.f;
+          const unsigned b = __float_as_uint(fabsf(x[j]));
+          if (b) atomicMax(&s_max[col + j], b);
+        }
+      } else if (MODE == 1) {
+        float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        const uint4 cm = *reinterpret_cast<const uint4*>(t->colmax + col);
+        const unsigned cmv[4] = {cm.x, cm.y, cm.z, cm.w};
+        int q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float bs = __fdiv_rn(__uint_as_float(cmv[j]), nb);   // QU:86
+          const float bnz = bs > 0.f ? bs : 1.f;                       // QU:89-90
+          if (extract && col + j == row) { t->diag[row] = x[j]; x[j] = __fsub_rn(x[j], x[j]); }
+          q[j] = encode1(x[j], bnz);
+        }
+        const long long o = off0 + 1024 * k;
+        if (t->bits == 16) {
+          uint2 pk;
+          pk.x = ((unsigned)q[0] & 0xffffu) | ((unsigned)q[1] << 16);
+          pk.y = ((unsigned)q[2] & 0xffffu) | ((unsigned)q[3] << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<short*>(t->codes) + o) = pk;
+        } else {
+          const unsigned pk = ((unsigned)q[0] & 0xffu) | (((unsigned)q[1] & 0xffu) << 8) |
+                              (((unsigned)q[2] & 0xffu) << 16) | ((unsigned)q[3] << 24);
+          *reinterpret_cast<unsigned*>(reinterpret_cast<signed char*>(t->codes) + o) = pk;
+        }
+      } else {
+        int q[4];
+        if (t->bits == 16) {
+          q[0] = (short)(pk16[k].x & 0xffffu); q[1] = (short)(pk16[k].x >> 16);
+          q[2] = (short)(pk16[k].y & 0xffffu); q[3] = (short)(pk16[k].y >> 16);
+        } else {
+          const unsigned pk = pk8[k];
+          q[0] = (signed char)(pk & 0xffu); q[1] = (signed char)((pk >> 8) & 0xffu);
+          q[2] = (signed char)((pk >> 16) & 0xffu); q[3] = (signed char)(pk >> 24);
+        }
+        const F4 b4 = ldg4(t->bucket + col);
+        const float bs[4] = {b4.x, b4.y, b4.z, b4.w};
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[j] = __fmul_rn((float)q[j], bs[j]);                                       // QU:109
+          if (extract && col + j == row) x[j] = __fadd_rn(x[j], t->diag[row]);        // QU:111
+        }
+        *reinterpret_cast<float4*>(t->fout + off0 + 1024 * k) = make_float4(x[0], x[1], x[2], x[3]);
+      }
+    }
+    col += step_c; row += step_r;
+    if (col >= cols) { col -= (int)cols; row += 1; }
+  }
+  if (MODE == 0) {
+    __syncthreads();
+    for (int c = tid; c < cols; c += 256) {
+      const unsigned a = s_max[c];
+      if (a) atomicMax(t->colmax + c, a);
+    }
+  }
+}
+
 __device__ inline int encode1(float x, float bs_nonzero) {
   return (int)rintf(__fdiv_rn(x, bs_nonzero));  // QU:91-94; rint = round half to even
 }
 
 // ---- pass 2: bucket sizes, diagonal, codes ---------------------------------------------
-__global__ __launch_bounds__(256) void quant_encode_kernel(const QTensor* ts, int count) {
-  const QTensor* t = find_tensor(ts, count, blockIdx.x);
-  const int local = blockIdx.x - t->chunk0;
+__global__ __launch_bounds__(256) void quant_encode_kernel(const QTensor* ts, const int* cmap, int chunk_base) {
+  const int chunk = blockIdx.x + chunk_base;
+  const QTensor* t = &ts[cmap[chunk]];
+  if (t->flat) return;   // quant_flat_kernel took it
+  const int local = chunk - t->chunk0;
   const int strip = local % t->strips, rc = local / t->strips;
   const int tid = threadIdx.x;
   const long long rows = t->rows, cols = t->cols, ld = t->ld, ldq = t->ldq;
@@ -143,17 +288,20 @@ __global__ __launch_bounds__(256) void quant_encode_kernel(const QTensor* ts, in
     }
     if (rc == 0 && wave == 0)
       *reinterpret_cast<float4*>(t->bucket + col) = make_float4(bs[0], bs[1], bs[2], bs[3]);
-    for (long long rb = r0 + wave; rb < r1; rb += 16) {
-      F4 v[4];
+    uint32_t loff = (uint32_t)((wave * ld + lane * 4) * 4);
+    asm volatile("" : "+v"(loff));
+    for (long long rb = r0 + wave; rb == r0 + wave; rb += 64) {   // QR = 64 rows: one pass
+      F4 v[16];
+      const float* ub = t->fin + (rb - wave) * ld + (long long)strip * QW;   // wave-uniform
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const long long r = rb + 4 * u;
-        v[u] = r < r1 ? ldg4(t->fin + r * ld + col) : F4{0.f, 0.f, 0.f, 0.f};
+        v[u] = r < r1 ? ldg4_so(ub + (long long)(4 * u) * ld, loff) : F4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const long long r = rb + 4 * u;
-        if (r >= r1) break;
+        if (r >= r1) continue;   // (not `break`: the loop must unroll completely, or v[] lives in scratch)
         float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
         int q[4];
 #pragma unroll
@@ -190,8 +338,9 @@ __global__ __launch_bounds__(256) void quant_encode_kernel(const QTensor* ts, in
 }
 
 // ---- to_float --------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void quant_decode_kernel(const QTensor* ts, int count) {
-  const QTensor* t = find_tensor(ts, count, blockIdx.x);
+__global__ __launch_bounds__(256) void quant_decode_kernel(const QTensor* ts, const int* cmap) {
+  const QTensor* t = &ts[cmap[blockIdx.x]];
+  if (t->flat) return;
   const int local = blockIdx.x - t->chunk0;
   const int strip = local % t->strips, rc = local / t->strips;
   const int tid = threadIdx.x;
@@ -204,24 +353,45 @@ __global__ __launch_bounds__(256) void quant_decode_kernel(const QTensor* ts, in
     if (col >= cols) return;
     const F4 b4 = ldg4(t->bucket + col);
     const float bs[4] = {b4.x, b4.y, b4.z, b4.w};
-    for (long long r = r0 + wave; r < r1; r += 4) {
-      int q[4];
-      if (t->bits == 16) {
-        const uint2 pk = *reinterpret_cast<const uint2*>(reinterpret_cast<const short*>(t->codes) + r * ldq + col);
-        q[0] = (short)(pk.x & 0xffffu); q[1] = (short)(pk.x >> 16);
-        q[2] = (short)(pk.y & 0xffffu); q[3] = (short)(pk.y >> 16);
-      } else {
-        const unsigned pk = *reinterpret_cast<const unsigned*>(reinterpret_cast<const signed char*>(t->codes) + r * ldq + col);
-        q[0] = (signed char)(pk & 0xffu); q[1] = (signed char)((pk >> 8) & 0xffu);
-        q[2] = (signed char)((pk >> 16) & 0xffu); q[3] = (signed char)(pk >> 24);
-      }
-      float x[4];
+    // all 16 rows of the lane in flight before the first use (one load per lane at a time leaves the
+    // kernel latency-bound: 3.2 TB/s of its 6 bytes per element)
+    const int esz = t->bits == 16 ? 2 : 1;
+    uint32_t loff = (uint32_t)((wave * ldq + lane * 4) * esz);
+    asm volatile("" : "+v"(loff));
+    for (long long rb = r0 + wave; rb == r0 + wave; rb += 64) {   // QR = 64 rows: one pass
+      uint2 pk16[16];
+      unsigned pk8[16];
+      const char* ub = reinterpret_cast<const char*>(t->codes) + ((rb - wave) * ldq + (long long)strip * QW) * esz;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x[j] = __fmul_rn((float)q[j], bs[j]);                                     // QU:109
-        if (t->extract && col + j == r) x[j] = __fadd_rn(x[j], t->diag[r]);       // QU:111
+      for (int u = 0; u < 16; ++u) {
+        const long long r = rb + 4 * u;
+        pk16[u] = uint2{0u, 0u}; pk8[u] = 0u;
+        if (r < r1) {
+          if (t->bits == 16) pk16[u] = ldg2u_so(ub + (long long)(4 * u) * ldq * 2, loff);
+          else pk8[u] = ldg1u_so(ub + (long long)(4 * u) * ldq, loff);
+        }
       }
-      *reinterpret_cast<float4*>(t->fout + r * ld + col) = make_float4(x[0], x[1], x[2], x[3]);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const long long r = rb + 4 * u;
+        if (r >= r1) continue;   // (not `break`: the loop must unroll completely, or v[] lives in scratch)
+        int q[4];
+        if (t->bits == 16) {
+          q[0] = (short)(pk16[u].x & 0xffffu); q[1] = (short)(pk16[u].x >> 16);
+          q[2] = (short)(pk16[u].y & 0xffffu); q[3] = (short)(pk16[u].y >> 16);
+        } else {
+          const unsigned pk = pk8[u];
+          q[0] = (signed char)(pk & 0xffu); q[1] = (signed char)((pk >> 8) & 0xffu);
+          q[2] = (signed char)((pk >> 16) & 0xffu); q[3] = (signed char)(pk >> 24);
+        }
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[j] = __fmul_rn((float)q[j], bs[j]);                                     // QU:109
+          if (t->extract && col + j == r) x[j] = __fadd_rn(x[j], t->diag[r]);       // QU:111
+        }
+        *reinterpret_cast<float4*>(t->fout + r * ld + col) = make_float4(x[0], x[1], x[2], x[3]);
+      }
     }
   } else {
     const long long c = (long long)strip * QW + tid;
@@ -243,6 +413,7 @@ static bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 static long long build_tensors(const ps_quant_desc* desc, int count, bool encode,
                                std::vector<QTensor>& ht, size_t& total_cols) {
   ht.resize(count);
+  const bool flat_on = psh::resolve(nullptr).quant_flat != 0;
   long long chunk0 = 0;
   total_cols = 0;
   for (int i = 0; i < count; ++i) {
@@ -261,6 +432,9 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
     const size_t code_vec = d.bits == 16 ? 8 : 4;
     t.vec4 = (d.cols % 4 == 0 && d.ld % 4 == 0 && d.ldq % 4 == 0 && aligned(d.fvalue, 16) &&
               aligned(d.codes, code_vec) && aligned(d.bucket_size, 16)) ? 1 : 0;
+    t.flat = (flat_on && t.vec4 && d.ld == d.cols && d.ldq == d.cols && d.cols <= QFLAT_MAXC && d.rows > 0 &&
+              d.cols > 0 && count <= QMAXT && aligned(d.codes, 16)) ? 1 : 0;
+    t.fchunks = t.flat ? (int)((d.rows * d.cols + QFLAT - 1) / QFLAT) : 0;
     t.strips = (int)((d.cols + QW - 1) / QW);
     const long long rcs = (d.rows + QR - 1) / QR;
     t.chunk0 = (int)chunk0;
@@ -272,6 +446,29 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
   return chunk0;
 }
 
+// Per-chunk tensor index: first the flat chunks (contiguous float4-addressable tensors), then the
+// 64 x 256 tile chunks of the other tensors; chunk0 / fchunk0 of every tensor are set to its first
+// chunk inside its own list.
+static void build_chunk_maps(std::vector<QTensor>& ht, std::vector<int>& map, long long& fch,
+                             long long& tch) {
+  fch = 0; tch = 0;
+  for (size_t i = 0; i < ht.size(); ++i) {
+    QTensor& t = ht[i];
+    if (t.flat) { t.fchunk0 = (int)fch; fch += t.fchunks; }
+  }
+  map.reserve((size_t)fch);
+  for (size_t i = 0; i < ht.size(); ++i)
+    if (ht[i].flat) map.insert(map.end(), (size_t)ht[i].fchunks, (int)i);
+  for (size_t i = 0; i < ht.size(); ++i) {
+    QTensor& t = ht[i];
+    if (t.flat || t.rows <= 0 || t.cols <= 0) continue;
+    const long long n = (long long)t.strips * ((t.rows + QR - 1) / QR);
+    t.chunk0 = (int)tch;
+    tch += n;
+    map.insert(map.end(), (size_t)n, (int)i);
+  }
+}
+
 // Tensors without chunks would break the chunk -> tensor search (equal chunk0 keys resolve to
 // the LAST tensor with that key, which is the one that owns the chunk, because empty tensors
 // add no chunks); nothing else to do for them.
@@ -280,11 +477,24 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
 
 using namespace psk;
 
+// upper bound of the per-chunk table (a tensor is in one of the two chunk lists)
+static size_t quant_map_bytes(const ps_quant_desc* desc, int count) {
+  size_t n = 0;
+  for (int i = 0; i < count; ++i) {
+    if (desc[i].rows <= 0 || desc[i].cols <= 0) continue;
+    const size_t flat = (size_t)((desc[i].rows * desc[i].cols + QFLAT - 1) / QFLAT);
+    const size_t tile = (size_t)((desc[i].cols + QW - 1) / QW) * (size_t)((desc[i].rows + QR - 1) / QR);
+    n += flat > tile ? flat : tile;
+  }
+  return psh::align_up(sizeof(int) * (n + 1), 256);
+}
+
 extern "C" size_t ps_quantize_workspace_bytes(const ps_quant_desc* desc, int count) {
   if (!desc || count <= 0) return 0;
   size_t cols = 0;
   for (int i = 0; i < count; ++i) cols += psh::align_up((size_t)(desc[i].cols > 0 ? desc[i].cols : 0), 4);
-  return psh::align_up(sizeof(QTensor) * count, 256) + psh::align_up(sizeof(unsigned) * cols, 256) + 1024;
+  return psh::align_up(sizeof(QTensor) * count, 256) + psh::align_up(sizeof(unsigned) * cols, 256) +
+         quant_map_bytes(desc, count) + 1024;
 }
 
 extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int count, void* workspace,
@@ -308,17 +518,31 @@ extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int coun
     off += psh::align_up((size_t)ht[i].cols, 4);
   }
   PS_HIP(hipMemsetAsync(colmax, 0, sizeof(unsigned) * total_cols, st));
+  // flat tensors: one launch per pass over chunks of consecutive elements; the others (odd sizes,
+  // strided views) keep the tile kernels
+  std::vector<int> hmap;
+  long long fch = 0, tch = 0;
+  build_chunk_maps(ht, hmap, fch, tch);
+  int* dmap = ar.take<int>(hmap.size() + 1);
+  if (ar.overflow) return PS_EWORKSPACE;
   PS_RC(psh::upload_async(st, dt, ht.data(), sizeof(QTensor) * count));
-  const dim3 grid((unsigned)chunks), blk(256);
-  hipLaunchKernelGGL(quant_colmax_kernel, grid, blk, 0, st, dt, count);
-  hipLaunchKernelGGL(quant_encode_kernel, grid, blk, 0, st, dt, count);
+  PS_RC(psh::upload_async(st, dmap, hmap.data(), sizeof(int) * hmap.size()));
+  const dim3 blk(256);
+  if (fch > 0) {
+    hipLaunchKernelGGL(quant_flat_kernel<0>, dim3((unsigned)fch), blk, 0, st, dt, dmap);
+    hipLaunchKernelGGL(quant_flat_kernel<1>, dim3((unsigned)fch), blk, 0, st, dt, dmap);
+  }
+  if (tch > 0) {
+    hipLaunchKernelGGL(quant_colmax_kernel, dim3((unsigned)tch), blk, 0, st, dt, dmap + fch, 0);
+    hipLaunchKernelGGL(quant_encode_kernel, dim3((unsigned)tch), blk, 0, st, dt, dmap + fch, 0);
+  }
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
 
 extern "C" size_t ps_dequantize_workspace_bytes(const ps_quant_desc* desc, int count) {
   if (!desc || count <= 0) return 0;
-  return psh::align_up(sizeof(QTensor) * count, 256) + 1024;
+  return psh::align_up(sizeof(QTensor) * count, 256) + quant_map_bytes(desc, count) + 1024;
 }
 
 extern "C" int ps_dequantize_f32(void* stream, const ps_quant_desc* desc, int count, void* workspace,
@@ -335,8 +559,17 @@ extern "C" int ps_dequantize_f32(void* stream, const ps_quant_desc* desc, int co
   psh::Arena ar(workspace, workspace_bytes);
   QTensor* dt = ar.take<QTensor>(count);
   if (ar.overflow) return PS_EWORKSPACE;
+  std::vector<int> hmap;
+  long long fch = 0, tch = 0;
+  build_chunk_maps(ht, hmap, fch, tch);
+  int* dmap = ar.take<int>(hmap.size() + 1);
+  if (ar.overflow) return PS_EWORKSPACE;
   PS_RC(psh::upload_async(st, dt, ht.data(), sizeof(QTensor) * count));
-  hipLaunchKernelGGL(quant_decode_kernel, dim3((unsigned)chunks), dim3(256), 0, st, dt, count);
+  PS_RC(psh::upload_async(st, dmap, hmap.data(), sizeof(int) * hmap.size()));
+  if (fch > 0)
+    hipLaunchKernelGGL(quant_flat_kernel<2>, dim3((unsigned)fch), dim3(256), 0, st, dt, dmap);
+  if (tch > 0)
+    hipLaunchKernelGGL(quant_decode_kernel, dim3((unsigned)tch), dim3(256), 0, st, dt, dmap + fch);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
