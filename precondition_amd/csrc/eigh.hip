@@ -752,7 +752,7 @@ __global__ void eigh_set_active_kernel(EighBlock* blocks, int nblocks, int swap_
 }
 
 // ---- generic grouped product for the polish / finalisation ---------------------------
-enum GEpi { GE_STORE = 0, GE_POLISH = 1, GE_ERR = 2, GE_SYM_STORE = 3 };
+enum GEpi { GE_STORE = 0, GE_POLISH = 1, GE_ERR = 2, GE_SYM_STORE = 3, GE_ERR_UPPER = 4 };
 enum GBuf { GB_A = 0, GB_V, GB_D, GB_W, GB_X, GB_OUT };
 
 __device__ inline float* ebuf(EighBlock* eb, int id) {
@@ -775,6 +775,10 @@ __global__ __launch_bounds__(256, 2) void eigh_gemm_kernel(EighBlock* blocks,
   const ETile te = tiles[xcd_remap(blockIdx.x, ntiles)];
   EighBlock* eb = &blocks[te.block];
   const int ld = eb->npad;
+  // symmetric results (W W^T; V^T (D V) up to rounding): the upper tile triangle only.  GE_SYM_STORE
+  // mirrors a tile into its transposed position (element (j, i) of W W^T sums the same products in the
+  // same order as (i, j): the mirrored value is bit-identical to a computed one).
+  if ((epi == GE_SYM_STORE || epi == GE_ERR_UPPER) && te.k > te.t) return;
   Operand A{ebuf(eb, a_id), ld, te.k * TILE, ld, ld, true};
   Operand B{ebuf(eb, b_id), ld, te.t * TILE, ld, ld, true};
   f32x16 acc[2][2];
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(256, 2) void eigh_gemm_kernel(EighBlock* blocks,
         const int row = te.k * TILE + acc_row(wm, i, r, lane);
         const int col = te.t * TILE + acc_col(wn, j, lane);
         const float v = acc[i][j][r];
-        if (epi == GE_STORE) {
+        if (epi == GE_STORE || epi == GE_SYM_STORE) {
           if (c_id == GB_OUT) {
             if (row < eb->n_full && col < eb->n_full)
               gstore1(C + (int64_t)row * eb->ldo + col, v);
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void eigh_gemm_kernel(EighBlock* blocks,
           }
         } else if (epi == GE_POLISH) {
           gstore1(C + (int64_t)row * ld + col, (row == col ? 1.5f : 0.f) - 0.5f * v);
-        } else if (epi == GE_ERR) {
+        } else if (epi == GE_ERR || epi == GE_ERR_UPPER) {
           // DS:1017-1021: |u^T D u - diag(e)|, restricted to the unpadded part
           if (row < eb->n && col < eb->n) {
             const float d = row == col ? eb->evals[row] : 0.f;
@@ -810,7 +814,36 @@ __global__ __launch_bounds__(256, 2) void eigh_gemm_kernel(EighBlock* blocks,
           }
         }
       }
-  if (epi == GE_ERR) {
+  if (epi == GE_SYM_STORE && te.k != te.t) {
+    // mirrored tile through LDS (two 64-row halves, stride 129: conflict-free both ways), guarded
+    // stores in 256-byte runs
+    constexpr int TLD = 129;
+    const int n_out = c_id == GB_OUT ? eb->n_full : ld;
+    const int ldc = c_id == GB_OUT ? eb->ldo : ld;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();
+      if (wm == h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              smem[lr * TLD + acc_col(wn, j, lane)] = acc[i][j][r];
+            }
+      }
+      __syncthreads();
+      for (int e = tid; e < 128 * 64; e += NTHREADS) {
+        const int c = e >> 6, lr = e & 63;
+        const int orow = te.t * TILE + c, ocol = te.k * TILE + h * 64 + lr;
+        if (orow < n_out && ocol < n_out) gstore1(C + (int64_t)orow * ldc + ocol, smem[lr * TLD + c]);
+      }
+    }
+  }
+  if (epi == GE_ERR || epi == GE_ERR_UPPER) {
+    __syncthreads();
     emax = wave_max_u32(emax);
     unsigned* red = reinterpret_cast<unsigned*>(smem);
     if (lane == 0) red[wave] = emax;
@@ -1718,9 +1751,9 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       hipLaunchKernelGGL(cj_rayleigh_from_dv_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
       hipLaunchKernelGGL(eigh_scale_kernel, dim3(nsq), blk, 0, st, lo.blocks, lo.sq);
       hipLaunchKernelGGL((eigh_gemm_kernel<KC, KC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
-                         (int)GB_W, (int)GB_W, (int)GB_OUT, (int)GE_STORE);
+                         (int)GB_W, (int)GB_W, (int)GB_OUT, (int)GE_SYM_STORE);
       hipLaunchKernelGGL((eigh_gemm_kernel<MC, MC>), dim3(nsq), blk, 0, st, lo.blocks, lo.sq, nsq,
-                         (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_ERR);
+                         (int)GB_V, (int)GB_X, (int)GB_A, (int)GE_ERR_UPPER);
     } else {
     {
       const int refine = opt.eigh_refine;

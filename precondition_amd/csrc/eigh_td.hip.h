@@ -186,8 +186,12 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
   const int r0 = tid >> 5, c4 = (tid & 31) * 4;
   const float* src = tb->A + (int64_t)(I * TILE + r0) * ld + J * TILE + c4;
   f32x4 a[16];
+  // rows up to j (first tile row only) carry v = 0 and their sums are not used: they are not read
+  // (on average half of the first tile row: ~1 / (T + 1) of the launch's bytes)
+  const int rfirst = j + 1 - I * TILE - r0;   // rows 8 k < rfirst are masked
 #pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = gload4(src + (int64_t)(8 * k) * ld);
+  for (int k = 0; k < 16; ++k)
+    a[k] = 8 * k >= rfirst ? gload4(src + (int64_t)(8 * k) * ld) : f32x4{0.f, 0.f, 0.f, 0.f};
   float beta, tau, scale, v1;
   td_house(tb, j, beta, tau, scale, v1);
   if (tid < TILE) {
@@ -320,11 +324,10 @@ __global__ __launch_bounds__(256, 2) void td_syr2k_kernel(TdBlock* blocks, int p
   const float* Vp = tb->VHt + (int64_t)p * ld;
   Operand Av{Vp, ld, I * TILE, ld, TD_NB, true}, Bw{tb->Wt, ld, J * TILE, ld, TD_NB, true};
   Operand Aw{tb->Wt, ld, I * TILE, ld, TD_NB, true}, Bv{Vp, ld, J * TILE, ld, TD_NB, true};
-  f32x16 acc[2][2];
-  zero_acc(acc);
-  gemm_tile_accum<MC, MC, 16, false>(Av, Bw, TD_NB, smem, acc);
-  gemm_tile_accum<MC, MC, 16, false>(Aw, Bv, TD_NB, smem, acc);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+  // the tile of A is requested BEFORE the products (the kernel is a read-modify-write of the trailing
+  // matrix with 64 flops per element: its time is the latency chain operands -> LDS -> MFMA -> tile)
+  f32x16 old[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -332,8 +335,20 @@ __global__ __launch_bounds__(256, 2) void td_syr2k_kernel(TdBlock* blocks, int p
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = I * TILE + acc_row(wm, a, r, lane), col = J * TILE + acc_col(wn, b, lane);
-        float* dst = tb->A + (int64_t)row * ld + col;
-        gstore1(dst, gload1(dst) - acc[a][b][r]);
+        old[a][b][r] = gload1(tb->A + (int64_t)row * ld + col);
+      }
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  gemm_tile_accum<MC, MC, 16, false>(Av, Bw, TD_NB, smem, acc);
+  gemm_tile_accum<MC, MC, 16, false>(Aw, Bv, TD_NB, smem, acc);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = I * TILE + acc_row(wm, a, r, lane), col = J * TILE + acc_col(wn, b, lane);
+        gstore1(tb->A + (int64_t)row * ld + col, old[a][b][r] - acc[a][b][r]);
       }
 }
 
