@@ -1013,27 +1013,35 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
   // The blocks are dealt to `stream_groups` (1 | 2) groups that reduce on two streams: a column costs
   // three dependent launches, of which only the mat-vec is HBM-bound; one group's short vector kernels
   // run beside the other group's mat-vec.
-  static thread_local hipStream_t side = nullptr;
-  static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  const bool two = stream_groups >= 2 && B >= 2;
-  if (two && !side) {
-    PS_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    PS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    PS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  constexpr int MAXG = 4;
+  static thread_local hipStream_t side[MAXG - 1] = {nullptr, nullptr, nullptr};
+  static thread_local hipEvent_t ev_fork = nullptr, ev_join[MAXG - 1] = {nullptr, nullptr, nullptr};
+  const int ngroups = std::max(1, std::min(std::min(stream_groups, MAXG), B));
+  if (!ev_fork) PS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  for (int g = 0; g + 1 < ngroups; ++g) {
+    if (!side[g]) {
+      PS_HIP(hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking));
+      PS_HIP(hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming));
+    }
   }
   hipLaunchKernelGGL(td_zero_kernel, dim3(256, B), b256, 0, st, lo.blocks, 0);
   hipLaunchKernelGGL(td_zero_kernel, dim3(8, B), b256, 0, st, lo.blocks, 1);
-  const int ngroups = two ? 2 : 1;
-  const int gfirst[3] = {0, two ? (B + 1) / 2 : B, B};
-  hipStream_t gs[2] = {st, two ? side : st};
-  struct SideJoin {   // however this scope is left, the side stream is joined back into the caller's
-    hipStream_t st, side; hipEvent_t ev; bool forked;
-    ~SideJoin() { if (forked && hipEventRecord(ev, side) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0); }
-  } join{st, side, ev_join, false};
-  if (two) {
+  int gfirst[MAXG + 1];
+  for (int g = 0; g <= ngroups; ++g) gfirst[g] = (int)((int64_t)B * g / ngroups);
+  hipStream_t gs[MAXG];
+  gs[0] = st;
+  for (int g = 1; g < ngroups; ++g) gs[g] = side[g - 1];
+  struct SideJoin {   // however this scope is left, the side streams are joined back into the caller's
+    hipStream_t st; hipStream_t* side; hipEvent_t* ev; int n;
+    ~SideJoin() {
+      for (int g = 0; g < n; ++g)
+        if (hipEventRecord(ev[g], side[g]) == hipSuccess) (void)hipStreamWaitEvent(st, ev[g], 0);
+    }
+  } join{st, side, ev_join, 0};
+  if (ngroups > 1) {
     PS_HIP(hipEventRecord(ev_fork, st));
-    PS_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-    join.forked = true;
+    for (int g = 1; g < ngroups; ++g) PS_HIP(hipStreamWaitEvent(side[g - 1], ev_fork, 0));
+    join.n = ngroups - 1;
   }
   for (int j = 0; j < nmax; ++j) {
     const int i = j % TD_NB;
@@ -1054,11 +1062,11 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
       }
     }
   }
-  if (two) {
-    join.forked = false;
-    PS_HIP(hipEventRecord(ev_join, side));
-    PS_HIP(hipStreamWaitEvent(st, ev_join, 0));
+  for (int g = 1; g < ngroups; ++g) {
+    PS_HIP(hipEventRecord(ev_join[g - 1], side[g - 1]));
+    PS_HIP(hipStreamWaitEvent(st, ev_join[g - 1], 0));
   }
+  join.n = 0;
   PS_LAUNCH_CHECK();
   // ---- divide and conquer ----
   if (stage == 1) {
