@@ -1189,6 +1189,22 @@ def main():
       _sync()
       line["vit_b_cfg4"]["parity_vs_oracle"] = parity_sample_vit_b(vw, _roots, _met)
       del _roots, _met, _flat
+    if multi and not SELFTEST:
+      # BASELINE configs[4] over the ranks of this run: 8 factors of dim 4096 dealt to the ranks (one
+      # per GPU at N = 8), no exchange step inside an FD update -- measured on every rank, max over
+      # ranks reported, to be read against fd_cfg5_rank_share of the N = 1 line
+      import torch.distributed as dist
+      try:
+        fr = fd_cfg5(dev, factors=max(1, 8 // world))
+        t = torch.tensor([float(np.median(fr["ms_per_factor_update"]))], dtype=torch.float64, device="cuda")
+      except Exception as e:  # pylint: disable=broad-except
+        fr, t = {"error": f"{type(e).__name__}: {e}"[:300]}, torch.tensor([float("nan")], dtype=torch.float64, device="cuda")
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      if rank == 0:
+        line["fd_cfg5_sharded"] = {"factors_per_rank": max(1, 8 // world), "world": world,
+                                   "ms_per_factor_update_max_over_ranks": round(t.item(), 3),
+                                   "rank0": fr}
+        line["config"]["fd_cfg5_sharded_ms_per_factor"] = round(t.item(), 3)
     if world == 1 and rank == 0 and not SELFTEST:
       try:
         line["vit_b_cfg4_rank_share"] = vit_b_rank_share(vw, dev)

@@ -58,6 +58,205 @@ __global__ __launch_bounds__(256) void v0(const float* A, const float* v, float*
   }
 }
 
+__global__ __launch_bounds__(256, 6) void v0o6(const float* A, const float* v, float* slab) {
+  __shared__ float svI[TILE], svJ[TILE], srow[TILE], scol[8][TILE];
+  const float* a_ = A + (size_t)blockIdx.y * N * N;
+  int I, J; decode(blockIdx.x, NT, I, J);
+  const int tid = threadIdx.x, r0 = tid >> 5, c4 = (tid & 31) * 4;
+  const float* src = a_ + (size_t)(I * TILE + r0) * N + J * TILE + c4;
+  f32x4 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = gload4(src + (size_t)(8 * k) * N);
+  if (tid < TILE) { svI[tid] = v[blockIdx.y * N + I * TILE + tid]; svJ[tid] = v[blockIdx.y * N + J * TILE + tid]; }
+  __syncthreads();
+  const f32x4 vj = *reinterpret_cast<const f32x4*>(&svJ[c4]);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float rs = a[k][0] * vj[0] + a[k][1] * vj[1] + a[k][2] * vj[2] + a[k][3] * vj[3];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    if ((tid & 31) == 0) srow[r0 + 8 * k] = rs;
+    const float vi = svI[r0 + 8 * k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[e] += a[k][e] * vi;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) scol[r0][c4 + e] = cs[e];
+  __syncthreads();
+  float* sl = slab + (size_t)blockIdx.y * NT * NT * TILE;
+  if (tid < TILE) {
+    sl[(I * NT + J) * TILE + tid] = srow[tid];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += scol[g][tid];
+    if (I != J) sl[(J * NT + I) * TILE + tid] = s;
+  }
+}
+
+
+__global__ __launch_bounds__(256, 8) void v0o8(const float* A, const float* v, float* slab) {
+  __shared__ float svI[TILE], svJ[TILE], srow[TILE], scol[8][TILE];
+  const float* a_ = A + (size_t)blockIdx.y * N * N;
+  int I, J; decode(blockIdx.x, NT, I, J);
+  const int tid = threadIdx.x, r0 = tid >> 5, c4 = (tid & 31) * 4;
+  const float* src = a_ + (size_t)(I * TILE + r0) * N + J * TILE + c4;
+  f32x4 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = gload4(src + (size_t)(8 * k) * N);
+  if (tid < TILE) { svI[tid] = v[blockIdx.y * N + I * TILE + tid]; svJ[tid] = v[blockIdx.y * N + J * TILE + tid]; }
+  __syncthreads();
+  const f32x4 vj = *reinterpret_cast<const f32x4*>(&svJ[c4]);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float rs = a[k][0] * vj[0] + a[k][1] * vj[1] + a[k][2] * vj[2] + a[k][3] * vj[3];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    if ((tid & 31) == 0) srow[r0 + 8 * k] = rs;
+    const float vi = svI[r0 + 8 * k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[e] += a[k][e] * vi;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) scol[r0][c4 + e] = cs[e];
+  __syncthreads();
+  float* sl = slab + (size_t)blockIdx.y * NT * NT * TILE;
+  if (tid < TILE) {
+    sl[(I * NT + J) * TILE + tid] = srow[tid];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += scol[g][tid];
+    if (I != J) sl[(J * NT + I) * TILE + tid] = s;
+  }
+}
+
+
+__global__ __launch_bounds__(256) void v0a(const float* A, const float* v, float* slab) {
+  __shared__ float svI[TILE], svJ[TILE], srow[TILE], scol[8][TILE];
+  const float* a_ = A + (size_t)blockIdx.y * N * N;
+  int I, J; decode(blockIdx.x, NT, I, J);
+  const int tid = threadIdx.x, r0 = tid >> 5, c4 = (tid & 31) * 4;
+  const float* src = a_ + (size_t)(I * TILE + r0) * N + J * TILE + c4;
+  f32x4 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = gload4(src + (size_t)(8 * k) * N);
+  if (tid < TILE) { svI[tid] = v[blockIdx.y * N + I * TILE + tid]; svJ[tid] = v[blockIdx.y * N + J * TILE + tid]; }
+  __syncthreads();
+  const f32x4 vj = *reinterpret_cast<const f32x4*>(&svJ[c4]);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float rs = a[k][0] * vj[0] + a[k][1] * vj[1] + a[k][2] * vj[2] + a[k][3] * vj[3];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    if ((tid & 31) == 0) srow[r0 + 8 * k] = rs;
+    const float vi = svI[r0 + 8 * k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[e] += a[k][e] * vi;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) scol[r0][c4 + e] = cs[e];
+  __syncthreads();
+  float* sl = slab + (size_t)blockIdx.y * NT * NT * TILE;
+  if (tid < TILE) {
+    float s = srow[tid];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += scol[g][tid];
+    if (s == 12345.f) sl[(J * NT + I) * TILE + tid] = s;   // no stores
+  }
+}
+
+
+__global__ __launch_bounds__(256) void v0c(const float* A, const float* v, float* slab) {
+  __shared__ float svI[TILE], svJ[TILE], srow[TILE], scol[8][TILE];
+  const float* a_ = A + (size_t)blockIdx.y * N * N;
+  for (int rep = 0; rep < 2; ++rep) {
+  int I, J; decode(blockIdx.x * 2 + rep, NT, I, J);
+  __syncthreads();
+  const int tid = threadIdx.x, r0 = tid >> 5, c4 = (tid & 31) * 4;
+  const float* src = a_ + (size_t)(I * TILE + r0) * N + J * TILE + c4;
+  f32x4 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = gload4(src + (size_t)(8 * k) * N);
+  if (tid < TILE) { svI[tid] = v[blockIdx.y * N + I * TILE + tid]; svJ[tid] = v[blockIdx.y * N + J * TILE + tid]; }
+  __syncthreads();
+  const f32x4 vj = *reinterpret_cast<const f32x4*>(&svJ[c4]);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float rs = a[k][0] * vj[0] + a[k][1] * vj[1] + a[k][2] * vj[2] + a[k][3] * vj[3];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    if ((tid & 31) == 0) srow[r0 + 8 * k] = rs;
+    const float vi = svI[r0 + 8 * k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[e] += a[k][e] * vi;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) scol[r0][c4 + e] = cs[e];
+  __syncthreads();
+  float* sl = slab + (size_t)blockIdx.y * NT * NT * TILE;
+  if (tid < TILE) {
+    sl[(I * NT + J) * TILE + tid] = srow[tid];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += scol[g][tid];
+    if (I != J) sl[(J * NT + I) * TILE + tid] = s;
+  }
+  }
+}
+
+// v5: 16 lanes per row piece (64 columns), row sums by four DPP rotate-adds inside a row of 16 lanes
+template <int N>
+__device__ inline float row16_add_ror(float x) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xf, 0xf, false);
+  return x + __int_as_float(r);
+}
+__device__ inline float row16_sum(float x) {
+  x = row16_add_ror<8>(x); x = row16_add_ror<4>(x); x = row16_add_ror<2>(x);
+  return row16_add_ror<1>(x);
+}
+__global__ __launch_bounds__(256) void v5(const float* A, const float* v, float* slab) {
+  __shared__ float svI[TILE], svJ[TILE], srow[TILE], scol[16][TILE];
+  const float* a_ = A + (size_t)blockIdx.y * N * N;
+  int I, J; decode(blockIdx.x, NT, I, J);
+  const int tid = threadIdx.x, rg = tid >> 4, l16 = tid & 15;
+  const float* src = a_ + (size_t)(I * TILE + rg) * N + J * TILE + l16 * 4;
+  f32x4 a[8][2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k][0] = gload4(src + (size_t)(16 * k) * N);
+    a[k][1] = gload4(src + (size_t)(16 * k) * N + 64);
+  }
+  if (tid < TILE) { svI[tid] = v[blockIdx.y * N + I * TILE + tid]; svJ[tid] = v[blockIdx.y * N + J * TILE + tid]; }
+  __syncthreads();
+  const f32x4 vj0 = *reinterpret_cast<const f32x4*>(&svJ[l16 * 4]);
+  const f32x4 vj1 = *reinterpret_cast<const f32x4*>(&svJ[64 + l16 * 4]);
+  float cs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float rs = a[k][0][0] * vj0[0] + a[k][0][1] * vj0[1] + a[k][0][2] * vj0[2] + a[k][0][3] * vj0[3] +
+               a[k][1][0] * vj1[0] + a[k][1][1] * vj1[1] + a[k][1][2] * vj1[2] + a[k][1][3] * vj1[3];
+    rs = row16_sum(rs);
+    if (l16 == 0) srow[rg + 16 * k] = rs;
+    const float vi = svI[rg + 16 * k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cs[0][e] += a[k][0][e] * vi; cs[1][e] += a[k][1][e] * vi; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { scol[rg][l16 * 4 + e] = cs[0][e]; scol[rg][64 + l16 * 4 + e] = cs[1][e]; }
+  __syncthreads();
+  float* sl = slab + (size_t)blockIdx.y * NT * NT * TILE;
+  if (tid < TILE) {
+    sl[(I * NT + J) * TILE + tid] = srow[tid];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += scol[g][tid];
+    if (I != J) sl[(J * NT + I) * TILE + tid] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void v1(const float* A, const float* v, float* slab) {
   const float* a_ = A + (size_t)blockIdx.y * N * N;
   int I, J; decode(blockIdx.x, NT, I, J);
@@ -168,6 +367,13 @@ int main() {
     const int nt_ = T * (T + 1) / 2;
     time(nm, [&] { hipLaunchKernelGGL(v0, dim3(nt_, NB), dim3(256), 0, 0, A, v, slab); }, (double)NB * nt_ * TILE * TILE * 4);
   }
+  time("v0o6", [&] { hipLaunchKernelGGL(v0o6, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
+  time("v0o8", [&] { hipLaunchKernelGGL(v0o8, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
+  time("v0a", [&] { hipLaunchKernelGGL(v0a, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
+  time("v0c", [&] { hipLaunchKernelGGL(v0c, dim3(ntri / 2, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
+  time("v5", [&] { hipLaunchKernelGGL(v5, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
+  time("v0", [&] { hipLaunchKernelGGL(v0, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
+  time("v5", [&] { hipLaunchKernelGGL(v5, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
   time("v1", [&] { hipLaunchKernelGGL(v1, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
   time("v1b", [&] { hipLaunchKernelGGL(v1b, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
   // strips read the block triangle rounded to 128 columns as well
