@@ -144,22 +144,17 @@ constexpr int QFLAT_MAXC = 8192;  // columns kept in LDS by the column-max pass
 constexpr int QMAXT = 1 << 30;
 __device__ inline int encode1(float x, float bs_nonzero);
 
-template <int MODE>   // 0 = column maxima, 1 = encode, 2 = decode
-__global__ __launch_bounds__(256) void quant_flat_kernel(const QTensor* ts, const int* cmap) {
-  __shared__ unsigned s_max[MODE == 0 ? QFLAT_MAXC : 1];
-  // chunk -> tensor from a per-chunk table (one 4-byte load): a binary search over the tensor table
-  // costs nine dependent loads, a copy of its prefix column to LDS 50 KB of L2 reads per workgroup
-  const QTensor* t = &ts[cmap[blockIdx.x]];
-  const int local = blockIdx.x - t->fchunk0;
+// FULL: the chunk lies inside the tensor (every chunk but a tensor's last): no per-lane bounds tests.
+// With them every load sits behind a divergent branch and the compiler waits for it before the next one:
+// the sixteen loads of a lane are then issued one after the other (measured: half the rate of the same
+// stream without the tests, tools/bench_stream.hip).
+template <int MODE, bool FULL, int BITS>
+__device__ __forceinline__ void quant_flat_body(const QTensor* t, int local, unsigned* s_max) {
   const int tid = threadIdx.x;
-  const long long cols = t->cols, total = t->rows * t->cols;
+  const long long cols = t->cols, rows = t->rows, total = rows * cols;
   const long long base = (long long)local * QFLAT;
   const int extract = t->extract;
-  const float nb = t->bits == 8 ? 127.f : 32767.f;
-  if (MODE == 0) {
-    for (int c = tid; c < cols; c += 256) s_max[c] = 0u;
-    __syncthreads();
-  }
+  const float nb = BITS == 8 ? 127.f : 32767.f;
   // incremental (row, col) of the thread's float4s: offsets base + 4 tid + 1024 k
   const long long off0 = base + 4 * tid;
   long long row = off0 / cols;
@@ -168,25 +163,39 @@ __global__ __launch_bounds__(256) void quant_flat_kernel(const QTensor* ts, cons
   const long long step_r = 1024 / cols;
   uint32_t loff = (uint32_t)(4 * tid * 4);
   asm volatile("" : "+v"(loff));
-  F4 v[16];
-  uint2 pk16[16];
-  unsigned pk8[16];
   const char* fbase = reinterpret_cast<const char*>(t->fin) + base * 4;
-  const int esz = t->bits == 16 ? 2 : 1;
+  constexpr int esz = BITS == 16 ? 2 : 1;
   const char* cbase = reinterpret_cast<const char*>(t->codes) + base * esz;
   uint32_t coff = (uint32_t)(4 * tid * esz);
   asm volatile("" : "+v"(coff));
+  F4 v[16];
+  uint2 pk16[16];
+  unsigned pk8[16];
+  float dg[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const bool in = off0 + 1024 * k < total;
+    const bool in = FULL || off0 + 1024 * k < total;
     if (MODE != 2) {
-      v[k] = in ? ldg4_so(fbase + (long long)k * 4096, loff) : F4{0.f, 0.f, 0.f, 0.f};
+      v[k] = F4{0.f, 0.f, 0.f, 0.f};
+      if (in) v[k] = ldg4_so(fbase + (long long)k * 4096, loff);
     } else {
       pk16[k] = uint2{0u, 0u}; pk8[k] = 0u;
       if (in) {
-        if (t->bits == 16) pk16[k] = ldg2u_so(cbase + (long long)k * 2048, coff);
+        if (BITS == 16) pk16[k] = ldg2u_so(cbase + (long long)k * 2048, coff);
         else pk8[k] = ldg1u_so(cbase + (long long)k * 1024, coff);
       }
+    }
+  }
+  if (MODE == 2 && extract) {
+    // the diagonal entry of the lane's row, for every step, requested with the codes (unconditional:
+    // lanes of one row read one address; a float4 never straddles a row)
+    long long prow = row;
+    int pcol = col;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      dg[k] = ldg1(t->diag + (prow < rows ? prow : rows - 1));
+      pcol += step_c; prow += step_r;
+      if (pcol >= cols) { pcol -= (int)cols; prow += 1; }
     }
   }
   if (MODE == 1 && local == 0) {   // bucket sizes (QU:86), once per tensor
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256) void quant_flat_kernel(const QTensor* ts, cons
   }
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const bool in = off0 + 1024 * k < total;
+    const bool in = FULL || off0 + 1024 * k < total;
     if (in) {
       if (MODE == 0) {
         float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
@@ -206,30 +215,35 @@ __global__ __launch_bounds__(256) void quant_flat_kernel(const QTensor* ts, cons
         }
       } else if (MODE == 1) {
         float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-        const uint4 cm = *reinterpret_cast<const uint4*>(t->colmax + col);
-        const unsigned cmv[4] = {cm.x, cm.y, cm.z, cm.w};
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        const u4v cm = *(const u4v PS_GLOBAL*)(t->colmax + col);
+        const unsigned cmv[4] = {cm[0], cm[1], cm[2], cm[3]};
         int q[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float bs = __fdiv_rn(__uint_as_float(cmv[j]), nb);   // QU:86
           const float bnz = bs > 0.f ? bs : 1.f;                       // QU:89-90
-          if (extract && col + j == row) { t->diag[row] = x[j]; x[j] = __fsub_rn(x[j], x[j]); }
+          if (extract && col + j == row) {
+            *(float PS_GLOBAL*)(t->diag + row) = x[j];
+            x[j] = __fsub_rn(x[j], x[j]);
+          }
           q[j] = encode1(x[j], bnz);
         }
         const long long o = off0 + 1024 * k;
-        if (t->bits == 16) {
-          uint2 pk;
-          pk.x = ((unsigned)q[0] & 0xffffu) | ((unsigned)q[1] << 16);
-          pk.y = ((unsigned)q[2] & 0xffffu) | ((unsigned)q[3] << 16);
-          *reinterpret_cast<uint2*>(reinterpret_cast<short*>(t->codes) + o) = pk;
+        if (BITS == 16) {
+          typedef unsigned u2v __attribute__((ext_vector_type(2)));
+          u2v pk;
+          pk[0] = ((unsigned)q[0] & 0xffffu) | ((unsigned)q[1] << 16);
+          pk[1] = ((unsigned)q[2] & 0xffffu) | ((unsigned)q[3] << 16);
+          *(u2v PS_GLOBAL*)(reinterpret_cast<short*>(t->codes) + o) = pk;
         } else {
           const unsigned pk = ((unsigned)q[0] & 0xffu) | (((unsigned)q[1] & 0xffu) << 8) |
                               (((unsigned)q[2] & 0xffu) << 16) | ((unsigned)q[3] << 24);
-          *reinterpret_cast<unsigned*>(reinterpret_cast<signed char*>(t->codes) + o) = pk;
+          *(unsigned PS_GLOBAL*)(reinterpret_cast<signed char*>(t->codes) + o) = pk;
         }
       } else {
         int q[4];
-        if (t->bits == 16) {
+        if (BITS == 16) {
           q[0] = (short)(pk16[k].x & 0xffffu); q[1] = (short)(pk16[k].x >> 16);
           q[2] = (short)(pk16[k].y & 0xffffu); q[3] = (short)(pk16[k].y >> 16);
         } else {
@@ -239,17 +253,41 @@ __global__ __launch_bounds__(256) void quant_flat_kernel(const QTensor* ts, cons
         }
         const F4 b4 = ldg4(t->bucket + col);
         const float bs[4] = {b4.x, b4.y, b4.z, b4.w};
-        float x[4];
+        qf4 x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          x[j] = __fmul_rn((float)q[j], bs[j]);                                       // QU:109
-          if (extract && col + j == row) x[j] = __fadd_rn(x[j], t->diag[row]);        // QU:111
+          x[j] = __fmul_rn((float)q[j], bs[j]);                                     // QU:109
+          const float xd = __fadd_rn(x[j], dg[k]);                                  // QU:111
+          x[j] = (extract && col + j == row) ? xd : x[j];
         }
-        *reinterpret_cast<float4*>(t->fout + off0 + 1024 * k) = make_float4(x[0], x[1], x[2], x[3]);
+        *(qf4 PS_GLOBAL*)(t->fout + off0 + 1024 * k) = x;
       }
     }
     col += step_c; row += step_r;
     if (col >= cols) { col -= (int)cols; row += 1; }
+  }
+}
+
+template <int MODE>   // 0 = column maxima, 1 = encode, 2 = decode
+__global__ __launch_bounds__(256) void quant_flat_kernel(const QTensor* ts, const int* cmap) {
+  __shared__ unsigned s_max[MODE == 0 ? QFLAT_MAXC : 1];
+  // chunk -> tensor from a per-chunk table (one 4-byte load)
+  const QTensor* t = &ts[cmap[blockIdx.x]];
+  const int local = blockIdx.x - t->fchunk0;
+  const int tid = threadIdx.x;
+  const long long cols = t->cols;
+  if (MODE == 0) {
+    for (int c = tid; c < cols; c += 256) s_max[c] = 0u;
+    __syncthreads();
+  }
+  const bool full = (long long)(local + 1) * QFLAT <= t->rows * cols;
+  // (MODE 0 does not depend on the code width)
+  if (MODE == 0 || t->bits == 16) {
+    if (full) quant_flat_body<MODE, true, 16>(t, local, s_max);
+    else quant_flat_body<MODE, false, 16>(t, local, s_max);
+  } else {
+    if (full) quant_flat_body<MODE, true, 8>(t, local, s_max);
+    else quant_flat_body<MODE, false, 8>(t, local, s_max);
   }
   if (MODE == 0) {
     __syncthreads();

@@ -225,3 +225,49 @@ def test_donated_state_vit_b_shaped_tree_no_allocation_and_same_bits(device):
   p = outs[True][2]
   assert p[1] == p[2] and p[4] == p[5]      # steps 1 -> 2 and 4 -> 5: no recompute, same storage
   assert outs[False][2][1] != outs[False][2][2]   # the functional path allocates a new state every step
+
+
+def test_eigh_tridiagonal_path_non_finite_input_and_size_limit(device):
+  """A block with a NaN is handed to the Jacobi solvers (which propagate it: NaN root, NaN metric, as
+  jnp would) without disturbing its neighbours; 4096 rows is the largest size of the fast path (the
+  divide and conquer keeps a merge problem in LDS) and is checked through val^2 (A + eps I) = I."""
+  good = wishart(300, 1200, 5)
+  bad = wishart(256, 1024, 6).copy()
+  bad[7, 9] = bad[9, 7] = np.nan
+  roots, met = K().matrix_inverse_pth_root_batched(
+      [torch.tensor(good, device=device), torch.tensor(bad, device=device)], [2, 2], eigh=True)
+  h_ref, _ = orc.matrix_inverse_pth_root_eigh(good, 2)
+  assert np.linalg.norm(roots[0].cpu().numpy() - h_ref) / np.linalg.norm(h_ref) < 2e-5
+  m = met.cpu().numpy()
+  assert np.isnan(m[1, 0]) or not (m[1, 0] < 0.1)       # the failure select (DS:2936-2950) keeps the previous value
+  assert np.isfinite(m[0, 0])
+  n = 4096
+  gen = torch.Generator(device=device).manual_seed(4096)
+  g = torch.randn((n, 2 * n), generator=gen, device=device)
+  a = torch.zeros((n, n), device=device)
+  K().stats_update_grouped([(g, 0, a, a)], 0.0, 1.0)
+  del g
+  roots, met = K().matrix_inverse_pth_root_batched([a], [2], eigh=True)
+  assert met.cpu().numpy()[0, 5] == 0      # no Jacobi sweeps
+  lam, _ = K().power_iteration_batched([a])
+  d = a + 1e-6 * lam[0] * torch.eye(n, device=device)
+  resid = K().matmul(K().matmul(roots[0], roots[0]), d) - torch.eye(n, device=device)
+  assert float(resid.abs().max()) < 2e-3
+
+
+def test_quantize_plan_matches_grouped_calls_bit_for_bit(device):
+  """kernels.QuantizePlan (resident descriptors) = quantize_grouped / dequantize_grouped on the same
+  tensors, contiguous matrices (flat kernels) and an odd-sized one (tile kernels) in one call."""
+  gen = torch.Generator(device=device).manual_seed(9)
+  mats = [torch.randn((n, n), generator=gen, device=device) for n in (768, 1024, 197, 64)]
+  mats = [m + m.T for m in mats]
+  ref = K().quantize_grouped(mats, torch.int16, True)
+  out = [(torch.empty_like(c), torch.empty_like(d), torch.empty_like(b)) for c, d, b in ref]
+  plan = K().QuantizePlan(mats, torch.int16, True, out)
+  plan.quantize()
+  for (c0, d0, b0), (c1, d1, b1) in zip(ref, out):
+    assert torch.equal(c0, c1) and torch.equal(d0, d1) and torch.equal(b0, b1)
+  fl = [torch.empty_like(m) for m in mats]
+  K().QuantizePlan(fl, torch.int16, True, out).dequantize()
+  for f, f_ref in zip(fl, K().dequantize_grouped(ref)):
+    assert torch.equal(f, f_ref)

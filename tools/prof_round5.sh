@@ -24,4 +24,6 @@ for pair in "eigh:tools/dev_eigh_one.py" "update_step_vitb_donated:tools/dev_upd
   cp gpurun_out/r05_$name/trace/*/*kernel_stats.csv $R/r05_${name}_kernel_stats.csv 2>/dev/null
   cp gpurun_out/r05_$name/run.log $R/r05_${name}_run.log 2>/dev/null
 done
+# the raw traces stay on the box: only the summaries travel back (gpurun merges <= 64 MiB)
+rm -rf gpurun_out/r05_*
 ls -la $R
