@@ -184,14 +184,26 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
   if (J >= nt) return;
   // the tile: thread -> rows (tid >> 5) + 8 k, columns 4 (tid & 31) .. ; its loads go out first
   const int r0 = tid >> 5, c4 = (tid & 31) * 4;
-  const float* src = tb->A + (int64_t)(I * TILE + r0) * ld + J * TILE + c4;
+  // (wave-uniform 64-bit base in SGPRs) + (one 32-bit byte offset per lane): sixteen loads in flight on
+  // one address register (per-load 64-bit address pairs made the allocator reuse a destination as an
+  // address and wait for it: a vmcnt(0) after the second load)
+  const float* ubase = tb->A + (int64_t)(I * TILE) * ld + J * TILE;
+  uint32_t loff = (uint32_t)((r0 * ld + c4) * 4);
+  asm volatile("" : "+v"(loff));
   f32x4 a[16];
   // rows up to j (first tile row only) carry v = 0 and their sums are not used: they are not read
   // (on average half of the first tile row: ~1 / (T + 1) of the launch's bytes)
-  const int rfirst = j + 1 - I * TILE - r0;   // rows 8 k < rfirst are masked
+  // The test is WAVE-UNIFORM (a wavefront holds the row pair 2 w, 2 w + 1 of every group of 8: the load is
+  // skipped when both are masked): with a per-lane test every load sits under its own exec mask and the
+  // compiler put a vmcnt(0) between the first ones.
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = j - I * TILE;               // last masked row of this tile (< 0: none)
 #pragma unroll
-  for (int k = 0; k < 16; ++k)
-    a[k] = 8 * k >= rfirst ? gload4(src + (int64_t)(8 * k) * ld) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < 16; ++k) {
+    a[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (8 * k + 2 * wv + 1 > jl)
+      a[k] = *(const f32x4 PS_GLOBAL*)((const char PS_GLOBAL*)(ubase + (int64_t)(8 * k) * ld) + (uint64_t)loff);
+  }
   float beta, tau, scale, v1;
   td_house(tb, j, beta, tau, scale, v1);
   if (tid < TILE) {
