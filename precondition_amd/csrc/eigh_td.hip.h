@@ -1025,9 +1025,9 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
   // The blocks are dealt to `stream_groups` (1 | 2) groups that reduce on two streams: a column costs
   // three dependent launches, of which only the mat-vec is HBM-bound; one group's short vector kernels
   // run beside the other group's mat-vec.
-  constexpr int MAXG = 4;
-  static thread_local hipStream_t side[MAXG - 1] = {nullptr, nullptr, nullptr};
-  static thread_local hipEvent_t ev_fork = nullptr, ev_join[MAXG - 1] = {nullptr, nullptr, nullptr};
+  constexpr int MAXG = 8;
+  static thread_local hipStream_t side[MAXG - 1] = {};
+  static thread_local hipEvent_t ev_fork = nullptr, ev_join[MAXG - 1] = {};
   const int ngroups = std::max(1, std::min(std::min(stream_groups, MAXG), B));
   if (!ev_fork) PS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   for (int g = 0; g + 1 < ngroups; ++g) {

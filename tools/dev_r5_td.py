@@ -125,6 +125,28 @@ def bench():
 
 
 
+def streams():
+  """Stream groups of the reduction: 64 x 2048^2 and 64 x 1024^2, best of 5."""
+  for nb, n in ((64, 2048), (64, 1024), (256, 512)):
+    gen = torch.Generator(device=dev).manual_seed(n)
+    stats = torch.zeros((nb, n, n), device=dev)
+    for b0 in range(0, nb, 8):
+      g = torch.randn((8, n, 2 * n), generator=gen, device=dev)
+      K.stats_update_grouped([(g[i], 0, stats[b0 + i], stats[b0 + i]) for i in range(8)], 0.0, 1.0)
+    torch.cuda.synchronize()
+    out = torch.empty_like(stats)
+    for sg in os.environ.get("SG_LIST", "1,2,4,6,8").split(","):
+      os.environ["PS_EIGH_TD_STREAMS"] = sg
+      best = 1e9
+      for rep in range(6):
+        t0 = time.perf_counter()
+        _, m = K.matrix_inverse_pth_root_batched(list(stats.unbind(0)), [2] * nb, [n] * nb, eigh=True, out=list(out.unbind(0)))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if rep: best = min(best, dt)
+      print(f"streams {nb}x{n} groups={sg}: {best * 1e3:.1f} ms, err max {m[:, 0].max().item():.2e}", flush=True)
+  os.environ.pop("PS_EIGH_TD_STREAMS")
+
+
 def debug129():
   """stage 1 gives Q (T = Q^T A Q), stage 2 gives Z_T: which eigenpairs of T are off?"""
   for n, kind in ((129, "randsym"), (130, "randsym"), (129, "wishart"), (161, "randsym")):
