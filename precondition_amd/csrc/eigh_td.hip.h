@@ -39,7 +39,7 @@ struct TdBlock {
   float* ubuf;         // [ld] updated row of the current column
   float* wp;           // [ld] w before its last correction
   float* slab;         // [nt][nt][128] partial mat-vec products
-  float* part_ss;      // [nt]
+  double* part_ss;     // [nt] float64: squares of a trailing matrix that is rounding noise underflow in float32
   float* part_dot;     // [nt]
   float* part_ab;      // [nt][2][TD_NB]
   float* dT; float* eT; float* tau;   // [ld]
@@ -76,6 +76,15 @@ __device__ __forceinline__ float td_wg_sum128(float v, float* red) {   // 128 th
   __syncthreads();
   return r;
 }
+__device__ __forceinline__ double td_wg_sum128_f64(double v, double* red) {   // 128 threads
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double r = red[0] + red[1];
+  __syncthreads();
+  return r;
+}
 
 // ---- reduction, per column: (1) finish w of the previous column, updated row j, its norm ----------
 // grid (nt_max - j / 128, nblk), 128 threads: tile row X = j / 128 + blockIdx.x.
@@ -83,7 +92,7 @@ __device__ __forceinline__ float td_wg_sum128(float v, float* red) {   // 128 th
 //   jr >= 0: u[c] = A[jr][c] - sum_{i' < i} (V[jr, i'] W[c, i'] + W[jr, i'] V[c, i']),  d[jr] = u[jr],
 //            partial sums of u[c]^2 over c >= jr + 2
 __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, int jr) {
-  __shared__ float red[2];
+  __shared__ double red[2];
   __shared__ float sVj[TD_NB], sWj[TD_NB];
   TdBlock* tb = &blocks[blockIdx.y];
   const int n = tb->n, ld = tb->ld, nt = tb->nt, tid = threadIdx.x;
@@ -146,7 +155,11 @@ __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, in
   if (c >= n) u = 0.f;
   if (c == jr) tb->dT[jr] = u;
   tb->ubuf[c] = c > jr ? u : 0.f;
-  const float ss = td_wg_sum128(c >= jr + 2 ? u * u : 0.f, red);
+  // float64: the trailing matrix of an exactly low-rank input (all ones, say) is rounding noise of
+  // rounding noise, 1e-8 smaller with every column, and its squares leave the float32 range (a
+  // reflector with tau v^T v != 2: Q lost orthogonality to 4e-4); 1e18-sized entries overflow there
+  const double ud = c >= jr + 2 ? (double)u : 0.0;
+  const double ss = td_wg_sum128_f64(ud * ud, red);
   if (tid == 0) tb->part_ss[X] = ss;
 }
 
@@ -154,15 +167,26 @@ __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, in
 // stores the ZERO vector: the WY factor of the back-transformation then sees an identity.
 __device__ __forceinline__ void td_house(const TdBlock* tb, int j, float& beta, float& tau,
                                          float& scale, float& v1) {
-  float sigma = 0.f;
+  double sigma = 0.0;
   for (int x = j / TILE; x < tb->nt; ++x) sigma += tb->part_ss[x];
   const float alpha = tb->ubuf[j + 1];
-  if (!(sigma > 0.f) && sigma == sigma) {   // sigma == 0
-    beta = alpha; tau = 0.f; scale = 0.f; v1 = 0.f;
-  } else {
-    beta = -copysignf(sqrtf(alpha * alpha + sigma), alpha);
+  const float sf = (float)sigma, a2 = alpha * alpha;
+  if (sf > 1e-30f && sf < 1e30f && a2 < 1e30f) {   // the common case: float32 arithmetic is safe (wave-uniform branch)
+    beta = -copysignf(sqrtf(a2 + sf), alpha);
     tau = (beta - alpha) / beta;
     scale = 1.f / (alpha - beta);
+    v1 = 1.f;
+    return;
+  }
+  const double ad = (double)alpha, nrm = sqrt(ad * ad + sigma);
+  // sigma == 0: nothing to annihilate; a column below 1e-36 is dropped (1 / (alpha - beta) must stay a float)
+  if ((!(sigma > 0.0) && sigma == sigma) || nrm < 1e-36) {
+    beta = alpha; tau = 0.f; scale = 0.f; v1 = 0.f;
+  } else {
+    const double bd = alpha >= 0.f ? -nrm : nrm;
+    beta = (float)bd;
+    tau = (float)((bd - ad) / bd);
+    scale = (float)(1.0 / (ad - bd));
     v1 = 1.f;
   }
 }
@@ -718,33 +742,71 @@ __global__ __launch_bounds__(256) void td_dc_finish_kernel(TdBlock* blocks, int 
 
 // ======================= back-transformation Z <- Q Z ================================================
 
-// T^-1 = diag(1 / tau) + striu(Vb Vb^T) of WY block kb (reflectors 128 kb ..): grid (nbk_max, nblk)
-__global__ __launch_bounds__(256, 2) void td_vtv_kernel(TdBlock* blocks) {
-  __shared__ __align__(16) float smem[SmemCfg<16>::TOTAL];
+// T^-1 = diag(1 / tau) + striu(Vb Vb^T) of WY block kb (reflectors 128 kb ..): grid (4 nbk_max, nblk), one
+// 64 x 64 quarter per workgroup (the quarter below the diagonal is not needed), one wavefront per 32 x 32
+// quadrant on the float64 MFMA (products of float32 numbers are exact in float64).  Q = I - V^T T V is
+// orthogonal exactly when T^-1 + T^-T = V V^T: a float32 Gram matrix leaves eps32 sqrt(n) |v_i . v_j|
+// in that identity, which T amplifies by ||T||^2 -- 1e-6 of lost orthogonality on random inputs (nearly
+// orthogonal reflectors, T ~ diag(tau)), 2e-5 on an all-ones matrix (consecutive reflectors nearly
+// parallel); float64 accumulation brings both to the 1e-7 of the reflectors themselves at the same cost
+// (0.5 ms of 200 at 64 x 2048^2).
+__global__ __launch_bounds__(256) void td_vtv_kernel(TdBlock* blocks) {
+  __shared__ float sL[RK][RQ + 1];
+  __shared__ float sR[RK][RQ + 1];
   TdBlock* tb = &blocks[blockIdx.y];
-  const int n = tb->n, ld = tb->ld, kb = blockIdx.x, j0 = kb * TD_KB;
-  if (j0 > n - 3 || !tb->keep) return;
-  const float* Vb = tb->VHt + (int64_t)j0 * ld + j0;   // columns < j0 are zero
-  Operand A{Vb, ld, 0, TD_KB, ld - j0, true}, B{Vb, ld, 0, TD_KB, ld - j0, true};
-  f32x16 acc[2][2];
-  gemm_tile<KC, KC, 16, false>(A, B, ld - j0, smem, acc);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+  const int n = tb->n, ld = tb->ld, kb = blockIdx.x >> 2, sub = blockIdx.x & 3, j0 = kb * TD_KB;
+  if (j0 > n - 3 || !tb->keep || sub == 2) return;
+  const int r0 = (sub >> 1) * RQ, c0 = (sub & 1) * RQ;   // quarter (rows r0 .., columns c0 ..) of the 128 x 128 block
+  const float* Vb = tb->VHt + (int64_t)j0 * ld + j0;     // columns < j0 are zero
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int qr = 32 * (wave >> 1), qc = 32 * (wave & 1);
+  const int fi = lane & 15, fk = lane >> 4;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int m = tid >> 2, k4 = (tid & 3) * 4;
+  const int klen = ld - j0;   // a multiple of 128
+  // reflector j0 + i is zero up to column j0 + i: rows r0 .. of the left operand start at column r0 + 1,
+  // and the quarter needs only k >= max(r0, c0) (rounded down to the chunk)
+  for (int k0 = (r0 > c0 ? r0 : c0); k0 < klen; k0 += RK) {
+    const f32x4 vl = gload4(Vb + (int64_t)(r0 + m) * ld + k0 + k4);
+    const f32x4 vr = gload4(Vb + (int64_t)(c0 + m) * ld + k0 + k4);
+    sL[k4 + 0][m] = vl[0]; sL[k4 + 1][m] = vl[1]; sL[k4 + 2][m] = vl[2]; sL[k4 + 3][m] = vl[3];
+    sR[k4 + 0][m] = vr[0]; sR[k4 + 1][m] = vr[1]; sR[k4 + 2][m] = vr[2]; sR[k4 + 3][m] = vr[3];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < RK; kk += 4) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = (double)sL[kk + fk][qr + 16 * a + fi];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bf[b] = (double)sR[kk + fk][qc + 16 * b + fi];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
   float* T = tb->TT + (int64_t)kb * TD_KB * TD_KB;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(wm, a, r, lane), col = acc_col(wn, b, lane);
-        float v = 0.f;
-        if (col > row) v = acc[a][b][r];
+      for (int v = 0; v < 4; ++v) {
+        const int row = r0 + qr + 16 * a + fk + 4 * v, col = c0 + qc + 16 * b + fi;
+        float x = 0.f;
+        if (col > row) x = (float)acc[a][b][v];
         else if (col == row) {
           const int j = j0 + row;
           const float tau = j <= n - 2 ? tb->tau[j] : 0.f;
-          v = tau != 0.f ? 1.f / tau : 1.f;
+          x = tau != 0.f ? 1.f / tau : 1.f;
         }
-        T[row * TD_KB + col] = v;
+        T[row * TD_KB + col] = x;
       }
 }
 
@@ -969,7 +1031,7 @@ inline void td_carve(const TdPlan& pl, psh::Arena& ar, TdLayout* lo) {
     tb.ubuf = ar.take<float>(ld);
     tb.wp = ar.take<float>(ld);
     tb.slab = ar.take<float>(nt * nt * TILE);
-    tb.part_ss = ar.take<float>(nt);
+    tb.part_ss = ar.take<double>(nt);
     tb.part_dot = ar.take<float>(nt);
     tb.part_ab = ar.take<float>(2 * TD_NB * 32);
     tb.dT = ar.take<float>(ld); tb.eT = ar.take<float>(ld); tb.tau = ar.take<float>(ld);
@@ -1119,7 +1181,7 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
   PS_LAUNCH_CHECK();
   // ---- back-transformation ----
   const int nbk = pl.nbkmax;
-  hipLaunchKernelGGL(td_vtv_kernel, dim3(nbk, B), b256, 0, st, lo.blocks);
+  hipLaunchKernelGGL(td_vtv_kernel, dim3(4 * nbk, B), b256, 0, st, lo.blocks);
   hipLaunchKernelGGL(td_tinv_kernel, dim3(nbk, B), b128, (size_t)2 * TD_KB * (TD_KB + 1) * sizeof(float),
                      st, lo.blocks);
   hipLaunchKernelGGL(td_v2_kernel, dim3(ntmax, nbk, B), b256, 0, st, lo.blocks);

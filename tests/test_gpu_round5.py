@@ -94,6 +94,50 @@ def test_eigh_plain_eigenpairs_tridiagonal_path(device):
     assert np.abs(a.astype(np.float64) @ v - v * e).max() <= 5e-6 * nrm
 
 
+def _structured_inputs(n, rng):
+  q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  sym = lambda g: g + g.T
+  x = rng.standard_normal((n, 1))
+  wilk = (np.diag(np.abs(np.arange(n) - n // 2).astype(np.float64)) + np.diag(np.ones(n - 1), 1) +
+          np.diag(np.ones(n - 1), -1))
+  blk = np.zeros((n, n))
+  h = n // 3
+  for lo, hi in ((0, h), (h, 2 * h), (2 * h, n)):
+    blk[lo:hi, lo:hi] = sym(rng.standard_normal((hi - lo, hi - lo)))
+  reps = np.repeat([1.0, 2.0, 3.0, 5.0], (n + 3) // 4)[:n]
+  return [("identity", np.eye(n)), ("zero", np.zeros((n, n))),
+          ("2I_plus_noise", 2 * np.eye(n) + 1e-6 * sym(rng.standard_normal((n, n)))),
+          ("diagonal_repeats", np.diag(reps)), ("rotated_repeats", (q * reps) @ q.T),
+          ("rank1", x @ x.T), ("rank1_plus_I", x @ x.T + np.eye(n)), ("wilkinson", wilk),
+          ("block_diagonal", blk), ("negative_definite", -wishart(n, 2 * n, 1).astype(np.float64)),
+          ("scaled_1e-20", 1e-20 * sym(rng.standard_normal((n, n)))),
+          ("scaled_1e18", 1e18 * sym(rng.standard_normal((n, n)))), ("ones", np.ones((n, n)))]
+
+
+@pytest.mark.parametrize("n", [130, 257, 600])
+def test_eigh_tridiagonal_path_structured_inputs(n, device):
+  """Deflation-heavy, reducible, clustered, exactly low-rank and badly scaled inputs (tau = 0
+  reflectors, secular problems that deflate completely, squares outside the float32 range) against
+  NumPy float64.  The all-ones matrix is the hard one: its trailing matrix is rounding noise of
+  rounding noise with consecutive reflectors nearly parallel (the column norms of the reduction are
+  float64 and the Gram matrix of a WY block is accumulated on the float64 MFMA for it)."""
+  rng = np.random.default_rng(5 + n)
+  names, mats = zip(*_structured_inputs(n, rng))
+  mats = [((m + m.T) / 2).astype(np.float32) for m in mats]
+  es, vs = K().eigh_batched([torch.tensor(m, device=device) for m in mats])
+  for name, a, e, v in zip(names, mats, es, vs):
+    a64 = a.astype(np.float64)
+    w = np.linalg.eigvalsh(a64)
+    nrm = max(np.abs(w).max(), 1e-300)
+    e, v = e.cpu().numpy().astype(np.float64), v.cpu().numpy().astype(np.float64)
+    assert np.isfinite(e).all() and np.isfinite(v).all(), name
+    assert np.abs(e - w).max() <= 3e-6 * nrm, name
+    assert np.abs(a64 @ v - v * e).max() <= 3e-6 * nrm, name
+    # null-space cluster of the all-ones matrix: orthogonal to 1e-5 (the WY products with nearly
+    # parallel reflectors cancel in float32), everything else to a few eps32
+    assert np.abs(v.T @ v - np.eye(n)).max() < (5e-5 if name == "ones" else 5e-6), name
+
+
 def test_eigh_ill_conditioned_blocks_take_the_jacobi_solver_in_the_same_call(device):
   """A float32 tridiagonalisation leaves eps * ||D|| of unstructured error, which lambda^(-1/p)
   amplifies by ||D|| / lambda: blocks with lambda_max / lambda_min > 1e3 (ps_options default) are

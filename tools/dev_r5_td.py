@@ -147,6 +147,44 @@ def streams():
   os.environ.pop("PS_EIGH_TD_STREAMS")
 
 
+def special():
+  """Structured inputs that stress deflation, tau = 0 reflectors and the secular solver."""
+  rng = np.random.default_rng(5)
+  def cases(n):
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    tri = np.diag(rng.standard_normal(n)) + np.diag(rng.standard_normal(n - 1), 1); tri = tri + np.triu(tri, 1).T
+    wilk = np.diag(np.abs(np.arange(n) - n // 2).astype(np.float64)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    blk = np.zeros((n, n)); h = n // 3
+    for lo, hi in ((0, h), (h, 2 * h), (2 * h, n)):
+      g = rng.standard_normal((hi - lo, hi - lo)); blk[lo:hi, lo:hi] = g + g.T
+    arrow = np.diag(np.linspace(1, 2, n)); arrow[0, :] = 0.1; arrow[:, 0] = 0.1; arrow[0, 0] = 3
+    x = rng.standard_normal((n, 1))
+    yield "identity", np.eye(n)
+    yield "zero", np.zeros((n, n))
+    yield "2I+1e-6noise", 2 * np.eye(n) + 1e-6 * (lambda g: g + g.T)(rng.standard_normal((n, n)))
+    yield "diag_repeats", np.diag(np.repeat([1.0, 2.0, 3.0, 5.0], (n + 3) // 4)[:n])
+    yield "rotated_repeats", (q * np.repeat([1.0, 2.0, 3.0, 5.0], (n + 3) // 4)[:n]) @ q.T
+    yield "rank1", x @ x.T
+    yield "rank1+I", x @ x.T + np.eye(n)
+    yield "tridiagonal", tri
+    yield "wilkinson", wilk
+    yield "blockdiag", blk
+    yield "arrow", arrow
+    yield "neg_definite", -(lambda g: g @ g.T)(rng.standard_normal((n, 2 * n)))
+    yield "tiny_scale", 1e-20 * (lambda g: g + g.T)(rng.standard_normal((n, n)))
+    yield "huge_scale", 1e18 * (lambda g: g + g.T)(rng.standard_normal((n, n)))
+    yield "ones", np.ones((n, n))
+  for n in (130, 257, 600):
+    names, mats = zip(*cases(n))
+    mats = [((m + m.T) / 2).astype(np.float32) for m in mats]
+    e, v = run(list(mats))
+    for name, a, lam, z in zip(names, mats, e, v):
+      a64 = a.astype(np.float64); ref = np.linalg.eigvalsh(a64); nrm = max(np.abs(ref).max(), 1e-300)
+      ok = np.isfinite(z).all() and np.isfinite(lam).all()
+      print(f"special n={n:4d} {name:16s} ev_err={np.abs(lam - ref).max() / nrm:.2e} "
+            f"orth={np.abs(z.T @ z - np.eye(n)).max():.2e} res={np.abs(a64 @ z - z * lam).max() / nrm:.2e} finite={ok}", flush=True)
+
+
 def debug129():
   """stage 1 gives Q (T = Q^T A Q), stage 2 gives Z_T: which eigenpairs of T are off?"""
   for n, kind in ((129, "randsym"), (130, "randsym"), (129, "wishart"), (161, "randsym")):
