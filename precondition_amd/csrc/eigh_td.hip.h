@@ -86,6 +86,24 @@ __device__ __forceinline__ double td_wg_sum128_f64(double v, double* red) {   //
   return r;
 }
 
+// Sum of p[x], x0 <= x < nt (nt <= 32), the same bits in every lane of the calling wavefront: lane x requests
+// p[x] (ONE coalesced load; a loop over the uniform addresses compiles to up to 32 dependent loads with the
+// pointer re-read in between -- tools/bench_symv.hip v0d: a third of the mat-vec's time), then a butterfly.
+__device__ __forceinline__ double td_sum32_f64(const double* p, int x0, int nt) {
+  const int l = threadIdx.x & 63;
+  double v = (l >= x0 && l < nt) ? p[l] : 0.0;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v + __shfl_xor(v, 32, 64);   // lanes 32 .. 63 held 0
+}
+__device__ __forceinline__ float td_sum32_f32(const float* p, int x0, int nt) {
+  const int l = threadIdx.x & 63;
+  float v = (l >= x0 && l < nt) ? p[l] : 0.f;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
 // ---- reduction, per column: (1) finish w of the previous column, updated row j, its norm ----------
 // grid (nt_max - j / 128, nblk), 128 threads: tile row X = j / 128 + blockIdx.x.
 //   jf >= 0: W[:, jf] = wp - gamma v_jf with gamma = tau_jf / 2 * (wp . v_jf)
@@ -94,7 +112,10 @@ __device__ __forceinline__ double td_wg_sum128_f64(double v, double* red) {   //
 __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, int jr) {
   __shared__ double red[2];
   __shared__ float sVj[TD_NB], sWj[TD_NB];
-  TdBlock* tb = &blocks[blockIdx.y];
+  // the descriptor by value: ONE burst of scalar loads (through the pointer every field access is a
+  // dependent s_load + wait: the kernel writes global memory, so nothing read through it is hoisted)
+  const TdBlock tbv = blocks[blockIdx.y];
+  const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, nt = tb->nt, tid = threadIdx.x;
   const int jbase = jf >= 0 ? jf + 1 : jr;
   const int X = jbase / TILE + blockIdx.x;
@@ -104,12 +125,11 @@ __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, in
   const bool do_r = jr >= 0 && jr <= n - 1;
   const int i = do_r ? jr % TD_NB : 0, p = jr - i;
   // every load of the kernel is issued before the first use (one memory round trip)
-  float pd[32];
+  float pdl = 0.f;
   float tauf = 0.f, wpc = 0.f, vfc = 0.f, wpj = 0.f, vfj = 0.f;
   if (do_f) {
-    const int x0 = (jf + 1) / TILE;
-#pragma unroll
-    for (int x = 0; x < 32; ++x) pd[x] = (x >= x0 && x < nt) ? tb->part_dot[x] : 0.f;
+    const int x0 = (jf + 1) / TILE, l = tid & 63;
+    pdl = (l >= x0 && l < nt) ? tb->part_dot[l] : 0.f;   // lane x holds partial x (td_sum32_f32's load, issued here)
     tauf = tb->tau[jf];
     wpc = tb->wp[c];
     vfc = tb->VHt[(int64_t)jf * ld + c];
@@ -131,9 +151,10 @@ __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, in
   }
   float wfin = 0.f, gamma = 0.f;
   if (do_f) {
-    float s = 0.f;
+    float s = pdl;
 #pragma unroll
-    for (int x = 0; x < 32; ++x) s += pd[x];
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    s += __shfl_xor(s, 32, 64);
     gamma = 0.5f * tauf * s;
     wfin = wpc - gamma * vfc;
     tb->Wt[(int64_t)(jf % TD_NB) * ld + c] = wfin;
@@ -167,9 +188,8 @@ __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, in
 // stores the ZERO vector: the WY factor of the back-transformation then sees an identity.
 __device__ __forceinline__ void td_house(const TdBlock* tb, int j, float& beta, float& tau,
                                          float& scale, float& v1) {
-  double sigma = 0.0;
-  for (int x = j / TILE; x < tb->nt; ++x) sigma += tb->part_ss[x];
   const float alpha = tb->ubuf[j + 1];
+  const double sigma = td_sum32_f64(tb->part_ss, j / TILE, tb->nt);
   const float sf = (float)sigma, a2 = alpha * alpha;
   if (sf > 1e-30f && sf < 1e30f && a2 < 1e30f) {   // the common case: float32 arithmetic is safe (wave-uniform branch)
     beta = -copysignf(sqrtf(a2 + sf), alpha);
@@ -198,7 +218,10 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
   __shared__ float svI[TILE], svJ[TILE];
   __shared__ float srow[TILE];
   __shared__ float scol[8][TILE];
-  TdBlock* tb = &blocks[blockIdx.y];
+  // the descriptor by value: ONE burst of scalar loads (through the pointer every field access is a
+  // dependent s_load + wait: the kernel writes global memory, so nothing read through it is hoisted)
+  const TdBlock tbv = blocks[blockIdx.y];
+  const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, nt = tb->nt, tid = threadIdx.x;
   if (j > n - 2) return;
   const int I0 = (j + 1) / TILE;
@@ -228,12 +251,16 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
     if (8 * k + 2 * wv + 1 > jl)
       a[k] = *(const f32x4 PS_GLOBAL*)((const char PS_GLOBAL*)(ubase + (int64_t)(8 * k) * ld) + (uint64_t)loff);
   }
-  float beta, tau, scale, v1;
-  td_house(tb, j, beta, tau, scale, v1);
-  if (tid < TILE) {
+  // Householder scalars: wavefronts 0 and 1 only (they fill the vectors; both compute the same bits); the
+  // vector's loads go out before the scalars so that everything after the tile is ONE round trip
+  float beta = 0.f, tau = 0.f;
+  if (wv < 2) {
     const int cI = I * TILE + tid, cJ = J * TILE + tid;
-    svI[tid] = cI == j + 1 ? v1 : (cI > j + 1 && cI < n ? tb->ubuf[cI] * scale : 0.f);
-    svJ[tid] = cJ == j + 1 ? v1 : (cJ > j + 1 && cJ < n ? tb->ubuf[cJ] * scale : 0.f);
+    const float uI = tb->ubuf[cI], uJ = tb->ubuf[cJ];
+    float scale, v1;
+    td_house(tb, j, beta, tau, scale, v1);
+    svI[tid] = cI == j + 1 ? v1 : (cI > j + 1 && cI < n ? uI * scale : 0.f);
+    svJ[tid] = cJ == j + 1 ? v1 : (cJ > j + 1 && cJ < n ? uJ * scale : 0.f);
   }
   __syncthreads();
   const f32x4 vj = *reinterpret_cast<const f32x4*>(&svJ[c4]);
@@ -298,7 +325,10 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
 __global__ __launch_bounds__(128) void td_w_kernel(TdBlock* blocks, int j) {
   __shared__ float red[2];
   __shared__ float sab[2][TD_NB];
-  TdBlock* tb = &blocks[blockIdx.y];
+  // the descriptor by value: ONE burst of scalar loads (through the pointer every field access is a
+  // dependent s_load + wait: the kernel writes global memory, so nothing read through it is hoisted)
+  const TdBlock tbv = blocks[blockIdx.y];
+  const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, nt = tb->nt, tid = threadIdx.x;
   if (j > n - 2) return;
   const int I0 = (j + 1) / TILE, X = I0 + blockIdx.x;

@@ -337,6 +337,80 @@ __global__ __launch_bounds__(256) void v4(const float* A, const float* v, float*
   if (s == 12345.f) slab[blockIdx.x] = s;
 }
 
+
+// v0d: v0 behind the dependent chain of the real kernel: block descriptor -> tile loads, then the Householder
+// scalars (16 float64 partial sums + alpha) -> the vector scaled by them.  v0e: descriptor only.
+struct Desc { int n, ld, nt, pad; const float* A; const float* u; const double* pss; float* slab; };
+template <int HOUSE>
+__global__ __launch_bounds__(256) void v0d(const Desc* descs, int j) {
+  __shared__ float svI[TILE], svJ[TILE], srow[TILE], scol[8][TILE];
+  const Desc* d = &descs[blockIdx.y];
+  const int ld = d->ld, nt = d->nt;
+  const float* a_ = d->A;
+  int I, J; decode(blockIdx.x, nt, I, J);
+  const int tid = threadIdx.x, r0 = tid >> 5, c4 = (tid & 31) * 4;
+  const float* src = a_ + (size_t)(I * TILE + r0) * ld + J * TILE + c4;
+  f32x4 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = gload4(src + (size_t)(8 * k) * ld);
+  float scale = 1.f;
+  float uI = 0.f, uJ = 0.f;
+  if (HOUSE >= 3 && tid < TILE) { uI = d->u[I * TILE + tid]; uJ = d->u[J * TILE + tid]; }   // before the scalars: one round trip
+  if (HOUSE) {
+    double sigma = 0.0;
+    if (HOUSE == 1) {
+      for (int x = j / TILE; x < nt; ++x) sigma += d->pss[x];
+    } else if (HOUSE < 4) {   // all partial sums requested at once (same summation order: masked entries add 0.0)
+      double ps[32];
+      const int x0 = j / TILE;
+#pragma unroll
+      for (int x = 0; x < 32; ++x) ps[x] = (x >= x0 && x < nt) ? d->pss[x] : 0.0;
+#pragma unroll
+      for (int x = 0; x < 32; ++x) sigma += ps[x];
+    } else {   // the pointer read once, 32 unconditional loads (scalar: uniform addresses), masked in the sum
+      const double* __restrict__ pss = d->pss;
+      double ps[32];
+      const int x0 = j / TILE;
+#pragma unroll
+      for (int x = 0; x < 32; ++x) ps[x] = pss[x];
+#pragma unroll
+      for (int x = 0; x < 32; ++x) sigma += (x >= x0 && x < nt) ? ps[x] : 0.0;
+    }
+    const float alpha = d->u[j + 1];
+    const float sf = (float)sigma, a2 = alpha * alpha;
+    const float beta = -copysignf(sqrtf(a2 + sf), alpha);
+    scale = 1.f / (alpha - beta);
+  }
+  if (tid < TILE) {
+    if (HOUSE >= 3) { svI[tid] = uI * scale; svJ[tid] = uJ * scale; }
+    else { svI[tid] = d->u[I * TILE + tid] * scale; svJ[tid] = d->u[J * TILE + tid] * scale; }
+  }
+  __syncthreads();
+  const f32x4 vj = *reinterpret_cast<const f32x4*>(&svJ[c4]);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float rs = a[k][0] * vj[0] + a[k][1] * vj[1] + a[k][2] * vj[2] + a[k][3] * vj[3];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    if ((tid & 31) == 0) srow[r0 + 8 * k] = rs;
+    const float vi = svI[r0 + 8 * k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[e] += a[k][e] * vi;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) scol[r0][c4 + e] = cs[e];
+  __syncthreads();
+  float* sl = d->slab;
+  if (tid < TILE) {
+    sl[(I * nt + J) * TILE + tid] = srow[tid];
+    float s2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s2 += scol[g][tid];
+    if (I != J) sl[(J * nt + I) * TILE + tid] = s2;
+  }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main() {
@@ -366,6 +440,23 @@ int main() {
     char nm[16]; snprintf(nm, sizeof nm, "v0T%d", T);
     const int nt_ = T * (T + 1) / 2;
     time(nm, [&] { hipLaunchKernelGGL(v0, dim3(nt_, NB), dim3(256), 0, 0, A, v, slab); }, (double)NB * nt_ * TILE * TILE * 4);
+  }
+  {
+    Desc hd[NB]; Desc* dd; double* pss; CK(hipMalloc(&dd, sizeof(hd))); CK(hipMalloc(&pss, NB * 32 * 8));
+    { double hp[NB * 32]; for (int i = 0; i < NB * 32; ++i) hp[i] = 1.0 + i; CK(hipMemcpy(pss, hp, sizeof(hp), hipMemcpyHostToDevice)); }
+    for (int b = 0; b < NB; ++b)
+      hd[b] = Desc{N, N, NT, 0, A + (size_t)b * N * N, v + (size_t)b * N, pss + b * 32, slab + (size_t)b * NT * NT * TILE};
+    CK(hipMemcpy(dd, hd, sizeof(hd), hipMemcpyHostToDevice));
+    time("v0e", [&] { hipLaunchKernelGGL(v0d<0>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
+    time("v0d", [&] { hipLaunchKernelGGL(v0d<1>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
+    time("v0f", [&] { hipLaunchKernelGGL(v0d<2>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
+    time("v0", [&] { hipLaunchKernelGGL(v0, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
+    time("v0e", [&] { hipLaunchKernelGGL(v0d<0>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
+    time("v0d", [&] { hipLaunchKernelGGL(v0d<1>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
+    time("v0f", [&] { hipLaunchKernelGGL(v0d<2>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
+    time("v0g", [&] { hipLaunchKernelGGL(v0d<3>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
+    time("v0h", [&] { hipLaunchKernelGGL(v0d<4>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
+    time("v0h", [&] { hipLaunchKernelGGL(v0d<4>, dim3(ntri, NB), dim3(256), 0, 0, dd, 5); }, tri_bytes);
   }
   time("v0o6", [&] { hipLaunchKernelGGL(v0o6, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
   time("v0o8", [&] { hipLaunchKernelGGL(v0o8, dim3(ntri, NB), dim3(256), 0, 0, A, v, slab); }, tri_bytes);
