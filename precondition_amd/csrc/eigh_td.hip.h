@@ -1120,7 +1120,10 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
   constexpr int MAXG = 8;
   static thread_local hipStream_t side[MAXG - 1] = {};
   static thread_local hipEvent_t ev_fork = nullptr, ev_join[MAXG - 1] = {};
-  const int ngroups = std::max(1, std::min(std::min(stream_groups, MAXG), B));
+  // measured (64 x 2048 / 64 x 1024 / 256 x 512, ms): 1 group 181 / 43.1 / 28.9, 2 groups 173.5 / 43.0 / 28.0,
+  // 4 groups 170.3 / 47.8 / 28.0: short columns gain nothing from a third and fourth group
+  const int want = nmax >= 1536 ? stream_groups : std::min(stream_groups, 2);
+  const int ngroups = std::max(1, std::min(std::min(want, MAXG), B));
   if (!ev_fork) PS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   for (int g = 0; g + 1 < ngroups; ++g) {
     if (!side[g]) {
