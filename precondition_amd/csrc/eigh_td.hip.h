@@ -379,7 +379,8 @@ __global__ __launch_bounds__(128) void td_w_kernel(TdBlock* blocks, int j) {
 // grid (T (T + 1) / 2, nblk) with T = nt_max - (p + TD_NB) / 128, 256 threads.
 __global__ __launch_bounds__(256, 2) void td_syr2k_kernel(TdBlock* blocks, int p, int Tmax) {
   __shared__ __align__(16) float smem[SmemCfg<16>::TOTAL];
-  TdBlock* tb = &blocks[blockIdx.y];
+  const TdBlock tbv = blocks[blockIdx.y];   // by value: one burst of scalar loads
+  const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, nt = tb->nt;
   if (p + TD_NB > n - 1) return;   // nothing left to update
   const int I0 = (p + TD_NB) / TILE;
@@ -721,7 +722,8 @@ __global__ __launch_bounds__(256, 2) void td_dc_gemm_kernel(TdBlock* blocks, con
                                                             int src) {
   __shared__ __align__(16) float smem[SmemCfg<16>::TOTAL];
   const TdGTile t = tiles[blockIdx.x];
-  TdBlock* tb = &blocks[t.blk];
+  const TdBlock tbv = blocks[t.blk];   // by value: one burst of scalar loads
+  const TdBlock* tb = &tbv;
   const int ld = tb->ld;
   const float* Qc = tb->Q[src];
   float* Qn = tb->Q[src ^ 1];
@@ -783,7 +785,8 @@ __global__ __launch_bounds__(256) void td_dc_finish_kernel(TdBlock* blocks, int 
 __global__ __launch_bounds__(256) void td_vtv_kernel(TdBlock* blocks) {
   __shared__ float sL[RK][RQ + 1];
   __shared__ float sR[RK][RQ + 1];
-  TdBlock* tb = &blocks[blockIdx.y];
+  const TdBlock tbv = blocks[blockIdx.y];   // by value: one burst of scalar loads
+  const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, kb = blockIdx.x >> 2, sub = blockIdx.x & 3, j0 = kb * TD_KB;
   if (j0 > n - 3 || !tb->keep || sub == 2) return;
   const int r0 = (sub >> 1) * RQ, c0 = (sub & 1) * RQ;   // quarter (rows r0 .., columns c0 ..) of the 128 x 128 block
@@ -846,7 +849,8 @@ __global__ __launch_bounds__(128) void td_tinv_kernel(TdBlock* blocks) {
   constexpr int LDM = TD_KB + 1;
   float* M = reinterpret_cast<float*>(td_dyn);
   float* X = M + TD_KB * LDM;
-  TdBlock* tb = &blocks[blockIdx.y];
+  const TdBlock tbv = blocks[blockIdx.y];   // by value: one burst of scalar loads
+  const TdBlock* tb = &tbv;
   const int n = tb->n, kb = blockIdx.x, j0 = kb * TD_KB, k = threadIdx.x;
   if (j0 > n - 3 || !tb->keep) return;
   float* T = tb->TT + (int64_t)kb * TD_KB * TD_KB;
@@ -869,7 +873,8 @@ __global__ __launch_bounds__(128) void td_tinv_kernel(TdBlock* blocks) {
 // V2[j0 + i][c] = sum_i' T[i][i'] V[j0 + i'][c]: grid (nt_max, nbk_max, nblk)
 __global__ __launch_bounds__(256, 2) void td_v2_kernel(TdBlock* blocks) {
   __shared__ __align__(16) float smem[SmemCfg<16>::TOTAL];
-  TdBlock* tb = &blocks[blockIdx.z];
+  const TdBlock tbv = blocks[blockIdx.z];   // by value: one burst of scalar loads
+  const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, kb = blockIdx.y, j0 = kb * TD_KB, ct = blockIdx.x;
   if (j0 > n - 3 || !tb->keep || ct >= tb->nt || (ct + 1) * TILE <= j0) return;
   const float* T = tb->TT + (int64_t)kb * TD_KB * TD_KB;
@@ -893,7 +898,8 @@ __global__ __launch_bounds__(256, 2) void td_v2_kernel(TdBlock* blocks) {
 // Y2 = V2_b Z (128 x ld): grid (nt_max, nblk)
 __global__ __launch_bounds__(256, 2) void td_bt1_kernel(TdBlock* blocks, int kb) {
   __shared__ __align__(16) float smem[SmemCfg<16>::TOTAL];
-  TdBlock* tb = &blocks[blockIdx.y];
+  const TdBlock tbv = blocks[blockIdx.y];   // by value: one burst of scalar loads
+  const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, j0 = kb * TD_KB, ct = blockIdx.x;
   if (j0 > n - 3 || !tb->keep || ct >= tb->nt) return;
   Operand A{tb->S + (int64_t)j0 * ld + j0, ld, 0, TD_KB, ld - j0, true};
@@ -915,7 +921,8 @@ __global__ __launch_bounds__(256, 2) void td_bt1_kernel(TdBlock* blocks, int kb)
 // Z[c][col] -= sum_i V[j0 + i][c] Y2[i][col]: grid (nt_max (row tiles from j0 / 128) * nt_max, nblk)
 __global__ __launch_bounds__(256, 2) void td_bt3_kernel(TdBlock* blocks, int kb, int ntmax) {
   __shared__ __align__(16) float smem[SmemCfg<16>::TOTAL];
-  TdBlock* tb = &blocks[blockIdx.y];
+  const TdBlock tbv = blocks[blockIdx.y];   // by value: one burst of scalar loads
+  const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, j0 = kb * TD_KB;
   const int rt = kb + blockIdx.x / ntmax, ct = blockIdx.x % ntmax;
   if (j0 > n - 3 || !tb->keep || rt >= tb->nt || ct >= tb->nt) return;
