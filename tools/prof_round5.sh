@@ -24,6 +24,12 @@ for pair in "eigh:tools/dev_eigh_one.py" "update_step_vitb_donated:tools/dev_upd
   cp gpurun_out/r05_$name/trace/*/*kernel_stats.csv $R/r05_${name}_kernel_stats.csv 2>/dev/null
   cp gpurun_out/r05_$name/run.log $R/r05_${name}_run.log 2>/dev/null
 done
+# the eigh path on ONE stream group: kernel durations that do not overlap (the default run's sums do), and the
+# mat-vec's duration per trailing-matrix size against the bytes it reads
+LINES_SHOWN=40 bash tools/prof_r5_eigh.sh one PS_EIGH_TD_STREAMS=1 > $R/prof_eigh_one_stream_group.log 2>&1
+cp gpurun_out/prof_r5_eigh_one/kernel_stats.csv $R/r05_eigh_one_stream_group_kernel_stats.csv 2>/dev/null
+bash tools/prof_r5_symv_by_column.sh 1 > $R/r05_eigh_matvec_by_column.txt 2>&1
+rm -rf gpurun_out/prof_r5_eigh_one gpurun_out/prof_r5_symv_cols
 # the raw traces stay on the box: only the summaries travel back (gpurun merges <= 64 MiB)
 rm -rf gpurun_out/r05_*
 ls -la $R
