@@ -1174,10 +1174,12 @@ void finish_eplan(EPlan& pl, bool sizing = false) {
     if (!ids.empty()) td_make_plan(pl.td, ids, nn, pl.npad);
     return;
   }
-  bool td_ok = !pl.big_ids.empty();
+  // blocks of 129 ... TD_MAXN rows take the tridiagonalisation; larger ones go straight to the Jacobi
+  // solvers of the same call (like the blocks the fast path hands back)
+  std::vector<int> ids;
   for (int b : pl.big_ids)
-    if (pl.n_eff[b] <= SE_MAXN || pl.n_eff[b] > TD_MAXN) td_ok = false;
-  if (td_ok) td_make_plan(pl.td, pl.big_ids, pl.n_eff, pl.npad);
+    if (pl.n_eff[b] > SE_MAXN && pl.n_eff[b] <= TD_MAXN) ids.push_back(b);
+  if (!ids.empty()) td_make_plan(pl.td, ids, pl.n_eff, pl.npad);
 }
 
 void make_eplan(EPlan& pl, int batch, const int32_t* n, const int32_t* padding_start) {
@@ -1486,7 +1488,8 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
           pi_expired_before = PiPlan::expired_total();   // handled here: the Jacobi path below must not start over
           continue;
         }
-        const int redo = slot->active, nbig = (int)pl.big_ids.size();
+        const int nbig = (int)pl.big_ids.size();
+        const int redo = slot->active + (nbig - (int)pl.td.ids.size());   // + the blocks above TD_MAXN rows
         if (opt.eigh_trace)
           fprintf(stderr, "eigh td: %d of %d block(s) handed to the Jacobi solvers (%d for an iteration cap / "
                           "non-finite input, the rest for their condition number)\n", redo, nbig, slot->pad_);

@@ -299,6 +299,27 @@ def test_eigh_tridiagonal_path_non_finite_input_and_size_limit(device):
   assert float(resid.abs().max()) < 2e-3
 
 
+def test_eigh_blocks_above_the_fast_path_limit_do_not_take_their_neighbours_with_them(device):
+  """A block of more than 4096 rows is solved by the Jacobi path; a 300-row block of the same call
+  still takes the tridiagonalisation (no Jacobi sweeps in its metrics row)."""
+  small = wishart(300, 1200, 9)
+  n = 4224
+  gen = torch.Generator(device=device).manual_seed(n)
+  g = torch.randn((n, 2 * n), generator=gen, device=device)
+  a = torch.zeros((n, n), device=device)
+  K().stats_update_grouped([(g, 0, a, a)], 0.0, 1.0)
+  del g
+  roots, met = K().matrix_inverse_pth_root_batched([torch.tensor(small, device=device), a], [2, 2], eigh=True)
+  m = met.cpu().numpy()
+  assert m[0, 5] == 0 and m[1, 5] > 0
+  h_ref, _ = orc.matrix_inverse_pth_root_eigh(small, 2)
+  assert np.linalg.norm(roots[0].cpu().numpy() - h_ref) / np.linalg.norm(h_ref) < 2e-5
+  lam, _ = K().power_iteration_batched([a])
+  d = a + 1e-6 * lam[0] * torch.eye(n, device=device)
+  resid = K().matmul(K().matmul(roots[1], roots[1]), d) - torch.eye(n, device=device)
+  assert float(resid.abs().max()) < 2e-3
+
+
 def test_quantize_plan_matches_grouped_calls_bit_for_bit(device):
   """kernels.QuantizePlan (resident descriptors) = quantize_grouped / dequantize_grouped on the same
   tensors, contiguous matrices (flat kernels) and an odd-sized one (tile kernels) in one call."""
