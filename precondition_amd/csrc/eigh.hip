@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256) void eigh_init_kernel(EighBlock* blocks,
   __shared__ float red[4];
   const ETile te = tiles[blockIdx.x];
   EighBlock* eb = &blocks[te.block];
-  if (skip_td_done && eb->td_done) return;   // second start of the blocks eigh_td.hip.h handed back
+  // second start of the blocks eigh_td.hip.h handed back: its own results and the blocks the LDS-resident
+  // solver has already finished stay as they are
+  if (skip_td_done && (eb->td_done || eb->small)) return;
   const int n = eb->n, ld = eb->npad, tid = threadIdx.x;
   const int tpr = ld / TILE;
   const float ridge = eb->ridge;
@@ -1474,7 +1476,8 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     if (opt.eigh_td && any_big && !pl.td.empty()) {
       for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = td_run(st, pl.td, lo.td, lo.blocks, hb, opt.eigh_td_defl_eps, opt.eigh_td_stage,
-                         mode == 0 ? opt.eigh_td_max_cond : 0.f, opt.eigh_td_streams)))
+                         mode == 0 ? opt.eigh_td_max_cond : 0.f, opt.eigh_td_streams,
+                         std::max(0, std::min(opt.eigh_td_tail, TD_TAIL)))))
           return rc;
         EStatus* slot = &status[63];
         slot->gen = -1;

@@ -26,6 +26,8 @@ namespace psk {
 constexpr int TD_NB = 32;     // panel width of the reduction
 constexpr int TD_KB = 128;    // reflectors per WY block of the back-transformation
 constexpr int TD_MAXN = 4096; // the deflation kernel keeps a merge problem in LDS
+constexpr int TD_TAIL = 192;  // the last <= 192 columns of a block are reduced inside LDS by one workgroup
+static_assert(TD_TAIL <= 192, "td_tail_kernel: one thread per row, three 64-column strips, 160 KB of LDS");
 
 struct TdBlock {
   int eb;              // index of the EighBlock
@@ -33,6 +35,7 @@ struct TdBlock {
   int height;          // merge levels of the partition tree
   int fail;            // QL / secular iteration caps hit, or NaN input: solved again by the Jacobi path
   int keep;            // decided after the divide and conquer: this block's result stands
+  int jtail;           // columns jtail .. n - 1 are reduced by td_tail_kernel (n: no tail); a multiple of TD_NB
   float* A;            // working matrix: upper 128 x 128 tiles (I <= J) are maintained
   float* VHt;          // [ld][ld] reflector j in row j (zero up to and including column j)
   float* Wt;           // [TD_NB][ld]
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, in
   const int X = jbase / TILE + blockIdx.x;
   if (X >= nt) return;
   const int c = X * TILE + tid;
-  const bool do_f = jf >= 0 && jf <= n - 2;
-  const bool do_r = jr >= 0 && jr <= n - 1;
+  const bool do_f = jf >= 0 && jf <= n - 2 && jf < tb->jtail;
+  const bool do_r = jr >= 0 && jr <= n - 1 && jr < tb->jtail;
   const int i = do_r ? jr % TD_NB : 0, p = jr - i;
   // every load of the kernel is issued before the first use (one memory round trip)
   float pdl = 0.f;
@@ -186,10 +189,8 @@ __global__ __launch_bounds__(128) void td_row_kernel(TdBlock* blocks, int jf, in
 
 // Householder scalars of column j from the row kernel's outputs.  tau = 0 (nothing to annihilate)
 // stores the ZERO vector: the WY factor of the back-transformation then sees an identity.
-__device__ __forceinline__ void td_house(const TdBlock* tb, int j, float& beta, float& tau,
-                                         float& scale, float& v1) {
-  const float alpha = tb->ubuf[j + 1];
-  const double sigma = td_sum32_f64(tb->part_ss, j / TILE, tb->nt);
+__device__ __forceinline__ void td_house_scalars(float alpha, double sigma, float& beta, float& tau,
+                                                 float& scale, float& v1) {
   const float sf = (float)sigma, a2 = alpha * alpha;
   if (sf > 1e-30f && sf < 1e30f && a2 < 1e30f) {   // the common case: float32 arithmetic is safe (wave-uniform branch)
     beta = -copysignf(sqrtf(a2 + sf), alpha);
@@ -210,6 +211,12 @@ __device__ __forceinline__ void td_house(const TdBlock* tb, int j, float& beta, 
     v1 = 1.f;
   }
 }
+__device__ __forceinline__ void td_house(const TdBlock* tb, int j, float& beta, float& tau,
+                                         float& scale, float& v1) {
+  const float alpha = tb->ubuf[j + 1];
+  const double sigma = td_sum32_f64(tb->part_ss, j / TILE, tb->nt);
+  td_house_scalars(alpha, sigma, beta, tau, scale, v1);
+}
 
 // ---- reduction, per column: (2) y = A v on the upper tiles; v, e_j, tau_j stored -------------------
 // grid (T (T + 1) / 2, nblk) with T = nt_max - (j + 1) / 128, 256 threads: one 128 x 128 tile
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void td_symv_kernel(TdBlock* blocks, int j, in
   const TdBlock tbv = blocks[blockIdx.y];
   const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, nt = tb->nt, tid = threadIdx.x;
-  if (j > n - 2) return;
+  if (j > n - 2 || j >= tb->jtail) return;
   const int I0 = (j + 1) / TILE;
   int q = blockIdx.x, Ip = 0;
   while (q >= Tmax - Ip) { q -= Tmax - Ip; ++Ip; }
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(128) void td_w_kernel(TdBlock* blocks, int j) {
   const TdBlock tbv = blocks[blockIdx.y];
   const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, nt = tb->nt, tid = threadIdx.x;
-  if (j > n - 2) return;
+  if (j > n - 2 || j >= tb->jtail) return;
   const int I0 = (j + 1) / TILE, X = I0 + blockIdx.x;
   if (X >= nt) return;
   const int i = j % TD_NB, p = j - i;
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void td_syr2k_kernel(TdBlock* blocks, int p
   const TdBlock tbv = blocks[blockIdx.y];   // by value: one burst of scalar loads
   const TdBlock* tb = &tbv;
   const int n = tb->n, ld = tb->ld, nt = tb->nt;
-  if (p + TD_NB > n - 1) return;   // nothing left to update
+  if (p + TD_NB > n - 1 || p >= tb->jtail) return;   // nothing left to update
   const int I0 = (p + TD_NB) / TILE;
   int q = blockIdx.x, Ip = 0;
   while (q >= Tmax - Ip) { q -= Tmax - Ip; ++Ip; }
@@ -417,6 +424,114 @@ __global__ __launch_bounds__(256, 2) void td_syr2k_kernel(TdBlock* blocks, int p
         const int row = I * TILE + acc_row(wm, a, r, lane), col = J * TILE + acc_col(wn, b, lane);
         gstore1(tb->A + (int64_t)row * ld + col, old[a][b][r] - acc[a][b][r]);
       }
+}
+
+// ---- reduction, tail: the last m = n - jtail <= TD_TAIL columns of a block inside LDS ----------------------
+// Down there a column of the streaming path is three launches of ~6 us for a few KB of matrix.  One
+// workgroup per block holds the (fully updated) trailing matrix in LDS and runs the classical unblocked
+// reduction on it: per column the Householder vector, y = S v, w = tau (y - tau/2 (y.v) v), S -= v w^T + w v^T
+// (both triangles, so that rows stay readable), ~1.2 us per column on average.  Outputs as the column kernels':
+// d, e, tau, reflector k in row jtail + k of VHt.  grid (nblk), 512 threads (two per row), LDS (m (m | 1) + 2 m + 16) floats.
+__global__ __launch_bounds__(512) void td_tail_kernel(TdBlock* blocks) {
+  extern __shared__ __align__(16) float td_tail_lds[];
+  __shared__ double s_red64[8];
+  __shared__ float s_red32[8];
+  const TdBlock tbv = blocks[blockIdx.x];
+  const TdBlock* tb = &tbv;
+  const int n = tb->n, ld = tb->ld, jt = tb->jtail, tid = threadIdx.x;
+  const int m = n - jt;
+  if (m <= 0) return;
+  const int LS = m | 1;                  // odd row stride: a walk down a column is conflict-free
+  float* S = td_tail_lds;
+  float* vv = S + (size_t)m * LS;
+  float* ww = vv + m;
+  const int lane = tid & 63, wave = tid >> 6;   // 8 wavefronts
+  // upper tiles (I <= J) of A are maintained: element (r, c) of a lower tile is read at (c, r)
+  for (int r0 = 0; r0 < m; r0 += 32) {   // 4 rows x 3 column strips per wavefront and trip: 12 loads in flight
+    float x[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int r = r0 + 8 * a + wave, c = lane + 64 * b;
+        const int gr = jt + r, gc = jt + c;
+        x[a][b] = (r < m && c < m) ? ((gr / TILE <= gc / TILE) ? tb->A[(int64_t)gr * ld + gc] : tb->A[(int64_t)gc * ld + gr]) : 0.f;
+      }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int r = r0 + 8 * a + wave, c = lane + 64 * b;
+        if (r < m && c < m) S[r * LS + c] = x[a][b];
+      }
+  }
+  __syncthreads();
+  // two threads per row: thread (row, h) owns the columns c = k + 1 + h, k + 3 + h, ... of its row
+  const int row = tid >> 1, h = tid & 1;
+  for (int k = 0; k < m; ++k) {
+    if (tid == 0) tb->dT[jt + k] = S[k * LS + k];
+    if (k == m - 1) break;
+    // norm of the part to annihilate (float64: see the row kernel), alpha
+    double ss = 0.0;
+    for (int c = k + 2 + tid; c < m; c += 512) { const double u = (double)S[k * LS + c]; ss += u * u; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane == 0) s_red64[wave] = ss;
+    __syncthreads();
+    double sigma = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) sigma += s_red64[w8];
+    const float alpha = S[k * LS + k + 1];
+    float beta, tau, scale, v1;
+    td_house_scalars(alpha, sigma, beta, tau, scale, v1);
+    for (int c = tid; c < m; c += 512) {
+      const float v = c == k + 1 ? v1 : (c > k + 1 ? S[k * LS + c] * scale : 0.f);
+      vv[c] = v;
+      tb->VHt[(int64_t)(jt + k) * ld + jt + c] = v;
+    }
+    if (tid == 0) { tb->eT[jt + k] = beta; tb->tau[jt + k] = tau; }
+    __syncthreads();
+    if (tau != 0.f) {   // uniform
+      const bool mine = row > k && row < m;
+      float* sr = S + row * LS;
+      // y = S v over the trailing part (v is zero up to k); eight elements per trip, loads before uses
+      float y = 0.f;
+      if (mine) {
+        int c = k + 1 + h;
+        for (; c + 14 < m; c += 16) {
+          float a8[8], b8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a8[e] = sr[c + 2 * e]; b8[e] = vv[c + 2 * e]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y += a8[e] * b8[e];
+        }
+        for (; c < m; c += 2) y += sr[c] * vv[c];
+      }
+      y += __shfl_xor(y, 1, 64);   // the two halves of the row
+      float dot = (mine && h == 0) ? y * vv[row] : 0.f;
+      dot = wave_sum_f32(dot);
+      if (lane == 0) s_red32[wave] = dot;
+      __syncthreads();
+      dot = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) dot += s_red32[w8];
+      if (h == 0 && row < m) ww[row] = mine ? tau * (y - 0.5f * tau * dot * vv[row]) : 0.f;
+      __syncthreads();
+      if (mine) {
+        const float vr = vv[row], wr = ww[row];
+        int c = k + 1 + h;
+        for (; c + 14 < m; c += 16) {
+          float a8[8], b8[8], c8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a8[e] = sr[c + 2 * e]; b8[e] = ww[c + 2 * e]; c8[e] = vv[c + 2 * e]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sr[c + 2 * e] = a8[e] - (vr * b8[e] + wr * c8[e]);
+        }
+        for (; c < m; c += 2) sr[c] -= vr * ww[c] + wr * vv[c];
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // ---- zero fill of a [rows][ld] float region per block ------------------------------------------------
@@ -1088,7 +1203,7 @@ inline void td_carve(const TdPlan& pl, psh::Arena& ar, TdLayout* lo) {
 // the reduction (Z_T = I: the output vectors are Q, the values diag(T)).
 inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_ebs,
                   const std::vector<EighBlock>& hb, float eps_defl, int stage, float max_cond,
-                  int stream_groups) {
+                  int stream_groups, int tail_cols) {
   const int B = (int)pl.ids.size();
   for (int k = 0; k < B; ++k) {
     TdBlock& tb = lo.host[k];
@@ -1099,6 +1214,7 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
     tb.Q[0] = (tb.height & 1) ? eb.A : eb.V;
     tb.Q[1] = (tb.height & 1) ? eb.V : eb.A;
     tb.Z = eb.V;
+    tb.jtail = (tail_cols > 0) ? (tb.n <= tail_cols ? 0 : (tb.n - tail_cols + TD_NB - 1) / TD_NB * TD_NB) : tb.n;
   }
   PS_RC(psh::upload_async(st, lo.blocks, lo.host.data(), sizeof(TdBlock) * B));
   if (!pl.leaves.empty()) PS_RC(psh::upload_async(st, lo.leaves, pl.leaves.data(), sizeof(TdNode) * pl.leaves.size()));
@@ -1117,6 +1233,8 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
     (void)hipFuncSetAttribute((const void*)td_dc_zhat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)td_dc_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)td_tinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)td_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(((size_t)TD_TAIL * (TD_TAIL | 1) + 2 * TD_TAIL + 16) * sizeof(float)));
   });
   const dim3 b256(256), b128(128);
   const int nmax = pl.nmax, ntmax = pl.ntmax;
@@ -1157,7 +1275,12 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
     for (int g = 1; g < ngroups; ++g) PS_HIP(hipStreamWaitEvent(side[g - 1], ev_fork, 0));
     join.n = ngroups - 1;
   }
-  for (int j = 0; j < nmax; ++j) {
+  int jend = 0, mtail = 0;   // columns the streaming kernels reduce; largest tail
+  for (int k = 0; k < B; ++k) {
+    jend = std::max(jend, lo.host[k].jtail);
+    mtail = std::max(mtail, lo.host[k].n - lo.host[k].jtail);
+  }
+  for (int j = 0; j < jend; ++j) {
     const int i = j % TD_NB;
     for (int g = 0; g < ngroups; ++g) {
       TdBlock* gb = lo.blocks + gfirst[g];
@@ -1181,6 +1304,9 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
     PS_HIP(hipStreamWaitEvent(st, ev_join[g - 1], 0));
   }
   join.n = 0;
+  if (mtail > 0)
+    hipLaunchKernelGGL(td_tail_kernel, dim3(B), dim3(512), ((size_t)mtail * (mtail | 1) + 2 * mtail + 16) * sizeof(float),
+                       st, lo.blocks);
   PS_LAUNCH_CHECK();
   // ---- divide and conquer ----
   if (stage == 1) {

@@ -62,6 +62,7 @@ struct Options {
   int eigh_td_stage = 0;           // PS_EIGH_TD_STAGE: 1 = stop after the reduction (Z_T = I; tests of the stages)
   float eigh_td_defl_eps = 1e-8f;  // PS_EIGH_TD_DEFL_EPS: deflation tolerance of the divide and conquer (x 8 ||T||)
   int eigh_td_streams = 4;         // PS_EIGH_TD_STREAMS: stream groups of the reduction
+  int eigh_td_tail = 192;          // PS_EIGH_TD_TAIL: last columns of a block reduced inside LDS (0: off; <= 192)
   int quant_flat = 1;              // PS_QUANT_FLAT: chunks of consecutive elements for contiguous tensors (0 = 64 x 256 tiles for all)
   float eigh_td_max_cond = 1e3f;   // PS_EIGH_TD_MAX_COND: root mode keeps a block's result if lambda_max / lambda_min is below
 };

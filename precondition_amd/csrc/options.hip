@@ -69,6 +69,7 @@ void ps_dev_env_overrides(Options& o) {
   geti("PS_EIGH_TD_STAGE", o.eigh_td_stage);
   getf("PS_EIGH_TD_DEFL_EPS", o.eigh_td_defl_eps);
   geti("PS_EIGH_TD_STREAMS", o.eigh_td_streams);
+  geti("PS_EIGH_TD_TAIL", o.eigh_td_tail);
   getf("PS_EIGH_TD_MAX_COND", o.eigh_td_max_cond);
   geti("PS_QUANT_FLAT", o.quant_flat);
 }

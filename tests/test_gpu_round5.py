@@ -185,6 +185,26 @@ def test_eigh_tridiagonal_path_stream_groups_do_not_change_a_bit(device, monkeyp
   assert torch.equal(m1, m2) and torch.equal(m2, m3)
 
 
+def test_eigh_tridiagonal_tail_in_lds_agrees_with_the_streaming_columns(device, monkeypatch):
+  """The last <= 192 columns of a block are reduced by one workgroup inside LDS (td_tail_kernel); a block
+  of <= 192 rows never sees the streaming kernels.  Same roots as with the tail switched off, and both
+  against the oracle; mixed sizes in one call (every block has its own first tail column)."""
+  sizes = (150, 192, 193, 225, 320, 700)
+  mats = [wishart(n, 3 * n, 80 + n) for n in sizes]
+  ts = [torch.tensor(a, device=device) for a in mats]
+  r_tail, m_tail = K().matrix_inverse_pth_root_batched(ts, [2] * len(ts), eigh=True)
+  monkeypatch.setenv("PS_EIGH_TD_TAIL", "0")
+  r_str, m_str = K().matrix_inverse_pth_root_batched(ts, [2] * len(ts), eigh=True)
+  assert not m_tail.cpu().numpy()[:, 5].any() and not m_str.cpu().numpy()[:, 5].any()   # no Jacobi sweeps
+  for a, x, y in zip(mats, r_tail, r_str):
+    h_ref, _ = orc.matrix_inverse_pth_root_eigh(a, 2)
+    x, y = x.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64)
+    nrm = np.linalg.norm(h_ref)
+    assert np.linalg.norm(x - h_ref) / nrm < 1e-5, a.shape
+    assert np.linalg.norm(y - h_ref) / nrm < 1e-5, a.shape
+    assert np.linalg.norm(x - y) / nrm < 1e-5, a.shape
+
+
 def test_fd_cfg5_literal_input_vs_oracle(device):
   """BASELINE configs[4] on its literal input (grad blocks ~N(0,1), d = 4096, rank 64): two chained
   Frequent-Directions updates against oracle.fd_update_root (DS:1123-1290, LAPACK SVD).  The 64
@@ -309,9 +329,13 @@ def test_eigh_blocks_above_the_fast_path_limit_do_not_take_their_neighbours_with
   a = torch.zeros((n, n), device=device)
   K().stats_update_grouped([(g, 0, a, a)], 0.0, 1.0)
   del g
-  roots, met = K().matrix_inverse_pth_root_batched([torch.tensor(small, device=device), a], [2, 2], eigh=True)
+  tiny = wishart(64, 256, 10)   # solved by the LDS-resident kernel before the fast path runs: must survive the hand-over
+  roots, met = K().matrix_inverse_pth_root_batched(
+      [torch.tensor(small, device=device), a, torch.tensor(tiny, device=device)], [2, 2, 2], eigh=True)
   m = met.cpu().numpy()
   assert m[0, 5] == 0 and m[1, 5] > 0
+  t_ref, _ = orc.matrix_inverse_pth_root_eigh(tiny, 2)
+  assert np.linalg.norm(roots[2].cpu().numpy() - t_ref) / np.linalg.norm(t_ref) < 2e-5
   h_ref, _ = orc.matrix_inverse_pth_root_eigh(small, 2)
   assert np.linalg.norm(roots[0].cpu().numpy() - h_ref) / np.linalg.norm(h_ref) < 2e-5
   lam, _ = K().power_iteration_batched([a])
