@@ -1124,13 +1124,18 @@ __global__ void eigh_metrics_kernel(EighBlock* blocks, int nblocks, float* metri
   m[PS_M_POWER_ITERS] = (float)eb->power_iters;
 }
 
+// What the root products do not write of `out` (they cover the npad x npad tiles of the effective part,
+// zero beyond n inside them): everything for an all-padding block, and for a block whose padding_start
+// leaves npad < n_full the frame of rows / columns npad .. n_full - 1 (DS:1016: val is zero there).
 __global__ __launch_bounds__(256) void eigh_zero_out_kernel(EighBlock* blocks) {
   EighBlock* eb = &blocks[blockIdx.x];
-  if (eb->n != 0) return;
-  const int nf = eb->n_full;
+  const int nf = eb->n_full, np = eb->n != 0 ? eb->npad : 0;
+  if (np >= nf) return;
   for (int64_t e = blockIdx.y * 256 + threadIdx.x; e < (int64_t)nf * nf;
-       e += (int64_t)gridDim.y * 256)
-    eb->out[(e / nf) * eb->ldo + e % nf] = 0.f;
+       e += (int64_t)gridDim.y * 256) {
+    const int64_t row = e / nf, col = e % nf;
+    if (row >= np || col >= np) eb->out[row * eb->ldo + col] = 0.f;
+  }
 }
 
 }  // namespace psk

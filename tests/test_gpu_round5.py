@@ -344,6 +344,33 @@ def test_eigh_blocks_above_the_fast_path_limit_do_not_take_their_neighbours_with
   assert float(resid.abs().max()) < 2e-3
 
 
+def test_eigh_root_padding_far_below_the_matrix_size_zeroes_the_whole_frame(device):
+  """padding_start so small that the effective part's 128-tiles end before the matrix does (npad <
+  n): the rows / columns npad .. n - 1 of the result are zero like the rest of the padding (DS:1016),
+  whatever the output buffer held before (found by tools/dev_fuzz_eigh.py; the root products only
+  cover the npad x npad tiles).  Small solver, fast path and an ill-conditioned block."""
+  rng = np.random.default_rng(17)
+  cases = [(192, 14, 2, "w"), (500, 370, 4, "w"), (257, 64, 2, "w"), (192, 100, 2, "w"), (640, 300, 2, "g")]
+  mats = []
+  for n, pad, p, kind in cases:
+    if kind == "w":
+      a = wishart(n, 2 * n + 3, n + pad)
+    else:
+      q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+      a = (q * 10.0 ** rng.uniform(-3, 1, n)) @ q.T
+      a = ((a + a.T) / 2).astype(np.float32)
+    mats.append(a)
+  outs = [torch.full((n, n), float("nan"), device=device) for n, _, _, _ in cases]
+  roots, _ = K().matrix_inverse_pth_root_batched([torch.tensor(a, device=device) for a in mats],
+                                                 [c[2] for c in cases], [c[1] for c in cases], eigh=True, out=outs)
+  for (n, pad, p, kind), a, r in zip(cases, mats, roots):
+    h = r.cpu().numpy()
+    ref, _ = orc.matrix_inverse_pth_root_eigh(a, p, padding_start=pad)
+    assert np.isfinite(h).all(), (n, pad)
+    assert not h[pad:, :].any() and not h[:, pad:].any(), (n, pad)
+    assert np.linalg.norm(h - ref) / np.linalg.norm(ref) < (2e-5 if kind == "w" else 5e-3), (n, pad)
+
+
 def test_quantize_plan_matches_grouped_calls_bit_for_bit(device):
   """kernels.QuantizePlan (resident descriptors) = quantize_grouped / dequantize_grouped on the same
   tensors, contiguous matrices (flat kernels) and an odd-sized one (tile kernels) in one call."""
