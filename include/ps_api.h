@@ -156,11 +156,15 @@ const char* ps_error_string(int code);
  *   launch's waits, < 0 = default 5000, 0 = every wait counts as expired (tests).
  * eigh_* — ps_eigh_root_batched_opt_f32: eigh_sweep_tol (<= 0: default 2e-6) is the scaled
  *   off-diagonal bound that ends the one-sided Jacobi sweeps; eigh_streams (0: default 2);
- *   eigh_solver: PS_EIGH_AUTO (default) = PS_EIGH_TRIDIAGONAL for matrices of 129 ... 4096 rows:
- *   Householder tridiagonalisation + float64 divide and conquer + compact-WY back-transformation
+ *   eigh_solver: PS_EIGH_AUTO (default): matrices of 129 ... 4096 rows take the Householder
+ *   tridiagonalisation + float64 divide and conquer + compact-WY back-transformation
  *   (csrc/eigh_td.hip.h; the algorithm class of LAPACK's ssyevd, which the reference's
- *   jnp.linalg.eigh runs, DS:1007), with the Jacobi solvers as the fallback when an iteration cap is
- *   hit; PS_EIGH_ONE_SIDED (rounds 3-4: Hestenes block Jacobi on the float64-accumulated Cholesky
+ *   jnp.linalg.eigh runs, DS:1007) and keep its result if the matrix turns out positive definite with
+ *   lambda_max / lambda_min <= 1e3 -- a float32 tridiagonalisation is accurate to eps ||A||, which is
+ *   all a well-conditioned matrix can ask for; the others (graded spectra, rank-deficient statistics,
+ *   indefinite input, an iteration cap) are solved again by the Jacobi solvers inside the same call,
+ *   which are accurate RELATIVE to each eigenvalue.  PS_EIGH_TRIDIAGONAL keeps the fast path's result
+ *   for every block (absolute accuracy, ~3 x faster on such inputs); PS_EIGH_ONE_SIDED (rounds 3-4: Hestenes block Jacobi on the float64-accumulated Cholesky
  *   factor) or PS_EIGH_TWO_SIDED (blocked two-sided Jacobi on the matrix itself + float64
  *   re-projection).  The Jacobi solvers are at LAPACK-float32's distance from the
  *   float64 root on well-conditioned and graded inputs.  On RANK-DEFICIENT + ridge inputs (a noise
@@ -376,6 +380,11 @@ int ps_eigh_batched_f32(void* stream, const float* const* a, const int32_t* n,
                         const int32_t* lda, int batch, float* const* evals,
                         float* const* evecs, const int32_t* ldv, void* workspace,
                         size_t workspace_bytes);
+/* The same with per-call options (eigh_solver, eigh_sweep_tol, eigh_streams of ps_options; NULL = defaults). */
+int ps_eigh_batched_opt_f32(void* stream, const float* const* a, const int32_t* n,
+                            const int32_t* lda, int batch, float* const* evals,
+                            float* const* evecs, const int32_t* ldv, void* workspace,
+                            size_t workspace_bytes, const ps_options* options);
 
 /* ---- optional per-kernel timing of the Newton driver (bench/roofline only) ----
  * When enabled, ps_newton_root_batched_f32 brackets the product-stage launches of every

@@ -273,6 +273,9 @@ _SIGNATURES = {
     "ps_eigh_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ps_eigh_batched_opt_f32":
+        (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(PsOptions)]),
     "ps_eigh_sorted_max_n": (C.c_int, []),
     "ps_fd_filter_step_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1481,7 +1481,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     if (opt.eigh_td && any_big && !pl.td.empty()) {
       for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = td_run(st, pl.td, lo.td, lo.blocks, hb, opt.eigh_td_defl_eps, opt.eigh_td_stage,
-                         mode == 0 ? opt.eigh_td_max_cond : 0.f, opt.eigh_td_streams,
+                         opt.eigh_td_force ? 0.f : opt.eigh_td_max_cond, opt.eigh_td_streams,
                          std::max(0, std::min(opt.eigh_td_tail, TD_TAIL)))))
           return rc;
         EStatus* slot = &status[63];
@@ -1832,4 +1832,12 @@ extern "C" int ps_eigh_batched_f32(void* stream, const float* const* a, const in
                                    size_t workspace_bytes) {
   return eigh_driver(1, stream, a, n, lda, nullptr, nullptr, batch, 0.f, 0.f, 0, evecs, ldv,
                      evals, nullptr, workspace, workspace_bytes, nullptr);
+}
+
+extern "C" int ps_eigh_batched_opt_f32(void* stream, const float* const* a, const int32_t* n,
+                                       const int32_t* lda, int batch, float* const* evals,
+                                       float* const* evecs, const int32_t* ldv, void* workspace,
+                                       size_t workspace_bytes, const ps_options* options) {
+  return eigh_driver(1, stream, a, n, lda, nullptr, nullptr, batch, 0.f, 0.f, 0, evecs, ldv,
+                     evals, nullptr, workspace, workspace_bytes, options);
 }

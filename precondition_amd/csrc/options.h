@@ -64,7 +64,8 @@ struct Options {
   int eigh_td_streams = 4;         // PS_EIGH_TD_STREAMS: stream groups of the reduction
   int eigh_td_tail = 192;          // PS_EIGH_TD_TAIL: last columns of a block reduced inside LDS (0: off; <= 192)
   int quant_flat = 1;              // PS_QUANT_FLAT: chunks of consecutive elements for contiguous tensors (0 = 64 x 256 tiles for all)
-  float eigh_td_max_cond = 1e3f;   // PS_EIGH_TD_MAX_COND: root mode keeps a block's result if lambda_max / lambda_min is below
+  int eigh_td_force = 0;           // eigh_solver TRIDIAGONAL (PS_EIGH_TD_FORCE): every block keeps the fast path's result
+  float eigh_td_max_cond = 1e3f;   // PS_EIGH_TD_MAX_COND: AUTO keeps a block's result if it is positive definite with lambda_max / lambda_min below
 };
 
 // PS_EINVAL-style validation is the caller's: resolve() clamps what it does not understand to the

@@ -71,6 +71,7 @@ void ps_dev_env_overrides(Options& o) {
   geti("PS_EIGH_TD_STREAMS", o.eigh_td_streams);
   geti("PS_EIGH_TD_TAIL", o.eigh_td_tail);
   getf("PS_EIGH_TD_MAX_COND", o.eigh_td_max_cond);
+  geti("PS_EIGH_TD_FORCE", o.eigh_td_force);
   geti("PS_QUANT_FLAT", o.quant_flat);
 }
 
@@ -113,7 +114,8 @@ Options resolve(const ps_options* u, bool* bad) {
     if (c.eigh_streams > 0) o.eigh_streams = c.eigh_streams;
     if (c.eigh_solver == PS_EIGH_TWO_SIDED) { o.eigh_cj = 0; o.eigh_td = 0; }
     else if (c.eigh_solver == PS_EIGH_ONE_SIDED) o.eigh_td = 0;
-    else if (c.eigh_solver != PS_EIGH_AUTO && c.eigh_solver != PS_EIGH_TRIDIAGONAL && bad) *bad = true;
+    else if (c.eigh_solver == PS_EIGH_TRIDIAGONAL) o.eigh_td_force = 1;
+    else if (c.eigh_solver != PS_EIGH_AUTO && bad) *bad = true;
   }
   ps_dev_env_overrides(o);
   return o;

@@ -282,10 +282,12 @@ def matrix_inverse_pth_root_deflated_batched(*args, **kwargs):
 
 
 @_device_guarded
-def eigh_batched(matrices: Sequence[torch.Tensor]):
-  """jnp.linalg.eigh for a batch of symmetric matrices (blocked Jacobi on the
-  GPU).  Returns (eigenvalues ascending [n], eigenvectors [n, n] in columns) per
-  matrix, LAPACK order; signs of eigenvectors are arbitrary."""
+def eigh_batched(matrices: Sequence[torch.Tensor], options=None):
+  """jnp.linalg.eigh for a batch of symmetric matrices.  Returns (eigenvalues ascending [n],
+  eigenvectors [n, n] in columns) per matrix, LAPACK order; signs of eigenvectors are arbitrary.
+  `options`: eigh_solver / eigh_sweep_tol / eigh_streams of _lib.make_options (default 'auto':
+  the tridiagonalisation path where the matrix is positive definite and well conditioned, the
+  Jacobi solvers -- accurate relative to every eigenvalue -- otherwise)."""
   batch = len(matrices)
   dev = matrices[0].device
   for m in matrices:
@@ -299,11 +301,12 @@ def eigh_batched(matrices: Sequence[torch.Tensor]):
   L = lib()
   ws = _workspace(L.ps_eigh_root_workspace_bytes(batch, n.ctypes.data), dev)
   a_ptrs, e_ptrs, v_ptrs = _ptrs(mats), _ptrs(evals), _ptrs(evecs)
-  rc = L.ps_eigh_batched_f32(_stream(), a_ptrs.ctypes.data, n.ctypes.data,
-                             lda.ctypes.data, batch, e_ptrs.ctypes.data,
-                             v_ptrs.ctypes.data, ldv.ctypes.data, ws.data_ptr(),
-                             ws.numel())
-  check(rc, "ps_eigh_batched_f32")
+  popt, _keep = _lib.make_options(options)
+  rc = L.ps_eigh_batched_opt_f32(_stream(), a_ptrs.ctypes.data, n.ctypes.data,
+                                 lda.ctypes.data, batch, e_ptrs.ctypes.data,
+                                 v_ptrs.ctypes.data, ldv.ctypes.data, ws.data_ptr(),
+                                 ws.numel(), C.byref(popt))
+  check(rc, "ps_eigh_batched_opt_f32")
   sorted_n = L.ps_eigh_sorted_max_n()  # small matrices come back ascending already
   out_e, out_v = [], []
   for e, v in zip(evals, evecs):
