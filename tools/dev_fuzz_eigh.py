@@ -25,7 +25,9 @@ for batch in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     a = ((a + a.T) / 2).astype(np.float32)
     pad = n if rng.random() < 0.7 else int(rng.integers(0, n + 1))
     mats.append(a); ps.append(int(rng.choice([2, 4]))); pads.append(pad); kinds.append(kind)
-  roots, met = K.matrix_inverse_pth_root_batched([torch.tensor(a, device=dev) for a in mats], ps, pads, eigh=True)
+  solver = os.environ.get("FUZZ_EIGH_SOLVER")
+  roots, met = K.matrix_inverse_pth_root_batched([torch.tensor(a, device=dev) for a in mats], ps, pads, eigh=True,
+                                                 options={"eigh_solver": solver} if solver else None)
   met = met.cpu().numpy()
   for i, (a, p, pad, kind) in enumerate(zip(mats, ps, pads, kinds)):
     ref, m = orc.matrix_inverse_pth_root_eigh(a, p, padding_start=pad)
