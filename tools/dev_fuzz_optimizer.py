@@ -39,6 +39,14 @@ for case in range(ncases):
       skip_preconditioning_rank_lt=int(rng.choice([1, 1, 2])),
       matrix_epsilon=float(rng.choice([1e-6, 1e-3])),
   )
+  if os.environ.get("FUZZ_LOWRANK"):   # the compressed branches (DS:1033-1290)
+    kw.update(eigh=False, compression_rank=int(rng.choice([2, 4, 8])), frequent_directions=bool(rng.integers(0, 2)),
+              average_grad=bool(rng.integers(0, 2)), reset_preconditioner=bool(rng.integers(0, 2)),
+              generate_fd_metrics=bool(rng.integers(0, 2)))
+    if not kw["frequent_directions"]:
+      kw.update(average_grad=False, reset_preconditioner=False, generate_fd_metrics=False)
+    else:   # the reference's own constraints on the sketch branch
+      kw.update(reuse_preconditioner=True, statistics_compute_steps=kw["preconditioning_compute_steps"])
   block = int(rng.choice([64, 128, 256]))
   p0 = [np.asarray(rng.standard_normal(s) * 0.1, np.float32) for s in shapes]
   def grads_at(t):
@@ -57,7 +65,9 @@ for case in range(ncases):
         ups.append([u.detach().cpu().numpy().copy() for u in upd])
       outs[where] = ups
   except Exception as ex:
-    print(f"case {case}: {where}: {type(ex).__name__}: {str(ex)[:160]}  shapes={shapes}", flush=True)
+    import traceback
+    tb = [l.strip() for l in traceback.format_exc().splitlines() if l.strip().startswith("File")][-1]
+    print(f"case {case}: {where}: {type(ex).__name__}: {str(ex)[:160]}  at {tb}  shapes={shapes}", flush=True)
     bad += 1
     continue
   ok = True
