@@ -1,0 +1,28 @@
+"""Dev (round 5): the optimizer with eigh=True on a ViT-B/16-shaped tree (395 statistics of 197 ... 1024 rows, real
+Shampoo statistics: rank-deficient early on): a few steps incl. recomputes, finite updates, time per recompute step, how
+many blocks the fast path kept."""
+import os
+os.environ.setdefault("PS_DEV_ENV", "1")
+import sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import precondition_amd as pa
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+L = 12
+shapes = [(768, 768 * 3), (768 * 3,), (768, 768), (768,), (768, 3072), (3072,), (3072, 768), (768,), (768,), (768,)] * L
+shapes += [(1, 197, 768), (768, 1000), (1000,), (16 * 16 * 3, 768)]
+params = [torch.from_numpy(np.asarray(rng.standard_normal(s) * 0.02, np.float32)).to(dev) for s in shapes]
+for solver in ("auto", "one_sided"):
+  opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=2, start_preconditioning_step=1, eigh=True,
+                               eigh_solver=solver, graft_type=pa.GraftingType.RMSPROP_NORMALIZED)
+  st = opt.init(params)
+  times = []
+  for t in range(6):
+    r = np.random.default_rng(100 + t)
+    grads = [torch.from_numpy(np.asarray(r.standard_normal(s) * 0.02, np.float32)).to(dev) for s in shapes]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    upd, st = opt.update(grads, st, params)
+    torch.cuda.synchronize(); times.append((time.perf_counter() - t0) * 1e3)
+    ok = all(bool(torch.isfinite(u).all()) for u in upd)
+    print(f"{solver}: step {t}: {times[-1]:8.1f} ms finite={ok}", flush=True)
