@@ -86,7 +86,9 @@ enum {
   PS_M_POWER_ITERS = 6,  /* power-iteration steps executed */
   PS_M_AVG_STEPS = 7,    /* Newton root: number of steps, summed over tries, whose M update was computed in
                             full and averaged with its transpose (ps_newton_averaged_steps; for FLOP
-                            accounting) */
+                            accounting).  eigh root rows: the condition number lambda_max / lambda_min of the
+                            regularised block from its final eigenvalues (+inf if not positive definite) --
+                            next recompute's ps_options.iters_hint */
   PS_METRICS_STRIDE = 8
 };
 
@@ -147,6 +149,10 @@ const char* ps_error_string(int code);
  *   condition number below ~1e2) is well conditioned: it takes 0 averaged steps -- mirrored M
  *   updates are exact to 1e-6 there -- which saves the 6 extra tile products of an averaged step
  *   (-7 % at 256 x 512^2, -9 % at 64 x 1024^2).  NULL, 0 or NaN = no hint = the careful path.
+ *   ps_eigh_root_batched_opt_f32 (eigh_solver AUTO) reads the same array differently: the block's condition
+ *   number at the previous recompute (column PS_M_AVG_STEPS of that call's metrics: lambda_max / lambda_min of
+ *   the regularised block, +inf if not positive definite).  Above 2e3 (twice the keep rule's bound) the block goes
+ *   to the Jacobi solvers directly -- same bits as after a hand-over, minus the time of the fast path's attempt.
  *   Statistics move slowly (beta2 ~ 0.999), so last recompute's count is a sound predictor; a
  *   block that turns out slower than its hint is only less accurate (mirror noise ~ cond * eps).
  * execution — PS_EXEC_STAGED (default: one launch per product stage, one host event wait per

@@ -137,6 +137,7 @@ def sharded_inverse_pth_roots(
     iters_hint: Optional[Sequence[float]] = None,
     options: Optional[dict] = None,
     hint_in_ownership: bool = True,
+    eigh_skip_hint: Optional[Sequence[float]] = None,
 ) -> Tuple[List[torch.Tensor], torch.Tensor]:
   """Roots every statistic on its owner rank and all-gathers the results.
 
@@ -275,10 +276,13 @@ def sharded_inverse_pth_roots(
           m = compute_fn(mine, outs)
         else:
           extra = {}
-          if options or iters_hint is not None:
+          if options or iters_hint is not None or eigh_skip_hint is not None:
             o = dict(options or {})
             if iters_hint is not None and not eigh:
               o["iters_hint"] = np.asarray([iters_hint[i] for i in mine], dtype=np.float32)
+            if eigh_skip_hint is not None and eigh:
+              # the blocks' condition numbers at the last recompute: far above the keep rule = no attempt
+              o["iters_hint"] = np.asarray([eigh_skip_hint[i] for i in mine], dtype=np.float32)
             extra["options"] = o
 
           def _root():

@@ -1113,15 +1113,37 @@ __global__ __launch_bounds__(256) void eigh_copy_pairs_kernel(EighBlock* blocks,
   }
 }
 
-__global__ void eigh_metrics_kernel(EighBlock* blocks, int nblocks, float* metrics) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per block.  Besides the reference's error (DS:1022: only that field is populated there):
+// Jacobi sweeps, power-iteration steps, and in PS_M_AVG_STEPS the condition number lambda_max / lambda_min of
+// the regularised block from its final eigenvalues (+inf if not positive definite): the caller hands it back
+// as ps_options.iters_hint at the next recompute, where a block far above eigh_td_max_cond skips the fast
+// path's attempt (finish_eplan).
+__global__ __launch_bounds__(64) void eigh_metrics_kernel(EighBlock* blocks, int nblocks, float* metrics) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= nblocks) return;
   EighBlock* eb = &blocks[b];
+  const int n = eb->n;
+  float lo = 3.0e38f, hi = -3.0e38f;
+  bool nan = false;
+  for (int i = lane; i < n; i += 64) {
+    const float e = eb->evals[i];
+    nan |= e != e;
+    lo = fminf(lo, e); hi = fmaxf(hi, e);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    nan |= __shfl_xor((int)nan, off, 64) != 0;
+  }
+  if (lane != 0) return;
   float* m = metrics + (int64_t)b * PS_METRICS_STRIDE;
   for (int i = 0; i < PS_METRICS_STRIDE; ++i) m[i] = 0.f;  // DS:1022: only the error
-  m[PS_M_ERROR] = eb->n == 0 ? 0.f : __uint_as_float(eb->err_bits);  // DS:1024-1028
+  m[PS_M_ERROR] = n == 0 ? 0.f : __uint_as_float(eb->err_bits);  // DS:1024-1028
   m[PS_M_TOTAL_ITERS] = (float)eb->sweeps;
   m[PS_M_POWER_ITERS] = (float)eb->power_iters;
+  m[PS_M_AVG_STEPS] = n == 0 ? 0.f : (nan ? __uint_as_float(0x7fc00000u)
+                                         : (lo > 0.f ? hi / lo : __uint_as_float(0x7f800000u)));
 }
 
 // What the root products do not write of `out` (they cover the npad x npad tiles of the effective part,
@@ -1172,7 +1194,12 @@ struct EPlan {
 // sizing = true (ps_eigh_root_workspace_bytes: the caller's padding_start values are not known yet):
 // the tridiagonalisation workspace is carved for every block of more than 128 rows at
 // min(n, TD_MAXN), an upper bound of what any padding_start can make the call need.
-void finish_eplan(EPlan& pl, bool sizing = false) {
+// skip_hint (root calls; ps_options.iters_hint): the block's condition number at the previous recompute (column
+// PS_M_AVG_STEPS of that call's metrics).  Far above the keep rule's bound (> 2 x eigh_td_max_cond; statistics
+// move slowly) the block goes to the Jacobi solvers directly -- the same bits as after a hand-over (which starts
+// those solvers from scratch), minus the time of the attempt.  NaN / 0 / absent: the attempt is made.
+void finish_eplan(EPlan& pl, bool sizing = false, const float* skip_hint = nullptr, int hint_stride = 1,
+                  float skip_above = 0.f) {
   pl.pip.build(pl.batch, pl.n_eff);
   if (sizing) {
     std::vector<int> ids, nn = pl.n_eff;
@@ -1185,7 +1212,9 @@ void finish_eplan(EPlan& pl, bool sizing = false) {
   // solvers of the same call (like the blocks the fast path hands back)
   std::vector<int> ids;
   for (int b : pl.big_ids)
-    if (pl.n_eff[b] > SE_MAXN && pl.n_eff[b] <= TD_MAXN) ids.push_back(b);
+    if (pl.n_eff[b] > SE_MAXN && pl.n_eff[b] <= TD_MAXN &&
+        !(skip_hint && skip_hint[(size_t)b * hint_stride] > skip_above))
+      ids.push_back(b);
   if (!ids.empty()) td_make_plan(pl.td, ids, pl.n_eff, pl.npad);
 }
 
@@ -1313,7 +1342,8 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   hipStream_t st = (hipStream_t)stream;
   EPlan pl;
   make_eplan(pl, batch, n, padding_start);
-  finish_eplan(pl);
+  finish_eplan(pl, false, (mode == 0 && !opt.eigh_td_force) ? opt.iters_hint : nullptr, opt.iters_hint_stride,
+               2.f * opt.eigh_td_max_cond);
   pl.pip.set_options(opt);
   if (pl.max_n > 16384) return PS_EUNSUPPORTED;
   Arena ar(workspace, workspace_bytes);
@@ -1792,8 +1822,7 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   }
   if (mode == 1) return PS_OK;
   hipLaunchKernelGGL(eigh_zero_out_kernel, dim3(batch, 16), blk, 0, st, lo.blocks);
-  hipLaunchKernelGGL(eigh_metrics_kernel, dim3((batch + 255) / 256), blk, 0, st, lo.blocks,
-                     batch, metrics);
+  hipLaunchKernelGGL(eigh_metrics_kernel, dim3(batch), dim3(64), 0, st, lo.blocks, batch, metrics);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

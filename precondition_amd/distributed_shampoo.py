@@ -182,6 +182,7 @@ def distributed_shampoo(
     raise ValueError(f"eigh_solver must be auto | tridiagonal | one_sided | two_sided, found {eigh_solver!r}")
   if eigh and eigh_solver != "auto":
     root_options["eigh_solver"] = eigh_solver
+  _eigh_memo = {"cond": None}   # _compute_preconditioners: every block's condition number at the last eigh recompute
   products_for_precision(tensordot_precision)
   del tensordot_precision
   # (the partition specs describe XLA shardings; here the stacked statistics are always
@@ -656,6 +657,17 @@ def distributed_shampoo(
         flat = torch.cat([t_.reshape(-1).to(torch.float32) for t_ in its])
         if flat.numel() == len(sizes):
           iters_hint = flat.cpu().tolist()
+    # eigh path, default solver: the condition number every block had at the LAST recompute (metrics column 7 of
+    # the eigh rows).  Blocks far above the fast path's keep rule skip its attempt this time -- same bits (a
+    # hand-over starts the Jacobi solvers from scratch), minus the attempt's time; real Shampoo statistics are
+    # mostly ill conditioned.  The memo lives in the optimizer object, not in the state: a stale entry costs
+    # time, never accuracy.
+    eigh_skip = None
+    if (eigh and iteration_count_hint and eigh_solver == "auto" and compression_rank == 0 and
+        not lobpcg_topk_precondition and _backend_for_testing is None):
+      memo = _eigh_memo
+      if memo["cond"] is not None and len(memo["cond"]) == len(sizes):
+        eigh_skip = memo["cond"]
     if lobpcg_topk_precondition:
       # top-k deflated roots (DS:787-812, 889-928); blocks not larger than k (possible
       # here because nothing is padded to max_size) take the plain iteration
@@ -703,7 +715,8 @@ def distributed_shampoo(
             [statistics[i] for i in indices], [exponents[i] for i in indices],
             [sizes[i] for i in indices], ridge_epsilon=matrix_epsilon,
             relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh, out=tmp,
-            options=dict(root_options, **({} if iters_hint is None or eigh else {
+            options=dict(root_options, **({"iters_hint": [eigh_skip[i] for i in indices]} if (eigh and eigh_skip is not None)
+                                          else {} if iters_hint is None or eigh else {
                 "iters_hint": [iters_hint[i] for i in indices]})))
         backend.quantize_grouped(tmp, qdt_second_moment, True,
                                  out=[_unpack(o, sizes[i]) for o, i in zip(outs, indices)])
@@ -716,9 +729,12 @@ def distributed_shampoo(
         compute_fn=compute_fn, payload_elems=payload_elems, sizes=sizes,
         pi_first=(_backend_for_testing is None and not lobpcg_topk_precondition),
         metrics_cols=metrics_cols if compute_fn is not None else comm.METRICS_STRIDE,
-        iters_hint=iters_hint, hint_in_ownership=not shard_stats,
+        iters_hint=iters_hint, hint_in_ownership=not shard_stats, eigh_skip_hint=eigh_skip,
         options=(root_options if (compute_fn is None and not lobpcg_topk_precondition) else None))
-    errors = metrics[:, 0].detach().cpu().numpy()  # one small D2H per recompute
+    mhost = metrics[:, :comm.METRICS_STRIDE].detach().cpu().numpy()   # one small D2H per recompute
+    errors = mhost[:, 0]
+    if eigh and _backend_for_testing is None:
+      _eigh_memo["cond"] = [float(v) for v in mhost[:, 7]]
     if quantize_second_moment:
       roots = [QuantizedValue(*_unpack(r, n), qdt_second_moment, True, [n, n])
                for r, n in zip(roots, sizes)]

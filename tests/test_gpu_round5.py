@@ -172,6 +172,28 @@ def test_low_rank_root_bottom_eigenpairs_of_graded_matrices_default_solver(devic
     assert packed_matches(val.cpu().numpy(), ref, abs(mt[2]), tol=5e-3), mt
 
 
+def test_eigh_skip_hint_sends_blocks_straight_to_the_jacobi_solvers_same_bits(device):
+  """ps_options.iters_hint in an eigh root call = the blocks' condition numbers at the last recompute (metrics
+  column 7); far above the keep rule's bound the block skips the fast path's attempt.  For an ill-conditioned block that changes nothing but the time (same
+  bits as without the hint); a well-conditioned block with the hint is solved by the Jacobi solver (sweeps
+  counted) to the same accuracy; its unhinted neighbour stays on the fast path."""
+  rng = np.random.default_rng(21)
+  q, _ = np.linalg.qr(rng.standard_normal((300, 300)))
+  graded = ((q * 10.0 ** rng.uniform(-4, 1, 300)) @ q.T).astype(np.float32)
+  graded = (graded + graded.T) / 2
+  mats = [graded, wishart(320, 1300, 31), wishart(256, 1100, 32)]
+  ts = [torch.tensor(a, device=device) for a in mats]
+  r0, m0 = K().matrix_inverse_pth_root_batched(ts, [2, 2, 4], eigh=True)
+  assert m0.cpu().numpy()[0, 7] > 2e3 and 1.0 < m0.cpu().numpy()[1, 7] < 1e3   # the blocks' condition numbers
+  r1, m1 = K().matrix_inverse_pth_root_batched(ts, [2, 2, 4], eigh=True, options={"iters_hint": [1e5, 1e5, 30.0]})
+  m0, m1 = m0.cpu().numpy(), m1.cpu().numpy()
+  assert m0[0, 5] > 0 and m0[1, 5] == 0 and m0[2, 5] == 0
+  assert m1[0, 5] > 0 and m1[1, 5] > 0 and m1[2, 5] == 0
+  assert torch.equal(r0[0], r1[0]) and torch.equal(r0[2], r1[2])
+  h_ref, _ = orc.matrix_inverse_pth_root_eigh(mats[1], 2)
+  assert np.linalg.norm(r1[1].cpu().numpy() - h_ref) / np.linalg.norm(h_ref) < 2e-5
+
+
 def test_eigh_ill_conditioned_blocks_take_the_jacobi_solver_in_the_same_call(device):
   """A float32 tridiagonalisation leaves eps * ||D|| of unstructured error, which lambda^(-1/p)
   amplifies by ||D|| / lambda: blocks with lambda_max / lambda_min > 1e3 (ps_options default) are

@@ -13,16 +13,24 @@ L = 12
 shapes = [(768, 768 * 3), (768 * 3,), (768, 768), (768,), (768, 3072), (3072,), (3072, 768), (768,), (768,), (768,)] * L
 shapes += [(1, 197, 768), (768, 1000), (1000,), (16 * 16 * 3, 768)]
 params = [torch.from_numpy(np.asarray(rng.standard_normal(s) * 0.02, np.float32)).to(dev) for s in shapes]
-for solver in ("auto", "one_sided"):
+lowrank = len(sys.argv) > 1 and sys.argv[1] == "lowrank"   # gradients of rank 8: statistics stay ill conditioned
+def make_grad(r, s):
+  if lowrank and len(s) == 2 and min(s) > 8:
+    return (r.standard_normal((s[0], 8)) @ r.standard_normal((8, s[1])) * 0.02 / 3).astype(np.float32)
+  return np.asarray(r.standard_normal(s) * 0.02, np.float32)
+for solver, hint in (("auto", True), ("auto", False), ("one_sided", True)):
   opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=2, start_preconditioning_step=1, eigh=True,
-                               eigh_solver=solver, graft_type=pa.GraftingType.RMSPROP_NORMALIZED)
+                               eigh_solver=solver, graft_type=pa.GraftingType.RMSPROP_NORMALIZED,
+                               iteration_count_hint=hint)
   st = opt.init(params)
   times = []
-  for t in range(6):
+  for t in range(14):
     r = np.random.default_rng(100 + t)
-    grads = [torch.from_numpy(np.asarray(r.standard_normal(s) * 0.02, np.float32)).to(dev) for s in shapes]
+    grads = [torch.from_numpy(make_grad(r, s)).to(dev) for s in shapes]
     torch.cuda.synchronize(); t0 = time.perf_counter()
     upd, st = opt.update(grads, st, params)
     torch.cuda.synchronize(); times.append((time.perf_counter() - t0) * 1e3)
     ok = all(bool(torch.isfinite(u).all()) for u in upd)
-    print(f"{solver}: step {t}: {times[-1]:8.1f} ms finite={ok}", flush=True)
+    if not ok: print(f"{solver} hint={hint}: step {t}: non-finite update", flush=True)
+  rec = times[0::2]
+  print(f"{solver} hint={hint}: recompute steps (ms): " + " ".join(f"{x:.0f}" for x in rec) + f"   median of the last five {sorted(rec[-5:])[2]:.0f}", flush=True)
