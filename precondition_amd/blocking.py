@@ -218,6 +218,25 @@ class Preconditioner:
       shapes.extend(self._preconditioner_shape(d) for d in dims)
     return shapes
 
+  def contraction_lengths(self) -> List[int]:
+    """Per statistic (same order as shapes_for_preconditioners): the number of columns k of the block
+    matricised along that axis -- one update adds a Gram matrix of rank <= k to the statistic."""
+    split_sizes = self._partitioner.split_sizes()
+    rank = len(split_sizes)
+    out = []
+    for block in itertools.product(*split_sizes):
+      total = 1
+      for d in block:
+        total *= int(d)
+      if self._preconditioner_type == PreconditionerType.ALL or rank <= 1:
+        dims = block
+      elif self._preconditioner_type == PreconditionerType.INPUT:
+        dims = block[:-1]
+      else:
+        dims = block[-1:]
+      out.extend(total // max(int(d), 1) for d in dims)
+    return out
+
   def exponent_for_preconditioner(self) -> int:
     """p of M^{-1/p}: twice the number of preconditioned dims (DS:1639-1643)."""
     return 2 * sum(self.should_precondition_dims())

@@ -531,7 +531,7 @@ def distributed_shampoo(
   def _compute_preconditioners(states, params, step):
     """DS:3442-3494 + DS:2816-3010: shard the statistics over the ranks of
     `group`, root them, all-gather, select against the previous value."""
-    statistics, exponents, prev, counts = [], [], [], []
+    statistics, exponents, prev, counts, klens = [], [], [], [], []
     for state, param in zip(states, params):
       num = len(state.statistics)
       counts.append(num)
@@ -541,6 +541,7 @@ def distributed_shampoo(
         exponents.extend([e] * num)
         statistics.extend(state.statistics)
         prev.extend(state.preconditioners)
+        klens.extend(pc.contraction_lengths())
     if not statistics:
       return states
 
@@ -668,6 +669,11 @@ def distributed_shampoo(
       memo = _eigh_memo
       if memo["cond"] is not None and len(memo["cond"]) == len(sizes):
         eigh_skip = memo["cond"]
+      elif len(klens) == len(sizes):
+        # no recompute yet: a statistic that has seen fewer gradient columns than it has rows is rank
+        # deficient up to its epsilon (the usual state of the first recomputes): no attempt
+        updates = int(step) // max(int(statistics_compute_steps), 1) + 1
+        eigh_skip = [float("inf") if updates * k < n else 0.0 for k, n in zip(klens, sizes)]
     if lobpcg_topk_precondition:
       # top-k deflated roots (DS:787-812, 889-928); blocks not larger than k (possible
       # here because nothing is padded to max_size) take the plain iteration
