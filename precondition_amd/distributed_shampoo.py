@@ -661,8 +661,8 @@ def distributed_shampoo(
     # eigh path, default solver: the condition number every block had at the LAST recompute (metrics column 7 of
     # the eigh rows).  Blocks far above the fast path's keep rule skip its attempt this time -- same bits (a
     # hand-over starts the Jacobi solvers from scratch), minus the attempt's time; real Shampoo statistics are
-    # mostly ill conditioned.  The memo lives in the optimizer object, not in the state: a stale entry costs
-    # time, never accuracy.
+    # mostly ill conditioned.  The memo lives in the optimizer object, not in the state: a stale entry changes
+    # which of the two solvers roots a block (same accuracy class) or costs the attempt's time.
     eigh_skip = None
     if (eigh and iteration_count_hint and eigh_solver == "auto" and compression_rank == 0 and
         not lobpcg_topk_precondition and _backend_for_testing is None):

@@ -134,3 +134,25 @@ def test_fd_pack_unpack_roundtrip_bit_exact():
     assert torch.equal(again, packed)
     ev, inv2, const, hz = low_rank._low_rank_unpack(packed, -r)
     assert torch.equal(inv2, inv) and float(const) == 0.25 and bool(hz)
+
+
+def test_contraction_lengths_follow_the_statistics_order():
+  """Preconditioner.contraction_lengths(): per statistic the columns of the block matricised along that
+  axis (n * k = block size), in the order of shapes_for_preconditioners(), for every preconditioner type."""
+  import itertools
+  import torch
+  from precondition_amd.blocking import Preconditioner
+  from precondition_amd.state import PreconditionerType
+  for shape in [(768, 3072), (3072,), (768, 12, 64), (5,), (130, 200, 3)]:
+    for ptype in (PreconditionerType.ALL, PreconditionerType.INPUT, PreconditionerType.OUTPUT):
+      pc = Preconditioner(torch.empty(shape), 128, 4096, True, preconditioner_type=ptype)
+      shapes, ks = pc.shapes_for_preconditioners(), pc.contraction_lengths()
+      assert len(shapes) == len(ks)
+      blocks = list(itertools.product(*pc._partitioner.split_sizes()))
+      per_block = len(shapes) // len(blocks)
+      for b, blk in enumerate(blocks):
+        total = 1
+        for d in blk:
+          total *= int(d)
+        for s_, k in zip(shapes[b * per_block:(b + 1) * per_block], ks[b * per_block:(b + 1) * per_block]):
+          assert s_[0] * k == total

@@ -194,6 +194,33 @@ def test_eigh_skip_hint_sends_blocks_straight_to_the_jacobi_solvers_same_bits(de
   assert np.linalg.norm(r1[1].cpu().numpy() - h_ref) / np.linalg.norm(h_ref) < 2e-5
 
 
+def test_optimizer_eigh_condition_memo_changes_time_not_bits(device):
+  """distributed_shampoo(eigh=True): the optimizer hands every block's last condition number (and, before the
+  first recompute, the rank bound of its statistic) back to the root call so that ill-conditioned blocks skip
+  the fast path's attempt.  A hinted block gets the bits it would get after a hand-over; a STALE hint (the
+  statistic's rank grows between the first recomputes) only changes which of the two solvers roots a block, so
+  the updates agree with the memo switched off (iteration_count_hint=False) to the solvers' common accuracy."""
+  import precondition_amd as pa
+  rng = np.random.default_rng(4)
+  shapes = [(300, 200), (260,), (150, 320), (40, 40)]
+  params = [torch.from_numpy(np.asarray(rng.standard_normal(s) * 0.1, np.float32)).to(device) for s in shapes]
+  outs = {}
+  for hint in (True, False):
+    opt = pa.distributed_shampoo(0.1, 512, eigh=True, preconditioning_compute_steps=2, start_preconditioning_step=1,
+                                 graft_type=pa.GraftingType.RMSPROP_NORMALIZED, iteration_count_hint=hint)
+    st = opt.init(params)
+    ups = []
+    for t in range(6):
+      r = np.random.default_rng(50 + t)
+      grads = [torch.from_numpy(np.asarray(r.standard_normal(s) * 0.1, np.float32)).to(device) for s in shapes]
+      upd, st = opt.update(grads, st, params)
+      ups.append([u.clone() for u in upd])
+    outs[hint] = ups
+  for a, b in zip(outs[True], outs[False]):
+    for x, y in zip(a, b):
+      assert float((x - y).norm()) <= 2e-4 * float(y.norm())
+
+
 def test_eigh_ill_conditioned_blocks_take_the_jacobi_solver_in_the_same_call(device):
   """A float32 tridiagonalisation leaves eps * ||D|| of unstructured error, which lambda^(-1/p)
   amplifies by ||D|| / lambda: blocks with lambda_max / lambda_min > 1e3 (ps_options default) are
