@@ -703,16 +703,29 @@ def parity_sample(work, count=8):
 
 
 def parity_sample_eigh(work, count=2):
-  """The eigh leg against the oracle's LAPACK-float32 eigh root (DS:943-1030 restated) on the
-  first `count` blocks; eigenvectors are not unique, so the comparison is on the root."""
+  """The eigh leg against the oracle's eigh root (DS:943-1030 restated over TRUE float32 LAPACK, ssyevd:
+  what the reference's JAX CPU path runs) on the first `count` blocks; eigenvectors are not unique, so the
+  comparison is on the root.  Beside it: both roots' distance from the float64 closed form of the same
+  float32 matrix, and the reference's error metric (DS:1017-1021) of the build next to ssyevd's."""
   from oracle import shampoo_oracle as orc
-  errs = []
+  errs, e_build, e_ref, metric_ratio = [], [], [], []
+  met = work.metrics.cpu().numpy() if getattr(work, "metrics", None) is not None else None
   for i in range(min(count, work.nb)):
     a = work.stats[i].cpu().numpy()
-    h, _ = orc.matrix_inverse_pth_root_eigh(a, work.p, padding_start=work.n)
-    errs.append(_rel_fro(work.roots[i].cpu().numpy(), h))
-  return {"blocks": len(errs), "rel_fro_max": max(errs), "rel_fro_median": float(np.median(errs)),
-          "bar": 1e-4, "oracle": "oracle.matrix_inverse_pth_root_eigh (numpy.linalg.eigh, float32)"}
+    h, m = orc.matrix_inverse_pth_root_eigh(a, work.p, padding_start=work.n)
+    got = work.roots[i].cpu().numpy()
+    errs.append(_rel_fro(got, h))
+    truth = orc.eigh_root_float64(a, work.p, padding_start=work.n)
+    e_build.append(_rel_fro(got, truth))
+    e_ref.append(_rel_fro(h, truth))
+    if met is not None and m["inverse_pth_root_errors"] > 0:
+      metric_ratio.append(float(met[i, 0] / m["inverse_pth_root_errors"]))
+  out = {"blocks": len(errs), "rel_fro_max": max(errs), "rel_fro_median": float(np.median(errs)),
+         "bar": 1e-4, "oracle": "oracle.matrix_inverse_pth_root_eigh (scipy.linalg.lapack.ssyevd, float32)",
+         "root_error_vs_float64_build_max": max(e_build), "root_error_vs_float64_ssyevd_max": max(e_ref)}
+  if metric_ratio:
+    out["error_metric_over_ssyevds_max"] = max(metric_ratio)
+  return out
 
 
 def parity_sample_vit_b(vw, roots, metrics, per_class=1):

@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 300 /* 0.3.0 */
+#define PS_VERSION 306 /* 0.3.6: ps_options grew (eigh_keep_max_cond), PS_EIGH_ACCURATE */
 
 enum {
   PS_OK = 0,
@@ -165,27 +165,34 @@ const char* ps_error_string(int code);
  *   eigh_solver: PS_EIGH_AUTO (default): matrices of 129 ... 4096 rows take the Householder
  *   tridiagonalisation + float64 divide and conquer + compact-WY back-transformation
  *   (csrc/eigh_td.hip.h; the algorithm class of LAPACK's ssyevd, which the reference's
- *   jnp.linalg.eigh runs, DS:1007) and keep its result if the matrix turns out positive definite with
- *   lambda_max / lambda_min <= 1e3 -- a float32 tridiagonalisation is accurate to eps ||A||, which is
- *   all a well-conditioned matrix can ask for; the others (graded spectra, rank-deficient statistics,
- *   indefinite input, an iteration cap) are solved again by the Jacobi solvers inside the same call,
- *   which are accurate RELATIVE to each eigenvalue.  PS_EIGH_TRIDIAGONAL keeps the fast path's result
- *   for every block (absolute accuracy, ~3 x faster on such inputs); PS_EIGH_ONE_SIDED (rounds 3-4: Hestenes block Jacobi on the float64-accumulated Cholesky
- *   factor) or PS_EIGH_TWO_SIDED (blocked two-sided Jacobi on the matrix itself + float64
- *   re-projection).  The Jacobi solvers are at LAPACK-float32's distance from the
- *   float64 root on well-conditioned and graded inputs.  On RANK-DEFICIENT + ridge inputs (a noise
- *   cluster of eigenvalues around the ridge, where max(e, ridge)^(-1/p) has its kink) every float32
- *   solver is 5e-4 ... 5e-3 from float64; the two-sided solver then reproduces LAPACK's result to
- *   three digits, the one-sided one is another realisation of that noise (1.0 ... 1.5 x LAPACK's
- *   error, 3.4 x worst seen): pick TWO_SIDED where agreement with a LAPACK-based reference below
- *   1e-4 matters more than time.
+ *   jnp.linalg.eigh runs in float32, DS:35-38, DS:1007).  ROOT calls keep its result for every block:
+ *   measured against the float64 root of the same float32 matrix it is at or below the error of a true
+ *   float32 ssyevd on every statistics family tried (Wishart, graded 1e2 ... 1e6, log-uniform, rank
+ *   deficient + ridge, low-rank EMA; 169 ... 2048 rows: profiles/r06_eigh_keep_rule.json: 0.1 ... 1.25 x
+ *   ssyevd's error), i.e. at the reference's own accuracy, 2-3 x faster than the Jacobi hand-over that was
+ *   the default until round 6 (which compared against NumPy's float64-internal eigh by mistake).  Only an
+ *   iteration cap or non-finite input hands a block to the Jacobi solvers.  PS_EIGH_ACCURATE: the previous
+ *   rule -- a block keeps the fast path's result only if it is positive definite with lambda_max /
+ *   lambda_min <= eigh_keep_max_cond (default 1e3); the others (graded spectra, rank-deficient statistics,
+ *   indefinite input) are solved again inside the same call by the Jacobi solvers, which are accurate
+ *   RELATIVE to each eigenvalue (10 ... 300 x closer to the float64 root than ssyevd on such inputs, at
+ *   2-3 x the time).  PLAIN eigenpairs (ps_eigh_batched_opt_f32: _low_rank_root's smallest eigenpairs,
+ *   DS:1071) keep the ACCURATE rule under AUTO as well.  PS_EIGH_TRIDIAGONAL keeps the fast path's result
+ *   for every block in both modes; PS_EIGH_ONE_SIDED (Hestenes block Jacobi on the float64-accumulated
+ *   Cholesky factor) and PS_EIGH_TWO_SIDED (blocked two-sided Jacobi on the matrix itself + float64
+ *   re-projection) skip the fast path.  eigh_keep_max_cond (> 0) overrides the bound of whichever rule
+ *   applies (+inf = keep everything).
+ *   ABI note (PS_VERSION 306): the values of this enum changed twice -- round 5 (still reporting 300)
+ *   renumbered PS_EIGH_ONE_SIDED 0 -> 2 when 0 became AUTO; 306 adds PS_EIGH_ACCURATE = 4 and the field
+ *   eigh_keep_max_cond (struct_size grows: a caller built against the shorter struct gets the default).
+ *   Check ps_version() >= 306 before relying on either.
  * The PS_* environment variables of earlier rounds survive only as a developer override, read in
  * ONE function (csrc/options.cpp ps_dev_env_overrides) and only when PS_DEV_ENV=1 is set. */
 enum { PS_PRODUCTS_F32 = 0, PS_PRODUCTS_BF16X6 = 1, PS_PRODUCTS_BF16X3 = 2 };
 enum { PS_ACCUM_SEGMENTED = 0, PS_ACCUM_CHAIN = 1 };
 enum { PS_EXEC_STAGED = 0, PS_EXEC_PERSISTENT = 1 };
 enum { PS_PI_AUTO = 0, PS_PI_STREAMING = 1, PS_PI_RESIDENT = 2 };
-enum { PS_EIGH_AUTO = 0, PS_EIGH_TWO_SIDED = 1, PS_EIGH_ONE_SIDED = 2, PS_EIGH_TRIDIAGONAL = 3 };
+enum { PS_EIGH_AUTO = 0, PS_EIGH_TWO_SIDED = 1, PS_EIGH_ONE_SIDED = 2, PS_EIGH_TRIDIAGONAL = 3, PS_EIGH_ACCURATE = 4 };
 typedef struct {
   uint32_t struct_size;        /* sizeof(ps_options) of the caller's build */
   int32_t products;            /* PS_PRODUCTS_* */
@@ -200,8 +207,10 @@ typedef struct {
   int32_t pi_timeout_ms;       /* < 0 = default */
   float eigh_sweep_tol;        /* <= 0 = default */
   int32_t eigh_streams;        /* 0 = default */
-  int32_t eigh_solver;         /* PS_EIGH_AUTO (0, default) | PS_EIGH_TWO_SIDED | PS_EIGH_ONE_SIDED | PS_EIGH_TRIDIAGONAL */
+  int32_t eigh_solver;         /* PS_EIGH_AUTO (0, default) | PS_EIGH_TWO_SIDED | PS_EIGH_ONE_SIDED | PS_EIGH_TRIDIAGONAL | PS_EIGH_ACCURATE */
   int32_t reserved[5];         /* reserved[0] = PS_OPTIONS_MAGIC (written by ps_options_init), the rest 0 */
+  float eigh_keep_max_cond;    /* <= 0 = the solver rule's default; > 0 (may be +inf): keep the fast path's result up to this lambda_max / lambda_min */
+  int32_t reserved2[3];        /* 0 */
 } ps_options;
 /* Fills *opt with the defaults (struct_size = sizeof(ps_options), reserved[0] = PS_OPTIONS_MAGIC).
  * EVERY ps_options must start from this call: a zero-initialised struct is NOT the defaults

@@ -15,9 +15,12 @@ is asserted to agree **bit for bit** with those outputs on the generating
 machine (same NumPy/OpenBLAS op sequence), and ``tests/test_oracle_golden.py``
 re-checks it against the committed vectors to a tight tolerance on any machine
 (OpenBLAS picks different kernels per CPU, so bits may differ elsewhere).
-Third-party arithmetic the reference delegates to jax/XLA (dot, eigh) is
-*unpinned* upstream (pyproject.toml:17-28 lists a bare "jax"); here it is
-NumPy/OpenBLAS/LAPACK float32.
+Third-party arithmetic the reference delegates to jax/XLA is *unpinned* upstream
+(pyproject.toml:17-28 lists a bare "jax"); here dot is NumPy/OpenBLAS float32 and
+eigh / svd / qr are the SINGLE-PRECISION LAPACK routines jax's CPU path runs (ssyevd,
+sgesdd, sgeqrf through scipy.linalg.lapack: oracle/lapack32.py).  ``lapack="f64"``
+selects NumPy's float64-internal versions instead: an accuracy yardstick, not the
+parity target (NumPy computes float32 inputs in double — rounds 1-5 used it by mistake).
 
 Everything is float32 because ``_MAT_INV_PTH_ROOT_DTYPE = jnp.float64``
 (DS:38) silently degrades to float32 unless jax_enable_x64 is set (DS:35-38),
@@ -27,7 +30,19 @@ from __future__ import annotations
 
 import numpy as np
 
+from oracle import lapack32 as _lapack
+
 F32 = np.float32
+
+
+def _lapack_fns(lapack):
+  """The LAPACK-delegated routines (DS:1007, 1071, 1193, 1502): ``"f32"`` = the single-precision
+  routines the reference's JAX CPU path runs (ssyevd / sgesdd / sgeqrf: the PARITY target);
+  ``"f64"`` = NumPy's float64-internal versions (accuracy yardstick only; oracle/lapack32.py)."""
+  if lapack == "f32":
+    return _lapack.eigh32, _lapack.svd32, _lapack.qr_r32
+  assert lapack == "f64", lapack
+  return _lapack.eigh64, _lapack.svd64, _lapack.qr_r64
 _EPSILON = 1e-25  # DS:41
 
 
@@ -168,7 +183,8 @@ def matrix_inverse_pth_root(matrix, p, num_iters=100, ridge_epsilon=1e-6,
 def matrix_inverse_pth_root_eigh(matrix, p, ridge_epsilon=1e-6,
                                  error_tolerance=1e-6,
                                  relative_matrix_epsilon=True,
-                                 padding_start=None):
+                                 padding_start=None, lapack="f32"):
+  eigh_fn = _lapack_fns(lapack)[0]
   matrix = np.array(matrix, dtype=F32)
   n = matrix.shape[0]
   alpha = F32(-1.0 / int(p))
@@ -186,7 +202,7 @@ def matrix_inverse_pth_root_eigh(matrix, p, ridge_epsilon=1e-6,
   ridge = F32(F32(ridge_epsilon) * np.maximum(F32(max_ev), F32(error_tolerance)))  # DS:1005
   regularized = matrix + ridge * identity  # DS:1006
   if np.all(np.isfinite(regularized)):
-    e, u = np.linalg.eigh(regularized)  # DS:1007 (LAPACK ssyevd, ascending)
+    e, u = eigh_fn(regularized)  # DS:1007 (LAPACK ssyevd in float32, ascending)
   else:  # all-padding block: max_ev is 0/0; XLA yields NaNs where LAPACK raises
     e, u = np.full(n, np.nan, F32), np.full((n, n), np.nan, F32)
   e = e.astype(F32)
@@ -221,6 +237,34 @@ def matrix_inverse_pth_root_eigh(matrix, p, ridge_epsilon=1e-6,
 
 # ---------------------------------------------------------------------------
 # DS:1440-1470 gram_weighted_update ; DS:2635-2636 weights
+# ---------------------------------------------------------------------------
+# accuracy yardstick (no counterpart in the reference)
+# ---------------------------------------------------------------------------
+def eigh_root_float64(matrix, p, ridge_epsilon=1e-6, error_tolerance=1e-6,
+                      relative_matrix_epsilon=True, padding_start=None):
+  """Float64 closed form of the eigh root of the float32 matrix every solver is handed:
+  D = A + ridge I is formed in float32 exactly as DS:995-1006 does (power-iteration lambda_max,
+  float32 addition); the eigendecomposition and DS:1012-1016 are then exact to float64.  The
+  distance of a float32 solver's root from this is ITS OWN rounding error (the reference's
+  ssyevd, the build's solvers), not the shared rounding of the ridge addition."""
+  a = np.asarray(matrix, F32)
+  n = a.shape[0]
+  ps = n if padding_start is None else int(padding_start)
+  out = np.zeros((n, n), np.float64)
+  if ps == 0:
+    return out
+  am = a[:ps, :ps]
+  if relative_matrix_epsilon:
+    _, max_ev, _ = power_iteration(am, 100, error_tolerance, None)
+  else:
+    max_ev = F32(1.0)
+  ridge = F32(F32(ridge_epsilon) * np.maximum(F32(max_ev), F32(error_tolerance)))
+  d32 = (am + ridge * np.eye(ps, dtype=F32)).astype(F32)
+  w, v = np.linalg.eigh(d32.astype(np.float64))
+  out[:ps, :ps] = (v * np.maximum(w, float(ridge)) ** (-1.0 / int(p))) @ v.T
+  return out
+
+
 # ---------------------------------------------------------------------------
 def gram_weighted_update(old_stats, g, axis, w1, w2):
   g = np.asarray(g, dtype=F32)
@@ -375,8 +419,9 @@ def fd_low_rank_pack(eigvecs, deflated, inverted, const, tail, has_zeros, rank):
 
 
 def low_rank_root(matrix, p, compression_rank, ridge_epsilon=1e-6, error_tolerance=1e-6,
-                  relative_matrix_epsilon=True, padding_start=None):
+                  relative_matrix_epsilon=True, padding_start=None, lapack="f32"):
   """DS:1033-1120, statement by statement (LAPACK ssyevd for jnp.linalg.eigh)."""
+  eigh_fn = _lapack_fns(lapack)[0]
   matrix = np.array(matrix, F32)
   d = matrix.shape[0]
   alpha = F32(-1.0 / int(p))
@@ -394,7 +439,7 @@ def low_rank_root(matrix, p, compression_rank, ridge_epsilon=1e-6, error_toleran
   ridge = F32(F32(ridge_epsilon) * np.maximum(F32(max_ev), F32(error_tolerance)))
   reg = matrix + ridge * identity
   if np.all(np.isfinite(reg)):
-    e, u = np.linalg.eigh(reg)
+    e, u = eigh_fn(reg)  # DS:1071
   else:
     e, u = np.full(d, np.nan, F32), np.full((d, d), np.nan, F32)
   e, u = e.astype(F32), u.astype(F32)
@@ -425,17 +470,18 @@ def low_rank_root(matrix, p, compression_rank, ridge_epsilon=1e-6, error_toleran
   return val, float(error)
 
 
-def frequent_directions_update(g, axis):
-  """DS:1497-1505: zero-padded R^T from qr(x^T, mode='r'); R R^T = x x^T."""
+def frequent_directions_update(g, axis, lapack="f32"):
+  """DS:1497-1505: zero-padded R^T from qr(x^T, mode='r') (LAPACK sgeqrf); R R^T = x x^T."""
   g = np.asarray(g, F32)
   x = np.reshape(np.moveaxis(g, axis, 0), (g.shape[axis], -1))
-  r = np.linalg.qr(x.T, mode="r").T
+  r = _lapack_fns(lapack)[2](np.ascontiguousarray(x.T)).T
   return np.pad(r, ((0, 0), (0, x.shape[0] - r.shape[1]))).astype(F32)
 
 
 def fd_update_root(new_grad, p, rank, ridge_epsilon=1e-6, error_tolerance=1e-6,
-                   relative_matrix_epsilon=True, decay=1.0, padding_start=None, prev=None):
-  """DS:1123-1290 (without FDDiagnostics), SVD by LAPACK sgesdd as in the reference."""
+                   relative_matrix_epsilon=True, decay=1.0, padding_start=None, prev=None,
+                   lapack="f32"):
+  """DS:1123-1290 (without FDDiagnostics), SVD by LAPACK sgesdd (float32) as in the reference."""
   new_grad = np.array(new_grad, F32)
   max_size = new_grad.shape[0]
   ps = max_size if padding_start is None else padding_start
@@ -449,7 +495,7 @@ def fd_update_root(new_grad, p, rank, ridge_epsilon=1e-6, error_tolerance=1e-6,
   weighted = (sketch * np.sqrt(fwd)).astype(F32)
   padded = new_grad * act_d * act_d[:, None]
   updated = np.concatenate([F32(np.sqrt(decay)) * weighted, padded], axis=1).astype(F32)
-  u, s, _ = np.linalg.svd(updated, full_matrices=False)
+  u, s, _ = _lapack_fns(lapack)[1](updated)  # DS:1193
   cutoff = s[rank]
   rho = cutoff ** 2
   top = s[:rank]
@@ -459,7 +505,9 @@ def fd_update_root(new_grad, p, rank, ridge_epsilon=1e-6, error_tolerance=1e-6,
   new_tail = F32(tail + rho)
   alpha = F32(-1.0 / int(p))
   with np.errstate(all="ignore"):
-    new_const = F32(0.0) if new_tail <= 0 else F32(new_tail ** alpha)
+    # np.power (the ufunc loop jnp.where(..., new_tail**alpha) runs over the stand-in), not the
+    # scalar `**`, which NumPy evaluates with a different powf and can differ by one ulp
+    new_const = F32(0.0) if new_tail <= 0 else F32(np.power(np.asarray(new_tail, F32), alpha))
   new_tail = F32(0.0) if new_tail <= 0 else new_tail
   deflated = np.where(deflated <= 0, F32(0.0), deflated).astype(F32)
   eigvecs = eigvecs * (deflated > 0)

@@ -112,6 +112,7 @@ PS_PRODUCTS = {"f32": 0, "bf16x6": 1, "bf16x3": 2}
 PS_ACCUM = {"segmented": 0, "chain": 1}
 PS_EXEC = {"staged": 0, "persistent": 1}
 PS_PI = {"auto": 0, "streaming": 1, "resident": 2}
+PS_EIGH = {"auto": 0, "two_sided": 1, "one_sided": 2, "tridiagonal": 3, "accurate": 4}
 
 
 class PsOptions(C.Structure):
@@ -132,6 +133,8 @@ class PsOptions(C.Structure):
       ("eigh_streams", C.c_int32),
       ("eigh_solver", C.c_int32),
       ("reserved", C.c_int32 * 5),
+      ("eigh_keep_max_cond", C.c_float),
+      ("reserved2", C.c_int32 * 3),
   ]
 
 
@@ -140,8 +143,9 @@ def make_options(options=None):
   accumulation ('segmented' | 'chain'), averaged_steps, iters_hint (host float array, one per
   block: last recompute's inverse_pth_root_iters), fast_max_iters, averaged_err_threshold,
   execution ('staged' | 'persistent'), power_iteration ('auto' | 'streaming' | 'resident'),
-  pi_timeout_ms, eigh_sweep_tol, eigh_streams, eigh_solver ('auto' | 'tridiagonal' | 'one_sided' | 'two_sided').  Unknown keys
-  raise."""
+  pi_timeout_ms, eigh_sweep_tol, eigh_streams, eigh_solver ('auto' | 'accurate' | 'tridiagonal' | 'one_sided' |
+  'two_sided'), eigh_keep_max_cond (the keep rule's lambda_max / lambda_min bound; inf = keep everything).
+  Unknown keys raise."""
   import numpy as np
   o = PsOptions()
   lib().ps_options_init(C.byref(o))
@@ -162,12 +166,12 @@ def make_options(options=None):
   enum("accumulation", PS_ACCUM)
   enum("execution", PS_EXEC)
   enum("power_iteration", PS_PI)
-  enum("eigh_solver", {"auto": 0, "two_sided": 1, "one_sided": 2, "tridiagonal": 3})
+  enum("eigh_solver", PS_EIGH)
   for key in ("averaged_steps", "fast_max_iters", "pi_timeout_ms", "eigh_streams"):
     if opts.get(key) is not None:
       setattr(o, key, int(opts[key]))
     opts.pop(key, None)
-  for key in ("averaged_err_threshold", "eigh_sweep_tol"):
+  for key in ("averaged_err_threshold", "eigh_sweep_tol", "eigh_keep_max_cond"):
     if opts.get(key) is not None:
       setattr(o, key, float(opts[key]))
     opts.pop(key, None)

@@ -1342,7 +1342,13 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
   hipStream_t st = (hipStream_t)stream;
   EPlan pl;
   make_eplan(pl, batch, n, padding_start);
-  finish_eplan(pl, false, (mode == 0 && !opt.eigh_td_force) ? opt.iters_hint : nullptr, opt.iters_hint_stride,
+  // The keep rule (a block's fast-path result stands only if positive definite with lambda_max / lambda_min
+  // below the bound) applies to plain eigenpairs always and to roots under eigh_solver ACCURATE; AUTO roots
+  // keep every block (the fast path is at or below a true float32 ssyevd's root error: options.h, ps_api.h).
+  const bool keep_rule = !opt.eigh_td_force && (mode == 1 || opt.eigh_td_accurate) &&
+                         opt.eigh_td_max_cond < 3.0e38f;
+  const float keep_cond = keep_rule ? opt.eigh_td_max_cond : 0.f;
+  finish_eplan(pl, false, (mode == 0 && keep_rule) ? opt.iters_hint : nullptr, opt.iters_hint_stride,
                2.f * opt.eigh_td_max_cond);
   pl.pip.set_options(opt);
   if (pl.max_n > 16384) return PS_EUNSUPPORTED;
@@ -1502,16 +1508,17 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
     // Blocks of 129 ... 4096 rows: tridiagonalisation + divide and conquer (eigh_td.hip.h).  One host
     // wait at its end tells whether any block hit an iteration cap (or the resident power iteration
     // expired); such a call starts over on the Jacobi solvers below.
-    // Blocks it keeps (all of them in mode 1; in root mode those whose spectrum spans less than
-    // eigh_td_max_cond: a float32 tridiagonalisation leaves eps * ||D|| of unstructured error, which
-    // the root function amplifies by ||D|| / lambda) are marked td_done and skipped by everything
-    // between here and the common finish; the others start over on the Jacobi solvers.
+    // Blocks it keeps (all of them unless the keep rule applies, see keep_cond above: then those whose
+    // spectrum spans less than eigh_td_max_cond -- a float32 tridiagonalisation leaves eps * ||D|| of
+    // unstructured error, which the root function amplifies by ||D|| / lambda, exactly as the reference's
+    // float32 ssyevd does) are marked td_done and skipped by everything between here and the common
+    // finish; the others start over on the Jacobi solvers.
     bool td_all = false;   // every block of more than 128 rows is done
     bool td_any = false;
     if (opt.eigh_td && any_big && !pl.td.empty()) {
       for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = td_run(st, pl.td, lo.td, lo.blocks, hb, opt.eigh_td_defl_eps, opt.eigh_td_stage,
-                         opt.eigh_td_force ? 0.f : opt.eigh_td_max_cond, opt.eigh_td_streams,
+                         keep_cond, opt.eigh_td_streams,
                          std::max(0, std::min(opt.eigh_td_tail, TD_TAIL)))))
           return rc;
         EStatus* slot = &status[63];

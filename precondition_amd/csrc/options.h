@@ -65,7 +65,8 @@ struct Options {
   int eigh_td_tail = 192;          // PS_EIGH_TD_TAIL: last columns of a block reduced inside LDS (0: off; <= 192)
   int quant_flat = 1;              // PS_QUANT_FLAT: chunks of consecutive elements for contiguous tensors (0 = 64 x 256 tiles for all)
   int eigh_td_force = 0;           // eigh_solver TRIDIAGONAL (PS_EIGH_TD_FORCE): every block keeps the fast path's result
-  float eigh_td_max_cond = 1e3f;   // PS_EIGH_TD_MAX_COND: AUTO keeps a block's result if it is positive definite with lambda_max / lambda_min below
+  float eigh_td_max_cond = 1e3f;   // PS_EIGH_TD_MAX_COND / ps_options.eigh_keep_max_cond: the ACCURATE rule keeps a block's result if it is positive definite with lambda_max / lambda_min below
+  int eigh_td_accurate = 0;        // eigh_solver ACCURATE: the rule above in root calls too (AUTO: root calls keep every block, plain eigh keeps the rule)
 };
 
 // PS_EINVAL-style validation is the caller's: resolve() clamps what it does not understand to the

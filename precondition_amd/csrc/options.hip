@@ -72,6 +72,7 @@ void ps_dev_env_overrides(Options& o) {
   geti("PS_EIGH_TD_TAIL", o.eigh_td_tail);
   getf("PS_EIGH_TD_MAX_COND", o.eigh_td_max_cond);
   geti("PS_EIGH_TD_FORCE", o.eigh_td_force);
+  geti("PS_EIGH_TD_ACCURATE", o.eigh_td_accurate);
   geti("PS_QUANT_FLAT", o.quant_flat);
 }
 
@@ -115,7 +116,12 @@ Options resolve(const ps_options* u, bool* bad) {
     if (c.eigh_solver == PS_EIGH_TWO_SIDED) { o.eigh_cj = 0; o.eigh_td = 0; }
     else if (c.eigh_solver == PS_EIGH_ONE_SIDED) o.eigh_td = 0;
     else if (c.eigh_solver == PS_EIGH_TRIDIAGONAL) o.eigh_td_force = 1;
+    else if (c.eigh_solver == PS_EIGH_ACCURATE) o.eigh_td_accurate = 1;
     else if (c.eigh_solver != PS_EIGH_AUTO && bad) *bad = true;
+    if (c.eigh_keep_max_cond > 0.f) {   // +inf included; NaN is not > 0
+      o.eigh_td_max_cond = c.eigh_keep_max_cond;
+      o.eigh_td_accurate = 1;           // an explicit bound applies wherever a rule could
+    }
   }
   ps_dev_env_overrides(o);
   return o;

@@ -148,10 +148,13 @@ def distributed_shampoo(
     # state is then rank-local: checkpoint every rank (or gather) to save it.
     shard_statistics: bool = False,
     # eigh=True only: which eigensolver roots the blocks of more than 128 rows (ps_options.eigh_solver).
-    # "auto" = tridiagonalisation + divide and conquer (the class of the reference's LAPACK ssyevd);
-    # blocks whose spectrum spans more than 1e3 -- rank-deficient statistics + ridge among them -- are
-    # handed to the one-sided Jacobi solver inside the call; "two_sided" reproduces LAPACK's result on
-    # such blocks to three digits at 2.7 x the time (include/ps_api.h).
+    # "auto" = tridiagonalisation + divide and conquer (the class of the reference's float32 LAPACK
+    # ssyevd, DS:35-38 / DS:1007), result kept for every block: at or below ssyevd's own root error on
+    # every statistics family measured (profiles/r06_eigh_keep_rule.json).  "accurate" = blocks whose
+    # spectrum spans more than 1e3 -- rank-deficient statistics + ridge among them -- are solved again
+    # by the one-sided Jacobi solver inside the call (10-300 x closer to the float64 root than the
+    # reference itself on such blocks, 2-3 x the time; the default until round 6); "two_sided"
+    # reproduces a float64-internal LAPACK result on such blocks to three digits (include/ps_api.h).
     eigh_solver: str = "auto",
     # Newton branch: the previous recompute's iteration counts (state.training_metrics) steer the
     # per-block accuracy policy of the next root call (ps_options.iters_hint: blocks that took <= 8
@@ -178,8 +181,9 @@ def distributed_shampoo(
   # (None, the reference's default there, means "highest the backend has").
   from .kernels import products_for_precision
   root_options = {"products": products_for_precision(precision)}
-  if eigh_solver not in ("auto", "tridiagonal", "one_sided", "two_sided"):
-    raise ValueError(f"eigh_solver must be auto | tridiagonal | one_sided | two_sided, found {eigh_solver!r}")
+  if eigh_solver not in ("auto", "accurate", "tridiagonal", "one_sided", "two_sided"):
+    raise ValueError("eigh_solver must be auto | accurate | tridiagonal | one_sided | two_sided, "
+                     f"found {eigh_solver!r}")
   if eigh and eigh_solver != "auto":
     root_options["eigh_solver"] = eigh_solver
   _eigh_memo = {"cond": None}   # _compute_preconditioners: every block's condition number at the last eigh recompute
@@ -658,20 +662,26 @@ def distributed_shampoo(
         flat = torch.cat([t_.reshape(-1).to(torch.float32) for t_ in its])
         if flat.numel() == len(sizes):
           iters_hint = flat.cpu().tolist()
-    # eigh path, default solver: the condition number every block had at the LAST recompute (metrics column 7 of
-    # the eigh rows).  Blocks far above the fast path's keep rule skip its attempt this time -- same bits (a
-    # hand-over starts the Jacobi solvers from scratch), minus the attempt's time; real Shampoo statistics are
-    # mostly ill conditioned.  The memo lives in the optimizer object, not in the state: a stale entry changes
-    # which of the two solvers roots a block (same accuracy class) or costs the attempt's time.
+    # eigh path, eigh_solver="accurate" (the only solver with a keep rule in root calls): the condition number
+    # every block had at the LAST recompute (metrics column 7 of the eigh rows).  Blocks far above the keep
+    # rule's bound skip the fast path's attempt this time -- same bits (a hand-over starts the Jacobi solvers
+    # from scratch), minus the attempt's time.  The memo lives in the optimizer object, not in the state: a
+    # stale entry changes which of the two solvers roots a block (both within the Jacobi solvers' accuracy) or
+    # costs the attempt's time; a run resumed from a checkpoint starts with an empty memo, so ITS "accurate"
+    # roots can differ from the uninterrupted run's in the last digits (iteration_count_hint=False for
+    # bit-reproducible restarts).  The default solver ("auto") keeps every block's fast-path result and
+    # neither reads nor needs the memo: its roots depend on the statistics alone.
     eigh_skip = None
-    if (eigh and iteration_count_hint and eigh_solver == "auto" and compression_rank == 0 and
+    if (eigh and iteration_count_hint and eigh_solver == "accurate" and compression_rank == 0 and
         not lobpcg_topk_precondition and _backend_for_testing is None):
       memo = _eigh_memo
       if memo["cond"] is not None and len(memo["cond"]) == len(sizes):
         eigh_skip = memo["cond"]
       elif len(klens) == len(sizes):
         # no recompute yet: a statistic that has seen fewer gradient columns than it has rows is rank
-        # deficient up to its epsilon (the usual state of the first recomputes): no attempt
+        # deficient up to its epsilon (the usual state of the first recomputes): no attempt.  A
+        # heuristic that costs time only: a block that has seen zero gradients (frozen parameter) is
+        # epsilon I, perfectly conditioned, and still goes to the Jacobi solvers once.
         updates = int(step) // max(int(statistics_compute_steps), 1) + 1
         eigh_skip = [float("inf") if updates * k < n else 0.0 for k, n in zip(klens, sizes)]
     if lobpcg_topk_precondition:
@@ -739,7 +749,7 @@ def distributed_shampoo(
         options=(root_options if (compute_fn is None and not lobpcg_topk_precondition) else None))
     mhost = metrics[:, :comm.METRICS_STRIDE].detach().cpu().numpy()   # one small D2H per recompute
     errors = mhost[:, 0]
-    if eigh and _backend_for_testing is None:
+    if eigh and eigh_solver == "accurate" and _backend_for_testing is None:
       _eigh_memo["cond"] = [float(v) for v in mhost[:, 7]]
     if quantize_second_moment:
       roots = [QuantizedValue(*_unpack(r, n), qdt_second_moment, True, [n, n])

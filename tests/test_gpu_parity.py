@@ -435,7 +435,14 @@ def test_eigh_root_hip_vs_reference_golden(device):
     if nrm == 0:
       assert not h.any() and met[i, 0] == 0.0, c["name"]
       continue
-    assert np.linalg.norm(h - ref) / nrm < 5e-5, (c["name"], np.linalg.norm(h - ref) / nrm)
+    # the golden is the reference over float32 ssyevd: two float32 solvers agree to the reference's own
+    # distance from the float64 root (index: root_error_vs_f64; 1e-6 on Wishart blocks, 4e-2 at cond 1e6),
+    # and the build must be at least as close to that root as the reference is
+    e_ref = c["root_error_vs_f64"]
+    assert np.linalg.norm(h - ref) / nrm < 3 * e_ref + 5e-5, (c["name"], np.linalg.norm(h - ref) / nrm, e_ref)
+    truth = orc.eigh_root_float64(z[c["name"] + "__a"], c["p"], padding_start=c["padding_start"])
+    e_hip = np.linalg.norm(h - truth) / np.linalg.norm(truth)
+    assert e_hip < 1.5 * e_ref + 3e-6, (c["name"], e_hip, e_ref)
     # error metric = max|u^T D u - diag(e)|: same order as LAPACK's (it measures the
     # solver's own residual, so only the magnitude is comparable)
     assert met[i, 0] <= max(4 * float(z[c["name"] + "__err"]), 1e-6 * float(np.abs(z[c["name"] + "__a"]).max()) * 64), \

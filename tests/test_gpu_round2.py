@@ -617,13 +617,16 @@ def test_power_iteration_concurrent_streams(device):
 @pytest.mark.parametrize("n,kind,p", [(169, "graded", 4), (512, "graded", 2), (260, "lowrank", 2),
                                       (1024, "graded", 4), (64, "graded", 2), (96, "graded", 4),
                                       (128, "lowrank", 4), (100, "lowrank", 2)])
-def test_eigh_root_accuracy_on_graded_spectra_near_lapack(n, kind, p, device):
-  """The eigh root (DS:943-1030) on spectra graded over six decades / rank-deficient + ridge:
-  the re-projection A <- V^T D V accumulated in float64 and finishing sweeps driven by the
-  SCALED off-diagonal entries bring the blocked Jacobi path to LAPACK-float32 accuracy (both
-  measured against the float64 closed form; it was 1e-2 ... 4e-2 with the absolute stopping
-  rule alone, LAPACK ~1e-4).  n <= 128: the LDS-resident one-sided solver with its float64
-  refresh of G = A V (it was 5e-4 ... 2e-3; now LAPACK's error to three digits)."""
+def test_eigh_root_accuracy_on_graded_spectra_vs_true_float32_lapack(n, kind, p, device):
+  """The eigh root (DS:943-1030) on spectra graded over six decades / rank-deficient + ridge, every error
+  measured against the float64 closed form of the same float32 matrix (oracle.eigh_root_float64):
+
+    default solver ("auto"): at or below the error of the reference's own arithmetic, a TRUE float32
+      ssyevd (oracle lapack="f32"; rounds 1-5 compared with NumPy's float64-internal eigh by mistake).
+      n > 128 keeps the tridiagonalisation path's result (no Jacobi sweep), n <= 128 is the LDS-resident
+      Jacobi solver;
+    "accurate": the Jacobi hand-over for ill-conditioned blocks -- near the float64-internal LAPACK
+      result (the bar of rounds 2-5, unchanged), decades below ssyevd."""
   from precondition_amd import kernels as K
   rng = np.random.default_rng(n + p)
   if kind == "lowrank":
@@ -632,21 +635,29 @@ def test_eigh_root_accuracy_on_graded_spectra_near_lapack(n, kind, p, device):
     q, _ = np.linalg.qr(rng.standard_normal((n, n)))
     a = (q * 10.0 ** rng.uniform(-4, 2, n)) @ q.T
   a = ((a + a.T) / 2).astype(np.float32)
-  a64 = a.astype(np.float64)
-  ridge = 1e-6 * np.linalg.eigvalsh(a64).max()
-  w, v = np.linalg.eigh(a64 + ridge * np.eye(n))
-  f = lambda e: np.maximum(e, ridge) ** (-1.0 / p)
-  truth = (v * f(w)) @ v.T
-  d32 = (a + np.float32(ridge) * np.eye(n, dtype=np.float32)).astype(np.float32)
-  wl, vl = np.linalg.eigh(d32)
-  lap = (vl.astype(np.float64) * f(wl.astype(np.float64))) @ vl.T.astype(np.float64)
-  roots, _ = K.matrix_inverse_pth_root_batched([torch.tensor(a, device=device)], [p], [n],
-                                               eigh=True)
-  got = roots[0].cpu().numpy().astype(np.float64)
+  truth = orc.eigh_root_float64(a, p)
   tn = np.linalg.norm(truth)
-  e_hip, e_lap = np.linalg.norm(got - truth) / tn, np.linalg.norm(lap - truth) / tn
-  assert e_hip < 6 * e_lap + 2e-4, (e_hip, e_lap)
-  assert e_hip < 2e-3
+  h32, m32 = orc.matrix_inverse_pth_root_eigh(a, p, lapack="f32")
+  h64, _ = orc.matrix_inverse_pth_root_eigh(a, p, lapack="f64")
+  e_ssyevd, e_yard = np.linalg.norm(h32 - truth) / tn, np.linalg.norm(h64 - truth) / tn
+  assert e_ssyevd > 20 * e_yard                                   # these inputs tell the two apart
+  t = torch.tensor(a, device=device)
+  roots, met = K.matrix_inverse_pth_root_batched([t], [p], [n], eigh=True)
+  e_auto = np.linalg.norm(roots[0].cpu().numpy().astype(np.float64) - truth) / tn
+  assert e_auto < 1.25 * e_ssyevd + 2e-6, (e_auto, e_ssyevd)
+  met = met.cpu().numpy()
+  if n > 128:
+    assert met[0, 5] == 0, "auto keeps the fast path's result: no Jacobi sweep"
+  # the reference's error metric (DS:1017-1021) of the build's eigenpairs is of ssyevd's size
+  assert met[0, 0] < 4 * m32["inverse_pth_root_errors"] + 1e-6 * float(np.abs(a).max()), (met[0, 0], m32)
+  roots, met = K.matrix_inverse_pth_root_batched([t], [p], [n], eigh=True, options={"eigh_solver": "accurate"})
+  e_acc = np.linalg.norm(roots[0].cpu().numpy().astype(np.float64) - truth) / tn
+  # (rank-deficient + ridge: the null-space cluster sits at the kink of max(e, ridge)^(-1/p); the Jacobi
+  # solvers are 5e-4 ... 1e-3 from the float64 root there, ssyevd 1e-2 ... 2e-2)
+  assert (e_acc < 6 * e_yard + 2e-4 or e_acc < 0.1 * e_ssyevd) and e_acc < 2e-3, (e_acc, e_yard, e_ssyevd)
+  assert e_acc < 0.5 * e_ssyevd
+  if n > 128:
+    assert met.cpu().numpy()[0, 5] > 0, "accurate: the ill-conditioned block was handed to the Jacobi solver"
 
 
 def test_comm_entry_points_one_rank_rccl(device):

@@ -173,8 +173,8 @@ def test_low_rank_root_bottom_eigenpairs_of_graded_matrices_default_solver(devic
 
 
 def test_eigh_skip_hint_sends_blocks_straight_to_the_jacobi_solvers_same_bits(device):
-  """ps_options.iters_hint in an eigh root call = the blocks' condition numbers at the last recompute (metrics
-  column 7); far above the keep rule's bound the block skips the fast path's attempt.  For an ill-conditioned block that changes nothing but the time (same
+  """ps_options.iters_hint in an eigh root call under eigh_solver="accurate" = the blocks' condition numbers at
+  the last recompute (metrics column 7); far above the keep rule's bound the block skips the fast path's attempt.  For an ill-conditioned block that changes nothing but the time (same
   bits as without the hint); a well-conditioned block with the hint is solved by the Jacobi solver (sweeps
   counted) to the same accuracy; its unhinted neighbour stays on the fast path."""
   rng = np.random.default_rng(21)
@@ -183,9 +183,16 @@ def test_eigh_skip_hint_sends_blocks_straight_to_the_jacobi_solvers_same_bits(de
   graded = (graded + graded.T) / 2
   mats = [graded, wishart(320, 1300, 31), wishart(256, 1100, 32)]
   ts = [torch.tensor(a, device=device) for a in mats]
-  r0, m0 = K().matrix_inverse_pth_root_batched(ts, [2, 2, 4], eigh=True)
+  acc = {"eigh_solver": "accurate"}   # the solver with a keep rule in root calls (the default keeps every block)
+  r0, m0 = K().matrix_inverse_pth_root_batched(ts, [2, 2, 4], eigh=True, options=acc)
   assert m0.cpu().numpy()[0, 7] > 2e3 and 1.0 < m0.cpu().numpy()[1, 7] < 1e3   # the blocks' condition numbers
-  r1, m1 = K().matrix_inverse_pth_root_batched(ts, [2, 2, 4], eigh=True, options={"iters_hint": [1e5, 1e5, 30.0]})
+  r1, m1 = K().matrix_inverse_pth_root_batched(ts, [2, 2, 4], eigh=True,
+                                               options=dict(acc, iters_hint=[1e5, 1e5, 30.0]))
+  # the default solver ignores the hint: no Jacobi sweep anywhere, same bits with and without it
+  rd0, md0 = K().matrix_inverse_pth_root_batched(ts, [2, 2, 4], eigh=True)
+  rd1, md1 = K().matrix_inverse_pth_root_batched(ts, [2, 2, 4], eigh=True, options={"iters_hint": [1e5, 1e5, 30.0]})
+  assert not md0.cpu().numpy()[:, 5].any() and torch.equal(md0, md1)
+  assert all(torch.equal(x, y) for x, y in zip(rd0, rd1))
   m0, m1 = m0.cpu().numpy(), m1.cpu().numpy()
   assert m0[0, 5] > 0 and m0[1, 5] == 0 and m0[2, 5] == 0
   assert m1[0, 5] > 0 and m1[1, 5] > 0 and m1[2, 5] == 0
@@ -195,7 +202,7 @@ def test_eigh_skip_hint_sends_blocks_straight_to_the_jacobi_solvers_same_bits(de
 
 
 def test_optimizer_eigh_condition_memo_changes_time_not_bits(device):
-  """distributed_shampoo(eigh=True): the optimizer hands every block's last condition number (and, before the
+  """distributed_shampoo(eigh=True, eigh_solver="accurate"): the optimizer hands every block's last condition number (and, before the
   first recompute, the rank bound of its statistic) back to the root call so that ill-conditioned blocks skip
   the fast path's attempt.  A hinted block gets the bits it would get after a hand-over; a STALE hint (the
   statistic's rank grows between the first recomputes) only changes which of the two solvers roots a block, so
@@ -207,7 +214,8 @@ def test_optimizer_eigh_condition_memo_changes_time_not_bits(device):
   outs = {}
   for hint in (True, False):
     opt = pa.distributed_shampoo(0.1, 512, eigh=True, preconditioning_compute_steps=2, start_preconditioning_step=1,
-                                 graft_type=pa.GraftingType.RMSPROP_NORMALIZED, iteration_count_hint=hint)
+                                 graft_type=pa.GraftingType.RMSPROP_NORMALIZED, iteration_count_hint=hint,
+                                 eigh_solver="accurate")
     st = opt.init(params)
     ups = []
     for t in range(6):
@@ -223,8 +231,8 @@ def test_optimizer_eigh_condition_memo_changes_time_not_bits(device):
 
 def test_eigh_ill_conditioned_blocks_take_the_jacobi_solver_in_the_same_call(device):
   """A float32 tridiagonalisation leaves eps * ||D|| of unstructured error, which lambda^(-1/p)
-  amplifies by ||D|| / lambda: blocks with lambda_max / lambda_min > 1e3 (ps_options default) are
-  handed to the one-sided block Jacobi on the Cholesky factor (relative accuracy on small
+  amplifies by ||D|| / lambda (as the reference's float32 ssyevd does).  eigh_solver="accurate": blocks with
+  lambda_max / lambda_min > 1e3 (eigh_keep_max_cond) are handed to the one-sided block Jacobi on the Cholesky factor (relative accuracy on small
   eigenvalues) inside the call.  Their roots are bit-identical to a call pinned to that solver;
   the well-conditioned blocks of the same call stay on the fast path."""
   rng = np.random.default_rng(12)
@@ -235,7 +243,7 @@ def test_eigh_ill_conditioned_blocks_take_the_jacobi_solver_in_the_same_call(dev
   mats = [wishart(512, 2048, 1), graded, wishart(300, 1200, 2), lowrank]
   ts = [torch.tensor(m, device=device) for m in mats]
   ps = [2, 4, 2, 2]
-  r_auto, m_auto = K().matrix_inverse_pth_root_batched(ts, ps, eigh=True)
+  r_auto, m_auto = K().matrix_inverse_pth_root_batched(ts, ps, eigh=True, options={"eigh_solver": "accurate"})
   r_jac, m_jac = K().matrix_inverse_pth_root_batched(ts, ps, eigh=True, options={"eigh_solver": "one_sided"})
   m_auto, m_jac = m_auto.cpu().numpy(), m_jac.cpu().numpy()
   assert m_auto[0, 5] == 0 and m_auto[2, 5] == 0          # no Jacobi sweeps on the Wishart blocks
@@ -246,7 +254,7 @@ def test_eigh_ill_conditioned_blocks_take_the_jacobi_solver_in_the_same_call(dev
     d = (r_auto[i] - r_jac[i]).norm() / r_jac[i].norm()
     assert float(d) < 1e-5
   for a, p, h in zip(mats, ps, r_auto):
-    h_ref, _ = orc.matrix_inverse_pth_root_eigh(a, p)
+    h_ref, _ = orc.matrix_inverse_pth_root_eigh(a, p, lapack="f64")   # the yardstick, not the reference's ssyevd
     w, v = np.linalg.eigh(a.astype(np.float64))
     _, lam_pi, _ = orc.power_iteration(a, 100, 1e-6)
     eps = 1e-6 * max(float(lam_pi), 1e-6)

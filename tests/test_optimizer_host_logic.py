@@ -61,7 +61,15 @@ def run_e2e_case(c, z, device, backend, skip_params=(), group=None, extra_kwargs
       ref = z[f"{name}__upd{i}_t{t}"]
       got = upd[i].cpu().numpy()
       assert got.dtype == np.float32 and got.shape == ref.shape
-      err = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+      dist = np.linalg.norm(got - ref)
+      # configurations that reach LAPACK (eigh / low-rank / FD roots) carry the same run over a float64-
+      # internal LAPACK: twice the distance between the two goldens -- the reference's own float32
+      # arithmetic uncertainty (bottom eigenpairs of rank-deficient statistics are rounding noise in
+      # ssyevd) -- is not held against the build
+      alt = f"{name}__upd{i}_t{t}_f64lapack"
+      if alt in z.files:
+        dist = max(0.0, dist - 2.0 * np.linalg.norm(ref - z[alt]))
+      err = dist / max(np.linalg.norm(ref), 1e-30)
       worst = max(worst, err)
   assert int(st.count) == c["count"]
   return st, worst
@@ -90,9 +98,12 @@ def stat_matches(mine, ref, quantized=False):
   return np.allclose(mine, ref @ ref.T, rtol=1e-4, atol=1e-5 * max(np.abs(mine).max(), 1e-30))
 
 
-def packed_matches(mine, ref, rank, tol=2e-3):
+def packed_matches(mine, ref, rank, tol=2e-3, alt=None):
   """Rank-compressed preconditioner [d, r+2] (DS:555-592): scalars by value;
-  eigenvectors only through what the application uses, sum_i w_i v_i v_i^T."""
+  eigenvectors only through what the application uses, sum_i w_i v_i v_i^T.
+  `alt`: the same quantity from the reference over a float64-internal LAPACK (the goldens are float32
+  LAPACK): twice its distance from `ref`, the reference's own arithmetic uncertainty, is added to the
+  tolerance of the scalars."""
   r = abs(rank)
   ok = True
   slices = [(slice(0, r), -2), (slice(-r, None), -1)]
@@ -100,7 +111,8 @@ def packed_matches(mine, ref, rank, tol=2e-3):
     slices.append((slice(0, 2), -1))
   for sl in slices:
     a, b = mine[sl], ref[sl]
-    ok &= bool(np.allclose(a, b, rtol=tol, atol=tol * max(np.abs(b).max(), 1e-30)))
+    slack = 0.0 if alt is None else 2.0 * float(np.abs(b - alt[sl]).max())
+    ok &= bool(np.allclose(a, b, rtol=tol, atol=tol * max(np.abs(b).max(), 1e-30) + slack))
   ok &= bool(mine[-1, -2] == ref[-1, -2])
   if rank > 0:
     # (rank < 0 keeps the SMALLEST eigenpairs, which for few-sample statistics sit
@@ -129,11 +141,14 @@ def check_final_state(case, z, st, skip_params=()):
       ref = z[f"{name}__precond{i}_{j}"]
       got = np_float(x)
       assert got.shape == ref.shape, (name, i, j, got.shape, ref.shape)
+      akey = f"{name}__precond{i}_{j}_f64lapack"
+      alt = z[akey] if akey in z.files else None
       if ref.shape[0] != ref.shape[1]:
-        assert packed_matches(got, ref, rank), (name, i, j)
+        assert packed_matches(got, ref, rank, alt=alt), (name, i, j)
       else:
         # few-sample statistics are ill conditioned (cond ~ 1e6): roots move by ~1e-2
-        assert np.linalg.norm(got - ref) <= 3e-2 * np.linalg.norm(ref), (name, i, j)
+        slack = 0.0 if alt is None else 2.0 * np.linalg.norm(ref - alt)
+        assert np.linalg.norm(got - ref) <= 3e-2 * np.linalg.norm(ref) + slack, (name, i, j)
 
 
 def check_momentum(case, z, st, skip_params=(), tol=2e-3):

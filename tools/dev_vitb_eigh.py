@@ -1,4 +1,4 @@
-"""Dev (round 5): the optimizer with eigh=True on a ViT-B/16-shaped tree (395 statistics of 197 ... 1024 rows, real
+"""Dev (rounds 5-6): the optimizer with eigh=True on a ViT-B/16-shaped tree (395 statistics of 197 ... 1024 rows, real
 Shampoo statistics: rank-deficient early on): a few steps incl. recomputes, finite updates, time per recompute step, how
 many blocks the fast path kept."""
 import os
@@ -18,7 +18,9 @@ def make_grad(r, s):
   if lowrank and len(s) == 2 and min(s) > 8:
     return (r.standard_normal((s[0], 8)) @ r.standard_normal((8, s[1])) * 0.02 / 3).astype(np.float32)
   return np.asarray(r.standard_normal(s) * 0.02, np.float32)
-for solver, hint in (("auto", True), ("auto", False), ("one_sided", True)):
+# round 6: "auto" keeps every block's fast-path result (at or below a true float32 ssyevd's root error);
+# "accurate" is round 5's default (Jacobi hand-over above cond 1e3, with / without the optimizer's memo)
+for solver, hint in (("auto", True), ("accurate", True), ("accurate", False), ("one_sided", True)):
   opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=2, start_preconditioning_step=1, eigh=True,
                                eigh_solver=solver, graft_type=pa.GraftingType.RMSPROP_NORMALIZED,
                                iteration_count_hint=hint)

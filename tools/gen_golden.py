@@ -10,8 +10,15 @@ While generating, every numerical case is also run through oracle/ and the
 two are required to agree bit for bit on this machine (same NumPy/OpenBLAS op
 sequence); the flag is stored in each fixture as ``oracle_bitexact_at_gen``.
 
+LAPACK-delegated sites (jnp.linalg.eigh / svd / qr: DS:1007, 1071, 1193, 1502) run the
+SINGLE-PRECISION routines jax's CPU path runs (ssyevd / sgesdd / sgeqrf through
+scipy.linalg.lapack, oracle/lapack32.py) since round 6; every fixture of such a site also
+carries the float64-internal result NumPy would give (``*_f64lapack`` keys, the accuracy
+yardstick: what rounds 1-5 stored as the golden by mistake).
+
 Usage:  python tools/gen_golden.py            (writes tests/golden/)
 """
+import contextlib
 import dataclasses
 import json
 import os
@@ -34,6 +41,20 @@ from oracle import shampoo_oracle as orc  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
 F32 = np.float32
+
+
+@contextlib.contextmanager
+def f64_lapack():
+  """Runs the reference with NumPy's float64-internal eigh / svd / qr (yardstick fixtures)."""
+  os.environ["REFSHIM_LAPACK"] = "f64"
+  try:
+    yield
+  finally:
+    os.environ.pop("REFSHIM_LAPACK")
+
+
+def root_f64(a, p, ridge_epsilon=1e-6, padding_start=None):
+  return orc.eigh_root_float64(a, p, ridge_epsilon, padding_start=padding_start)
 
 
 def npy(x):
@@ -199,6 +220,14 @@ def gen_power_iteration_and_matpower():
   np.savez_compressed(os.path.join(OUT, "power_iter_matpower.npz"), **out)
 
 
+def graded_matrix(n, seed):
+  """Haar Q, eigenvalues 10^U(-4, 2): six decades, unordered."""
+  rng = np.random.default_rng(seed)
+  q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  a = (q * 10.0 ** rng.uniform(-4, 2, n)) @ q.T
+  return ((a + a.T) / 2).astype(F32)
+
+
 def gen_eigh():
   out = {}
   idx = []
@@ -209,21 +238,42 @@ def gen_eigh():
       ("padded20in32_p2", orc.pad_square_matrix(wishart(20, 80, 3), 32), 2, 20),
       ("all_padding_n10", np.eye(10, dtype=F32), 2, 0),
       ("ragged200_p2", wishart(200, 800, 21), 2, None),
+      # ill-conditioned statistics: where float32 ssyevd and a float64-internal eigh part ways
+      ("graded169_cond1e4_p4", spectrum_matrix(169, 1e4, 31), 4, None),
+      ("graded130_cond1e6_p2", spectrum_matrix(130, 1e6, 32), 2, None),
+      ("loguniform200_p4", graded_matrix(200, 33), 4, None),
+      ("rank_deficient160_p2", wishart(160, 40, 34), 2, None),
   ]
   for nm, a, p, ps in cases:
-    h, m = ds.matrix_inverse_pth_root(jnp.array(a), p, ridge_epsilon=1e-6,
-                                      padding_start=ps, eigh=True)
-    h = npy(h)
-    err = float(np.asarray(m.inverse_pth_root_errors))
+    def run():
+      h, m = ds.matrix_inverse_pth_root(jnp.array(a), p, ridge_epsilon=1e-6,
+                                        padding_start=ps, eigh=True)
+      return npy(h), float(np.asarray(m.inverse_pth_root_errors)), float(np.asarray(m.max_eigen_value))
+    h, err, max_ev = run()
+    assert h.dtype == F32
+    with f64_lapack():
+      h64, err64, _ = run()
     ho, mo = orc.matrix_inverse_pth_root_eigh(a, p, padding_start=ps)
     bx = bitexact(h, ho) and np.float32(err) == np.float32(
         mo["inverse_pth_root_errors"])
-    print(f"eigh {nm}: err={err:.3e} oracle_bitexact={bx}")
+    ho64, mo64 = orc.matrix_inverse_pth_root_eigh(a, p, padding_start=ps, lapack="f64")
+    bx = bx and bitexact(h64, ho64) and np.float32(err64) == np.float32(mo64["inverse_pth_root_errors"])
+    e_ref = e_yard = 0.0
+    if ps != 0:
+      truth = root_f64(a, p, 1e-6, ps)
+      tn = np.linalg.norm(truth)
+      e_ref = float(np.linalg.norm(h - truth) / tn)
+      e_yard = float(np.linalg.norm(h64 - truth) / tn)
+    print(f"eigh {nm}: err={err:.3e} (f64-internal {err64:.3e}) root error vs float64: "
+          f"ssyevd {e_ref:.2e}, f64-internal {e_yard:.2e} oracle_bitexact={bx}")
     assert bx, nm
     out[nm + "__a"] = a
     out[nm + "__root"] = h
     out[nm + "__err"] = np.array(err, F32)
-    idx.append(dict(name=nm, p=p, padding_start=ps))
+    out[nm + "__root_f64lapack"] = h64
+    out[nm + "__err_f64lapack"] = np.array(err64, F32)
+    idx.append(dict(name=nm, p=p, padding_start=ps, lapack="ssyevd (float32)",
+                    root_error_vs_f64=e_ref, root_error_vs_f64_f64lapack=e_yard))
   np.savez_compressed(os.path.join(OUT, "eigh_root.npz"), **out)
   with open(os.path.join(OUT, "eigh_root_index.json"), "w") as f:
     json.dump(idx, f, indent=1)
@@ -449,6 +499,22 @@ def _run_e2e_configs(configs, grads_small, npz_name, index_name):
       ups.append(tuple(npy(u) for u in upd))
       for u in upd:
         assert np.asarray(u).dtype == F32
+    # configurations that reach LAPACK (eigh / low-rank / FD roots): the same run over NumPy's
+    # float64-internal routines, stored beside the float32-LAPACK goldens -- the distance between the
+    # two is the reference's OWN arithmetic uncertainty (bottom eigenpairs of rank-deficient
+    # statistics are rounding noise in float32 ssyevd), which the tests add to their tolerances
+    if kw.get("eigh") or kw.get("compression_rank"):
+      with f64_lapack():
+        opt64 = ds.distributed_shampoo(lr, batch_axis_name=axis, **kw)
+        st64 = opt64.init(p_j)
+        for t in range(steps):
+          with np.errstate(all="ignore"):
+            upd64, st64 = opt64.update(tuple(jnp.array(x) for x in grs[t]), st64, p_j)
+          for i, u in enumerate(upd64):
+            out[f"{name}__upd{i}_t{t}_f64lapack"] = npy(u)
+        for i in range(len(params)):
+          for j, x in enumerate(st64.stats[i].preconditioners):
+            out[f"{name}__precond{i}_{j}_f64lapack"] = npy(x)
     for i, p in enumerate(params):
       out[f"{name}__param{i}"] = p
       for t in range(steps):
@@ -628,9 +694,18 @@ def gen_lowrank():
     with np.errstate(all="ignore"):
       r, m = ds._low_rank_root(jnp.array(a), p, compression_rank=rank, ridge_epsilon=ridge,
                                relative_matrix_epsilon=rel, padding_start=ps)
+    with np.errstate(all="ignore"), f64_lapack():
+      r64, m64 = ds._low_rank_root(jnp.array(a), p, compression_rank=rank, ridge_epsilon=ridge,
+                                   relative_matrix_epsilon=rel, padding_start=ps)
+    ro, eo = orc.low_rank_root(a, p, rank, ridge_epsilon=ridge, relative_matrix_epsilon=rel,
+                               padding_start=ps)
+    assert bitexact(npy(r), ro) and np.float32(eo) == np.float32(
+        float(np.asarray(m.inverse_pth_root_errors))), name
     out[f"lr_{name}__a"] = a.astype(F32)
     out[f"lr_{name}__packed"] = npy(r)
     out[f"lr_{name}__err"] = np.array(float(np.asarray(m.inverse_pth_root_errors)), F32)
+    out[f"lr_{name}__packed_f64lapack"] = npy(r64)
+    out[f"lr_{name}__err_f64lapack"] = np.array(float(np.asarray(m64.inverse_pth_root_errors)), F32)
     index.append(dict(kind="low_rank_root", name=name, p=p, rank=rank, ridge=ridge,
                       rel=rel, padding_start=ps))
     print("low_rank_root", name, "err", float(np.asarray(m.inverse_pth_root_errors)))
@@ -647,27 +722,41 @@ def gen_lowrank():
   lr_case("padded24in32_rm3", pa, 2, -3, 1e-6, True, 24)
 
   def fd_chain(name, d, rank, p, ps, decay, rel, ridge, steps, seed):
-    r = np.random.default_rng(seed)
-    prev = jnp.zeros((d, rank + 2), jnp.float32)
-    for t in range(steps):
-      g = r.standard_normal((ps, 3 * ps)).astype(F32) * (1.0 + 0.3 * t)
-      # directions with clear gaps so that the top-rank subspace is well defined
-      g[:rank + 2] *= np.linspace(6.0, 2.0, rank + 2)[:, None].astype(F32)
-      gfull = np.zeros((d, g.shape[1]), F32); gfull[:ps] = g
-      fac = ds.frequent_directions_update(None, jnp.array(gfull), 0, 0.0, 0.0)
-      out[f"fd_{name}__grad{t}"] = gfull
-      out[f"fd_{name}__factor{t}"] = npy(fac)
-      with np.errstate(all="ignore"):
-        new, _ = ds._fd_update_root(fac, p, rank=rank, ridge_epsilon=ridge,
-                                    relative_matrix_epsilon=rel, decay=decay,
-                                    padding_start=ps, prev=prev, error_tolerance=0.0)
-      out[f"fd_{name}__prev{t}"] = npy(prev)
-      out[f"fd_{name}__new{t}"] = npy(new)
-      prev = new
-    index.append(dict(kind="fd_chain", name=name, d=d, rank=rank, p=p, padding_start=ps,
-                      decay=decay, rel=rel, ridge=ridge, steps=steps))
-    ev = np.asarray(ds._fd_low_rank_unpack(prev, rank)[1])
-    print("fd_chain", name, "final deflated eigs", ev[:4], "tail", float(np.asarray(prev)[1, -1]))
+    for sfx, ctx, lp in (("", contextlib.nullcontext, "f32"), ("_f64lapack", f64_lapack, "f64")):
+      r = np.random.default_rng(seed)
+      prev = jnp.zeros((d, rank + 2), jnp.float32)
+      prev_o = np.zeros((d, rank + 2), F32)
+      for t in range(steps):
+        g = r.standard_normal((ps, 3 * ps)).astype(F32) * (1.0 + 0.3 * t)
+        # directions with clear gaps so that the top-rank subspace is well defined
+        g[:rank + 2] *= np.linspace(6.0, 2.0, rank + 2)[:, None].astype(F32)
+        gfull = np.zeros((d, g.shape[1]), F32); gfull[:ps] = g
+        with ctx():
+          fac = ds.frequent_directions_update(None, jnp.array(gfull), 0, 0.0, 0.0)
+          with np.errstate(all="ignore"):
+            new, _ = ds._fd_update_root(fac, p, rank=rank, ridge_epsilon=ridge,
+                                        relative_matrix_epsilon=rel, decay=decay,
+                                        padding_start=ps, prev=prev, error_tolerance=0.0)
+        # the oracle follows the reference bit for bit through sgeqrf / sgesdd as well
+        fac_o = orc.frequent_directions_update(gfull, 0, lapack=lp)
+        assert bitexact(npy(fac), fac_o), (name, t, "factor")
+        with np.errstate(all="ignore"):
+          new_o = orc.fd_update_root(fac_o, p, rank, ridge_epsilon=ridge, error_tolerance=0.0,
+                                     relative_matrix_epsilon=rel, decay=decay, padding_start=ps,
+                                     prev=prev_o, lapack=lp)
+        assert bitexact(npy(new), new_o), (name, t, "sketch")
+        if not sfx:
+          out[f"fd_{name}__grad{t}"] = gfull
+          out[f"fd_{name}__prev{t}"] = npy(prev)
+        out[f"fd_{name}__factor{t}{sfx}"] = npy(fac)
+        out[f"fd_{name}__new{t}{sfx}"] = npy(new)
+        prev = new
+        prev_o = new_o
+      if not sfx:
+        index.append(dict(kind="fd_chain", name=name, d=d, rank=rank, p=p, padding_start=ps,
+                          decay=decay, rel=rel, ridge=ridge, steps=steps, lapack="sgeqrf / sgesdd (float32)"))
+        ev = np.asarray(ds._fd_low_rank_unpack(prev, rank)[1])
+        print("fd_chain", name, "final deflated eigs", ev[:4], "tail", float(np.asarray(prev)[1, -1]))
 
   fd_chain("d24_r4_p2", 24, 4, 2, 24, 1.0, False, 0.0, 3, 1)
   fd_chain("d24_r4_p4_decay", 24, 4, 4, 24, 0.9, True, 1e-6, 3, 2)
@@ -727,20 +816,22 @@ def gen_lowrank_big():
   out, index = {}, []
   for name, d, rank, p, decay, steps, seed in (("d1024_r8", 1024, 8, 4, 0.999, 2, 21),
                                                ("d2048_r64", 2048, 64, 4, 0.999, 2, 22)):
-    rng = np.random.default_rng(seed)
-    prev = jnp.zeros((d, rank + 2), jnp.float32)
-    for t in range(steps):
-      g = fd_big_grad(d, rank, t, rng)
-      fac = ds.frequent_directions_update(None, jnp.array(g), 0, 0.0, 0.0)
-      with np.errstate(all="ignore"):
-        new, _ = ds._fd_update_root(fac, p, rank=rank, ridge_epsilon=1e-6,
-                                    relative_matrix_epsilon=True, decay=decay,
-                                    padding_start=d, prev=prev, error_tolerance=0.0)
-      assert np.asarray(new).dtype == np.float32
-      out[f"fd_{name}__new{t}"] = npy(new)
-      prev = new
-      print("fd_big", name, "step", t, "tail", float(np.asarray(new)[1, -1]),
-            "const", float(np.asarray(new)[0, -1]))
+    for sfx, ctx in (("", contextlib.nullcontext), ("_f64lapack", f64_lapack)):
+      rng = np.random.default_rng(seed)
+      prev = jnp.zeros((d, rank + 2), jnp.float32)
+      for t in range(steps):
+        g = fd_big_grad(d, rank, t, rng)
+        with ctx():
+          fac = ds.frequent_directions_update(None, jnp.array(g), 0, 0.0, 0.0)
+          with np.errstate(all="ignore"):
+            new, _ = ds._fd_update_root(fac, p, rank=rank, ridge_epsilon=1e-6,
+                                        relative_matrix_epsilon=True, decay=decay,
+                                        padding_start=d, prev=prev, error_tolerance=0.0)
+        assert np.asarray(new).dtype == np.float32
+        out[f"fd_{name}__new{t}{sfx}"] = npy(new)
+        prev = new
+        print("fd_big", name, sfx or "sgeqrf/sgesdd", "step", t, "tail", float(np.asarray(new)[1, -1]),
+              "const", float(np.asarray(new)[0, -1]))
     index.append(dict(kind="fd_chain_big", name=name, d=d, rank=rank, p=p, padding_start=d,
                       decay=decay, rel=True, ridge=1e-6, steps=steps, seed=seed))
   np.savez_compressed(os.path.join(OUT, "low_rank_big.npz"), **out)
