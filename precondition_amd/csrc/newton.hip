@@ -649,14 +649,16 @@ __device__ inline void finish_try(NewtonState* st) {
 
 // mode 0: after init2 (enter the inner loop, DS:874-877); mode 1: after one
 // Newton step (DS:848 carry + DS:836-840 condition).
+// ids (may be NULL = blocks 0 .. nblocks - 1): the blocks of one stream group (newton_driver).
 __global__ __launch_bounds__(256) void newton_control_kernel(
     NewtonState* states, int nblocks, int mode, int num_iters, float tol, int gen,
-    HostStatus* status, float avg_thr) {
+    HostStatus* status, float avg_thr, const int* ids = nullptr) {
   __shared__ int s_nd, s_ni;
   if (threadIdx.x == 0) { s_nd = 0; s_ni = 0; }
   __syncthreads();
   int nd = 0, ni = 0;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+  for (int k = threadIdx.x; k < nblocks; k += blockDim.x) {
+    const int b = ids ? ids[k] : k;
     NewtonState* st = &states[b];
     if (mode == 0 && st->phase == PH_INIT) {
       st->err = __uint_as_float(st->err_bits);
@@ -1153,10 +1155,17 @@ struct Plan {
   // the same tiles in the order used while M updates are averaged (two-pass tiles first)
   std::vector<std::vector<TileEntry>> stage_tiles_avg;
   std::vector<TileEntry> init_tiles;  // one per (block, tile)
+  // stream groups (staged execution): the tile lists above are group-major; group g owns the
+  // slice [goff[s][g], goff[s][g + 1]) of stage s (ioff: of the init list) and the blocks gids[g]
+  int ngroups = 1;
+  std::vector<std::vector<int>> goff;   // [nstages][ngroups + 1]
+  std::vector<int> ioff;                // [ngroups + 1]
+  std::vector<std::vector<int>> gids;   // [ngroups] block ids, ascending
   PiPlan pip;
   int max_n = 0;
   bool ok = true;
 };
+constexpr int MAX_GROUPS = 4;
 
 // Which execution a call takes (read per call: tests and A/B runs flip it inside one
 // process).  Default = staged: measured on MI355X (profiles/r02_*), cfg2 256 x 512^2:
@@ -1167,8 +1176,11 @@ struct Plan {
 // persistent kernel (no host round trip at all: the call only enqueues).
 // (selected per call: ps_options.execution)
 
+// groups: stream groups of the staged execution (newton_driver); weight (may be NULL): relative number of
+// Newton steps a block is expected to take (the caller's iteration-count hint) for balancing them.
 void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
-               const int32_t* padding_start, bool staged) {
+               const int32_t* padding_start, bool staged, int groups = 1,
+               const float* weight = nullptr, int weight_stride = 1) {
   pl.batch = batch;
   pl.n_eff.resize(batch);
   pl.npad.resize(batch);
@@ -1252,18 +1264,47 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
     if (!c.empty())
       pl.nstages = std::max(pl.nstages, stage_of(c.size() - 1, c.size()) + 1);
   pl.stage_tiles.assign(pl.nstages, {});
-  for (int b = 0; b < batch; ++b) {
-    auto& c = pl.chains[b];
-    if (c.empty()) continue;
-    const int t = pl.npad[b] / TILE;
-    for (int tm = 0; tm < t; ++tm)
-      for (int tn = 0; tn < t; ++tn) pl.init_tiles.push_back({b, (short)tm, (short)tn});
-    for (size_t k = 0; k < c.size(); ++k) {
-      const int s = stage_of(k, c.size());
-      for (int tm = 0; tm < t; ++tm)
-        for (int tn = tm; tn < t; ++tn)
-          pl.stage_tiles[s].push_back({b | ((int)k << 24), (short)tm, (short)tn});
+  // Stream groups: the live blocks are dealt to `groups` groups by longest-processing-time on (upper
+  // tile triangle x products per step x expected steps); every group runs the same per-block
+  // arithmetic on its own stream, so results do not depend on the grouping.
+  pl.ngroups = std::max(1, std::min(std::min(groups, MAX_GROUPS), std::max(1, pl.nlive)));
+  pl.gids.assign(pl.ngroups, {});
+  {
+    std::vector<int> order;
+    for (int b = 0; b < batch; ++b) if (!pl.chains[b].empty()) order.push_back(b);
+    auto cost = [&](int b) {
+      const double t = pl.npad[b] / TILE;
+      double w = 1.0;
+      if (weight) { const float h = weight[(size_t)b * weight_stride]; if (h >= 1.f && h <= 1000.f) w = h; }
+      return t * (t + 1) * 0.5 * (double)pl.chains[b].size() * w * (double)pl.npad[b];
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) > cost(y); });
+    std::vector<double> load(pl.ngroups, 0.0);
+    for (int b : order) {
+      int g = 0;
+      for (int k = 1; k < pl.ngroups; ++k) if (load[k] < load[g]) g = k;
+      load[g] += cost(b);
+      pl.gids[g].push_back(b);
     }
+    for (auto& v : pl.gids) std::sort(v.begin(), v.end());
+  }
+  pl.goff.assign(pl.nstages, std::vector<int>(pl.ngroups + 1, 0));
+  pl.ioff.assign(pl.ngroups + 1, 0);
+  for (int g = 0; g < pl.ngroups; ++g) {
+    for (int b : pl.gids[g]) {
+      auto& c = pl.chains[b];
+      const int t = pl.npad[b] / TILE;
+      for (int tm = 0; tm < t; ++tm)
+        for (int tn = 0; tn < t; ++tn) pl.init_tiles.push_back({b, (short)tm, (short)tn});
+      for (size_t k = 0; k < c.size(); ++k) {
+        const int s = stage_of(k, c.size());
+        for (int tm = 0; tm < t; ++tm)
+          for (int tn = tm; tn < t; ++tn)
+            pl.stage_tiles[s].push_back({b | ((int)k << 24), (short)tm, (short)tn});
+      }
+    }
+    pl.ioff[g + 1] = (int)pl.init_tiles.size();
+    for (int s = 0; s < pl.nstages; ++s) pl.goff[s][g + 1] = (int)pl.stage_tiles[s].size();
   }
   // Launches of steps that average the M update: the off-diagonal tiles of that product run two
   // passes (TF_RAW + TF_AVG), twice as long as every other tile of the launch.  Workgroup i runs
@@ -1272,19 +1313,20 @@ void make_plan(Plan& pl, int batch, const int32_t* n, const int32_t* p,
   // tail of the launch instead of waiting behind it; same tiles per XCD, so a block's operands
   // stay in one L2).
   pl.stage_tiles_avg = pl.stage_tiles;
-  for (int s = 0; s < pl.nstages; ++s) {
-    auto& v = pl.stage_tiles_avg[s];
-    const int nt = (int)v.size(), q = nt >> 3, r = nt & 7;
-    int first = 0;
-    for (int x = 0; x < 8; ++x) {
-      const int cnt = x < r ? q + 1 : q;
-      std::stable_partition(v.begin() + first, v.begin() + first + cnt, [&](const TileEntry& te) {
-        const int b = te.task & TE_BLOCK_MASK, k = te.task >> 24;
-        return k == (int)pl.chains[b].size() - 1 && te.tm != te.tn;
-      });
-      first += cnt;
+  for (int s = 0; s < pl.nstages; ++s)
+    for (int g = 0; g < pl.ngroups; ++g) {   // every group's slice is a launch of its own
+      auto& v = pl.stage_tiles_avg[s];
+      const int nt = pl.goff[s][g + 1] - pl.goff[s][g], q = nt >> 3, r = nt & 7;
+      int first = pl.goff[s][g];
+      for (int x = 0; x < 8; ++x) {
+        const int cnt = x < r ? q + 1 : q;
+        std::stable_partition(v.begin() + first, v.begin() + first + cnt, [&](const TileEntry& te) {
+          const int b = te.task & TE_BLOCK_MASK, k = te.task >> 24;
+          return k == (int)pl.chains[b].size() - 1 && te.tm != te.tn;
+        });
+        first += cnt;
+      }
     }
-  }
 }
 
 // dev A/B: PS_NEWTON_GRID=g caps the stage launches at g workgroups that loop over the tile
@@ -1302,6 +1344,7 @@ struct WsLayout {
   TileEntry* tiles[MAX_PROD];
   TileEntry* tiles_avg[MAX_PROD];
   TileEntry* init_tiles;
+  int* group_ids;     // [batch]: the block ids of the stream groups, group-major
   std::vector<float*> mat[10];
   std::vector<float*> sumsq;
 };
@@ -1323,7 +1366,8 @@ size_t carve(Plan& pl, Arena& ar, WsLayout* lo, bool staged) {
       if (lo) { lo->tiles[s] = e; lo->tiles_avg[s] = e2; }
     }
     TileEntry* it = ar.take<TileEntry>(pl.init_tiles.size());
-    if (lo) { lo->init_tiles = it; }
+    int* gi = ar.take<int>(B);
+    if (lo) { lo->init_tiles = it; lo->group_ids = gi; }
   }
   for (int b = 0; b < B; ++b) {
     const size_t sq = (size_t)pl.npad[b] * pl.npad[b];
@@ -1345,51 +1389,82 @@ struct Profile {
 };
 Profile g_prof;
 
-// Event pairs recorded on the caller's stream; resolved after the call.
+// Event pairs recorded on the stream the bracketed launches go to; resolved after the call.
 struct ProfRun {
   struct Span { hipEvent_t a, b; int kind; int count; };  // kind 0 products, 1 power iter, 2 other
   std::vector<Span> spans;
   bool active;
   hipStream_t st;
-  explicit ProfRun(hipStream_t s) : active(g_prof.on), st(s) {}
+  hipEvent_t base = nullptr;   // time origin (caller's stream): spans of different streams on one axis
+  explicit ProfRun(hipStream_t s) : active(g_prof.on), st(s) {
+    if (active && (hipEventCreate(&base) != hipSuccess || hipEventRecord(base, st) != hipSuccess)) active = false;
+  }
   // count: launches the span brackets (kind 0).  An event record is a queue packet with a
   // completion signal: a pair around EVERY product launch kept the next kernel from starting
   // under the tail of the previous one and read 0.487 ms per launch where rocprofv3 and the
   // step time say 0.44; the product launches of a Newton step are bracketed together.
-  void begin(int kind, int count = 1) {
+  void begin(int kind, int count = 1, hipStream_t on = nullptr) {
     if (!active) return;
     Span sp; sp.kind = kind; sp.count = count;
     if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) { active = false; return; }
-    (void)hipEventRecord(sp.a, st);
+    (void)hipEventRecord(sp.a, on ? on : st);
     spans.push_back(sp);
   }
-  void end() {
+  void end(hipStream_t on = nullptr) {
     if (!active || spans.empty()) return;
-    (void)hipEventRecord(spans.back().b, st);
+    (void)hipEventRecord(spans.back().b, on ? on : st);
   }
+  // Product spans of the stream groups overlap in time: stage_ms is the length of the UNION of their
+  // intervals (the time during which at least one group had product launches in flight), so that
+  // flops / stage_ms is the device's rate over the product phase whatever the grouping.
   void finish() {
-    if (spans.empty()) return;
-    (void)hipStreamSynchronize(st);
+    if (spans.empty()) { if (base) (void)hipEventDestroy(base); return; }
+    (void)hipStreamSynchronize(st);   // the side streams were joined into st before this
+    std::vector<std::pair<float, float>> prod;
     for (auto& sp : spans) {
-      float ms = 0.f;
+      float ms = 0.f, t0 = 0.f;
       if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-        if (sp.kind == 0) { g_prof.stage_ms += ms; g_prof.stage_launches += sp.count; }
+        if (sp.kind == 0) {
+          g_prof.stage_launches += sp.count;
+          if (hipEventElapsedTime(&t0, base, sp.a) == hipSuccess) prod.push_back({t0, t0 + ms});
+          else g_prof.stage_ms += ms;
+        }
         else if (sp.kind == 1) g_prof.pi_ms += ms;
         else g_prof.other_ms += ms;
       }
       (void)hipEventDestroy(sp.a);
       (void)hipEventDestroy(sp.b);
     }
+    std::sort(prod.begin(), prod.end());
+    float cur_a = 0.f, cur_b = -1.f;
+    for (auto& iv : prod) {
+      if (cur_b < cur_a) { cur_a = iv.first; cur_b = iv.second; }
+      else if (iv.first <= cur_b) cur_b = std::max(cur_b, iv.second);
+      else { g_prof.stage_ms += cur_b - cur_a; cur_a = iv.first; cur_b = iv.second; }
+    }
+    if (cur_b >= cur_a && !prod.empty()) g_prof.stage_ms += cur_b - cur_a;
     spans.clear();
+    if (base) { (void)hipEventDestroy(base); base = nullptr; }
   }
 };
+
+// Side streams of the stream groups (staged execution): per host thread and device, created once.
+hipStream_t side_stream(int k) {
+  constexpr int MAXDEV = 16;
+  static thread_local hipStream_t cache[MAXDEV][MAX_GROUPS] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV || k < 0 || k >= MAX_GROUPS) return nullptr;
+  if (!cache[dev][k] && hipStreamCreateWithFlags(&cache[dev][k], hipStreamNonBlocking) != hipSuccess)
+    cache[dev][k] = nullptr;
+  return cache[dev][k];
+}
 
 // One mapped status ring per host thread: a thread runs one call at a time, so calls
 // on distinct (stream, workspace) pairs from different threads never share slots.
 HostStatus* pinned_status() {
   static thread_local HostStatus* st = nullptr;
   if (!st) {
-    if (hipHostMalloc((void**)&st, 64 * sizeof(HostStatus), hipHostMallocMapped) !=
+    if (hipHostMalloc((void**)&st, 64 * MAX_GROUPS * sizeof(HostStatus), hipHostMallocMapped) !=
         hipSuccess)
       st = nullptr;
   }
@@ -1465,7 +1540,28 @@ static int newton_driver(
   const float avg_thr = opt.averaged_err_threshold;
   const int seg_on = (opt.accumulation == PS_ACCUM_SEGMENTED && opt.products == PS_PRODUCTS_F32) ? 1 : 0;
   Plan pl;
-  make_plan(pl, batch, n, p, padding_start, staged);
+  // Stream groups of the staged execution (see the product loop below): 2 by default when the call has
+  // work for them (PS_NEWTON_GROUPS / psh::Options::newton_groups: 1 = the single-stream execution).
+  // Measured (tools/dev_stage_variants.py groups, profiles/r06_newton_stream_groups.txt): calls whose
+  // blocks differ in size or exponent (a ViT-B tree: 139.6 -> 133.9 ms with 2 groups, 135-136 with 3 / 4)
+  // gain; homogeneous batches do not (256 x 512^2: 16.1 vs 16.2-16.3 ms, 64 x 1024^2: 23.5 vs 23.7 -- their
+  // launches are whole rounds of equal tiles and the second stream only costs L2 locality), so the default
+  // is 2 groups for mixed calls and 1 otherwise.
+  int want_groups = opt.newton_groups;
+  if (want_groups <= 0) {
+    want_groups = 1;
+    int n0 = -1, p0 = -1;
+    for (int b = 0; b < batch; ++b) {
+      int ne = n[b];
+      if (padding_start) ne = std::max(0, std::min(ne, (int)padding_start[b]));
+      if (ne < 1) continue;
+      const int np_ = psh::round_up(ne, TILE);
+      if (n0 < 0) { n0 = np_; p0 = p[b]; }
+      else if (np_ != n0 || p[b] != p0) { want_groups = 2; break; }
+    }
+  }
+  if (!staged || opt.newton_trace) want_groups = 1;
+  make_plan(pl, batch, n, p, padding_start, staged, want_groups, opt.iters_hint, opt.iters_hint_stride);
   if (!pl.ok) return PS_EUNSUPPORTED;
   if (pl.max_n > 16384) return PS_EUNSUPPORTED;
   // De-phasing of co-resident workgroups (newton_stage_kernel): measured 64 x 1024^2: 21.6 -> 20.9 ms
@@ -1554,6 +1650,9 @@ static int newton_driver(
     }
     PS_RC(psh::upload_async(st, lo.init_tiles, pl.init_tiles.data(),
                             sizeof(TileEntry) * pl.init_tiles.size()));
+    std::vector<int> ids;
+    for (auto& v : pl.gids) ids.insert(ids.end(), v.begin(), v.end());
+    PS_RC(psh::upload_async(st, lo.group_ids, ids.data(), sizeof(int) * ids.size()));
   }
   PS_RC(enqueue_front());
 
@@ -1658,92 +1757,165 @@ static int newton_driver(
   const int ninit = (int)pl.init_tiles.size();
   int executed = 0;
   if (ninit > 0) {
-    hipEvent_t ev[2];
-    PS_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    {
-      const hipError_t e1 = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
-      if (e1 != hipSuccess) { (void)hipEventDestroy(ev[0]); return (int)e1; }
-    }
-    const int cap = 6 * (num_iters + 2) + 4;
-    bool need_init = true, pi_retried = false;
+    // ---- stream groups -----------------------------------------------------------------------
+    // The blocks are dealt to G groups (make_plan); every group runs the reference's loop for its
+    // blocks -- the same launches, tile for tile, as the single-stream execution -- on a stream of
+    // its own: group 0 on the caller's, the others on side streams forked behind the power iteration
+    // and joined in front of the copy-out.  A stage launch depends on the previous one of ITS group
+    // only, so while one group's launch drains (the last, partly filled round of 512 resident
+    // workgroups; the burst of epilogue stores; the first HBM round trip of the next launch) the
+    // other group's tiles keep the CUs busy.  Per-block arithmetic, and therefore every bit of the
+    // result, does not depend on G.  One host event wait per group and step, one step behind the GPU.
+    const int G = pl.ngroups;
+    struct Grp {
+      hipStream_t st = nullptr;
+      hipEvent_t ev[2] = {nullptr, nullptr};
+      hipEvent_t join = nullptr;
+      bool need_init = true, done = false;
+      int since_init = 0, steps = 0, nblk = 0, ninit = 0;
+      const int* ids = nullptr;
+      const TileEntry* init_tiles = nullptr;
+      HostStatus* ring = nullptr;
+    };
+    Grp grp[MAX_GROUPS];
+    hipEvent_t fork_ev = nullptr;
     int rc = 0;
-    int since_init = 0;   // steps since the last (re)initialisation launch: < navg => averaged M updates
-    for (int g = 0; g < cap; ++g) {
-      HostStatus* slot = &status[g % 64];
-      slot->gen = -1;
-      if (need_init) {
-        prof.begin(2);
-        hipLaunchKernelGGL(newton_init1_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
-                           lo.states, lo.init_tiles);
-        hipLaunchKernelGGL(newton_init2_kernel, dim3(ninit), dim3(256), 0, st, lo.blocks,
-                           lo.states, lo.init_tiles);
-        hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
-                           batch, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr, avg_thr);
-        prof.end();
-        since_init = 0;
+    auto cleanup = [&]() {
+      for (int q = 0; q < G; ++q) {
+        for (int k = 0; k < 2; ++k) if (grp[q].ev[k]) (void)hipEventDestroy(grp[q].ev[k]);
+        if (grp[q].join) (void)hipEventDestroy(grp[q].join);
       }
-      const bool avg_order = any_avg && opt.avg_lpt && since_init < navg;
-      ++since_init;
-      prof.begin(0, pl.nstages);
-      for (int s = 0; s < pl.nstages; ++s) {
-        const int nt = (int)pl.stage_tiles[s].size();
-        const TileEntry* tl = avg_order ? lo.tiles_avg[s] : lo.tiles[s];
-        const dim3 grid(stage_grid(nt, opt.grid_cap));
-        const size_t lds = SmemCfg<32>::TOTAL * sizeof(float);
-#define PS_STAGE(...)                                                                       \
-  hipLaunchKernelGGL((newton_stage_kernel<__VA_ARGS__>), grid, dim3(256), lds, st, lo.blocks, \
-                     lo.states, tl, nt, stagger)
-        if (pipe_mode && xmode == 0 && trace_on)
-          hipLaunchKernelGGL((newton_stage_kernel<32, true, 0, true, true>), grid, dim3(256), lds, st,
-                             lo.blocks, lo.states, tl, nt, navg, trace_on, trace_seq++, TRACE_CAP);
-        else if (pipe_mode && xmode == 0 && any_careful) PS_STAGE(32, true, 0, false, true, true);
-        else if (pipe_mode && xmode == 0) PS_STAGE(32, true, 0, false, true);
-        else if (trace_on)
-          hipLaunchKernelGGL((newton_stage_kernel<32, true, 0, true>), grid, dim3(256), lds, st,
-                             lo.blocks, lo.states, tl, nt, navg, trace_on, trace_seq++, TRACE_CAP);
-        else if (xmode == 6) PS_STAGE(32, true, 6);
-        else if (xmode == 3) PS_STAGE(32, true, 3);
-        else if (stage_bk == 32 && stage_deep) PS_STAGE(32, true);
-        else if (stage_bk == 32) PS_STAGE(32, false);
-        else if (stage_deep)
-          hipLaunchKernelGGL((newton_stage_kernel<16, true>), grid, dim3(256),
-                             SmemCfg<16>::TOTAL * sizeof(float), st, lo.blocks, lo.states, tl, nt, navg);
-        else
-          hipLaunchKernelGGL((newton_stage_kernel<16, false>), grid, dim3(256),
-                             SmemCfg<16>::TOTAL * sizeof(float), st, lo.blocks, lo.states, tl, nt, navg);
-#undef PS_STAGE
+      if (fork_ev) (void)hipEventDestroy(fork_ev);
+    };
+    {
+      int off = 0;
+      for (int q = 0; q < G && !rc; ++q) {
+        Grp& gr = grp[q];
+        gr.st = q == 0 ? st : side_stream(q - 1);   // (the caller's stream may be the null stream)
+        if (q > 0 && !gr.st) { rc = PS_EINTERNAL; break; }
+        gr.nblk = (int)pl.gids[q].size();
+        gr.ids = lo.group_ids + off;
+        off += gr.nblk;
+        gr.ninit = pl.ioff[q + 1] - pl.ioff[q];
+        gr.init_tiles = lo.init_tiles + pl.ioff[q];
+        gr.ring = status + 64 * q;
+        for (int k = 0; k < 2 && !rc; ++k) rc = (int)hipEventCreateWithFlags(&gr.ev[k], hipEventDisableTiming);
+        if (!rc && q > 0) rc = (int)hipEventCreateWithFlags(&gr.join, hipEventDisableTiming);
       }
-      prof.end();
-      hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, st, lo.states,
-                         batch, 1, num_iters, error_tolerance, g, slot, avg_thr);
-      if ((rc = (int)hipGetLastError()) != 0) break;
-      if ((rc = (int)hipEventRecord(ev[g & 1], st)) != 0) break;
-      ++executed;
-      if (g >= 1) {
-        if ((rc = (int)hipEventSynchronize(ev[(g - 1) & 1])) != 0) break;
-        const HostStatus seen = status[(g - 1) % 64];
-        if (seen.gen != g - 1) { rc = PS_EINTERNAL; break; }
-        if (g == 1 && !pi_retried && PiPlan::expired_total() != pi_expired_before) {
-          pi_retried = true;
-          // The resident power iteration gave up on a team mate that never became resident
-          // (CUs held by another stream's kernels): its blocks carry a NaN eigenvalue.  The
-          // process is on the streaming execution from now on (PiPlan::resident_enabled);
-          // queue the whole call again behind what is already queued and start over.
-          pl.pip.allow_resident = false;
-          if ((rc = enqueue_front()) != 0) break;
-          need_init = true;
-          g = -1;
-          executed = 0;
-          continue;
-        }
-        if (seen.not_done == 0) break;
-        need_init = seen.need_init > 0;
-      } else {
-        need_init = false;
-      }
+      if (!rc && G > 1) rc = (int)hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming);
     }
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
+    auto fork = [&]() -> int {   // the side streams start behind everything queued on st so far
+      if (G == 1) return 0;
+      PS_HIP(hipEventRecord(fork_ev, st));
+      for (int q = 1; q < G; ++q) PS_HIP(hipStreamWaitEvent(grp[q].st, fork_ev, 0));
+      return 0;
+    };
+    if (!rc) rc = fork();
+    const int cap = 6 * (num_iters + 2) + 4;
+    bool pi_retried = false;
+    for (int g = 0; g < cap && !rc; ++g) {
+      for (int q = 0; q < G && !rc; ++q) {
+        Grp& gr = grp[q];
+        if (gr.done) continue;
+        HostStatus* slot = &gr.ring[g % 64];
+        slot->gen = -1;
+        if (gr.need_init) {
+          prof.begin(2, 1, gr.st);
+          hipLaunchKernelGGL(newton_init1_kernel, dim3(gr.ninit), dim3(256), 0, gr.st, lo.blocks,
+                             lo.states, gr.init_tiles);
+          hipLaunchKernelGGL(newton_init2_kernel, dim3(gr.ninit), dim3(256), 0, gr.st, lo.blocks,
+                             lo.states, gr.init_tiles);
+          hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, gr.st, lo.states,
+                             gr.nblk, 0, num_iters, error_tolerance, g, (HostStatus*)nullptr, avg_thr, gr.ids);
+          prof.end(gr.st);
+          gr.since_init = 0;
+        }
+        const bool avg_order = any_avg && opt.avg_lpt && gr.since_init < navg;
+        ++gr.since_init;
+        prof.begin(0, pl.nstages, gr.st);
+        for (int s = 0; s < pl.nstages; ++s) {
+          const int nt = pl.goff[s][q + 1] - pl.goff[s][q];
+          if (nt == 0) continue;
+          const TileEntry* tl = (avg_order ? lo.tiles_avg[s] : lo.tiles[s]) + pl.goff[s][q];
+          const dim3 grid(stage_grid(nt, opt.grid_cap));
+          const size_t lds = SmemCfg<32>::TOTAL * sizeof(float);
+          hipStream_t gst = gr.st;
+#define PS_STAGE(...)                                                                        \
+  hipLaunchKernelGGL((newton_stage_kernel<__VA_ARGS__>), grid, dim3(256), lds, gst, lo.blocks, \
+                     lo.states, tl, nt, stagger)
+          if (pipe_mode && xmode == 0 && trace_on)
+            hipLaunchKernelGGL((newton_stage_kernel<32, true, 0, true, true>), grid, dim3(256), lds, gst,
+                               lo.blocks, lo.states, tl, nt, navg, trace_on, trace_seq++, TRACE_CAP);
+          else if (pipe_mode && xmode == 0 && any_careful) PS_STAGE(32, true, 0, false, true, true);
+          else if (pipe_mode && xmode == 0) PS_STAGE(32, true, 0, false, true);
+          else if (trace_on)
+            hipLaunchKernelGGL((newton_stage_kernel<32, true, 0, true>), grid, dim3(256), lds, gst,
+                               lo.blocks, lo.states, tl, nt, navg, trace_on, trace_seq++, TRACE_CAP);
+          else if (xmode == 6) PS_STAGE(32, true, 6);
+          else if (xmode == 3) PS_STAGE(32, true, 3);
+          else if (stage_bk == 32 && stage_deep) PS_STAGE(32, true);
+          else if (stage_bk == 32) PS_STAGE(32, false);
+          else if (stage_deep)
+            hipLaunchKernelGGL((newton_stage_kernel<16, true>), grid, dim3(256),
+                               SmemCfg<16>::TOTAL * sizeof(float), gst, lo.blocks, lo.states, tl, nt, navg);
+          else
+            hipLaunchKernelGGL((newton_stage_kernel<16, false>), grid, dim3(256),
+                               SmemCfg<16>::TOTAL * sizeof(float), gst, lo.blocks, lo.states, tl, nt, navg);
+#undef PS_STAGE
+        }
+        prof.end(gr.st);
+        hipLaunchKernelGGL(newton_control_kernel, dim3(1), dim3(256), 0, gr.st, lo.states,
+                           gr.nblk, 1, num_iters, error_tolerance, g, slot, avg_thr, gr.ids);
+        if ((rc = (int)hipGetLastError()) != 0) break;
+        if ((rc = (int)hipEventRecord(gr.ev[g & 1], gr.st)) != 0) break;
+        ++gr.steps;
+      }
+      if (rc) break;
+      if (g == 0) {
+        for (int q = 0; q < G; ++q) grp[q].need_init = false;
+        continue;
+      }
+      bool restart = false;
+      for (int q = 0; q < G && !rc; ++q) {
+        Grp& gr = grp[q];
+        if (gr.done) continue;
+        if ((rc = (int)hipEventSynchronize(gr.ev[(g - 1) & 1])) != 0) break;
+        const HostStatus seen = gr.ring[(g - 1) % 64];
+        if (seen.gen != g - 1) { rc = PS_EINTERNAL; break; }
+        if (g == 1 && !pi_retried && PiPlan::expired_total() != pi_expired_before) { restart = true; break; }
+        if (seen.not_done == 0) gr.done = true;
+        gr.need_init = seen.need_init > 0;
+      }
+      if (rc) break;
+      if (restart) {
+        pi_retried = true;
+        // The resident power iteration gave up on a team mate that never became resident
+        // (CUs held by another stream's kernels): its blocks carry a NaN eigenvalue.  The
+        // process is on the streaming execution from now on (PiPlan::resident_enabled);
+        // queue the whole call again behind what is already queued and start over.
+        for (int q = 1; q < G && !rc; ++q) {   // join the side streams first: the front runs on st
+          if ((rc = (int)hipEventRecord(grp[q].join, grp[q].st)) != 0) break;
+          rc = (int)hipStreamWaitEvent(st, grp[q].join, 0);
+        }
+        if (rc) break;
+        pl.pip.allow_resident = false;
+        if ((rc = enqueue_front()) != 0) break;
+        if ((rc = fork()) != 0) break;
+        for (int q = 0; q < G; ++q) { grp[q].need_init = true; grp[q].done = false; grp[q].steps = 0; }
+        g = -1;
+        continue;
+      }
+      bool all_done = true;
+      for (int q = 0; q < G; ++q) all_done &= grp[q].done;
+      if (all_done) break;
+    }
+    // join: the copy-out (and whatever the caller queues next on st) runs behind every group
+    for (int q = 1; q < G && !rc; ++q) {
+      if ((rc = (int)hipEventRecord(grp[q].join, grp[q].st)) != 0) break;
+      rc = (int)hipStreamWaitEvent(st, grp[q].join, 0);
+    }
+    for (int q = 0; q < G; ++q) executed = std::max(executed, grp[q].steps);
+    cleanup();
     if (rc) return rc;
   }
   prof.begin(2);

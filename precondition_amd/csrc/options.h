@@ -32,6 +32,7 @@ struct Options {
   int persistent_deep = 0;         // PS_NEWTON_DEEP (persistent execution)
   int pipe = 1;                    // PS_NEWTON_PIPE
   int grid_cap = 0;                // PS_NEWTON_GRID
+  int newton_groups = 0;           // PS_NEWTON_GROUPS: stream groups of the staged execution (0 = default 2; 1 = one stream)
   int wg_per_cu = 0;               // PS_NEWTON_WG_PER_CU
   bool newton_prof = false;        // PS_NEWTON_PROF
   const char* newton_trace = nullptr;  // PS_NEWTON_TRACE=<file>

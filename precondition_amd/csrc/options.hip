@@ -36,6 +36,7 @@ void ps_dev_env_overrides(Options& o) {
   if (const char* e = getenv("PS_NEWTON_DEEP")) o.stage_deep = o.persistent_deep = atoi(e) != 0;
   geti("PS_NEWTON_PIPE", o.pipe);
   geti("PS_NEWTON_GRID", o.grid_cap);
+  geti("PS_NEWTON_GROUPS", o.newton_groups);
   geti("PS_NEWTON_WG_PER_CU", o.wg_per_cu);
   geti("PS_NEWTON_AVG_LPT", o.avg_lpt);
   geti("PS_NEWTON_STAGGER", o.stagger);

@@ -988,6 +988,8 @@ def distributed_shampoo(
             all(g.dtype == torch.float32 and g.is_contiguous() for g in grads_flat))
       if not ok or not ds.bind(stats_flat, grads_flat, params_flat, symmetric_precs=True):
         return None
+    if not ds.qualifies(grads_flat, params_flat):   # every step: strides / dtype / device / shape
+      return None
     do_stats = statistics_compute_steps <= 1 or step % statistics_compute_steps == 0
     w2 = beta2 if beta2 == 1.0 else 1.0 - beta2
     return ds.step(grads_flat, params_flat, _transform_cfg(step), do_stats, beta2, w2)

@@ -367,16 +367,27 @@ class DonatedStep:
     self.pp_params = None
     return True
 
+  def qualifies(self, grads_flat, params_flat) -> bool:
+    """Checked on EVERY step, before the pointer comparison: the raw-pointer tables read a gradient as a
+    contiguous float32 tensor of the bound shape.  A tensor with the same data_ptr and shape but other
+    strides (a `.t()` view of a square weight, an expanded tensor) or another dtype must not reach them;
+    such a step takes the functional path (which copies / converts), it does not raise."""
+    for g, u in zip(grads_flat, self.upd):
+      if (g.dtype != torch.float32 or not g.is_contiguous() or g.device != self.dev or
+          g.shape != u.shape):
+        return False
+    if self.use_params:
+      for p_, u in zip(params_flat, self.upd):
+        if (p_.dtype != torch.float32 or not p_.is_contiguous() or p_.device != self.dev or
+            p_.shape != u.shape):
+          return False
+    return True
+
   def _patch_grads(self, grads_flat):
     pl = self.plan
     gp = pl._ptrs(grads_flat)
     if self.gp is not None and np.array_equal(gp, self.gp):
       return
-    for g, u in zip(grads_flat, self.upd):   # (only when the pointers moved)
-      if (g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous() or
-          g.device != self.dev or g.shape != u.shape):
-        kernels._require_gpu(g, "update (donated state)")
-        raise ValueError("update (donated state): contiguous float32 gradients of the bound shapes on one device")
     self.gp = gp
     if len(self.st_tbl):
       self.st_tbl["g"] = gp[pl.st_param] + pl.st_goff
@@ -391,11 +402,10 @@ class DonatedStep:
 
   def step(self, grads_flat, params_flat, cfg, do_stats: bool, w1: float, w2: float):
     """Enqueues the step; returns the update tensors (owned by this object)."""
-    self._patch_grads(grads_flat)
+    self._patch_grads(grads_flat)    # (the caller checked qualifies() for this step)
     if self.use_params:
       pp = self.plan._ptrs(params_flat)
       if self.pp_params is None or not np.array_equal(pp, self.pp_params):
-        self.plan.check_dense(params_flat, "update (donated state)")
         self.pp_params = pp
         self.tt["param"] = pp
     L = lib()

@@ -143,8 +143,9 @@ def test_low_rank_root_bottom_eigenpairs_of_graded_matrices_default_solver(devic
   """_low_rank_root with a negative rank keeps the SMALLEST eigenpairs (DS:1033-1120): that needs eigenvalues
   accurate relative to themselves, which the float32 tridiagonalisation cannot give on graded / rank-deficient
   spectra (tools/dev_fuzz_lowrank.py: 7 of 60 cases off by up to 0.7 when plain eigh kept its result
-  unconditionally).  The default hands such matrices to the Jacobi solvers inside the same call -- a mixed
-  batch in plain mode: kept blocks, handed-over blocks, small blocks."""
+  unconditionally; the reference's float32 ssyevd has the same limitation).  Plain eigenpairs keep the ACCURATE
+  rule by default: such matrices go to the Jacobi solvers inside the same call -- a mixed batch in plain mode:
+  kept blocks, handed-over blocks, small blocks -- and match the float64-internal LAPACK yardstick."""
   from precondition_amd import low_rank
   from tests.test_optimizer_host_logic import packed_matches
   rng = np.random.default_rng(77)
@@ -165,7 +166,9 @@ def test_low_rank_root_bottom_eigenpairs_of_graded_matrices_default_solver(devic
     full = n + (5 if case % 4 == 0 else 0)
     m = np.zeros((full, full), np.float32); m[:n, :n] = a
     with np.errstate(all="ignore"):
-      ref, _ = orc.low_rank_root(m, p, rank, padding_start=n)
+      # float64-internal LAPACK (the accuracy yardstick): the reference's own float32 ssyevd loses the
+      # bottom eigenpairs of graded / rank-deficient matrices just like an unconditional fast path would
+      ref, _ = orc.low_rank_root(m, p, rank, padding_start=n, lapack="f64")
     calls.append(dict(matrix=torch.tensor(m, device=device), p=p, compression_rank=rank, padding_start=n))
     refs.append(ref); meta.append((n, full, rank, p, kind))
   for (val, _), ref, mt in zip(low_rank._low_rank_root_batched(calls), refs, meta):

@@ -30,6 +30,9 @@ if "vit" in os.environ.get("PS_DEV_EXTRA", ""):
 combos = [dict(), dict(PS_NEWTON_PIPE="0", PS_NEWTON_BK="16", PS_NEWTON_DEEP="1"), dict(PS_NEWTON_PIPE="0", PS_NEWTON_BK="16", PS_NEWTON_DEEP="0"), dict(), dict(PS_NEWTON_PIPE="0", PS_NEWTON_BK="16", PS_NEWTON_DEEP="1")]
 if len(sys.argv) > 1 and sys.argv[1] == "bk":
   combos = [dict(PS_NEWTON_BK=bk, PS_NEWTON_DEEP=deep) for bk, deep in (("32", "1"), ("16", "1"), ("16", "0"), ("32", "0"))]
+if len(sys.argv) > 1 and sys.argv[1] == "groups":   # round 6: stream groups of the staged execution (same bits for every count)
+  os.environ["PS_DEV_EXTRA"] = "vit"
+  combos = [dict(PS_NEWTON_GROUPS=g) for g in ("1", "2", "3", "4", "1", "2")]
 for c in combos:
   env = dict(os.environ, **c)
   print(c, flush=True)

@@ -20,7 +20,10 @@ def make_grad(r, s):
   return np.asarray(r.standard_normal(s) * 0.02, np.float32)
 # round 6: "auto" keeps every block's fast-path result (at or below a true float32 ssyevd's root error);
 # "accurate" is round 5's default (Jacobi hand-over above cond 1e3, with / without the optimizer's memo)
-for solver, hint in (("auto", True), ("accurate", True), ("accurate", False), ("one_sided", True)):
+configs = (("auto", True), ("accurate", True), ("accurate", False), ("one_sided", True))
+if os.environ.get("VITB_ONLY"):
+  configs = tuple(c for c in configs if c[0] == os.environ["VITB_ONLY"])[:1]
+for solver, hint in configs:
   opt = pa.distributed_shampoo(0.1, 1024, preconditioning_compute_steps=2, start_preconditioning_step=1, eigh=True,
                                eigh_solver=solver, graft_type=pa.GraftingType.RMSPROP_NORMALIZED,
                                iteration_count_hint=hint)
