@@ -16,7 +16,11 @@ params = [torch.from_numpy(np.asarray(rng.standard_normal(s) * 0.02, np.float32)
 lowrank = len(sys.argv) > 1 and sys.argv[1] == "lowrank"   # gradients of rank 8: statistics stay ill conditioned
 def make_grad(r, s):
   if lowrank and len(s) == 2 and min(s) > 8:
-    return (r.standard_normal((s[0], 8)) @ r.standard_normal((8, s[1])) * 0.02 / 3).astype(np.float32)
+    # (plain loops, no BLAS: a threaded host matmul leaves its worker threads spinning into the timed region,
+    # where they slow the enqueue of the ~25 000 launches of an eigh recompute -- round 5's 274-314 ms for this
+    # mode were partly that)
+    a, b = r.standard_normal((s[0], 8)), r.standard_normal((8, s[1]))
+    return (np.einsum("ik,kj->ij", a, b, optimize=False) * 0.02 / 3).astype(np.float32)
   return np.asarray(r.standard_normal(s) * 0.02, np.float32)
 # round 6: "auto" keeps every block's fast-path result (at or below a true float32 ssyevd's root error);
 # "accurate" is round 5's default (Jacobi hand-over above cond 1e3, with / without the optimizer's memo)
