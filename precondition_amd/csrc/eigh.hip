@@ -784,7 +784,14 @@ __global__ __launch_bounds__(256, 2) void eigh_gemm_kernel(EighBlock* blocks,
   Operand A{ebuf(eb, a_id), ld, te.k * TILE, ld, ld, true};
   Operand B{ebuf(eb, b_id), ld, te.t * TILE, ld, ld, true};
   f32x16 acc[2][2];
-  gemm_tile<LA, LB, EBK, false>(A, B, ld, smem, acc);
+  // The error metric's own product (DS:1017: u^T (D u)) is summed in segments of 128 (gemm_core.hip.h SEG_K):
+  // a diagonal entry is lambda_j as a sum of n positive terms, and ONE float32 chain over k = 2048 rounds
+  // it by ~eps sqrt(n) lambda / 2 -- 0.02-0.03 at lambda_max 1.2e4, which IS the metric of a cfg3 block
+  // (the eigenvectors are orthogonal to 1.3e-6, a true ssyevd's to 2.3e-6: tools/dev_r6_orth.py), against
+  // 0.011-0.015 for the reference's K-blocked sgemm.  Blocked summation brings it below that.  The other
+  // products of this kernel keep the single chain (same bits as before).
+  const bool seg = epi == GE_ERR || epi == GE_ERR_UPPER;
+  gemm_tile<LA, LB, EBK, false, false, false, true>(A, B, ld, smem, acc, nullptr, seg);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   float* C = ebuf(eb, c_id);
