@@ -1048,6 +1048,9 @@ def distributed_shampoo(
       if upd is not None:   # state updated in place: the same objects go back
         return (treedef.unflatten(upd), ShampooState(count=state.count + 1, stats=state.stats))
     grads_flat = [g if g.dtype == torch.float32 else g.to(torch.float32) for g in grads_flat]
+    # strided views (a `.t()` of a square buffer, an expanded tensor) are copied: the kernels address a
+    # gradient block as base pointer + planned offsets of a contiguous tensor
+    grads_flat = [g if g.is_contiguous() else g.contiguous() for g in grads_flat]
     if any(p.dtype != torch.float32 for p in params_flat):
       params_flat = [p if p.dtype == torch.float32 else p.to(torch.float32)
                      for p in params_flat]
@@ -1213,6 +1216,9 @@ def distributed_shampoo(
     grads_flat = treedef.flatten_up_to(grads)
     grad_dtypes = [g.dtype for g in grads_flat]
     grads_flat = [g if g.dtype == torch.float32 else g.to(torch.float32) for g in grads_flat]
+    # strided views (a `.t()` of a square buffer, an expanded tensor) are copied: the kernels address a
+    # gradient block as base pointer + planned offsets of a contiguous tensor
+    grads_flat = [g if g.is_contiguous() else g.contiguous() for g in grads_flat]
     if any(p.dtype != torch.float32 for p in params_flat):
       params_flat = [p if p.dtype == torch.float32 else p.to(torch.float32) for p in params_flat]
     step = int(state.count)

@@ -89,8 +89,9 @@ def test_newton_stream_groups_do_not_change_a_bit(device, monkeypatch):
   assert np.array_equal(m.cpu().numpy(), outs[("1", True)][1].cpu().numpy(), equal_nan=True)
   for i, (a, p, pad) in enumerate(zip(mats, ps, pads)):             # and the oracle, as ever
     h_ref, m_ref = orc.matrix_inverse_pth_root(a, p, padding_start=pad)
-    if np.linalg.norm(h_ref) > 0 and i != 2:   # (the cond 1e5 block's stop sits within rounding of 1e-6: +-1 step)
-      assert m.cpu().numpy()[i, 1] == m_ref["inverse_pth_root_iters"], i
+    if np.linalg.norm(h_ref) > 0:
+      # (blocks 2 and 5 -- cond 1e5, a nearly square Wishart -- stop within rounding of the 1e-6 threshold: +-1 step)
+      assert abs(m.cpu().numpy()[i, 1] - m_ref["inverse_pth_root_iters"]) <= (1 if i in (2, 5) else 0), i
       assert m.cpu().numpy()[i, 4] == m_ref["total_retries"], i
 
 
