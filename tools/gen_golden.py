@@ -923,9 +923,63 @@ def gen_e2e_sharded():
     json.dump(index, f, indent=1)
 
 
+def gen_fd_resume():
+  """A Frequent-Directions run of the reference INTERRUPTED after 3 updates: the complete optimizer state at
+  that point (statistics slots = the reference's triangular factors R, DS:1497-1505; packed sketches;
+  diagonal statistics; momenta; count) and the updates of the 3 steps that follow.  The build keeps the Gram
+  matrix R R^T in the statistics slot instead of R; precondition_amd/interop.py converts a reference state on
+  import, and the test continues the run from it."""
+  out, index = {}, []
+  shapes_d = ([40, 24], [64, 48], [8, 40])
+  r0 = np.random.default_rng(10)
+  params = tuple(r0.standard_normal(s).astype(F32) for s in shapes_d)
+  for name, kw in (("resume_fd_r4", dict(
+      block_size=32, preconditioning_compute_steps=1, statistics_compute_steps=1,
+      start_preconditioning_step=1, compression_rank=4, frequent_directions=True,
+      reuse_preconditioner=True, merge_small_dims_block_size=1)),
+                   ("resume_fd_r3_avg", dict(
+      block_size=32, preconditioning_compute_steps=2, statistics_compute_steps=2,
+      start_preconditioning_step=2, compression_rank=3, frequent_directions=True,
+      reuse_preconditioner=True, average_grad=True, beta2=0.8, merge_small_dims_block_size=1))):
+    opt = ds.distributed_shampoo(0.1, batch_axis_name=None, **kw)
+    p_j = tuple(jnp.array(p) for p in params)
+    st = opt.init(p_j)
+    gr_rng = np.random.default_rng(zlib.crc32(name.encode()))
+    first, later = 3, 3
+    for t in range(first + later):
+      g = tuple((gr_rng.standard_normal(p.shape) * (1 + 0.1 * t)).astype(F32) for p in params)
+      with np.errstate(all="ignore"):
+        upd, st = opt.update(tuple(jnp.array(x) for x in g), st, p_j)
+      for i in range(len(params)):
+        out[f"{name}__grad{i}_t{t}"] = g[i]
+        out[f"{name}__upd{i}_t{t}"] = npy(upd[i])
+      if t == first - 1 or t == first + later - 1:
+        tag = "mid" if t == first - 1 else "end"
+        out[f"{name}__count_{tag}"] = np.asarray(st.count).astype(np.int32)
+        for i, s in enumerate(st.stats):
+          for kind, lst in (("stat", s.statistics), ("precond", s.preconditioners)):
+            for j, x in enumerate(lst):
+              out[f"{name}__{tag}_{kind}{i}_{j}"] = npy(x)
+          out[f"{name}__{tag}_momentum{i}"] = npy(s.momentum.to_float())
+          out[f"{name}__{tag}_diag_momentum{i}"] = npy(s.diagonal_momentum.to_float())
+          dsf = s.diagonal_statistics.to_float()
+          if not (isinstance(dsf, list) and not dsf):
+            out[f"{name}__{tag}_diag_stats{i}"] = npy(dsf)
+          if kw.get("average_grad"):
+            out[f"{name}__{tag}_avg_grad{i}"] = npy(s.avg_grad)
+    for i, p in enumerate(params):
+      out[f"{name}__param{i}"] = p
+    index.append(dict(name=name, n_params=len(params), first=first, later=later, lr=0.1,
+                      kwargs={k: v for k, v in kw.items()}))
+    print(f"fd_resume {name}: state after {first} updates + {later} more updates")
+  np.savez_compressed(os.path.join(OUT, "fd_resume.npz"), **out)
+  with open(os.path.join(OUT, "fd_resume_index.json"), "w") as f:
+    json.dump(index, f, indent=1)
+
+
 if __name__ == "__main__":
   which = sys.argv[1:] or ["newton", "pi", "eigh", "gram", "book", "e2e", "lowrank", "quant",
-                           "e2e_quant", "e2e_more", "lowrank_big", "fd_metrics", "e2e_sharded"]
+                           "e2e_quant", "e2e_more", "lowrank_big", "fd_metrics", "e2e_sharded", "fd_resume"]
   if "newton" in which:
     gen_newton()
   if "pi" in which:
@@ -952,4 +1006,6 @@ if __name__ == "__main__":
     gen_fd_metrics()
   if "e2e_sharded" in which:
     gen_e2e_sharded()
+  if "fd_resume" in which:
+    gen_fd_resume()
   print("golden fixtures written to", OUT)
