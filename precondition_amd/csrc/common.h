@@ -54,6 +54,20 @@ inline int bind_device() {
   return bound == d ? 0 : PS_EDEVICE;
 }
 
+// Side streams of the multi-stream drivers (stream groups of the staged Newton execution, of the eigh
+// reduction, the second group of the one-sided Jacobi sweeps): ONE pool per host thread, shared by all of
+// them.  The runtime maps streams onto a few hardware queues (4 by default): with a pool per driver a
+// process that had run a mixed Newton call (1 side stream) and then an eigh call (3 more) held 5 streams,
+// two of the eigh groups shared a hardware queue and serialised -- cfg3 measured 219 ms inside the full
+// bench against 172 ms standalone.  Streams are created on first use and live as long as the thread.
+constexpr int PS_MAX_SIDE_STREAMS = 7;
+inline hipStream_t side_stream(int k) {
+  static thread_local hipStream_t pool[PS_MAX_SIDE_STREAMS] = {};
+  if (k < 0 || k >= PS_MAX_SIDE_STREAMS) return nullptr;
+  if (!pool[k] && hipStreamCreateWithFlags(&pool[k], hipStreamNonBlocking) != hipSuccess) pool[k] = nullptr;
+  return pool[k];
+}
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 

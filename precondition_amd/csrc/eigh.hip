@@ -1617,9 +1617,9 @@ static int eigh_driver(int mode, void* stream, const float* const* a, const int3
       // one box (466 vs 476 ms) and slower on the next (500 vs 483); smaller problems gain from two
       // (64 x 1024^2: 72 vs 80 ms, 256 x 512^2: 50 vs 54 ms).
       const int nstreams = opt.eigh_streams > 0 ? opt.eigh_streams : 2;
-      static thread_local hipStream_t side = nullptr;
+      hipStream_t side = psh::side_stream(0);   // the library's shared pool (common.h)
       static thread_local hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
-      if (!side) PS_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      if (!side) return PS_EINTERNAL;
       for (int i = 0; i < 3; ++i)
         if (!side_ev[i]) PS_HIP(hipEventCreateWithFlags(&side_ev[i], hipEventDisableTiming));
       // K-tile depth of the update products: 8 = 20 KB of LDS, which fits beside a pivot workgroup

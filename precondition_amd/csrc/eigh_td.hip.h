@@ -1243,7 +1243,7 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
   // three dependent launches, of which only the mat-vec is HBM-bound; one group's short vector kernels
   // run beside the other group's mat-vec.
   constexpr int MAXG = 8;
-  static thread_local hipStream_t side[MAXG - 1] = {};
+  hipStream_t side[MAXG - 1] = {};   // from the library's shared pool (common.h psh::side_stream)
   static thread_local hipEvent_t ev_fork = nullptr, ev_join[MAXG - 1] = {};
   // measured (64 x 2048 / 64 x 1024 / 256 x 512, ms): 1 group 181 / 43.1 / 28.9, 2 groups 173.5 / 43.0 / 28.0,
   // 4 groups 170.3 / 47.8 / 28.0: short columns gain nothing from a third and fourth group
@@ -1251,10 +1251,9 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
   const int ngroups = std::max(1, std::min(std::min(want, MAXG), B));
   if (!ev_fork) PS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   for (int g = 0; g + 1 < ngroups; ++g) {
-    if (!side[g]) {
-      PS_HIP(hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking));
-      PS_HIP(hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming));
-    }
+    side[g] = psh::side_stream(g);
+    if (!side[g]) return PS_EINTERNAL;
+    if (!ev_join[g]) PS_HIP(hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming));
   }
   hipLaunchKernelGGL(td_zero_kernel, dim3(256, B), b256, 0, st, lo.blocks, 0);
   hipLaunchKernelGGL(td_zero_kernel, dim3(8, B), b256, 0, st, lo.blocks, 1);

@@ -1448,16 +1448,9 @@ struct ProfRun {
   }
 };
 
-// Side streams of the stream groups (staged execution): per host thread and device, created once.
-hipStream_t side_stream(int k) {
-  constexpr int MAXDEV = 16;
-  static thread_local hipStream_t cache[MAXDEV][MAX_GROUPS] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV || k < 0 || k >= MAX_GROUPS) return nullptr;
-  if (!cache[dev][k] && hipStreamCreateWithFlags(&cache[dev][k], hipStreamNonBlocking) != hipSuccess)
-    cache[dev][k] = nullptr;
-  return cache[dev][k];
-}
+// Side streams of the stream groups: the library's shared pool (common.h psh::side_stream; one device per
+// process: PS_DEVICE_CHECK).
+inline hipStream_t side_stream(int k) { return psh::side_stream(k); }
 
 // One mapped status ring per host thread: a thread runs one call at a time, so calls
 // on distinct (stream, workspace) pairs from different threads never share slots.
