@@ -127,3 +127,42 @@ def test_donated_step_strided_gradient_view_takes_the_functional_path(device):
       assert torch.equal(x, y), t
   # the view really differs from reading the buffer as contiguous
   assert not torch.equal(bufs[0].t().contiguous(), bufs[0])
+
+
+def test_expired_power_iteration_restart_with_stream_groups(device, monkeypatch):
+  """The recovery path of an expired resident power iteration (tests/test_gpu_round3.py) in a call that runs
+  TWO stream groups (mixed sizes): the driver notices the expiry at its first host wait, joins the side
+  stream, queues the whole front again on the caller's stream, forks again and starts every group over.
+  Same bits as an undisturbed call (the streaming power iteration is bit-identical to the resident one)."""
+  import ctypes as C
+  from precondition_amd import _lib
+  L = _lib.lib()
+
+  def health():
+    e, c, r = C.c_uint(), C.c_int(), C.c_int()
+    assert L.ps_power_iteration_health(C.addressof(e), C.addressof(c), C.addressof(r)) == 0
+    return e.value, c.value, r.value
+
+  L.ps_power_iteration_reset_health()
+  arrs = [wishart(512, 2048, 400 + i) for i in range(6)] + [wishart(384, 1536, 410 + i) for i in range(6)]
+  ps = [4] * 6 + [2] * 6
+  ts = [torch.tensor(a, device=device) for a in arrs]
+  r0, m0 = K().matrix_inverse_pth_root_batched(ts, ps)
+  r0 = [x.clone() for x in r0]
+  m0 = m0.clone()
+  assert health()[0] == 0
+  monkeypatch.setenv("PS_PI_TIMEOUT_MS", "0")
+  try:
+    r1, m1 = K().matrix_inverse_pth_root_batched(ts, ps)
+    torch.cuda.synchronize()
+    expired, _, resident = health()
+    assert expired > 0 and resident == 0, (expired, resident)
+    assert np.isfinite(m1.cpu().numpy()[:, :5]).all()
+    # column 6 (power-iteration steps) and everything else: the same
+    assert np.array_equal(m1.cpu().numpy(), m0.cpu().numpy())
+    for x, y in zip(r1, r0):
+      assert torch.equal(x, y)
+  finally:
+    monkeypatch.delenv("PS_PI_TIMEOUT_MS")
+    L.ps_power_iteration_reset_health()
+  assert health() == (0, 0, 1)
