@@ -152,7 +152,7 @@ class TreePlan:
     # X^T comes out bit-identical -- but the left operand is now k-contiguous (16-byte LDS
     # fragment reads instead of four 4-byte ones) and the stage-B product reads X^T the same way:
     # 0.72-0.77 -> 0.80-0.83 of the fp32 MFMA peak on uniform batches of ViT-B's block shapes
-    # (tools/dev_r4_apply_layouts.py).  One-row products stay in the streaming mat-vec form.
+    # (round 4 measurement).  One-row products stay in the streaming mat-vec form.
     pl.sa_tbl = gemm_tbl(sa_rows)
     pl.sb_tbl = gemm_tbl(sb_rows)
     if sa_rows:

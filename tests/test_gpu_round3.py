@@ -109,7 +109,7 @@ def test_resident_power_iteration_beside_a_kernel_holding_most_cus(device, monke
 def test_expired_resident_wait_falls_back_to_streaming_in_the_same_call(device, monkeypatch):
   """The recovery path of an expired wait.  (On this hardware a filler kernel could not be made
   to split a team for longer than a deadline: workgroups start in launch order, and with most
-  CUs held the whole launch simply starts late -- previous test; tools/dev_pi_expiry*.py.  The
+  CUs held the whole launch simply starts late -- previous test (dev scripts of round 3, see the git history).  The
   expiry is therefore forced: PS_PI_TIMEOUT_MS=0 makes every wait count as expired.)  The
   resident launch gives up at once (counted in pinned host memory, eigenvalues NaN), the Newton
   root driver sees the count move at its first host wait and runs the call again on the
