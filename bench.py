@@ -485,7 +485,7 @@ def fd_parity_literal(dev, d=4096, rank=64, updates=2, p=4):
     del g, pg, pr, lg, lr
   return {"input": f"one factor of dim {d}, rank {rank}, grad blocks ~N(0,1) (the literal BASELINE input), "
                    f"{updates} chained updates, p={p}",
-          "oracle": "oracle.fd_update_root (numpy.linalg.svd of [sqrt(decay) W | R])",
+          "oracle": "oracle.fd_update_root (float32 LAPACK sgesdd of [sqrt(decay) W | R], scipy.linalg.lapack)",
           "updates": rows,
           "operator_rel_fro_max": max(x["operator_rel_fro"] for x in rows),
           "tail_rel_max": max(x["tail_rel"] for x in rows)}

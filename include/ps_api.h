@@ -691,6 +691,46 @@ typedef struct {
   int32_t reserved;
 } ps_fd_round_desc;
 int ps_fd_round_f32(void* stream, const ps_fd_round_desc* d);
+
+/* ---- ps_fd_update_batched_f32: ONE call per Frequent-Directions sketch update ----------------------
+ * Replaces _fd_update_root (DS:1123-1290; called per factor under vmap at DS:2732-2738) for `batch`
+ * factors of equal dimension d, sketch rank and exponent p -- SURVEY.md 8(b)'s ps_fd_update_batched:
+ *   prepare  W_j = sketch_j sqrt(eigs_j + ridge_j) (DS:1160-1172), C_j = sym(decay W_j W_j^T + Gram_j)
+ *            (the SVD of [sqrt(decay) W | R] at DS:1193 <=> the eigenpairs of C), bf16 planes of C_j;
+ *   iterate  Chebyshev-filtered block subspace iteration for the leading rank + 1 eigenpairs: per outer
+ *            round ps_fd_round_f32 + ONE 16-byte host read + ps_fd_filter_round_f32, <= max_outer rounds;
+ *   finish   DS:1196-1290: deflation by the cutoff singular value, tail, sanity masks (unit norm within
+ *            1 %), inverted eigenvalues, packing into the [d, rank + 2] layout of DS:555-592.
+ * new_grad: HOST array of `batch` device pointers to contiguous d x d matrices: the Gram matrix of the
+ *   (averaged) gradient block, or -- input_is_factor != 0 -- a factor R with R R^T = Gram, which is what the
+ *   reference keeps in its statistics slot (DS:1497-1505).
+ * prev / out: device [batch][d][rank + 2] packed sketches (may not alias); converged: device [batch] int32,
+ *   0 marks a factor whose block iteration did not converge in max_outer rounds (its `out` row is then NOT to
+ *   be used: the reference-equivalent full decomposition is the caller's fallback).
+ * x0: device [batch][d][b] float32 start block, b = ps_fd_block_columns(rank, d) (any full-rank block; the
+ *   Python host passes its seeded Gaussian block, which keeps results bit-identical to the per-step path).
+ * tol / degree / max_outer: <= 0 selects 1e-5 / 12 / 14.  Only padding_start == d is supported (no padding).
+ * PS_EUNSUPPORTED outside the fused kernels' domain (batch <= 16, d % 128 == 0, b in {32, 64, 96},
+ * 4 (rank + 33) <= d): the caller takes its general path.  Synchronises the stream once per outer round.
+ * info_host (may be NULL): {outer rounds, filter products, b}. */
+typedef struct {
+  int32_t batch, d, rank, p;
+  float decay, ridge_epsilon, error_tolerance;
+  int32_t relative_matrix_epsilon;
+  int32_t input_is_factor;
+  int32_t degree, max_outer;
+  float tol;
+  const float* const* new_grad;
+  const float* prev;
+  float* out;
+  int32_t* converged;
+  const float* x0;
+  void* workspace;
+  size_t workspace_bytes;
+} ps_fd_update_desc;
+int ps_fd_block_columns(int rank, int d);
+size_t ps_fd_update_workspace_bytes(const ps_fd_update_desc* d);   /* 0 = unsupported shape */
+int ps_fd_update_batched_f32(void* stream, const ps_fd_update_desc* d, int32_t* info_host);
 int ps_chol_rinv_max_n(void);
 int ps_chol_rinv_batched_f32(void* stream, const float* gram, float* out, int b, int batch,
                              float drop_rel);

@@ -67,6 +67,16 @@ class FdRoundDesc(C.Structure):
               [("tol", C.c_float), ("reserved", C.c_int32)])
 
 
+class FdUpdateDesc(C.Structure):
+  """Mirror of ps_fd_update_desc."""
+  _fields_ = ([(n, C.c_int32) for n in ("batch", "d", "rank", "p")] +
+              [(n, C.c_float) for n in ("decay", "ridge_epsilon", "error_tolerance")] +
+              [(n, C.c_int32) for n in ("relative_matrix_epsilon", "input_is_factor", "degree", "max_outer")] +
+              [("tol", C.c_float)] +
+              [(n, C.c_void_p) for n in ("new_grad", "prev", "out", "converged", "x0", "workspace")] +
+              [("workspace_bytes", C.c_size_t)])
+
+
 class TransformDesc(C.Structure):
   """Mirror of ps_transform_desc."""
   _fields_ = [(n, C.c_void_p) for n in ("grad", "pgrad", "param", "diag_in", "diag_out",
@@ -303,6 +313,9 @@ _SIGNATURES = {
     "ps_fd_cov_update_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_float]),
     "ps_fd_round_f32": (C.c_int, [C.c_void_p, C.POINTER(FdRoundDesc)]),
+    "ps_fd_block_columns": (C.c_int, [C.c_int, C.c_int]),
+    "ps_fd_update_workspace_bytes": (C.c_size_t, [C.POINTER(FdUpdateDesc)]),
+    "ps_fd_update_batched_f32": (C.c_int, [C.c_void_p, C.POINTER(FdUpdateDesc), C.c_void_p]),
     "ps_chol_rinv_max_n": (C.c_int, []),
     "ps_chol_rinv_batched_f32":
         (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]),

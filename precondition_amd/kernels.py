@@ -1004,6 +1004,57 @@ def low_rank_root_batched(calls):
   return low_rank._low_rank_root_batched(calls)
 
 
+_FD_WS = {}   # (device, bytes needed) -> workspace of the last ps_fd_update_batched_f32 call (reused across steps)
+
+
+@_device_guarded
+def fd_update_batched(new_grads, prev, p, rank, decay, ridge_epsilon, error_tolerance, relative_matrix_epsilon,
+                      x0, input_is_factor=False, tol=1e-5, degree=12, max_outer=14):
+  """ONE library call per Frequent-Directions sketch update of a group of factors (ps_fd_update_batched_f32;
+  DS:1123-1290): new_grads: B contiguous float32 [d, d] Gram matrices (or factors R, input_is_factor); prev:
+  [B, d, rank + 2] packed sketches; x0: [B, d, b] start block, b = fd_block_columns(rank, d).  Returns
+  (packed [B, d, rank + 2], converged [B] int32 device tensor, info) or None where the library does not
+  support the shape (the caller takes the step-by-step path)."""
+  from ._lib import FdUpdateDesc
+  L = lib()
+  bsz = len(new_grads)
+  d = int(new_grads[0].shape[0])
+  for t in (*new_grads, prev, x0):
+    _require_gpu(t, "fd_update_batched")
+    if not t.is_contiguous() or t.dtype != torch.float32:
+      raise ValueError("fd_update_batched expects contiguous float32 tensors")
+  dev = prev.device
+  u = FdUpdateDesc()
+  u.batch, u.d, u.rank, u.p = bsz, d, int(rank), int(p)
+  u.decay, u.ridge_epsilon, u.error_tolerance = float(decay), float(ridge_epsilon), float(error_tolerance)
+  u.relative_matrix_epsilon, u.input_is_factor = int(bool(relative_matrix_epsilon)), int(bool(input_is_factor))
+  u.degree, u.max_outer, u.tol = int(degree), int(max_outer), float(tol)
+  need = int(L.ps_fd_update_workspace_bytes(C.byref(u)))
+  if need == 0:
+    return None
+  b = int(L.ps_fd_block_columns(int(rank), d))
+  if (tuple(prev.shape) != (bsz, d, rank + 2) or tuple(x0.shape) != (bsz, d, b) or
+      any(tuple(g.shape) != (d, d) for g in new_grads)):
+    raise ValueError("fd_update_batched: shape mismatch")
+  key = (dev, need)
+  ws = _FD_WS.get(key)
+  if ws is None:
+    _FD_WS.clear()           # one resident workspace (2-3 GB at 8 x 4096^2): the last shape wins
+    ws = _FD_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+  out = torch.empty((bsz, d, rank + 2), dtype=torch.float32, device=dev)
+  conv = torch.empty((bsz,), dtype=torch.int32, device=dev)
+  ptrs = (C.c_void_p * bsz)(*[g.data_ptr() for g in new_grads])
+  u.new_grad = C.cast(ptrs, C.c_void_p).value
+  u.prev, u.out, u.converged, u.x0 = prev.data_ptr(), out.data_ptr(), conv.data_ptr(), x0.data_ptr()
+  u.workspace, u.workspace_bytes = ws.data_ptr(), ws.numel()
+  info = (C.c_int32 * 4)()
+  rc = L.ps_fd_update_batched_f32(_stream(), C.byref(u), C.cast(info, C.c_void_p))
+  if rc == -3:               # PS_EUNSUPPORTED
+    return None
+  check(rc, "ps_fd_update_batched_f32")
+  return out, conv, {"outer_iterations": int(info[0]), "filter_products": int(info[1]), "block": int(info[2])}
+
+
 def fd_update_root(*args, **kwargs):
   from . import low_rank
   return low_rank._fd_update_root(*args, **kwargs)

@@ -295,6 +295,24 @@ def _fd_update_root_group(calls, key):
   d, rank, p, decay, ridge_eps, err_tol, rel, is_gram, dev = key
   bsz, r = len(calls), rank
   prev = torch.stack([kw["prev"] for kw in calls])                       # [B, d, r + 2]
+  # ONE library call for the whole update (ps_fd_update_batched_f32: preparation, every outer round of the
+  # subspace iteration, DS:1196-1290 and the packing) where the fused kernels apply; the start block is the
+  # seeded Gaussian block of subspace.top_eigenpairs_batched, so the eigenpairs are bit-identical to the
+  # step-by-step path below (PS_FD_ONE_CALL=0 selects it; it is also the fallback for other shapes / modes).
+  if (dev.type == "cuda" and os.environ.get("PS_FD_ONE_CALL", "1") != "0" and
+      subspace._filter_precision(d) == "bf16x3" and subspace._fused_filter() and
+      all(os.environ.get(k_, "1") != "0" for k_ in ("PS_FD_TILED", "PS_FD_ROUND_CALL", "PS_FD_FRAG", "PS_FD_RR_X6",
+                                                     "PS_FD_PLANS", "PS_FD_ROUND_LIB", "PS_FD_CHOLQR"))):
+    b = int(kernels.lib().ps_fd_block_columns(r, d))
+    gen = torch.Generator(device=dev).manual_seed(1729)
+    x0 = torch.randn((bsz, d, b), generator=gen, device=dev, dtype=torch.float32)
+    res = kernels.fd_update_batched(
+        [kw["new_grad"].contiguous() for kw in calls], prev.contiguous(), p, r, decay, ridge_eps, err_tol, rel, x0,
+        input_is_factor=not is_gram, degree=int(os.environ.get("PS_FD_DEGREE", 12)))
+    if res is not None:
+      packed, conv, _ = res
+      ok = conv.cpu().tolist()
+      return [(packed[j], _metrics(0.0)) if ok[j] else None for j in range(bsz)]
   sketch = prev[:, :, :r]
   fwd_eigvals = prev[:, d - r:, -1]                                       # [B, r]
   tail = prev[:, 1, -1]                                                   # [B]

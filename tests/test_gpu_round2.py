@@ -261,6 +261,15 @@ def test_fd_update_root_subspace_path_vs_reference_golden(name, device, monkeypa
   real = subspace.top_eigenpairs_batched
   monkeypatch.setattr(subspace, "top_eigenpairs_batched",
                       lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+  # (round 6: the block method of a supported shape runs inside ONE library call, ps_fd_update_batched_f32)
+  from precondition_amd import kernels as _kern
+  real_one = _kern.fd_update_batched
+  def _spy_one(*a, **k):
+    res = real_one(*a, **k)
+    if res is not None:
+      calls.append(1)
+    return res
+  monkeypatch.setattr(_kern, "fd_update_batched", _spy_one)
   rng = np.random.default_rng(c["seed"])
   d, r = c["d"], c["rank"]
   prev = torch.zeros((d, r + 2), device=device)

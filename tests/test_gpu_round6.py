@@ -166,3 +166,66 @@ def test_expired_power_iteration_restart_with_stream_groups(device, monkeypatch)
     monkeypatch.delenv("PS_PI_TIMEOUT_MS")
     L.ps_power_iteration_reset_health()
   assert health() == (0, 0, 1)
+
+
+@pytest.mark.parametrize("d,rank,bsz,factor", [(1024, 8, 3, False), (2048, 64, 2, False), (1024, 20, 2, True)])
+def test_fd_update_one_library_call_equals_the_step_by_step_path(d, rank, bsz, factor, device, monkeypatch):
+  """ps_fd_update_batched_f32 (SURVEY 8(b)'s ps_fd_update_batched; DS:1123-1290 for a group of factors in ONE
+  call: preparation, every outer round of the subspace iteration, deflation / masks / packing) against the
+  step-by-step Python-driven path (PS_FD_ONE_CALL=0: the same library calls issued one by one + torch
+  elementwise ops): two chained updates, the packed sketches agree to float32 rounding (the eigenpairs come from
+  the same calls on the same start block; only the column norms of the finish are summed in another order), and
+  both match the oracle's SVD-based update (float32 sgesdd) through what the optimizer uses."""
+  from precondition_amd import low_rank
+  from tests.test_optimizer_host_logic import packed_matches
+  rng = np.random.default_rng(d + rank)
+  outs = {}
+  grads = []
+  for t in range(2):
+    gs = []
+    for j in range(bsz):
+      g = rng.standard_normal((d, 2 * d)).astype(np.float32) * np.float32(1.0 + 0.3 * t)
+      g[:rank + 2] *= np.linspace(6.0, 2.0, rank + 2)[:, None].astype(np.float32)   # a separated leading subspace
+      gs.append(g)
+    grads.append(gs)
+  for one_call in ("1", "0"):
+    monkeypatch.setenv("PS_FD_ONE_CALL", one_call)
+    prevs = [torch.zeros((d, rank + 2), dtype=torch.float32, device=device) for _ in range(bsz)]
+    chain = []
+    for t in range(2):
+      calls = []
+      for j in range(bsz):
+        g = torch.tensor(grads[t][j], device=device)
+        gram = K().matmul(g, g, transb=True)
+        if factor:   # a factor R with R R^T = Gram (what the reference keeps in its statistics slot)
+          e, v = torch.linalg.eigh(gram.double().cpu())
+          new_grad = (v * e.clamp_min(0).sqrt()).float().to(device).contiguous()
+        else:
+          new_grad = gram
+        calls.append(dict(new_grad=new_grad, p=4, rank=rank, ridge_epsilon=1e-6, decay=0.999, padding_start=d,
+                          prev=prevs[j], new_grad_is_gram=not factor))
+      res = low_rank._fd_update_root_batched(calls)
+      prevs = [r[0] for r in res]
+      chain.append([p_.cpu().numpy() for p_ in prevs])
+    outs[one_call] = chain
+  monkeypatch.delenv("PS_FD_ONE_CALL")
+  for t in range(2):
+    for a, b in zip(outs["1"][t], outs["0"][t]):
+      assert a.shape == b.shape == (d, rank + 2)
+      if t == 0:
+        assert np.allclose(a[:, -2:], b[:, -2:], rtol=5e-6, atol=0), np.abs(a[:, -2:] - b[:, -2:]).max()
+        assert np.abs(a[:, :rank] - b[:, :rank]).max() <= 1e-5                # unit vectors, same signs
+      else:
+        # the second update starts from sketches that differ in the last bits of their normalisation: the small
+        # eigensolver may then return an eigenvector with the other sign -- compare what the optimizer uses
+        assert np.allclose(a[:, -2:], b[:, -2:], rtol=5e-5, atol=0), np.abs(a[:, -2:] - b[:, -2:]).max()
+        assert packed_matches(a, b, rank, tol=1e-3)
+      assert a[-1, -2] == b[-1, -2]
+  # and the oracle (float32 LAPACK) on the first factor of the first update
+  g0 = grads[0][0]
+  gram0 = (g0.astype(np.float64) @ g0.astype(np.float64).T)
+  w, v = np.linalg.eigh(gram0)
+  fac = (v * np.sqrt(np.maximum(w, 0))).astype(np.float32)
+  ref = orc.fd_update_root(fac, 4, rank, ridge_epsilon=1e-6, error_tolerance=1e-6, relative_matrix_epsilon=True,
+                           decay=0.999, padding_start=d, prev=np.zeros((d, rank + 2), np.float32))
+  assert packed_matches(outs["1"][0][0], ref, rank, tol=2e-3)
