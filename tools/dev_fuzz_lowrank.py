@@ -27,7 +27,10 @@ for case in range(60):
   full = n + int(rng.choice([0, 0, 5]))
   m = np.zeros((full, full), np.float32); m[:n, :n] = a
   with np.errstate(all="ignore"):
-    ref, err = orc.low_rank_root(m, p, rank, padding_start=n)
+    # the float64-internal yardstick: the reference's own float32 ssyevd (oracle default since round 6) loses the
+    # bottom eigenpairs of graded / rank-deficient matrices (18 of 60 cases "mismatch" against it by up to 0.4),
+    # the build's plain eigenpairs keep the accurate rule and match the yardstick
+    ref, err = orc.low_rank_root(m, p, rank, padding_start=n, lapack="f64")
   calls.append(dict(matrix=torch.tensor(m, device=dev), p=p, compression_rank=rank, padding_start=n))
   refs.append(ref); meta.append((n, full, rank, p, kind))
 res = low_rank._low_rank_root_batched(calls)
