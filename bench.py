@@ -906,7 +906,20 @@ def main():
       # tests / dev only: RCCL refuses two ranks on one GPU; gloo exercises the same control flow
       dist.init_process_group(backend="gloo")
     else:
-      dist.init_process_group(backend="nccl", device_id=dev)
+      # RCCL (ROCm 7) prints a five-line version banner to STDOUT when the communicator is created; the line
+      # contract of this script is ONE JSON line on rank 0's stdout, so file descriptor 1 points at stderr while
+      # the group is created and warmed up (one barrier: the communicator is built lazily at the latest there)
+      sys.stdout.flush()
+      saved = os.dup(1)
+      os.dup2(2, 1)
+      try:
+        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.barrier()
+        torch.cuda.synchronize()
+      finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
   work = Workload(args.workload, rank, world, dev, multi)
   if args.profile_hinted_only:
