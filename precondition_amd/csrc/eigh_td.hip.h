@@ -1247,7 +1247,11 @@ inline int td_run(hipStream_t st, const TdPlan& pl, TdLayout& lo, EighBlock* d_e
   static thread_local hipEvent_t ev_fork = nullptr, ev_join[MAXG - 1] = {};
   // measured (64 x 2048 / 64 x 1024 / 256 x 512, ms): 1 group 181 / 43.1 / 28.9, 2 groups 173.5 / 43.0 / 28.0,
   // 4 groups 170.3 / 47.8 / 28.0: short columns gain nothing from a third and fourth group
-  const int want = nmax >= 1536 ? stream_groups : std::min(stream_groups, 2);
+  // while an asynchronous collective is in flight (ps_collective_in_flight: the N > 1 exchange of the previous
+  // phase on RCCL's own stream) at most two groups: the runtime has four hardware queues, and more live streams
+  // than queues serialise groups that share one (common.h psh::side_stream)
+  const int cap_groups = PiPlan::health().collectives.load() > 0 ? 2 : stream_groups;
+  const int want = nmax >= 1536 ? cap_groups : std::min(cap_groups, 2);
   const int ngroups = std::max(1, std::min(std::min(want, MAXG), B));
   if (!ev_fork) PS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   for (int g = 0; g + 1 < ngroups; ++g) {
