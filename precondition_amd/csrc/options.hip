@@ -75,6 +75,7 @@ void ps_dev_env_overrides(Options& o) {
   geti("PS_EIGH_TD_FORCE", o.eigh_td_force);
   geti("PS_EIGH_TD_ACCURATE", o.eigh_td_accurate);
   geti("PS_QUANT_FLAT", o.quant_flat);
+  geti("PS_QUANT_STRIP", o.quant_strip);
 }
 
 }  // namespace

@@ -42,6 +42,8 @@ struct QTensor {
   int chunk0, strips;
   int flat;               // contiguous [rows, cols] float4-addressable tensor: the flat kernels take it
   int fchunk0, fchunks;   // its chunks of QFLAT consecutive elements
+  int strip;              // quantize only: the register-resident strip kernel takes it (quant_strip_kernel)
+  int schunk0, schunks;   // its strips of QS_COLS columns
 };
 
 typedef float qf4 __attribute__((ext_vector_type(4)));
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void quant_colmax_kernel(const QTensor* ts, co
           float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (t->extract && col + j == r) x[j] = 0.f;
+            if (t->extract && col + j == r) x[j] = __fsub_rn(x[j], x[j]);   // QU:79-80 (NaN for a non-finite diagonal)
             const unsigned b = __float_as_uint(fabsf(x[j]));
             m[j] = b > m[j] ? b : m[j];
           }
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void quant_colmax_kernel(const QTensor* ts, co
     unsigned m = 0u;
     for (long long r = r0; r < r1; ++r) {
       float x = ldg1(t->fin + r * ld + c);
-      if (t->extract && c == r) x = 0.f;
+      if (t->extract && c == r) x = __fsub_rn(x, x);
       const unsigned b = __float_as_uint(fabsf(x));
       m = b > m ? b : m;
     }
@@ -209,7 +211,7 @@ __device__ __forceinline__ void quant_flat_body(const QTensor* t, int local, uns
         float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (extract && col + j == row) x[j] = 0.f;
+          if (extract && col + j == row) x[j] = __fsub_rn(x[j], x[j]);
           const unsigned b = __float_as_uint(fabsf(x[j]));
           if (b) atomicMax(&s_max[col + j], b);
         }
@@ -300,6 +302,193 @@ __global__ __launch_bounds__(256) void quant_flat_kernel(const QTensor* ts, cons
 
 __device__ inline int encode1(float x, float bs_nonzero) {
   return (int)rintf(__fdiv_rn(x, bs_nonzero));  // QU:91-94; rint = round half to even
+}
+
+// ---- quantize in ONE read (round 6): register-resident column strips -----------------------------------------
+// The scale of a column is the maximum over ALL its rows, so the streaming kernels above read the input twice
+// (column maxima, then codes: 4 + 4 + 2 bytes of traffic per element for int16).  For matrices of up to 1024 rows a
+// workgroup of 512 threads can keep a strip of 64 columns x all rows in REGISTERS (32 float4 per lane): one read,
+// maxima through the wavefronts' lanes and 2 KB of LDS, codes from the same registers: 4 + 2 bytes per element.
+// Lane = (column quad q = tid & 15, row group g = tid >> 4): a wavefront reads 4 rows x 256 contiguous bytes per
+// instruction and has all of a lane's loads in flight at once (<= 32 x 16 bytes per lane, 256 KB per workgroup); int16
+// codes leave as whole 128-byte lines.  Same arithmetic as the other kernels (IEEE division, round half to even, the
+// maximum taken on bit patterns): codes, diagonals and bucket sizes are bit-identical.
+constexpr int QS_COLS = 64;
+constexpr int QS_THREADS = 512;
+constexpr int QS_GROUPS = QS_THREADS / 16;   // 32 row groups
+constexpr int QS_NV = 32;                    // rows per lane: up to 32 x 32 = 1024 rows
+constexpr int QS_MINR = 64;                  // below that a strip is too little work per workgroup
+
+// Instruction count matters as much as bytes here: a workgroup's 65536 elements pass through the VALU twice (maximum,
+// codes) behind loads that cannot overlap them (one workgroup per CU).  The first version spent ~45 instructions per
+// element (the compiler's 11-instruction IEEE division, 64-bit row/column tests per element, spilled scalars) and was
+// VALU-bound at 0.37 of the HBM peak.  Here:
+//  * the diagonal (extract) is handled before the passes, for the two steps k whose rows can cross the strip's
+//    columns (a scalar test per step instead of a 64-bit comparison per element);
+//  * the division x / b runs the SAME operation sequence as the compiler's expansion of IEEE division
+//    (rcp, two fmas refining it, then mul, fma, fma, fma, fma) with the part that depends only on the column's b
+//    hoisted out of the element loop: five instructions per element.  The expansion's scaling (v_div_scale) and
+//    fix-up (v_div_fixup) steps leave operands and result unchanged unless the denominator is outside
+//    [2^-60, 2^60] (kept out of this path) or the quotient is below 2^-43 (rounds to code 0 either way), so the codes
+//    are those of __fdiv_rn bit for bit; a wavefront with any column outside the range takes the plain division;
+//  * round-half-even + integer conversion + packing: q + 1.5*2^23 holds the rounded integer in its low mantissa
+//    bits (|q| <= 32767), two byte-permutes pack four of them.
+template <int BITS>
+__device__ __forceinline__ unsigned qs_pack_pair(unsigned lo_bits, unsigned hi_bits) {
+  // low 16 (or 8) bits of each operand, concatenated
+  return BITS == 16 ? __builtin_amdgcn_perm(hi_bits, lo_bits, 0x05040100u)
+                    : __builtin_amdgcn_perm(hi_bits, lo_bits, 0x0c0c0400u);
+}
+
+template <int BITS, bool FULL>
+__device__ __forceinline__ void quant_strip_body(const QTensor* t, int local, unsigned (*s_red)[QS_COLS]) {
+  const int tid = threadIdx.x, q = tid & 15, g = tid >> 4, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // every field is read before the first store (stays a scalar load); rows <= 1024, rows * cols * 4 < 2^31
+  const int rows = (int)t->rows, cols = (int)t->cols;
+  const int extract = t->extract;
+  const float* const fin = t->fin;
+  char* const codes0 = reinterpret_cast<char*>(t->codes);
+  float* const diag = t->diag;
+  float* const bucket = t->bucket;
+  const int c0 = local * QS_COLS, col = c0 + 4 * q;
+  const bool col_in = FULL || col < cols;              // cols % 4 == 0: a quad is inside or outside as a whole
+  const float nb = BITS == 8 ? 127.f : 32767.f;
+  // FULL: rows % 32 == 0 and the strip lies inside the tensor -- every condition below is wave-uniform
+  const int nv_full = rows / QS_GROUPS, rem = FULL ? 0 : rows % QS_GROUPS;
+  const int nv_used = nv_full + (rem != 0 ? 1 : 0);
+  // wave-uniform running base (first row of the wavefront's row groups, first column of the strip) + one lane offset
+  const char* lb = reinterpret_cast<const char*>(fin + (long long)(4 * wave) * cols + c0);
+  uint32_t loff = (uint32_t)((((g & 3) * cols) + 4 * q) * 4);
+  asm volatile("" : "+v"(loff));
+  const long long step_bytes = (long long)QS_GROUPS * cols * 4;
+  F4 v[QS_NV];
+#pragma unroll
+  for (int k = 0; k < QS_NV; ++k) {
+    v[k] = F4{0.f, 0.f, 0.f, 0.f};
+    if (k < nv_full) {
+      if (FULL) v[k] = ldg4_so(lb, loff);
+      else if (col_in) v[k] = ldg4_so(lb, loff);
+    } else if (!FULL && k == nv_full && rem != 0) {
+      if (col_in && g < rem) v[k] = ldg4_so(lb, loff);
+    }
+    lb += step_bytes;
+    asm volatile("" : "+s"(lb));
+  }
+  // diagonal: row 32 k + g meets the strip's columns [c0, c0 + 64) only for k = c0 / 32 and k = c0 / 32 + 1
+  if (extract) {
+    const int kd = c0 / QS_GROUPS;
+#pragma unroll
+    for (int k = 0; k < QS_NV; ++k) {
+      if (k != kd && k != kd + 1) continue;            // scalar
+      const int r = QS_GROUPS * k + g;
+      const int d = r - col;                           // the lane holds the diagonal element in component d
+      if ((unsigned)d < 4u && r < rows && col_in) {
+        float* xs = &v[k].x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (d == j) {
+            *(float PS_GLOBAL*)(diag + r) = xs[j];
+            xs[j] = __fsub_rn(xs[j], xs[j]);           // QU:79-80: value - diag(diagonal)
+          }
+        }
+      }
+    }
+  }
+  unsigned m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < QS_NV; ++k) {
+    if (k >= nv_used) continue;                        // scalar; (rows not loaded are zeros)
+    const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned b = __float_as_uint(x[j]) & 0x7fffffffu;
+      m[j] = b > m[j] ? b : m[j];
+    }
+  }
+  // the four row groups of a wavefront (lanes q, q + 16, q + 32, q + 48), then the eight wavefronts through LDS
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned o = __shfl_xor(m[j], 16, 64); m[j] = o > m[j] ? o : m[j];
+    o = __shfl_xor(m[j], 32, 64); m[j] = o > m[j] ? o : m[j];
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_red[wave][4 * q + j] = m[j];
+  }
+  __syncthreads();
+  float bnz[4], y1[4];
+  bool sane = true;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned a = s_red[0][4 * q + j];
+#pragma unroll
+    for (int w = 1; w < QS_THREADS / 64; ++w) { const unsigned o = s_red[w][4 * q + j]; a = o > a ? o : a; }
+    const float bs = __fdiv_rn(__uint_as_float(a), nb);     // QU:86
+    bnz[j] = bs > 0.f ? bs : 1.f;                            // QU:89-90
+    if (g == 0 && col_in) *(float PS_GLOBAL*)(bucket + col + j) = bs;
+    // the denominator-only part of the IEEE division sequence
+    const float rc = __builtin_amdgcn_rcpf(bnz[j]);
+    const float e = __fmaf_rn(-bnz[j], rc, 1.0f);
+    y1[j] = __fmaf_rn(e, rc, rc);
+    sane = sane && bnz[j] >= 0x1p-60f && bnz[j] <= 0x1p60f;
+  }
+  constexpr int esz = BITS == 16 ? 2 : 1;
+  char* cb = codes0 + ((long long)(4 * wave) * cols + c0) * esz;
+  uint32_t coff = (uint32_t)((((g & 3) * cols) + 4 * q) * esz);
+  asm volatile("" : "+v"(coff));
+  const long long cstep = (long long)QS_GROUPS * cols * esz;
+  const bool fast = __all(sane ? 1 : 0) != 0;           // wave-uniform
+#pragma unroll
+  for (int k = 0; k < QS_NV; ++k) {
+    if (k < nv_used) {                                   // scalar
+      const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      unsigned cq[4];
+      if (fast) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float q0 = __fmul_rn(x[j], y1[j]);
+          const float r0 = __fmaf_rn(-bnz[j], q0, x[j]);
+          const float q1 = __fmaf_rn(r0, y1[j], q0);
+          const float r1 = __fmaf_rn(-bnz[j], q1, x[j]);
+          const float qq = __fmaf_rn(r1, y1[j], q1);
+          cq[j] = __float_as_uint(__fadd_rn(qq, 12582912.0f));   // 1.5 * 2^23: integer in the low mantissa bits
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cq[j] = (unsigned)encode1(x[j], bnz[j]);
+      }
+      const bool valid = FULL || (col_in && QS_GROUPS * k + g < rows);
+      char* dst = cb + coff;
+      if (BITS == 16) {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        u2v pk;
+        pk[0] = qs_pack_pair<16>(cq[0], cq[1]);
+        pk[1] = qs_pack_pair<16>(cq[2], cq[3]);
+        if (valid) *(u2v PS_GLOBAL*)dst = pk;
+      } else {
+        const unsigned lo = qs_pack_pair<8>(cq[0], cq[1]), hi = qs_pack_pair<8>(cq[2], cq[3]);
+        const unsigned pk = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        if (valid) *(unsigned PS_GLOBAL*)dst = pk;
+      }
+    }
+    cb += cstep;
+    asm volatile("" : "+s"(cb));
+  }
+}
+
+__global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* ts, const int* cmap) {
+  __shared__ unsigned s_red[QS_THREADS / 64][QS_COLS];
+  const QTensor* t = &ts[cmap[blockIdx.x]];
+  const int local = blockIdx.x - t->schunk0;
+  const bool full = t->rows % QS_GROUPS == 0 && (long long)(local + 1) * QS_COLS <= t->cols;
+  if (t->bits == 16) {
+    if (full) quant_strip_body<16, true>(t, local, s_red);
+    else quant_strip_body<16, false>(t, local, s_red);
+  } else {
+    if (full) quant_strip_body<8, true>(t, local, s_red);
+    else quant_strip_body<8, false>(t, local, s_red);
+  }
 }
 
 // ---- pass 2: bucket sizes, diagonal, codes ---------------------------------------------
@@ -452,6 +641,7 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
                                std::vector<QTensor>& ht, size_t& total_cols) {
   ht.resize(count);
   const bool flat_on = psh::resolve(nullptr).quant_flat != 0;
+  const bool strip_on = psh::resolve(nullptr).quant_strip != 0;
   long long chunk0 = 0;
   total_cols = 0;
   for (int i = 0; i < count; ++i) {
@@ -472,6 +662,11 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
               aligned(d.codes, code_vec) && aligned(d.bucket_size, 16)) ? 1 : 0;
     t.flat = (flat_on && t.vec4 && d.ld == d.cols && d.ldq == d.cols && d.cols <= QFLAT_MAXC && d.rows > 0 &&
               d.cols > 0 && count <= QMAXT && aligned(d.codes, 16)) ? 1 : 0;
+    // quantize: matrices of 64 ... 1024 rows are encoded from registers in one read (quant_strip_kernel)
+    t.strip = (encode && strip_on && t.flat && d.rows >= QS_MINR && d.rows <= (long long)QS_NV * QS_GROUPS &&
+               (d.rows * d.cols) * 4 < (1LL << 31)) ? 1 : 0;
+    t.schunks = t.strip ? (int)((d.cols + QS_COLS - 1) / QS_COLS) : 0;
+    if (t.strip) t.flat = 0;
     t.fchunks = t.flat ? (int)((d.rows * d.cols + QFLAT - 1) / QFLAT) : 0;
     t.strips = (int)((d.cols + QW - 1) / QW);
     const long long rcs = (d.rows + QR - 1) / QR;
@@ -480,7 +675,6 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
     if (chunk0 > 0x7fffffffLL) return PS_EUNSUPPORTED;
     total_cols += psh::align_up((size_t)d.cols, 4);
   }
-  (void)encode;
   return chunk0;
 }
 
@@ -488,7 +682,7 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
 // 64 x 256 tile chunks of the other tensors; chunk0 / fchunk0 of every tensor are set to its first
 // chunk inside its own list.
 static void build_chunk_maps(std::vector<QTensor>& ht, std::vector<int>& map, long long& fch,
-                             long long& tch) {
+                             long long& tch, long long* sch_out = nullptr) {
   fch = 0; tch = 0;
   for (size_t i = 0; i < ht.size(); ++i) {
     QTensor& t = ht[i];
@@ -499,12 +693,21 @@ static void build_chunk_maps(std::vector<QTensor>& ht, std::vector<int>& map, lo
     if (ht[i].flat) map.insert(map.end(), (size_t)ht[i].fchunks, (int)i);
   for (size_t i = 0; i < ht.size(); ++i) {
     QTensor& t = ht[i];
-    if (t.flat || t.rows <= 0 || t.cols <= 0) continue;
+    if (t.flat || t.strip || t.rows <= 0 || t.cols <= 0) continue;
     const long long n = (long long)t.strips * ((t.rows + QR - 1) / QR);
     t.chunk0 = (int)tch;
     tch += n;
     map.insert(map.end(), (size_t)n, (int)i);
   }
+  long long sch = 0;   // the register-resident strips (quantize only) come last in the table
+  for (size_t i = 0; i < ht.size(); ++i) {
+    QTensor& t = ht[i];
+    if (!t.strip) continue;
+    t.schunk0 = (int)sch;
+    sch += t.schunks;
+    map.insert(map.end(), (size_t)t.schunks, (int)i);
+  }
+  if (sch_out) *sch_out = sch;
 }
 
 // Tensors without chunks would break the chunk -> tensor search (equal chunk0 keys resolve to
@@ -522,7 +725,8 @@ static size_t quant_map_bytes(const ps_quant_desc* desc, int count) {
     if (desc[i].rows <= 0 || desc[i].cols <= 0) continue;
     const size_t flat = (size_t)((desc[i].rows * desc[i].cols + QFLAT - 1) / QFLAT);
     const size_t tile = (size_t)((desc[i].cols + QW - 1) / QW) * (size_t)((desc[i].rows + QR - 1) / QR);
-    n += flat > tile ? flat : tile;
+    const size_t strips = (size_t)((desc[i].cols + QS_COLS - 1) / QS_COLS);
+    n += std::max(std::max(flat, tile), strips);
   }
   return psh::align_up(sizeof(int) * (n + 1), 256);
 }
@@ -559,13 +763,15 @@ extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int coun
   // flat tensors: one launch per pass over chunks of consecutive elements; the others (odd sizes,
   // strided views) keep the tile kernels
   std::vector<int> hmap;
-  long long fch = 0, tch = 0;
-  build_chunk_maps(ht, hmap, fch, tch);
+  long long fch = 0, tch = 0, sch = 0;
+  build_chunk_maps(ht, hmap, fch, tch, &sch);
   int* dmap = ar.take<int>(hmap.size() + 1);
   if (ar.overflow) return PS_EWORKSPACE;
   PS_RC(psh::upload_async(st, dt, ht.data(), sizeof(QTensor) * count));
   PS_RC(psh::upload_async(st, dmap, hmap.data(), sizeof(int) * hmap.size()));
   const dim3 blk(256);
+  if (sch > 0)
+    hipLaunchKernelGGL(quant_strip_kernel, dim3((unsigned)sch), dim3(QS_THREADS), 0, st, dt, dmap + fch + tch);
   if (fch > 0) {
     hipLaunchKernelGGL(quant_flat_kernel<0>, dim3((unsigned)fch), blk, 0, st, dt, dmap);
     hipLaunchKernelGGL(quant_flat_kernel<1>, dim3((unsigned)fch), blk, 0, st, dt, dmap);

@@ -229,3 +229,49 @@ def test_fd_update_one_library_call_equals_the_step_by_step_path(d, rank, bsz, f
   ref = orc.fd_update_root(fac, 4, rank, ridge_epsilon=1e-6, error_tolerance=1e-6, relative_matrix_epsilon=True,
                            decay=0.999, padding_start=d, prev=np.zeros((d, rank + 2), np.float32))
   assert packed_matches(outs["1"][0][0], ref, rank, tol=2e-3)
+
+
+_TQ6 = {8: torch.int8, 16: torch.int16}
+
+
+@pytest.mark.parametrize("shape,bits,extract", [
+    ((1024, 1024), 16, True), ((768, 768), 8, True), ((512, 320), 16, False), ((100, 132), 16, False),
+    ((1000, 260), 8, False), ((96, 96), 16, True), ((64, 4), 8, False), ((1024, 8192), 16, False)])
+def test_quantize_register_strips_on_rounding_boundaries_and_extreme_scales(shape, bits, extract, device):
+  """quant_strip_kernel (matrices of 64 ... 1024 rows, one read): its division is the IEEE sequence with the
+  column-only part hoisted, its rounding a magic-constant add.  Inputs aimed at exactly those steps: elements AT
+  and one ulp either side of (k + 1/2) * bucket (round half to even decides), columns scaled by 2^-80 ... 2^80
+  (outside [2^-60, 2^60] a wavefront takes the plain division), denormals, exact zeros, zero columns, row counts
+  that are not multiples of 32 and column counts that are not multiples of 64.  Codes, diagonal and bucket sizes
+  bit-identical to the oracle's (numpy float32 division is correctly rounded; np.round is half-even)."""
+  from oracle import quantization_oracle as qorc
+  rng = np.random.default_rng(hash((shape, bits, 6)) % (2 ** 31))
+  rows, cols = shape
+  nb = np.float32(127.0 if bits == 8 else 32767.0)
+  colmax = (rng.uniform(1.0, 2.0, size=cols) * np.exp2(rng.integers(-6, 7, size=cols))).astype(np.float32)
+  wild = rng.uniform(size=cols) < 0.15
+  colmax[wild] = (colmax[wild] * np.exp2(rng.choice([-80.0, -61.0, -59.0, 59.0, 61.0, 80.0], size=int(wild.sum())))
+                  ).astype(np.float32)
+  bucket = (colmax / nb).astype(np.float32)
+  k = rng.integers(-int(nb) + 1, int(nb) - 1, size=shape).astype(np.float64)
+  x = ((k + 0.5) * bucket.astype(np.float64)[None, :]).astype(np.float32)       # on a rounding boundary (or next to it)
+  bump = rng.integers(-1, 2, size=shape)
+  x = np.where(bump > 0, np.nextafter(x, np.float32(np.inf)), np.where(bump < 0, np.nextafter(x, np.float32(-np.inf)), x))
+  x = x.astype(np.float32)
+  x[rng.uniform(size=shape) < 0.05] = 0.0
+  x[rng.uniform(size=shape) < 0.02] = np.float32(1e-41)                            # denormal
+  x[rng.integers(0, rows, size=cols), np.arange(cols)] = colmax                     # the column maximum itself
+  if cols > 2:
+    x[:, 1] = 0.0
+  if extract:
+    x = np.triu(x) + np.triu(x, 1).T
+    x[np.arange(rows), np.arange(rows)] = (colmax * 7).astype(np.float32)           # diagonal above every column maximum
+  x = np.ascontiguousarray(x, np.float32)
+  npdt = np.int8 if bits == 8 else np.int16
+  oq, od, ob = qorc.quantize(x, npdt, extract)
+  q, d, b = K().quantize_grouped([torch.tensor(x, device=device)], _TQ6[bits], extract)[0]
+  assert np.array_equal(b.cpu().numpy().view(np.uint32), np.asarray(ob, np.float32).view(np.uint32))
+  bad = np.argwhere(q.cpu().numpy() != oq)
+  assert bad.size == 0, (len(bad), bad[:4], [(x[i, j], ob[j]) for i, j in bad[:4]])
+  if extract:
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
