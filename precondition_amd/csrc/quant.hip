@@ -340,154 +340,192 @@ __device__ __forceinline__ unsigned qs_pack_pair(unsigned lo_bits, unsigned hi_b
                     : __builtin_amdgcn_perm(hi_bits, lo_bits, 0x0c0c0400u);
 }
 
-template <int BITS, bool FULL>
-__device__ __forceinline__ void quant_strip_body(const QTensor* t, int local, unsigned (*s_red)[QS_COLS]) {
+// One workgroup per CU (152+ VGPRs x 8 wavefronts): within ONE strip the loads cannot overlap the codes' stores, and
+// a second workgroup does not fit.  So the kernel is persistent -- 256 workgroups (one per CU) take strips from a queue
+// (an atomic counter) -- and rolls the register file: step k of the encode pass stores the codes of row group k and
+// at once loads row group k of the NEXT strip into the registers it has just freed.  The memory pipe then idles only
+// during the maximum pass and its reduction.
+struct QsStrip {          // wave-uniform description of one strip (scalars)
+  const char* lb;         // first row of the wavefront's row groups, first column of the strip (input)
+  char* cb;               // same, codes
+  float* diag; float* bucket;
+  int rows, cols, c0, extract, bits;
+};
+
+// (after the first store the compiler reads descriptor fields through the vector unit: back to scalars)
+__device__ __forceinline__ int qs_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <class P>
+__device__ __forceinline__ P* qs_uni(P* p) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return reinterpret_cast<P*>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ QsStrip qs_strip(const QTensor* ts, const int* cmap, int idx, int wave) {
+  const QTensor* t = &ts[qs_uni(cmap[idx])];
+  QsStrip s;
+  s.rows = qs_uni((int)t->rows); s.cols = qs_uni((int)t->cols);   // rows <= 1024, rows * cols * 4 < 2^31
+  s.c0 = (idx - qs_uni(t->schunk0)) * QS_COLS;
+  s.extract = qs_uni(t->extract); s.bits = qs_uni(t->bits);
+  s.diag = qs_uni(t->diag); s.bucket = qs_uni(t->bucket);
+  s.lb = reinterpret_cast<const char*>(qs_uni(t->fin) + (long long)(4 * wave) * s.cols + s.c0);
+  s.cb = reinterpret_cast<char*>(qs_uni(t->codes)) + ((long long)(4 * wave) * s.cols + s.c0) * (s.bits == 16 ? 2 : 1);
+  return s;
+}
+
+__global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* ts, const int* cmap, int nstrips,
+                                                                unsigned* queue) {
+  __shared__ unsigned s_red[2][QS_THREADS / 64][QS_COLS];
+  __shared__ int s_next[2];
   const int tid = threadIdx.x, q = tid & 15, g = tid >> 4, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // every field is read before the first store (stays a scalar load); rows <= 1024, rows * cols * 4 < 2^31
-  const int rows = (int)t->rows, cols = (int)t->cols;
-  const int extract = t->extract;
-  const float* const fin = t->fin;
-  char* const codes0 = reinterpret_cast<char*>(t->codes);
-  float* const diag = t->diag;
-  float* const bucket = t->bucket;
-  const int c0 = local * QS_COLS, col = c0 + 4 * q;
-  const bool col_in = FULL || col < cols;              // cols % 4 == 0: a quad is inside or outside as a whole
-  const float nb = BITS == 8 ? 127.f : 32767.f;
-  // FULL: rows % 32 == 0 and the strip lies inside the tensor -- every condition below is wave-uniform
-  const int nv_full = rows / QS_GROUPS, rem = FULL ? 0 : rows % QS_GROUPS;
-  const int nv_used = nv_full + (rem != 0 ? 1 : 0);
-  // wave-uniform running base (first row of the wavefront's row groups, first column of the strip) + one lane offset
-  const char* lb = reinterpret_cast<const char*>(fin + (long long)(4 * wave) * cols + c0);
-  uint32_t loff = (uint32_t)((((g & 3) * cols) + 4 * q) * 4);
-  asm volatile("" : "+v"(loff));
-  const long long step_bytes = (long long)QS_GROUPS * cols * 4;
+  const int idx = blockIdx.x;
+  if (idx >= nstrips) return;
+  QsStrip cur = qs_strip(ts, cmap, idx, wave);
   F4 v[QS_NV];
-#pragma unroll
-  for (int k = 0; k < QS_NV; ++k) {
-    v[k] = F4{0.f, 0.f, 0.f, 0.f};
-    if (k < nv_full) {
-      if (FULL) v[k] = ldg4_so(lb, loff);
-      else if (col_in) v[k] = ldg4_so(lb, loff);
-    } else if (!FULL && k == nv_full && rem != 0) {
-      if (col_in && g < rem) v[k] = ldg4_so(lb, loff);
-    }
-    lb += step_bytes;
-    asm volatile("" : "+s"(lb));
-  }
-  // diagonal: row 32 k + g meets the strip's columns [c0, c0 + 64) only for k = c0 / 32 and k = c0 / 32 + 1
-  if (extract) {
-    const int kd = c0 / QS_GROUPS;
+  {
+    // the first strip's loads (every later strip's are issued by the encode pass of the strip before it)
+    const bool col_in = cur.c0 + 4 * q < cur.cols;         // cols % 4 == 0: a quad is inside or outside as a whole
+    uint32_t loff = (uint32_t)((((g & 3) * cur.cols) + 4 * q) * 4);
+    asm volatile("" : "+v"(loff));
+    const long long step = (long long)QS_GROUPS * cur.cols * 4;
+    const char* lb = qs_uni(cur.lb);
 #pragma unroll
     for (int k = 0; k < QS_NV; ++k) {
-      if (k != kd && k != kd + 1) continue;            // scalar
-      const int r = QS_GROUPS * k + g;
-      const int d = r - col;                           // the lane holds the diagonal element in component d
-      if ((unsigned)d < 4u && r < rows && col_in) {
-        float* xs = &v[k].x;
+      v[k] = F4{0.f, 0.f, 0.f, 0.f};
+      if (col_in && QS_GROUPS * k + g < cur.rows) v[k] = ldg4_so(lb, loff);
+      lb += step;
+      asm volatile("" : "+s"(lb));
+    }
+  }
+  for (int it = 0;; ++it) {
+    const int par = it & 1;
+    if (tid == 0)
+      s_next[par] = (int)gridDim.x + (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int rows = cur.rows, cols = cur.cols;
+    const int col = cur.c0 + 4 * q;
+    const bool col_in = col < cols;
+    const float nb = cur.bits == 8 ? 127.f : 32767.f;
+    const int nv_used = (rows + QS_GROUPS - 1) / QS_GROUPS;
+    // diagonal: row 32 k + g meets the strip's columns [c0, c0 + 64) only for k = c0 / 32 and k = c0 / 32 + 1
+    if (cur.extract) {
+      const int kd = cur.c0 / QS_GROUPS;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (d == j) {
-            *(float PS_GLOBAL*)(diag + r) = xs[j];
-            xs[j] = __fsub_rn(xs[j], xs[j]);           // QU:79-80: value - diag(diagonal)
+      for (int k = 0; k < QS_NV; ++k) {
+        if (k != kd && k != kd + 1) continue;              // scalar
+        const int r = QS_GROUPS * k + g;
+        const int d = r - col;                             // the lane holds the diagonal element in component d
+        if ((unsigned)d < 4u && r < rows && col_in) {
+          float* xs = &v[k].x;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (d == j) {
+              *(float PS_GLOBAL*)(cur.diag + r) = xs[j];
+              xs[j] = __fsub_rn(xs[j], xs[j]);             // QU:79-80: value - diag(diagonal)
+            }
           }
         }
       }
     }
-  }
-  unsigned m[4] = {0u, 0u, 0u, 0u};
+    unsigned m[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int k = 0; k < QS_NV; ++k) {
-    if (k >= nv_used) continue;                        // scalar; (rows not loaded are zeros)
-    const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    for (int k = 0; k < QS_NV; ++k) {
+      if (k >= nv_used) continue;                          // scalar; (rows not loaded are zeros)
+      const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned b = __float_as_uint(x[j]) & 0x7fffffffu;
+        m[j] = b > m[j] ? b : m[j];
+      }
+    }
+    // the four row groups of a wavefront (lanes q, q + 16, q + 32, q + 48), then the eight wavefronts through LDS
+    // (two buffers: a wavefront may enter the next strip's reduction while another still reads this one's)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const unsigned b = __float_as_uint(x[j]) & 0x7fffffffu;
-      m[j] = b > m[j] ? b : m[j];
+      unsigned o = __shfl_xor(m[j], 16, 64); m[j] = o > m[j] ? o : m[j];
+      o = __shfl_xor(m[j], 32, 64); m[j] = o > m[j] ? o : m[j];
     }
-  }
-  // the four row groups of a wavefront (lanes q, q + 16, q + 32, q + 48), then the eight wavefronts through LDS
+    if (lane < 16) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned o = __shfl_xor(m[j], 16, 64); m[j] = o > m[j] ? o : m[j];
-    o = __shfl_xor(m[j], 32, 64); m[j] = o > m[j] ? o : m[j];
-  }
-  if (lane < 16) {
+      for (int j = 0; j < 4; ++j) s_red[par][wave][4 * q + j] = m[j];
+    }
+    __syncthreads();
+    float bnz[4], y1[4];
+    bool sane = true;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s_red[wave][4 * q + j] = m[j];
-  }
-  __syncthreads();
-  float bnz[4], y1[4];
-  bool sane = true;
+    for (int j = 0; j < 4; ++j) {
+      unsigned a = s_red[par][0][4 * q + j];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned a = s_red[0][4 * q + j];
+      for (int w = 1; w < QS_THREADS / 64; ++w) { const unsigned o = s_red[par][w][4 * q + j]; a = o > a ? o : a; }
+      const float bs = __fdiv_rn(__uint_as_float(a), nb);   // QU:86
+      bnz[j] = bs > 0.f ? bs : 1.f;                          // QU:89-90
+      if (g == 0 && col_in) *(float PS_GLOBAL*)(cur.bucket + col + j) = bs;
+      // the denominator-only part of the IEEE division sequence
+      const float rc = __builtin_amdgcn_rcpf(bnz[j]);
+      const float e = __fmaf_rn(-bnz[j], rc, 1.0f);
+      y1[j] = __fmaf_rn(e, rc, rc);
+      sane = sane && bnz[j] >= 0x1p-60f && bnz[j] <= 0x1p60f;
+    }
+    const bool fast = __all(sane ? 1 : 0) != 0;             // wave-uniform
+    // the next strip (wave-uniform: read through the scalar unit)
+    const int nxt = __builtin_amdgcn_readfirstlane(s_next[par]);
+    const bool has_next = nxt < nstrips;
+    QsStrip nx = cur;
+    if (has_next) nx = qs_strip(ts, cmap, nxt, wave);
+    const bool ncol_in = has_next && nx.c0 + 4 * q < nx.cols;
+    uint32_t nloff = (uint32_t)((((g & 3) * nx.cols) + 4 * q) * 4);
+    asm volatile("" : "+v"(nloff));
+    const long long nstep = (long long)QS_GROUPS * nx.cols * 4;
+    const char* nlb = qs_uni(nx.lb);
+    const bool b16 = cur.bits == 16;
+    char* cb = qs_uni(cur.cb);
+    uint32_t coff = (uint32_t)((((g & 3) * cols) + 4 * q) * (b16 ? 2 : 1));
+    asm volatile("" : "+v"(coff));
+    const long long cstep = (long long)QS_GROUPS * cols * (b16 ? 2 : 1);
 #pragma unroll
-    for (int w = 1; w < QS_THREADS / 64; ++w) { const unsigned o = s_red[w][4 * q + j]; a = o > a ? o : a; }
-    const float bs = __fdiv_rn(__uint_as_float(a), nb);     // QU:86
-    bnz[j] = bs > 0.f ? bs : 1.f;                            // QU:89-90
-    if (g == 0 && col_in) *(float PS_GLOBAL*)(bucket + col + j) = bs;
-    // the denominator-only part of the IEEE division sequence
-    const float rc = __builtin_amdgcn_rcpf(bnz[j]);
-    const float e = __fmaf_rn(-bnz[j], rc, 1.0f);
-    y1[j] = __fmaf_rn(e, rc, rc);
-    sane = sane && bnz[j] >= 0x1p-60f && bnz[j] <= 0x1p60f;
-  }
-  constexpr int esz = BITS == 16 ? 2 : 1;
-  char* cb = codes0 + ((long long)(4 * wave) * cols + c0) * esz;
-  uint32_t coff = (uint32_t)((((g & 3) * cols) + 4 * q) * esz);
-  asm volatile("" : "+v"(coff));
-  const long long cstep = (long long)QS_GROUPS * cols * esz;
-  const bool fast = __all(sane ? 1 : 0) != 0;           // wave-uniform
+    for (int k = 0; k < QS_NV; ++k) {
+      if (k < nv_used) {                                     // scalar
+        const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        unsigned cq[4];
+        if (fast) {
 #pragma unroll
-  for (int k = 0; k < QS_NV; ++k) {
-    if (k < nv_used) {                                   // scalar
-      const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-      unsigned cq[4];
-      if (fast) {
+          for (int j = 0; j < 4; ++j) {
+            const float q0 = __fmul_rn(x[j], y1[j]);
+            const float r0 = __fmaf_rn(-bnz[j], q0, x[j]);
+            const float q1 = __fmaf_rn(r0, y1[j], q0);
+            const float r1 = __fmaf_rn(-bnz[j], q1, x[j]);
+            const float qq = __fmaf_rn(r1, y1[j], q1);
+            cq[j] = __float_as_uint(__fadd_rn(qq, 12582912.0f));   // 1.5 * 2^23: integer in the low mantissa bits
+          }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float q0 = __fmul_rn(x[j], y1[j]);
-          const float r0 = __fmaf_rn(-bnz[j], q0, x[j]);
-          const float q1 = __fmaf_rn(r0, y1[j], q0);
-          const float r1 = __fmaf_rn(-bnz[j], q1, x[j]);
-          const float qq = __fmaf_rn(r1, y1[j], q1);
-          cq[j] = __float_as_uint(__fadd_rn(qq, 12582912.0f));   // 1.5 * 2^23: integer in the low mantissa bits
+          for (int j = 0; j < 4; ++j) cq[j] = (unsigned)encode1(x[j], bnz[j]);
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cq[j] = (unsigned)encode1(x[j], bnz[j]);
+        const bool valid = col_in && QS_GROUPS * k + g < rows;
+        char* dst = cb + coff;
+        if (b16) {                                           // scalar
+          typedef unsigned u2v __attribute__((ext_vector_type(2)));
+          u2v pk;
+          pk[0] = qs_pack_pair<16>(cq[0], cq[1]);
+          pk[1] = qs_pack_pair<16>(cq[2], cq[3]);
+          if (valid) *(u2v PS_GLOBAL*)dst = pk;
+        } else {
+          const unsigned lo = qs_pack_pair<8>(cq[0], cq[1]), hi = qs_pack_pair<8>(cq[2], cq[3]);
+          const unsigned pk = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+          if (valid) *(unsigned PS_GLOBAL*)dst = pk;
+        }
       }
-      const bool valid = FULL || (col_in && QS_GROUPS * k + g < rows);
-      char* dst = cb + coff;
-      if (BITS == 16) {
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        u2v pk;
-        pk[0] = qs_pack_pair<16>(cq[0], cq[1]);
-        pk[1] = qs_pack_pair<16>(cq[2], cq[3]);
-        if (valid) *(u2v PS_GLOBAL*)dst = pk;
-      } else {
-        const unsigned lo = qs_pack_pair<8>(cq[0], cq[1]), hi = qs_pack_pair<8>(cq[2], cq[3]);
-        const unsigned pk = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-        if (valid) *(unsigned PS_GLOBAL*)dst = pk;
-      }
+      cb += cstep;
+      asm volatile("" : "+s"(cb));
+      // row group k of the next strip into the registers just encoded
+      v[k] = F4{0.f, 0.f, 0.f, 0.f};
+      if (ncol_in && QS_GROUPS * k + g < nx.rows) v[k] = ldg4_so(nlb, nloff);
+      nlb += nstep;
+      asm volatile("" : "+s"(nlb));
     }
-    cb += cstep;
-    asm volatile("" : "+s"(cb));
-  }
-}
-
-__global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* ts, const int* cmap) {
-  __shared__ unsigned s_red[QS_THREADS / 64][QS_COLS];
-  const QTensor* t = &ts[cmap[blockIdx.x]];
-  const int local = blockIdx.x - t->schunk0;
-  const bool full = t->rows % QS_GROUPS == 0 && (long long)(local + 1) * QS_COLS <= t->cols;
-  if (t->bits == 16) {
-    if (full) quant_strip_body<16, true>(t, local, s_red);
-    else quant_strip_body<16, false>(t, local, s_red);
-  } else {
-    if (full) quant_strip_body<8, true>(t, local, s_red);
-    else quant_strip_body<8, false>(t, local, s_red);
+    if (!has_next) break;
+    cur = nx;
   }
 }
 
@@ -731,11 +769,24 @@ static size_t quant_map_bytes(const ps_quant_desc* desc, int count) {
   return psh::align_up(sizeof(int) * (n + 1), 256);
 }
 
+static int quant_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
 extern "C" size_t ps_quantize_workspace_bytes(const ps_quant_desc* desc, int count) {
   if (!desc || count <= 0) return 0;
   size_t cols = 0;
   for (int i = 0; i < count; ++i) cols += psh::align_up((size_t)(desc[i].cols > 0 ? desc[i].cols : 0), 4);
-  return psh::align_up(sizeof(QTensor) * count, 256) + psh::align_up(sizeof(unsigned) * cols, 256) +
+  return psh::align_up(sizeof(QTensor) * count, 256) + psh::align_up(sizeof(unsigned) * (cols + 4), 256) +
          quant_map_bytes(desc, count) + 1024;
 }
 
@@ -752,14 +803,14 @@ extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int coun
   hipStream_t st = (hipStream_t)stream;
   psh::Arena ar(workspace, workspace_bytes);
   QTensor* dt = ar.take<QTensor>(count);
-  unsigned* colmax = ar.take<unsigned>(total_cols);
+  unsigned* colmax = ar.take<unsigned>(total_cols + 4);   // + the strip queue's counter
   if (ar.overflow) return PS_EWORKSPACE;
   size_t off = 0;
   for (int i = 0; i < count; ++i) {
     ht[i].colmax = colmax + off;
     off += psh::align_up((size_t)ht[i].cols, 4);
   }
-  PS_HIP(hipMemsetAsync(colmax, 0, sizeof(unsigned) * total_cols, st));
+  PS_HIP(hipMemsetAsync(colmax, 0, sizeof(unsigned) * (total_cols + 4), st));
   // flat tensors: one launch per pass over chunks of consecutive elements; the others (odd sizes,
   // strided views) keep the tile kernels
   std::vector<int> hmap;
@@ -770,8 +821,12 @@ extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int coun
   PS_RC(psh::upload_async(st, dt, ht.data(), sizeof(QTensor) * count));
   PS_RC(psh::upload_async(st, dmap, hmap.data(), sizeof(int) * hmap.size()));
   const dim3 blk(256);
-  if (sch > 0)
-    hipLaunchKernelGGL(quant_strip_kernel, dim3((unsigned)sch), dim3(QS_THREADS), 0, st, dt, dmap + fch + tch);
+  if (sch > 0) {
+    // persistent: one workgroup per CU, the strips beyond the first 256 from a queue (the counter after the arrivals)
+    const unsigned grid = (unsigned)std::min<long long>(sch, quant_cus());
+    hipLaunchKernelGGL(quant_strip_kernel, dim3(grid), dim3(QS_THREADS), 0, st, dt, dmap + fch + tch, (int)sch,
+                       colmax + total_cols);
+  }
   if (fch > 0) {
     hipLaunchKernelGGL(quant_flat_kernel<0>, dim3((unsigned)fch), blk, 0, st, dt, dmap);
     hipLaunchKernelGGL(quant_flat_kernel<1>, dim3((unsigned)fch), blk, 0, st, dt, dmap);

@@ -275,3 +275,30 @@ def test_quantize_register_strips_on_rounding_boundaries_and_extreme_scales(shap
   assert bad.size == 0, (len(bad), bad[:4], [(x[i, j], ob[j]) for i, j in bad[:4]])
   if extract:
     assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_quantize_strip_queue_mixed_tensors_bit_exact(device):
+  """One call with more strips than workgroups (the persistent kernel takes the rest from its queue and loads the
+  NEXT strip while it encodes the current one): tensors of different heights, widths and code widths in one
+  descriptor list, every code / bucket size / diagonal entry against the oracle."""
+  from oracle import quantization_oracle as qorc
+  rng = np.random.default_rng(66)
+  shapes = [(1024, 1024), (768, 768), (64, 4096), (100, 132), (512, 320), (1000, 260), (96, 96), (256, 2048)] * 4
+  xs = []
+  for i, (r, c) in enumerate(shapes):
+    x = (rng.standard_normal((r, c)) * np.exp(rng.uniform(-6, 6, size=c))).astype(np.float32)
+    if r == c:
+      x = (x + x.T).astype(np.float32)
+    x[rng.uniform(size=x.shape) < 0.03] = 0.0
+    xs.append(np.ascontiguousarray(x))
+  assert sum((c + 63) // 64 for _, c in shapes) > 2 * 256
+  for bits, extract_square in ((16, True), (8, False)):
+    npdt = np.int8 if bits == 8 else np.int16
+    group = [x for x in xs if (x.shape[0] == x.shape[1]) == extract_square] if extract_square else xs
+    out = K().quantize_grouped([torch.tensor(x, device=device) for x in group], _TQ6[bits], extract_square)
+    for x, (q, d, b) in zip(group, out):
+      oq, od, ob = qorc.quantize(x, npdt, extract_square)
+      assert np.array_equal(q.cpu().numpy(), oq), x.shape
+      assert np.array_equal(b.cpu().numpy().view(np.uint32), np.asarray(ob, np.float32).view(np.uint32)), x.shape
+      if extract_square:
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32)), x.shape
