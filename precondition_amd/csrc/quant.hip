@@ -122,14 +122,23 @@ __global__ __launch_bounds__(256) void quant_colmax_kernel(const QTensor* ts, co
       if (a) atomicMax(t->colmax + c, a);
     }
   } else {
+    // one column per lane; eight rows in flight (descriptor fields in locals: a store through another pointer
+    // makes the compiler re-read them, which chained every row's load behind the one before)
     const long long c = (long long)strip * QW + tid;
     if (c >= cols) return;
+    const float* const fin = t->fin;
+    const int extract = t->extract;
     unsigned m = 0u;
-    for (long long r = r0; r < r1; ++r) {
-      float x = ldg1(t->fin + r * ld + c);
-      if (t->extract && c == r) x = __fsub_rn(x, x);
-      const unsigned b = __float_as_uint(fabsf(x));
-      m = b > m ? b : m;
+    for (long long rb = r0; rb < r1; rb += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = rb + u < r1 ? ldg1(fin + (rb + u) * ld + c) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (extract && c == rb + u) x[u] = __fsub_rn(x[u], x[u]);
+        const unsigned b = __float_as_uint(fabsf(x[u]));
+        m = b > m ? b : m;
+      }
     }
     if (m) atomicMax(t->colmax + c, m);
   }
@@ -159,10 +168,10 @@ __device__ __forceinline__ void quant_flat_body(const QTensor* t, int local, uns
   const float nb = BITS == 8 ? 127.f : 32767.f;
   // incremental (row, col) of the thread's float4s: offsets base + 4 tid + 1024 k
   const long long off0 = base + 4 * tid;
-  long long row = off0 / cols;
+  int row = (int)(off0 / cols);                      // rows * cols <= QMAXT: 32-bit row / column arithmetic
   int col = (int)(off0 - row * cols);
   const int step_c = (int)(1024 % cols);
-  const long long step_r = 1024 / cols;
+  const int step_r = (int)(1024 / cols);
   uint32_t loff = (uint32_t)(4 * tid * 4);
   asm volatile("" : "+v"(loff));
   const char* fbase = reinterpret_cast<const char*>(t->fin) + base * 4;
@@ -189,13 +198,13 @@ __device__ __forceinline__ void quant_flat_body(const QTensor* t, int local, uns
     }
   }
   if (MODE == 2 && extract) {
-    // the diagonal entry of the lane's row, for every step, requested with the codes (unconditional:
-    // lanes of one row read one address; a float4 never straddles a row)
-    long long prow = row;
-    int pcol = col;
+    // the diagonal entry of the lane's row, requested with the codes by the lanes whose float4 holds the diagonal
+    // element (a float4 never straddles a row: row - col in 0 .. 3)
+    int prow = row, pcol = col;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      dg[k] = ldg1(t->diag + (prow < rows ? prow : rows - 1));
+      dg[k] = 0.f;
+      if ((unsigned)(prow - pcol) < 4u && prow < (int)rows) dg[k] = ldg1(t->diag + prow);
       pcol += step_c; prow += step_r;
       if (pcol >= cols) { pcol -= (int)cols; prow += 1; }
     }
@@ -257,10 +266,11 @@ __device__ __forceinline__ void quant_flat_body(const QTensor* t, int local, uns
         const float bs[4] = {b4.x, b4.y, b4.z, b4.w};
         qf4 x;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x[j] = __fmul_rn((float)q[j], bs[j]);                                     // QU:109
-          const float xd = __fadd_rn(x[j], dg[k]);                                  // QU:111
-          x[j] = (extract && col + j == row) ? xd : x[j];
+        for (int j = 0; j < 4; ++j) x[j] = __fmul_rn((float)q[j], bs[j]);          // QU:109
+        const int dj = row - col;
+        if (extract && (unsigned)dj < 4u) {                                         // QU:111
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[j] = dj == j ? __fadd_rn(x[j], dg[k]) : x[j];
         }
         *(qf4 PS_GLOBAL*)(t->fout + off0 + 1024 * k) = x;
       }
@@ -591,13 +601,24 @@ __global__ __launch_bounds__(256) void quant_encode_kernel(const QTensor* ts, co
     if (c >= cols) return;
     const float bs = __fdiv_rn(__uint_as_float(t->colmax[c]), nb);
     const float bnz = bs > 0.f ? bs : 1.f;
+    const float* const fin = t->fin;
+    float* const diag = t->diag;
+    void* const codes = t->codes;
+    const int extract = t->extract, bits = t->bits;
     if (rc == 0) t->bucket[c] = bs;
-    for (long long r = r0; r < r1; ++r) {
-      float x = ldg1(t->fin + r * ld + c);
-      if (t->extract && c == r) { t->diag[r] = x; x = __fsub_rn(x, x); }
-      const int q = encode1(x, bnz);
-      if (t->bits == 16) reinterpret_cast<short*>(t->codes)[r * ldq + c] = (short)q;
-      else reinterpret_cast<signed char*>(t->codes)[r * ldq + c] = (signed char)q;
+    for (long long rb = r0; rb < r1; rb += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = rb + u < r1 ? ldg1(fin + (rb + u) * ld + c) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long r = rb + u;
+        if (r >= r1) break;
+        if (extract && c == r) { diag[r] = x[u]; x[u] = __fsub_rn(x[u], x[u]); }
+        const int q = encode1(x[u], bnz);
+        if (bits == 16) reinterpret_cast<short*>(codes)[r * ldq + c] = (short)q;
+        else reinterpret_cast<signed char*>(codes)[r * ldq + c] = (signed char)q;
+      }
     }
   }
 }
@@ -662,12 +683,27 @@ __global__ __launch_bounds__(256) void quant_decode_kernel(const QTensor* ts, co
     const long long c = (long long)strip * QW + tid;
     if (c >= cols) return;
     const float bs = t->bucket[c];
-    for (long long r = r0; r < r1; ++r) {
-      const int q = t->bits == 16 ? (int)reinterpret_cast<const short*>(t->codes)[r * ldq + c]
-                                  : (int)reinterpret_cast<const signed char*>(t->codes)[r * ldq + c];
-      float x = __fmul_rn((float)q, bs);
-      if (t->extract && c == r) x = __fadd_rn(x, t->diag[r]);
-      t->fout[r * ld + c] = x;
+    const void* const codes = t->codes;
+    const float* const diag = t->diag;
+    float* const fout = t->fout;
+    const int extract = t->extract, bits = t->bits;
+    const float dg = (extract && c >= r0 && c < r1) ? diag[c] : 0.f;
+    for (long long rb = r0; rb < r1; rb += 8) {
+      int q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long r = rb + u < r1 ? rb + u : r1 - 1;
+        q[u] = bits == 16 ? (int)reinterpret_cast<const short*>(codes)[r * ldq + c]
+                          : (int)reinterpret_cast<const signed char*>(codes)[r * ldq + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long r = rb + u;
+        if (r >= r1) break;
+        float x = __fmul_rn((float)q[u], bs);                   // QU:109
+        if (extract && c == r) x = __fadd_rn(x, dg);            // QU:111
+        fout[r * ld + c] = x;
+      }
     }
   }
 }
