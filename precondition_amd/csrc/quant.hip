@@ -44,6 +44,7 @@ struct QTensor {
   int fchunk0, fchunks;   // its chunks of QFLAT consecutive elements
   int strip;              // quantize only: the register-resident strip kernel takes it (quant_strip_kernel)
   int schunk0, schunks;   // its strips of QS_COLS columns
+  int small;              // quantize only: one workgroup of the strip launch takes the whole tensor (quant_small_body)
 };
 
 typedef float qf4 __attribute__((ext_vector_type(4)));
@@ -384,13 +385,93 @@ __device__ __forceinline__ QsStrip qs_strip(const QTensor* ts, const int* cmap, 
   return s;
 }
 
+// Small tensors (up to QSM_ELEMS elements, any alignment and stride: biases, a 197 x 197 statistic, vectors) ride in
+// the strip launch, one workgroup each, FIRST in the grid: column maxima through LDS, then the codes from a second
+// read (L2).  As launches of their own (tile kernels: two passes, two launches) they ran 20-50 us behind the big kernel
+// on the same stream.  Same arithmetic as every other path: bit-identical codes.
+constexpr int QSM_ELEMS = 65536;
+constexpr int QSM_COLS = 2048;
+
+__device__ __forceinline__ void quant_small_body(const QTensor* t, unsigned* s_max) {
+  const int tid = threadIdx.x;
+  const int rows = (int)t->rows, cols = (int)t->cols, total = rows * cols;
+  const long long ld = t->ld, ldq = t->ldq;
+  const float* const fin = t->fin;
+  void* const codes = t->codes;
+  float* const diag = t->diag;
+  float* const bucket = t->bucket;
+  const int extract = t->extract, bits = t->bits;
+  const float nb = bits == 8 ? 127.f : 32767.f;
+  for (int c = tid; c < cols; c += QS_THREADS) s_max[c] = 0u;
+  __syncthreads();
+  // pass 1: a lane keeps the running maximum of the column it is in and merges it when the column changes
+  // (vectors, and widths that divide the thread count, merge once per lane)
+  {
+    int ccol = -1;
+    unsigned cmax = 0u;
+    for (int e0 = tid; e0 < total; e0 += 8 * QS_THREADS) {
+      float x[8];
+      int rr[8], cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * QS_THREADS;
+        rr[u] = e / cols; cc[u] = e - rr[u] * cols;
+        x[u] = e < total ? ldg1(fin + (long long)rr[u] * ld + cc[u]) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (e0 + u * QS_THREADS >= total) break;
+        if (extract && rr[u] == cc[u]) x[u] = __fsub_rn(x[u], x[u]);   // QU:79-80
+        const unsigned b = __float_as_uint(x[u]) & 0x7fffffffu;
+        if (cc[u] != ccol) {
+          if (cmax) atomicMax(&s_max[ccol], cmax);
+          ccol = cc[u]; cmax = 0u;
+        }
+        cmax = b > cmax ? b : cmax;
+      }
+    }
+    if (cmax) atomicMax(&s_max[ccol], cmax);
+  }
+  __syncthreads();
+  for (int c = tid; c < cols; c += QS_THREADS) {
+    const float bs = __fdiv_rn(__uint_as_float(s_max[c]), nb);   // QU:86
+    bucket[c] = bs;
+    s_max[c] = __float_as_uint(bs > 0.f ? bs : 1.f);             // QU:89-90
+  }
+  __syncthreads();
+  for (int e0 = tid; e0 < total; e0 += 8 * QS_THREADS) {
+    float x[8];
+    int rr[8], cc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * QS_THREADS;
+      rr[u] = e / cols; cc[u] = e - rr[u] * cols;
+      x[u] = e < total ? ldg1(fin + (long long)rr[u] * ld + cc[u]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (e0 + u * QS_THREADS >= total) break;
+      if (extract && rr[u] == cc[u]) { diag[rr[u]] = x[u]; x[u] = __fsub_rn(x[u], x[u]); }
+      const int q = encode1(x[u], __uint_as_float(s_max[cc[u]]));
+      if (bits == 16) reinterpret_cast<short*>(codes)[(long long)rr[u] * ldq + cc[u]] = (short)q;
+      else reinterpret_cast<signed char*>(codes)[(long long)rr[u] * ldq + cc[u]] = (signed char)q;
+    }
+  }
+}
+
 __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* ts, const int* cmap, int nstrips,
-                                                                unsigned* queue) {
-  __shared__ unsigned s_red[2][QS_THREADS / 64][QS_COLS];
+                                                                unsigned* queue, const int* smap, int nsmall) {
+  __shared__ unsigned s_mem[QSM_COLS];   // the strips' reduction buffers (2 x 8 x 64), a small tensor's column maxima
   __shared__ int s_next[2];
+  if ((int)blockIdx.x < nsmall) {
+    quant_small_body(&ts[smap[blockIdx.x]], s_mem);
+    return;
+  }
+  unsigned (*s_red)[QS_THREADS / 64][QS_COLS] = reinterpret_cast<unsigned (*)[QS_THREADS / 64][QS_COLS]>(s_mem);
   const int tid = threadIdx.x, q = tid & 15, g = tid >> 4, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int idx = blockIdx.x;
+  const int idx = (int)blockIdx.x - nsmall;
+  const int nstatic = (int)gridDim.x - nsmall;   // strips handed out by workgroup index; the queue continues from here
   if (idx >= nstrips) return;
   QsStrip cur = qs_strip(ts, cmap, idx, wave);
   F4 v[QS_NV];
@@ -412,7 +493,7 @@ __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* 
   for (int it = 0;; ++it) {
     const int par = it & 1;
     if (tid == 0)
-      s_next[par] = (int)gridDim.x + (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_next[par] = nstatic + (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int rows = cur.rows, cols = cur.cols;
     const int col = cur.c0 + 4 * q;
     const bool col_in = col < cols;
@@ -624,10 +705,10 @@ __global__ __launch_bounds__(256) void quant_encode_kernel(const QTensor* ts, co
 }
 
 // ---- to_float --------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void quant_decode_kernel(const QTensor* ts, const int* cmap) {
-  const QTensor* t = &ts[cmap[blockIdx.x]];
+__device__ __forceinline__ void quant_decode_tile(const QTensor* ts, const int* cmap, int chunk) {
+  const QTensor* t = &ts[cmap[chunk]];
   if (t->flat) return;
-  const int local = blockIdx.x - t->chunk0;
+  const int local = chunk - t->chunk0;
   const int strip = local % t->strips, rc = local / t->strips;
   const int tid = threadIdx.x;
   const long long rows = t->rows, cols = t->cols, ld = t->ld, ldq = t->ldq;
@@ -708,6 +789,27 @@ __global__ __launch_bounds__(256) void quant_decode_kernel(const QTensor* ts, co
   }
 }
 
+// to_float of a whole descriptor list in ONE launch: the tile chunks (strided views, tensors that are not
+// float4-addressable -- few, latency-bound workgroups) come first in the grid and finish under the stream of flat
+// chunks; as a launch of their own they ran 20-50 us BEHIND the big kernel on the same stream.
+__global__ __launch_bounds__(256) void quant_decode_all_kernel(const QTensor* ts, const int* cmap, int fch, int tch) {
+  if ((int)blockIdx.x < tch) {
+    quant_decode_tile(ts, cmap + fch, (int)blockIdx.x);
+    return;
+  }
+  const int chunk = (int)blockIdx.x - tch;
+  const QTensor* t = &ts[cmap[chunk]];
+  const int local = chunk - t->fchunk0;
+  const bool full = (long long)(local + 1) * QFLAT <= t->rows * t->cols;
+  if (t->bits == 16) {
+    if (full) quant_flat_body<2, true, 16>(t, local, nullptr);
+    else quant_flat_body<2, false, 16>(t, local, nullptr);
+  } else {
+    if (full) quant_flat_body<2, true, 8>(t, local, nullptr);
+    else quant_flat_body<2, false, 8>(t, local, nullptr);
+  }
+}
+
 static bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // Validates descriptors and fills the device table image.  Returns total chunks or <0.
@@ -740,7 +842,10 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
     t.strip = (encode && strip_on && t.flat && d.rows >= QS_MINR && d.rows <= (long long)QS_NV * QS_GROUPS &&
                (d.rows * d.cols) * 4 < (1LL << 31)) ? 1 : 0;
     t.schunks = t.strip ? (int)((d.cols + QS_COLS - 1) / QS_COLS) : 0;
-    if (t.strip) t.flat = 0;
+    // ... and small ones of any layout by one workgroup of the same launch (quant_small_body)
+    t.small = (encode && strip_on && !t.strip && d.rows > 0 && d.cols > 0 && d.cols <= QSM_COLS &&
+               d.rows * d.cols <= QSM_ELEMS) ? 1 : 0;
+    if (t.strip || t.small) t.flat = 0;
     t.fchunks = t.flat ? (int)((d.rows * d.cols + QFLAT - 1) / QFLAT) : 0;
     t.strips = (int)((d.cols + QW - 1) / QW);
     const long long rcs = (d.rows + QR - 1) / QR;
@@ -756,7 +861,7 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
 // 64 x 256 tile chunks of the other tensors; chunk0 / fchunk0 of every tensor are set to its first
 // chunk inside its own list.
 static void build_chunk_maps(std::vector<QTensor>& ht, std::vector<int>& map, long long& fch,
-                             long long& tch, long long* sch_out = nullptr) {
+                             long long& tch, long long* sch_out = nullptr, long long* nsm_out = nullptr) {
   fch = 0; tch = 0;
   for (size_t i = 0; i < ht.size(); ++i) {
     QTensor& t = ht[i];
@@ -767,7 +872,7 @@ static void build_chunk_maps(std::vector<QTensor>& ht, std::vector<int>& map, lo
     if (ht[i].flat) map.insert(map.end(), (size_t)ht[i].fchunks, (int)i);
   for (size_t i = 0; i < ht.size(); ++i) {
     QTensor& t = ht[i];
-    if (t.flat || t.strip || t.rows <= 0 || t.cols <= 0) continue;
+    if (t.flat || t.strip || t.small || t.rows <= 0 || t.cols <= 0) continue;
     const long long n = (long long)t.strips * ((t.rows + QR - 1) / QR);
     t.chunk0 = (int)tch;
     tch += n;
@@ -782,6 +887,11 @@ static void build_chunk_maps(std::vector<QTensor>& ht, std::vector<int>& map, lo
     map.insert(map.end(), (size_t)t.schunks, (int)i);
   }
   if (sch_out) *sch_out = sch;
+  // the small tensors (quantize only): tensor indices, last in the table
+  long long nsm = 0;
+  for (size_t i = 0; i < ht.size(); ++i)
+    if (ht[i].small) { map.push_back((int)i); ++nsm; }
+  if (nsm_out) *nsm_out = nsm;
 }
 
 // Tensors without chunks would break the chunk -> tensor search (equal chunk0 keys resolve to
@@ -800,7 +910,7 @@ static size_t quant_map_bytes(const ps_quant_desc* desc, int count) {
     const size_t flat = (size_t)((desc[i].rows * desc[i].cols + QFLAT - 1) / QFLAT);
     const size_t tile = (size_t)((desc[i].cols + QW - 1) / QW) * (size_t)((desc[i].rows + QR - 1) / QR);
     const size_t strips = (size_t)((desc[i].cols + QS_COLS - 1) / QS_COLS);
-    n += std::max(std::max(flat, tile), strips);
+    n += std::max(std::max(flat, tile), strips) + 1;
   }
   return psh::align_up(sizeof(int) * (n + 1), 256);
 }
@@ -850,18 +960,20 @@ extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int coun
   // flat tensors: one launch per pass over chunks of consecutive elements; the others (odd sizes,
   // strided views) keep the tile kernels
   std::vector<int> hmap;
-  long long fch = 0, tch = 0, sch = 0;
-  build_chunk_maps(ht, hmap, fch, tch, &sch);
+  long long fch = 0, tch = 0, sch = 0, nsm = 0;
+  build_chunk_maps(ht, hmap, fch, tch, &sch, &nsm);
   int* dmap = ar.take<int>(hmap.size() + 1);
   if (ar.overflow) return PS_EWORKSPACE;
   PS_RC(psh::upload_async(st, dt, ht.data(), sizeof(QTensor) * count));
   PS_RC(psh::upload_async(st, dmap, hmap.data(), sizeof(int) * hmap.size()));
   const dim3 blk(256);
-  if (sch > 0) {
-    // persistent: one workgroup per CU, the strips beyond the first 256 from a queue (the counter after the arrivals)
-    const unsigned grid = (unsigned)std::min<long long>(sch, quant_cus());
-    hipLaunchKernelGGL(quant_strip_kernel, dim3(grid), dim3(QS_THREADS), 0, st, dt, dmap + fch + tch, (int)sch,
-                       colmax + total_cols);
+  if (sch + nsm > 0) {
+    // the small tensors' workgroups, then the persistent ones: one per CU, the strips beyond the first 256 from a
+    // queue (the counter behind the column maxima)
+    const long long grid = nsm + std::min<long long>(sch, quant_cus());
+    if (grid > 0x7fffffffLL) return PS_EUNSUPPORTED;
+    hipLaunchKernelGGL(quant_strip_kernel, dim3((unsigned)grid), dim3(QS_THREADS), 0, st, dt, dmap + fch + tch,
+                       (int)sch, colmax + total_cols, dmap + fch + tch + sch, (int)nsm);
   }
   if (fch > 0) {
     hipLaunchKernelGGL(quant_flat_kernel<0>, dim3((unsigned)fch), blk, 0, st, dt, dmap);
@@ -901,10 +1013,9 @@ extern "C" int ps_dequantize_f32(void* stream, const ps_quant_desc* desc, int co
   if (ar.overflow) return PS_EWORKSPACE;
   PS_RC(psh::upload_async(st, dt, ht.data(), sizeof(QTensor) * count));
   PS_RC(psh::upload_async(st, dmap, hmap.data(), sizeof(int) * hmap.size()));
-  if (fch > 0)
-    hipLaunchKernelGGL(quant_flat_kernel<2>, dim3((unsigned)fch), dim3(256), 0, st, dt, dmap);
-  if (tch > 0)
-    hipLaunchKernelGGL(quant_decode_kernel, dim3((unsigned)tch), dim3(256), 0, st, dt, dmap + fch);
+  if (fch + tch > 0x7fffffffLL) return PS_EUNSUPPORTED;
+  hipLaunchKernelGGL(quant_decode_all_kernel, dim3((unsigned)(fch + tch)), dim3(256), 0, st, dt, dmap, (int)fch,
+                     (int)tch);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -33,6 +33,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "bk":
 if len(sys.argv) > 1 and sys.argv[1] == "groups":   # round 6: stream groups of the staged execution (same bits for every count)
   os.environ["PS_DEV_EXTRA"] = "vit"
   combos = [dict(PS_NEWTON_GROUPS=g) for g in ("1", "2", "3", "4", "1", "2")]
+if len(sys.argv) > 1 and sys.argv[1] == "grid":   # stage launches capped at g workgroups walking the tile list (descriptor prefetch)
+  combos = [dict(), dict(PS_NEWTON_GRID="512"), dict(PS_NEWTON_GRID="1024"), dict(PS_NEWTON_GRID="256"), dict()]
 for c in combos:
   env = dict(os.environ, **c)
   print(c, flush=True)
