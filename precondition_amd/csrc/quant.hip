@@ -45,6 +45,8 @@ struct QTensor {
   int strip;              // quantize only: the register-resident strip kernel takes it (quant_strip_kernel)
   int schunk0, schunks;   // its strips of QS_COLS columns
   int small;              // quantize only: one workgroup of the strip launch takes the whole tensor (quant_small_body)
+  int team;               // strips of more than 1024 rows: parts of 1024 rows, one workgroup each (1 = whole strips)
+  unsigned* sarrive;      // workspace: per strip, the parts whose column maxima are merged
 };
 
 typedef float qf4 __attribute__((ext_vector_type(4)));
@@ -356,11 +358,14 @@ __device__ __forceinline__ unsigned qs_pack_pair(unsigned lo_bits, unsigned hi_b
 // (an atomic counter) -- and rolls the register file: step k of the encode pass stores the codes of row group k and
 // at once loads row group k of the NEXT strip into the registers it has just freed.  The memory pipe then idles only
 // during the maximum pass and its reduction.
-struct QsStrip {          // wave-uniform description of one strip (scalars)
+struct QsStrip {          // wave-uniform description of one strip, or of one part of a tall strip (scalars)
   const char* lb;         // first row of the wavefront's row groups, first column of the strip (input)
   char* cb;               // same, codes
   float* diag; float* bucket;
-  int rows, cols, c0, extract, bits;
+  unsigned* colmax;       // team > 1: the tensor's merged column maxima (bit patterns), the strip's arrival counter
+  unsigned* arrive;
+  int rows, cols, c0, extract, bits;   // rows: of this part
+  int r_off, team;        // first row of the part; parts per strip
 };
 
 // (after the first store the compiler reads descriptor fields through the vector unit: back to scalars)
@@ -376,12 +381,20 @@ __device__ __forceinline__ P* qs_uni(P* p) {
 __device__ __forceinline__ QsStrip qs_strip(const QTensor* ts, const int* cmap, int idx, int wave) {
   const QTensor* t = &ts[qs_uni(cmap[idx])];
   QsStrip s;
-  s.rows = qs_uni((int)t->rows); s.cols = qs_uni((int)t->cols);   // rows <= 1024, rows * cols * 4 < 2^31
-  s.c0 = (idx - qs_uni(t->schunk0)) * QS_COLS;
+  const int local = idx - qs_uni(t->schunk0);
+  s.team = qs_uni(t->team);
+  const int strip = local / s.team, part = local - strip * s.team;
+  const int rows_all = qs_uni((int)t->rows);                        // rows_all * cols * 4 < 2^31
+  s.r_off = part * (QS_NV * QS_GROUPS);
+  s.rows = rows_all - s.r_off < QS_NV * QS_GROUPS ? rows_all - s.r_off : QS_NV * QS_GROUPS;
+  s.cols = qs_uni((int)t->cols);
+  s.c0 = strip * QS_COLS;
   s.extract = qs_uni(t->extract); s.bits = qs_uni(t->bits);
   s.diag = qs_uni(t->diag); s.bucket = qs_uni(t->bucket);
-  s.lb = reinterpret_cast<const char*>(qs_uni(t->fin) + (long long)(4 * wave) * s.cols + s.c0);
-  s.cb = reinterpret_cast<char*>(qs_uni(t->codes)) + ((long long)(4 * wave) * s.cols + s.c0) * (s.bits == 16 ? 2 : 1);
+  s.colmax = qs_uni(t->colmax); s.arrive = qs_uni(t->sarrive) + strip;
+  s.lb = reinterpret_cast<const char*>(qs_uni(t->fin) + (long long)(s.r_off + 4 * wave) * s.cols + s.c0);
+  s.cb = reinterpret_cast<char*>(qs_uni(t->codes)) +
+         ((long long)(s.r_off + 4 * wave) * s.cols + s.c0) * (s.bits == 16 ? 2 : 1);
   return s;
 }
 
@@ -463,6 +476,7 @@ __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* 
                                                                 unsigned* queue, const int* smap, int nsmall) {
   __shared__ unsigned s_mem[QSM_COLS];   // the strips' reduction buffers (2 x 8 x 64), a small tensor's column maxima
   __shared__ int s_next[2];
+  __shared__ int s_team_ok;
   if ((int)blockIdx.x < nsmall) {
     quant_small_body(&ts[smap[blockIdx.x]], s_mem);
     return;
@@ -470,8 +484,11 @@ __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* 
   unsigned (*s_red)[QS_THREADS / 64][QS_COLS] = reinterpret_cast<unsigned (*)[QS_THREADS / 64][QS_COLS]>(s_mem);
   const int tid = threadIdx.x, q = tid & 15, g = tid >> 4, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int idx = (int)blockIdx.x - nsmall;
-  const int nstatic = (int)gridDim.x - nsmall;   // strips handed out by workgroup index; the queue continues from here
+  // every item comes from the queue, the first one too: only RUNNING workgroups hold items (a part of a tall strip
+  // waits for its team mates -- see below -- and a workgroup that is not resident yet must not be one of them)
+  if (tid == 0) s_next[1] = (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int idx = __builtin_amdgcn_readfirstlane(s_next[1]);
   if (idx >= nstrips) return;
   QsStrip cur = qs_strip(ts, cmap, idx, wave);
   F4 v[QS_NV];
@@ -492,8 +509,9 @@ __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* 
   }
   for (int it = 0;; ++it) {
     const int par = it & 1;
-    if (tid == 0)
-      s_next[par] = nstatic + (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a part of a tall strip takes its next item only AFTER its team has met: see the team step)
+    if (tid == 0 && cur.team == 1)
+      s_next[par] = (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int rows = cur.rows, cols = cur.cols;
     const int col = cur.c0 + 4 * q;
     const bool col_in = col < cols;
@@ -501,18 +519,18 @@ __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* 
     const int nv_used = (rows + QS_GROUPS - 1) / QS_GROUPS;
     // diagonal: row 32 k + g meets the strip's columns [c0, c0 + 64) only for k = c0 / 32 and k = c0 / 32 + 1
     if (cur.extract) {
-      const int kd = cur.c0 / QS_GROUPS;
+      const int kd = (cur.c0 - cur.r_off) / QS_GROUPS;     // (exact: both are multiples of 32; may lie outside 0 .. 31)
 #pragma unroll
       for (int k = 0; k < QS_NV; ++k) {
         if (k != kd && k != kd + 1) continue;              // scalar
         const int r = QS_GROUPS * k + g;
-        const int d = r - col;                             // the lane holds the diagonal element in component d
+        const int d = cur.r_off + r - col;                 // the lane holds the diagonal element in component d
         if ((unsigned)d < 4u && r < rows && col_in) {
           float* xs = &v[k].x;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (d == j) {
-              *(float PS_GLOBAL*)(cur.diag + r) = xs[j];
+              *(float PS_GLOBAL*)(cur.diag + cur.r_off + r) = xs[j];
               xs[j] = __fsub_rn(xs[j], xs[j]);             // QU:79-80: value - diag(diagonal)
             }
           }
@@ -542,16 +560,55 @@ __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* 
       for (int j = 0; j < 4; ++j) s_red[par][wave][4 * q + j] = m[j];
     }
     __syncthreads();
-    float bnz[4], y1[4];
-    bool sane = true;
+    unsigned amax[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned a = s_red[par][0][4 * q + j];
 #pragma unroll
       for (int w = 1; w < QS_THREADS / 64; ++w) { const unsigned o = s_red[par][w][4 * q + j]; a = o > a ? o : a; }
-      const float bs = __fdiv_rn(__uint_as_float(a), nb);   // QU:86
+      amax[j] = a;
+    }
+    if (cur.team > 1) {                                      // scalar
+      // Team step of a tall strip (1024 < rows <= 4096): this workgroup holds 1024 rows of it.  The parts merge their
+      // maxima with agent-scope atomics (64 per part), count themselves in and wait for the others.  No deadlock: items
+      // leave the queue in order, a strip's parts are consecutive items, only running workgroups hold items and a
+      // waiting one holds exactly one (it takes its next item after the wait): every team but the one at the queue's
+      // head is complete among the running workgroups, and that one is completed by the next workgroup to finish
+      // an item or to start.  The wait is bounded (10 s); on expiry the part publishes NaN bucket sizes.
+      if (g == 0 && col_in) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (amax[j]) __hip_atomic_fetch_max(cur.colmax + col + j, amax[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the atomics acknowledged (s_waitcnt), no cache write-back
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(cur.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + 1000000000ull;   // 100 MHz clock
+        int ok = 1;
+        while (__hip_atomic_load(cur.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cur.team) {
+          if (__builtin_amdgcn_s_memrealtime() > deadline) { ok = 0; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        s_next[par] = (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_team_ok = ok;
+      }
+      __syncthreads();
+      const bool expired = s_team_ok == 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        amax[j] = col_in ? __hip_atomic_load(cur.colmax + col + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (expired) amax[j] = 0x7fc00000u;
+      }
+    }
+    float bnz[4], y1[4];
+    bool sane = true;
+    const bool writes_bucket = g == 0 && col_in && cur.r_off == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bs = __fdiv_rn(__uint_as_float(amax[j]), nb);   // QU:86
       bnz[j] = bs > 0.f ? bs : 1.f;                          // QU:89-90
-      if (g == 0 && col_in) *(float PS_GLOBAL*)(cur.bucket + col + j) = bs;
+      if (writes_bucket) *(float PS_GLOBAL*)(cur.bucket + col + j) = bs;
       // the denominator-only part of the IEEE division sequence
       const float rc = __builtin_amdgcn_rcpf(bnz[j]);
       const float e = __fmaf_rn(-bnz[j], rc, 1.0f);
@@ -838,10 +895,13 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
               aligned(d.codes, code_vec) && aligned(d.bucket_size, 16)) ? 1 : 0;
     t.flat = (flat_on && t.vec4 && d.ld == d.cols && d.ldq == d.cols && d.cols <= QFLAT_MAXC && d.rows > 0 &&
               d.cols > 0 && count <= QMAXT && aligned(d.codes, 16)) ? 1 : 0;
-    // quantize: matrices of 64 ... 1024 rows are encoded from registers in one read (quant_strip_kernel)
-    t.strip = (encode && strip_on && t.flat && d.rows >= QS_MINR && d.rows <= (long long)QS_NV * QS_GROUPS &&
+    // quantize: matrices of 64 ... 1024 rows are encoded from registers in one read (quant_strip_kernel),
+    // (taller ones, up to 4096 rows, in parts of 1024 rows that merge their column maxima: QTensor::team)
+    t.strip = (encode && strip_on && t.flat && d.rows >= QS_MINR && d.rows <= 4LL * QS_NV * QS_GROUPS &&
                (d.rows * d.cols) * 4 < (1LL << 31)) ? 1 : 0;
-    t.schunks = t.strip ? (int)((d.cols + QS_COLS - 1) / QS_COLS) : 0;
+    t.team = t.strip ? (int)((d.rows + QS_NV * QS_GROUPS - 1) / (QS_NV * QS_GROUPS)) : 1;
+    t.sarrive = nullptr;
+    t.schunks = t.strip ? (int)((d.cols + QS_COLS - 1) / QS_COLS) * t.team : 0;
     // ... and small ones of any layout by one workgroup of the same launch (quant_small_body)
     t.small = (encode && strip_on && !t.strip && d.rows > 0 && d.cols > 0 && d.cols <= QSM_COLS &&
                d.rows * d.cols <= QSM_ELEMS) ? 1 : 0;
@@ -909,7 +969,7 @@ static size_t quant_map_bytes(const ps_quant_desc* desc, int count) {
     if (desc[i].rows <= 0 || desc[i].cols <= 0) continue;
     const size_t flat = (size_t)((desc[i].rows * desc[i].cols + QFLAT - 1) / QFLAT);
     const size_t tile = (size_t)((desc[i].cols + QW - 1) / QW) * (size_t)((desc[i].rows + QR - 1) / QR);
-    const size_t strips = (size_t)((desc[i].cols + QS_COLS - 1) / QS_COLS);
+    const size_t strips = 4 * (size_t)((desc[i].cols + QS_COLS - 1) / QS_COLS);
     n += std::max(std::max(flat, tile), strips) + 1;
   }
   return psh::align_up(sizeof(int) * (n + 1), 256);
@@ -931,7 +991,11 @@ static int quant_cus() {
 extern "C" size_t ps_quantize_workspace_bytes(const ps_quant_desc* desc, int count) {
   if (!desc || count <= 0) return 0;
   size_t cols = 0;
-  for (int i = 0; i < count; ++i) cols += psh::align_up((size_t)(desc[i].cols > 0 ? desc[i].cols : 0), 4);
+  // per tensor: column maxima + one arrival counter per strip of 64 columns (tall strips); + the strip queue's counter
+  for (int i = 0; i < count; ++i) {
+    const size_t c = (size_t)(desc[i].cols > 0 ? desc[i].cols : 0);
+    cols += psh::align_up(c, 4) + (c + QS_COLS - 1) / QS_COLS;
+  }
   return psh::align_up(sizeof(QTensor) * count, 256) + psh::align_up(sizeof(unsigned) * (cols + 4), 256) +
          quant_map_bytes(desc, count) + 1024;
 }
@@ -949,14 +1013,22 @@ extern "C" int ps_quantize_f32(void* stream, const ps_quant_desc* desc, int coun
   hipStream_t st = (hipStream_t)stream;
   psh::Arena ar(workspace, workspace_bytes);
   QTensor* dt = ar.take<QTensor>(count);
-  unsigned* colmax = ar.take<unsigned>(total_cols + 4);   // + the strip queue's counter
+  size_t team_strips = 0;
+  for (int i = 0; i < count; ++i)
+    if (ht[i].team > 1) team_strips += (size_t)ht[i].schunks / (size_t)ht[i].team;
+  // column maxima | the strip queue's counter (4 words) | arrival counters of the tall strips: one memset
+  unsigned* colmax = ar.take<unsigned>(total_cols + 4 + team_strips);
   if (ar.overflow) return PS_EWORKSPACE;
-  size_t off = 0;
+  size_t off = 0, soff = 0;
   for (int i = 0; i < count; ++i) {
     ht[i].colmax = colmax + off;
     off += psh::align_up((size_t)ht[i].cols, 4);
+    if (ht[i].team > 1) {
+      ht[i].sarrive = colmax + total_cols + 4 + soff;
+      soff += (size_t)ht[i].schunks / (size_t)ht[i].team;
+    }
   }
-  PS_HIP(hipMemsetAsync(colmax, 0, sizeof(unsigned) * (total_cols + 4), st));
+  PS_HIP(hipMemsetAsync(colmax, 0, sizeof(unsigned) * (total_cols + 4 + team_strips), st));
   // flat tensors: one launch per pass over chunks of consecutive elements; the others (odd sizes,
   // strided views) keep the tile kernels
   std::vector<int> hmap;

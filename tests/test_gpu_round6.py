@@ -236,13 +236,16 @@ _TQ6 = {8: torch.int8, 16: torch.int16}
 
 @pytest.mark.parametrize("shape,bits,extract", [
     ((1024, 1024), 16, True), ((768, 768), 8, True), ((512, 320), 16, False), ((100, 132), 16, False),
-    ((1000, 260), 8, False), ((96, 96), 16, True), ((64, 4), 8, False), ((1024, 8192), 16, False)])
+    ((1000, 260), 8, False), ((96, 96), 16, True), ((64, 4), 8, False), ((1024, 8192), 16, False),
+    ((2048, 2048), 16, True), ((3072, 768), 8, False), ((1500, 260), 16, False), ((4096, 64), 8, False),
+    ((4100, 64), 16, False)])
 def test_quantize_register_strips_on_rounding_boundaries_and_extreme_scales(shape, bits, extract, device):
   """quant_strip_kernel (matrices of 64 ... 1024 rows, one read): its division is the IEEE sequence with the
   column-only part hoisted, its rounding a magic-constant add.  Inputs aimed at exactly those steps: elements AT
   and one ulp either side of (k + 1/2) * bucket (round half to even decides), columns scaled by 2^-80 ... 2^80
   (outside [2^-60, 2^60] a wavefront takes the plain division), denormals, exact zeros, zero columns, row counts
-  that are not multiples of 32 and column counts that are not multiples of 64.  Codes, diagonal and bucket sizes
+  that are not multiples of 32 and column counts that are not multiples of 64; tall matrices (1025 ... 4096 rows:
+  parts of 1024 rows on different workgroups that merge their column maxima; 4100 rows: the two-pass kernels).  Codes, diagonal and bucket sizes
   bit-identical to the oracle's (numpy float32 division is correctly rounded; np.round is half-even)."""
   from oracle import quantization_oracle as qorc
   rng = np.random.default_rng(hash((shape, bits, 6)) % (2 ** 31))
@@ -283,7 +286,8 @@ def test_quantize_strip_queue_mixed_tensors_bit_exact(device):
   descriptor list, every code / bucket size / diagonal entry against the oracle."""
   from oracle import quantization_oracle as qorc
   rng = np.random.default_rng(66)
-  shapes = [(1024, 1024), (768, 768), (64, 4096), (100, 132), (512, 320), (1000, 260), (96, 96), (256, 2048)] * 4
+  shapes = [(1024, 1024), (768, 768), (64, 4096), (100, 132), (3072, 768), (512, 320), (1000, 260), (96, 96),
+            (256, 2048), (2048, 2048), (1500, 128)] * 4
   xs = []
   for i, (r, c) in enumerate(shapes):
     x = (rng.standard_normal((r, c)) * np.exp(rng.uniform(-6, 6, size=c))).astype(np.float32)
@@ -302,3 +306,30 @@ def test_quantize_strip_queue_mixed_tensors_bit_exact(device):
       assert np.array_equal(b.cpu().numpy().view(np.uint32), np.asarray(ob, np.float32).view(np.uint32)), x.shape
       if extract_square:
         assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32)), x.shape
+
+
+def test_quantize_tall_strips_next_to_a_busy_stream(device):
+  """Parts of a tall strip wait for each other on the device (quant_strip_kernel's team step).  With another stream
+  keeping most of the chip busy the parts of a team become resident at different times: the wait must neither hang
+  nor expire (an expired wait publishes NaN bucket sizes), and the codes stay the oracle's."""
+  from oracle import quantization_oracle as qorc
+  rng = np.random.default_rng(67)
+  xs = [np.ascontiguousarray((rng.standard_normal((3072, 768)) * np.exp(rng.uniform(-3, 3, size=768))).astype(np.float32))
+        for _ in range(6)]
+  ts = [torch.tensor(x, device=device) for x in xs]
+  a = torch.randn((6144, 6144), device=device)
+  side = torch.cuda.Stream(device=device)
+  torch.cuda.synchronize()
+  with torch.cuda.stream(side):
+    for _ in range(40):
+      a = torch.nn.functional.normalize(a @ a, dim=0)      # ~3 ms each: the chip stays busy for the whole test
+  outs = []
+  for _ in range(20):
+    outs.append(K().quantize_grouped(ts, torch.int8, False))
+  torch.cuda.synchronize()
+  ref = [qorc.quantize(x, np.int8, False) for x in xs]
+  for out in (outs[0], outs[-1]):
+    for (q, d, b), (oq, od, ob) in zip(out, ref):
+      assert torch.isfinite(b).all()
+      assert np.array_equal(b.cpu().numpy().view(np.uint32), np.asarray(ob, np.float32).view(np.uint32))
+      assert np.array_equal(q.cpu().numpy(), oq)
