@@ -44,7 +44,8 @@ struct QTensor {
   int fchunk0, fchunks;   // its chunks of QFLAT consecutive elements
   int strip;              // quantize only: the register-resident strip kernel takes it (quant_strip_kernel)
   int schunk0, schunks;   // its strips of QS_COLS columns
-  int small;              // quantize only: one workgroup of the strip launch takes the whole tensor (quant_small_body)
+  int small;              // quantize only: workgroups at the head of the strip launch take it (quant_small_body):
+  int small_w;            //   every one ALL rows of a range of small_w columns
   int team;               // strips of more than 1024 rows: parts of 1024 rows, one workgroup each (1 = whole strips)
   unsigned* sarrive;      // workspace: per strip, the parts whose column maxima are merged
 };
@@ -405,9 +406,13 @@ __device__ __forceinline__ QsStrip qs_strip(const QTensor* ts, const int* cmap, 
 constexpr int QSM_ELEMS = 65536;
 constexpr int QSM_COLS = 2048;
 
-__device__ __forceinline__ void quant_small_body(const QTensor* t, unsigned* s_max) {
+// item = (tensor, first column): ALL rows of a range of up to `width` columns (QTensor::small_w; rows * width <=
+// QSM_ELEMS, width <= QSM_COLS).  Columns are independent, so a wide and short tensor ([1, 197, 768] embeddings:
+// 151 296 columns of one row) is simply many items.
+__device__ __forceinline__ void quant_small_body(const QTensor* t, int c0, unsigned* s_max) {
   const int tid = threadIdx.x;
-  const int rows = (int)t->rows, cols = (int)t->cols, total = rows * cols;
+  const int rows = (int)t->rows, cols = (int)t->cols;
+  const int nc = cols - c0 < t->small_w ? cols - c0 : t->small_w, total = rows * nc;
   const long long ld = t->ld, ldq = t->ldq;
   const float* const fin = t->fin;
   void* const codes = t->codes;
@@ -415,7 +420,7 @@ __device__ __forceinline__ void quant_small_body(const QTensor* t, unsigned* s_m
   float* const bucket = t->bucket;
   const int extract = t->extract, bits = t->bits;
   const float nb = bits == 8 ? 127.f : 32767.f;
-  for (int c = tid; c < cols; c += QS_THREADS) s_max[c] = 0u;
+  for (int c = tid; c < nc; c += QS_THREADS) s_max[c] = 0u;
   __syncthreads();
   // pass 1: a lane keeps the running maximum of the column it is in and merges it when the column changes
   // (vectors, and widths that divide the thread count, merge once per lane)
@@ -428,13 +433,13 @@ __device__ __forceinline__ void quant_small_body(const QTensor* t, unsigned* s_m
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int e = e0 + u * QS_THREADS;
-        rr[u] = e / cols; cc[u] = e - rr[u] * cols;
-        x[u] = e < total ? ldg1(fin + (long long)rr[u] * ld + cc[u]) : 0.f;
+        rr[u] = e / nc; cc[u] = e - rr[u] * nc;
+        x[u] = e < total ? ldg1(fin + (long long)rr[u] * ld + c0 + cc[u]) : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (e0 + u * QS_THREADS >= total) break;
-        if (extract && rr[u] == cc[u]) x[u] = __fsub_rn(x[u], x[u]);   // QU:79-80
+        if (extract && rr[u] == c0 + cc[u]) x[u] = __fsub_rn(x[u], x[u]);   // QU:79-80
         const unsigned b = __float_as_uint(x[u]) & 0x7fffffffu;
         if (cc[u] != ccol) {
           if (cmax) atomicMax(&s_max[ccol], cmax);
@@ -446,9 +451,9 @@ __device__ __forceinline__ void quant_small_body(const QTensor* t, unsigned* s_m
     if (cmax) atomicMax(&s_max[ccol], cmax);
   }
   __syncthreads();
-  for (int c = tid; c < cols; c += QS_THREADS) {
+  for (int c = tid; c < nc; c += QS_THREADS) {
     const float bs = __fdiv_rn(__uint_as_float(s_max[c]), nb);   // QU:86
-    bucket[c] = bs;
+    bucket[c0 + c] = bs;
     s_max[c] = __float_as_uint(bs > 0.f ? bs : 1.f);             // QU:89-90
   }
   __syncthreads();
@@ -458,16 +463,16 @@ __device__ __forceinline__ void quant_small_body(const QTensor* t, unsigned* s_m
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u * QS_THREADS;
-      rr[u] = e / cols; cc[u] = e - rr[u] * cols;
-      x[u] = e < total ? ldg1(fin + (long long)rr[u] * ld + cc[u]) : 0.f;
+      rr[u] = e / nc; cc[u] = e - rr[u] * nc;
+      x[u] = e < total ? ldg1(fin + (long long)rr[u] * ld + c0 + cc[u]) : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (e0 + u * QS_THREADS >= total) break;
-      if (extract && rr[u] == cc[u]) { diag[rr[u]] = x[u]; x[u] = __fsub_rn(x[u], x[u]); }
+      if (extract && rr[u] == c0 + cc[u]) { diag[rr[u]] = x[u]; x[u] = __fsub_rn(x[u], x[u]); }
       const int q = encode1(x[u], __uint_as_float(s_max[cc[u]]));
-      if (bits == 16) reinterpret_cast<short*>(codes)[(long long)rr[u] * ldq + cc[u]] = (short)q;
-      else reinterpret_cast<signed char*>(codes)[(long long)rr[u] * ldq + cc[u]] = (signed char)q;
+      if (bits == 16) reinterpret_cast<short*>(codes)[(long long)rr[u] * ldq + c0 + cc[u]] = (short)q;
+      else reinterpret_cast<signed char*>(codes)[(long long)rr[u] * ldq + c0 + cc[u]] = (signed char)q;
     }
   }
 }
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* 
   __shared__ int s_next[2];
   __shared__ int s_team_ok;
   if ((int)blockIdx.x < nsmall) {
-    quant_small_body(&ts[smap[blockIdx.x]], s_mem);
+    quant_small_body(&ts[smap[2 * blockIdx.x]], smap[2 * blockIdx.x + 1], s_mem);
     return;
   }
   unsigned (*s_red)[QS_THREADS / 64][QS_COLS] = reinterpret_cast<unsigned (*)[QS_THREADS / 64][QS_COLS]>(s_mem);
@@ -903,8 +908,9 @@ static long long build_tensors(const ps_quant_desc* desc, int count, bool encode
     t.sarrive = nullptr;
     t.schunks = t.strip ? (int)((d.cols + QS_COLS - 1) / QS_COLS) * t.team : 0;
     // ... and small ones of any layout by one workgroup of the same launch (quant_small_body)
-    t.small = (encode && strip_on && !t.strip && d.rows > 0 && d.cols > 0 && d.cols <= QSM_COLS &&
-               d.rows * d.cols <= QSM_ELEMS) ? 1 : 0;
+    // (short ones, rows < 64, of any width; others -- odd sizes, strided views -- up to 1024 rows)
+    t.small = (encode && strip_on && !t.strip && d.rows > 0 && d.cols > 0 && d.rows <= QS_NV * QS_GROUPS) ? 1 : 0;
+    t.small_w = t.small ? (int)std::min<long long>(std::min<long long>(d.cols, QSM_COLS), QSM_ELEMS / d.rows) : 0;
     if (t.strip || t.small) t.flat = 0;
     t.fchunks = t.flat ? (int)((d.rows * d.cols + QFLAT - 1) / QFLAT) : 0;
     t.strips = (int)((d.cols + QW - 1) / QW);
@@ -949,8 +955,12 @@ static void build_chunk_maps(std::vector<QTensor>& ht, std::vector<int>& map, lo
   if (sch_out) *sch_out = sch;
   // the small tensors (quantize only): tensor indices, last in the table
   long long nsm = 0;
-  for (size_t i = 0; i < ht.size(); ++i)
-    if (ht[i].small) { map.push_back((int)i); ++nsm; }
+  for (size_t i = 0; i < ht.size(); ++i) {
+    if (!ht[i].small) continue;
+    for (long long c0 = 0; c0 < ht[i].cols; c0 += ht[i].small_w) {   // (tensor, first column) pairs
+      map.push_back((int)i); map.push_back((int)c0); ++nsm;
+    }
+  }
   if (nsm_out) *nsm_out = nsm;
 }
 
@@ -970,7 +980,8 @@ static size_t quant_map_bytes(const ps_quant_desc* desc, int count) {
     const size_t flat = (size_t)((desc[i].rows * desc[i].cols + QFLAT - 1) / QFLAT);
     const size_t tile = (size_t)((desc[i].cols + QW - 1) / QW) * (size_t)((desc[i].rows + QR - 1) / QR);
     const size_t strips = 4 * (size_t)((desc[i].cols + QS_COLS - 1) / QS_COLS);
-    n += std::max(std::max(flat, tile), strips) + 1;
+    // (small tensors: one pair of words per range of >= 64 columns, or one pair in all)
+    n += std::max(std::max(flat, tile), strips) + 2 * ((size_t)desc[i].cols / 64 + 1);
   }
   return psh::align_up(sizeof(int) * (n + 1), 256);
 }

@@ -238,14 +238,15 @@ _TQ6 = {8: torch.int8, 16: torch.int16}
     ((1024, 1024), 16, True), ((768, 768), 8, True), ((512, 320), 16, False), ((100, 132), 16, False),
     ((1000, 260), 8, False), ((96, 96), 16, True), ((64, 4), 8, False), ((1024, 8192), 16, False),
     ((2048, 2048), 16, True), ((3072, 768), 8, False), ((1500, 260), 16, False), ((4096, 64), 8, False),
-    ((4100, 64), 16, False)])
+    ((4100, 64), 16, False), ((1, 151296), 8, False), ((3, 20000), 16, False), ((40, 5004), 8, False)])
 def test_quantize_register_strips_on_rounding_boundaries_and_extreme_scales(shape, bits, extract, device):
   """quant_strip_kernel (matrices of 64 ... 1024 rows, one read): its division is the IEEE sequence with the
   column-only part hoisted, its rounding a magic-constant add.  Inputs aimed at exactly those steps: elements AT
   and one ulp either side of (k + 1/2) * bucket (round half to even decides), columns scaled by 2^-80 ... 2^80
   (outside [2^-60, 2^60] a wavefront takes the plain division), denormals, exact zeros, zero columns, row counts
   that are not multiples of 32 and column counts that are not multiples of 64; tall matrices (1025 ... 4096 rows:
-  parts of 1024 rows on different workgroups that merge their column maxima; 4100 rows: the two-pass kernels).  Codes, diagonal and bucket sizes
+  parts of 1024 rows on different workgroups that merge their column maxima; 4100 rows: the two-pass kernels);
+  wide and short ones ([1, 197, 768] embeddings: ranges of columns, one workgroup each).  Codes, diagonal and bucket sizes
   bit-identical to the oracle's (numpy float32 division is correctly rounded; np.round is half-even)."""
   from oracle import quantization_oracle as qorc
   rng = np.random.default_rng(hash((shape, bits, 6)) % (2 ** 31))
