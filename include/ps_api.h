@@ -554,8 +554,11 @@ int ps_transform_grads_f32(void* stream, const ps_transform_desc* desc, int coun
  *   codes[r,c]     = round_half_even(x[r,c] / (bucket_size[c] > 0 ? bucket_size[c] : 1))
  *   extract_diagonal (rows == cols): diagonal[r] = x[r,r] and x[r,r] counts as 0.
  * Codes, diagonal and bucket sizes are bit-exact with the reference for finite input.
- * Every tensor of the tree goes in ONE call (two launches for quantize, one for
- * dequantize).  `fvalue` is read by ps_quantize_f32 and written by ps_dequantize_f32. */
+ * Every tensor of the tree goes in ONE call.  ps_dequantize_f32 is one launch.  ps_quantize_f32 reads
+ * contiguous float4-addressable matrices of 64 ... 4096 rows and every tensor of fewer than 64 rows ONCE
+ * (register-resident column strips; one launch); taller or large strided tensors take two passes over the
+ * input (column maxima, then codes: two more launches).  Same codes on every path.
+ * `fvalue` is read by ps_quantize_f32 and written by ps_dequantize_f32. */
 typedef struct {
   float* fvalue;        /* [rows, cols] float32, leading dimension ld */
   void* codes;          /* int8_t or int16_t [rows, cols], leading dimension ldq */
