@@ -555,6 +555,7 @@ def quant_f3(dev):
           "int16_quantize_plan_frac_of_hbm_peak": round(ne * 6 / tq3 / 8e12, 4),
           "int16_dequantize_plan_ms": round(td3 * 1e3, 3),
           "int16_dequantize_plan_GBps": round(ne * 6 / td3 / 1e9, 1),
+          "int16_dequantize_plan_frac_of_hbm_peak": round(ne * 6 / td3 / 8e12, 4),
           "int8_quantize_plan_ms": round(mq3 * 1e3, 3), "int8_quantize_plan_GBps": round(nm * 5 / mq3 / 1e9, 1),
           "int8_quantize_ms": round(mq * 1e3, 3), "int8_quantize_GBps": round(nm * 5 / mq / 1e9, 1),
           "int8_dequantize_ms": round(md * 1e3, 3), "int8_dequantize_GBps": round(nm * 5 / md / 1e9, 1)}
@@ -1355,6 +1356,17 @@ def main():
       cfg["fd_cfg5_tail_rel"] = par.get("tail_rel_max")
     if isinstance(line.get("fd_cfg5_rank_share"), dict) and "ms_per_factor_update" in line["fd_cfg5_rank_share"]:
       cfg["fd_cfg5_one_factor_per_gpu_ms"] = float(np.median(line["fd_cfg5_rank_share"]["ms_per_factor_update"]))
+    if isinstance(line.get("quant_f3"), dict) and "int16_quantize_plan_ms" in line["quant_f3"]:
+      q3 = line["quant_f3"]
+      cfg["quant_f3_int16_quantize_ms"] = q3.get("int16_quantize_plan_ms")
+      cfg["quant_f3_int16_quantize_frac_of_hbm_peak"] = q3.get("int16_quantize_plan_frac_of_hbm_peak")
+      cfg["quant_f3_int16_dequantize_ms"] = q3.get("int16_dequantize_plan_ms")
+      cfg["quant_f3_int16_dequantize_frac_of_hbm_peak"] = q3.get("int16_dequantize_plan_frac_of_hbm_peak")
+      cfg["quant_f3_int8_quantize_ms"] = q3.get("int8_quantize_plan_ms")
+    rs8 = ((line.get("vit_b_cfg4_rank_share") or {}).get("worlds") or {}).get("8") or {}
+    if "share_ms" in rs8:
+      cfg["vit_b_cfg4_rank_share_world8_ms"] = rs8.get("share_ms")
+      cfg["vit_b_cfg4_rank_share_world8_projected_speedup"] = rs8.get("projected_speedup")
     if isinstance(line.get("vit_b_cfg4"), dict):
       cfg["vit_b_cfg4_ms"] = line["vit_b_cfg4"].get("ms_per_step")
       vpar = line["vit_b_cfg4"].get("parity_vs_oracle") or {}
