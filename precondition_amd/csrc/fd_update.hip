@@ -44,12 +44,51 @@ __global__ __launch_bounds__(256) void fd_prep_kernel(const float* prev, float* 
   }
 }
 
-// DS:1196-1290 for factor j (one workgroup): theta [b] descending Ritz values, x [d][b] Ritz vectors (the first r
-// columns are used), prev as above -> out [d][r + 2].
+// Partial sums of squares of the Ritz vectors' columns: slice s of FD_NP row slices of factor j ->
+// part[(j * FD_NP + s) * r + c].  (As ONE workgroup per factor walking column after column this was 0.7 ms of a
+// 9 ms one-factor update: 64 strided passes over 4096 rows.)  Lane = column, so a row is one contiguous run; the row
+// groups of a workgroup are added in a fixed order, the slices in a fixed order by fd_finish_kernel.
+constexpr int FD_NP = 32;   // row slices of the column norms
+constexpr int FD_NS = 16;   // row slices of the packing
+__global__ __launch_bounds__(256) void fd_colnorm_part_kernel(const float* x, float* part, int d, int b, int r) {
+  __shared__ float red[256];
+  const int s = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+  const float* xj = x + (int64_t)j * d * b;
+  const int rows_per = (d + FD_NP - 1) / FD_NP;
+  const int row0 = s * rows_per, row1 = row0 + rows_per < d ? row0 + rows_per : d;
+  for (int c0 = 0; c0 < r; c0 += 256) {
+    const int rc = r - c0 < 256 ? r - c0 : 256;          // columns of this pass
+    const int cw = (rc + 63) & ~63;                       // lanes per row group
+    const int rg_n = 256 / cw, c = tid % cw, rg = tid / cw;
+    float ss = 0.f;
+    if (rg < rg_n && c < rc) {
+      int row = row0 + rg;
+      for (; row + 3 * rg_n < row1; row += 4 * rg_n) {
+        const float v0 = xj[(int64_t)row * b + c0 + c], v1 = xj[(int64_t)(row + rg_n) * b + c0 + c];
+        const float v2 = xj[(int64_t)(row + 2 * rg_n) * b + c0 + c], v3 = xj[(int64_t)(row + 3 * rg_n) * b + c0 + c];
+        ss = __fmaf_rn(v0, v0, ss); ss = __fmaf_rn(v1, v1, ss); ss = __fmaf_rn(v2, v2, ss); ss = __fmaf_rn(v3, v3, ss);
+      }
+      for (; row < row1; row += rg_n) { const float v = xj[(int64_t)row * b + c0 + c]; ss = __fmaf_rn(v, v, ss); }
+    }
+    red[tid] = ss;
+    __syncthreads();
+    if (tid < rc) {
+      float t = red[tid];
+      for (int g = 1; g < rg_n; ++g) t += red[g * cw + tid];
+      part[((int64_t)j * FD_NP + s) * r + c0 + tid] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// DS:1196-1290 for factor j: theta [b] descending Ritz values, x [d][b] Ritz vectors (the first r columns are used),
+// prev as above, part = fd_colnorm_part_kernel's sums -> out [d][r + 2].  grid (FD_NS, B): every workgroup evaluates
+// the O(r) scalars (same arithmetic, same values) and packs its slice of rows.
 __global__ __launch_bounds__(256) void fd_finish_kernel(const float* theta, const float* x, const float* prev,
-                                                        float* out, int d, int b, int r, int p, float decay) {
-  extern __shared__ float sm[];   // e[r + 1], deflated[r], scale[r], keep[r], red[4 * r]
-  const int j = blockIdx.x, tid = threadIdx.x;
+                                                        const float* part, float* out, int d, int b, int r, int p,
+                                                        float decay) {
+  extern __shared__ float sm[];   // e[r + 1], deflated[r], scale[r], inv[r], red[r]
+  const int j = blockIdx.y, tid = threadIdx.x;
   float* e = sm;
   float* defl = e + (r + 1);
   float* scale = defl + r;
@@ -60,6 +99,12 @@ __global__ __launch_bounds__(256) void fd_finish_kernel(const float* theta, cons
   const float* pj = prev + (int64_t)j * d * (r + 2);
   float* oj = out + (int64_t)j * d * (r + 2);
   __shared__ float s_scalars[4];   // new_const, new_tail, has_zeros, tail (decayed)
+  // column norms: the slices' partial sums in slice order
+  for (int c = tid; c < r; c += 256) {
+    float ss = 0.f;
+    for (int s = 0; s < FD_NP; ++s) ss += part[((int64_t)j * FD_NP + s) * r + c];
+    red[c] = ss;
+  }
   if (tid == 0) {
     float emax = th[0];
     for (int c = 1; c <= r; ++c) emax = fmaxf(emax, th[c]);
@@ -82,22 +127,13 @@ __global__ __launch_bounds__(256) void fd_finish_kernel(const float* theta, cons
     s_scalars[0] = new_const; s_scalars[1] = new_tail; s_scalars[3] = tail;
   }
   __syncthreads();
-  // column norms of the kept eigenvectors (columns with a zero deflated eigenvalue are zeroed first)
-  const int wave = tid >> 6, lane = tid & 63;
-  for (int c = 0; c < r; ++c) {
-    float ss = 0.f;
-    if (defl[c] > 0.f)
-      for (int row = tid; row < d; row += 256) { const float v = xj[(int64_t)row * b + c]; ss += v * v; }
-    ss = wave_sum_f32(ss);
-    if (lane == 0) red[4 * c + wave] = ss;
-  }
-  __syncthreads();
   if (tid == 0) {
     const float alpha = (float)(-1.0 / (double)p);
     const float tail = s_scalars[3];
     bool zeros = s_scalars[1] <= 0.f;
     for (int c = 0; c < r; ++c) {
-      const float nrm = sqrtf(((red[4 * c] + red[4 * c + 1]) + red[4 * c + 2]) + red[4 * c + 3]);
+      // (columns with a zero deflated eigenvalue are zeroed before the norms are taken: norm 0, not safe)
+      const float nrm = defl[c] > 0.f ? sqrtf(red[c]) : 0.f;
       const bool safe = 0.99f <= nrm && nrm <= 1.01f;
       const float dv = safe ? defl[c] : 0.f;            // deflated *= safe
       // eigvecs = eigvecs * (deflated > 0) * safe / where(safe, norms, 1): keep the norm (0 = dropped column)
@@ -113,7 +149,9 @@ __global__ __launch_bounds__(256) void fd_finish_kernel(const float* theta, cons
   }
   __syncthreads();
   const int pd = r + 2;
-  for (int64_t el = tid; el < (int64_t)d * pd; el += 256) {
+  const int rows_per = (d + FD_NS - 1) / FD_NS;
+  const int row0 = blockIdx.x * rows_per, row1 = row0 + rows_per < d ? row0 + rows_per : d;
+  for (int64_t el = (int64_t)row0 * pd + tid; el < (int64_t)row1 * pd; el += 256) {
     const int row = (int)(el / pd), c = (int)(el % pd);
     float v = 0.f;
     if (c < r) {
@@ -341,8 +379,11 @@ extern "C" int ps_fd_update_batched_f32(void* stream, const ps_fd_update_desc* u
     PS_RC(ps_fd_round_f32(stream, &rd));
   }
   // ---- finish ---------------------------------------------------------------------------------------
-  const size_t lds = (size_t)((r + 1) + 3 * r + 4 * r) * sizeof(float);
-  hipLaunchKernelGGL(fd_finish_kernel, dim3(B), dim3(256), lds, st, w.theta, w.x, u->prev, u->out, d, b, r, u->p, u->decay);
+  // (w.tmp, the rounds' [B][d][b] temporary, is free now: the column norms' partial sums go there)
+  hipLaunchKernelGGL(fd_colnorm_part_kernel, dim3(FD_NP, B), dim3(256), 0, st, w.x, w.tmp, d, b, r);
+  const size_t lds = (size_t)((r + 1) + 4 * r) * sizeof(float);
+  hipLaunchKernelGGL(fd_finish_kernel, dim3(FD_NS, B), dim3(256), lds, st, w.theta, w.x, u->prev, w.tmp, u->out, d, b, r,
+                     u->p, u->decay);
   PS_LAUNCH_CHECK();
   PS_HIP(hipMemcpyAsync(u->converged, w.conv, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   if (info_host) { info_host[0] = outer; info_host[1] = filter_steps; info_host[2] = b; }
