@@ -1,5 +1,6 @@
 """Dev (round 6): a few ViT-B tree recomputes (Newton roots) alone, for rocprofv3 --kernel-trace --stats."""
-import sys; sys.path.insert(0, ".")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, torch, bench
 dev = torch.device("cuda:0")
 w = bench.VitBWorkload(0, 1, dev, None)
