@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "gemm_core.hip.h"
+#include "options.h"
 
 namespace psk {
 
@@ -279,11 +280,172 @@ static size_t fd_update_sizes(const ps_fd_update_desc* u, int b, size_t plan_byt
   return fd_carve(ar, nullptr, B, d, r, b, u->input_is_factor != 0, plan_bytes, *eigh_bytes) + 256;
 }
 
+// ---- one group of factors as a resumable run ---------------------------------------------------------
+// begin = preparation + first round; step = the host read of a round, then filter + next round (or done);
+// finish = DS:1196-1290 and the packing.  A call with one group is begin, step ... step, finish -- the same commands
+// in the same order as the straight-line driver it replaces.  Two groups (B >= 4) run on two streams with their
+// steps interleaved: while the host waits for one group's 16-byte read, the other group's round is queued, and the
+// latency-bound kernels of a round (chol_rinv / eigh_small: ONE workgroup per factor, 0.7 of the ~3 ms of a round of
+// 8 factors) run under the other group's bandwidth-bound filter steps.  Factors are independent: same bits.
+namespace {
+struct FdRun {
+  ps_fd_update_desc u;       // this group's view of the call (pointers advanced to its first factor)
+  hipStream_t st = nullptr;
+  int b = 0, degree = 0, max_outer = 0;
+  float tol = 0.f;
+  FdCarve w;
+  std::vector<ps_gemm_desc> ds[9];
+  ps_gemm_plan* plans[8] = {};
+  ps_fd_round_desc rd;
+  std::vector<const void*> p0, p1, p2;
+  std::vector<ps_gemm_bf16_desc> cy;
+  int32_t* h_sum = nullptr;  // pinned, 4 words
+  hipEvent_t ev = nullptr;   // behind the summary's copy
+  int outer = 0, filter_steps = 0;
+  bool done = false;
+  ~FdRun() { for (int i = 0; i < 8; ++i) if (plans[i]) (void)ps_gemm_grouped_plan_destroy(plans[i]); }
+};
+
+int fd_run_post_round(FdRun& g) {
+  PS_HIP(hipMemcpyAsync(g.h_sum, g.w.summary, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, g.st));
+  PS_HIP(hipEventRecord(g.ev, g.st));
+  return PS_OK;
+}
+
+int fd_run_begin(FdRun& g, void* workspace, size_t workspace_bytes) {
+  const ps_fd_update_desc* u = &g.u;
+  void* stream = (void*)g.st;
+  hipStream_t st = g.st;
+  const int B = u->batch, d = u->d, r = u->rank, b = g.b, k = r + 1;
+  size_t pb[10], eb = 0;
+  const size_t need = fd_update_sizes(u, b, pb, &eb);
+  if (workspace_bytes < need) return PS_EWORKSPACE;
+  psh::Arena ar(workspace, workspace_bytes);
+  FdCarve& w = g.w;
+  fd_carve(ar, &w, B, d, r, b, u->input_is_factor != 0, pb, eb);
+  if (ar.overflow) return PS_EWORKSPACE;
+  for (int j = 0; j < B; ++j) if (!u->new_grad[j]) return PS_EINVAL;
+  fd_descs(g.ds, w, B, d, r, b);
+
+  // ---- prepare: C = sym(decay W W^T + Gram), bf16 planes ----------------------------------------
+  hipLaunchKernelGGL(fd_prep_kernel, dim3(64, B), dim3(256), 0, st, u->prev, w.weighted, d, r, u->ridge_epsilon,
+                     u->error_tolerance, u->relative_matrix_epsilon);
+  PS_LAUNCH_CHECK();
+  PS_RC(ps_gemm_grouped_f32(stream, g.ds[8].data(), B, w.plan_ws[8], w.plan_ws_bytes[8]));
+  std::vector<const float*> grams(B);
+  if (u->input_is_factor) {   // Gram = R R^T (the reference's statistics slot holds R, DS:1497-1505)
+    std::vector<ps_gemm_desc> gd(B);
+    for (int j = 0; j < B; ++j) {
+      ps_gemm_desc q; q.a = u->new_grad[j]; q.b = u->new_grad[j]; q.c = w.gram + (size_t)j * d * d;
+      q.m = d; q.n = d; q.k = d; q.transa = 0; q.transb = 1; q.lda = d; q.ldb = d; q.ldc = d;
+      gd[j] = q; grams[j] = q.c;
+    }
+    PS_RC(ps_gemm_grouped_f32(stream, gd.data(), B, w.plan_ws[9], w.plan_ws_bytes[9]));
+  } else {
+    for (int j = 0; j < B; ++j) grams[j] = u->new_grad[j];
+  }
+  PS_RC(ps_fd_cov_update_f32(stream, w.c, grams.data(), B, d, u->decay));
+  g.p0.resize(B); g.p1.resize(B); g.p2.resize(B);
+  for (int j = 0; j < B; ++j) {
+    g.p0[j] = (uint16_t*)w.planes[0] + (size_t)j * d * d;
+    g.p1[j] = (uint16_t*)w.planes[1] + (size_t)j * d * d;
+    g.p2[j] = (uint16_t*)w.planes[2] + (size_t)j * d * d;
+    PS_RC(ps_convert_f32_to_bf16x3_frag(stream, w.c + (size_t)j * d * d, (void*)g.p0[j], (void*)g.p1[j],
+                                        (void*)g.p2[j], d, d, d));
+  }
+  PS_HIP(hipMemcpyAsync(w.x, u->x0, (size_t)B * d * b * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+  // ---- iterate ------------------------------------------------------------------------------------
+  for (int q = 0; q < 8; ++q)
+    if (q != 4)
+      PS_RC(ps_gemm_grouped_plan_create(stream, g.ds[q].data(), B, w.plan_ws[q], w.plan_ws_bytes[q], &g.plans[q]));
+  ps_fd_round_desc& rd = g.rd;
+  memset(&rd, 0, sizeof(rd));
+  rd.gram_x = g.plans[0]; rd.xm = g.plans[1]; rd.gram_t = g.plans[2]; rd.pol = g.plans[3]; rd.cx = nullptr;
+  rd.xtz = g.plans[5]; rd.xy = g.plans[6]; rd.zy = g.plans[7];
+  rd.c0 = g.p0.data(); rd.c1 = g.p1.data(); rd.c2 = g.p2.data();
+  rd.xt0 = w.xt[0]; rd.xt1 = w.xt[1]; rd.xt2 = w.xt[2];
+  rd.x = w.x; rd.z = w.z; rd.tmp = w.tmp;
+  rd.gram = w.g; rd.m = w.m; rd.polish = w.polish; rd.t = w.t; rd.y = w.y; rd.sym = w.sym;
+  rd.evals = w.evals; rd.evecs = w.evecs; rd.theta = w.theta; rd.res = w.res;
+  rd.eigh_workspace = w.eigh_ws; rd.eigh_workspace_bytes = w.eigh_ws_bytes;
+  rd.params = w.params; rd.converged = w.conv; rd.summary = w.summary;
+  rd.batch = B; rd.n = d; rd.b = b; rd.k = k; rd.degree = g.degree; rd.orthonormalize = 1; rd.tol = g.tol;
+  g.cy.resize(B);
+  for (int j = 0; j < B; ++j) {
+    memset(&g.cy[j], 0, sizeof(g.cy[j]));
+    g.cy[j].a_hi = g.p0[j]; g.cy[j].a_lo = g.p1[j]; g.cy[j].lda = d; g.cy[j].a_tiled = 2;
+    g.cy[j].b_hi = (uint16_t*)w.yt_hi + (size_t)j * d; g.cy[j].b_lo = (uint16_t*)w.yt_lo + (size_t)j * d;
+    g.cy[j].c = w.z + (size_t)j * d * b;
+    g.cy[j].m = d; g.cy[j].n = b; g.cy[j].k = d; g.cy[j].ldb = (int64_t)B * d; g.cy[j].ldc = b;
+  }
+  PS_RC(ps_fd_round_f32(stream, &rd));
+  g.outer = 1;
+  return fd_run_post_round(g);
+}
+
+// the one host read of a round, then the next round (or done)
+int fd_run_step(FdRun& g) {
+  const int B = g.u.batch, d = g.u.d, b = g.b;
+  void* stream = (void*)g.st;
+  PS_HIP(hipEventSynchronize(g.ev));
+  if (g.h_sum[0] || g.outer > g.max_outer) { g.done = true; return PS_OK; }
+  const int max_deg = g.h_sum[1];
+  int32_t which = -1;
+  FdCarve& w = g.w;
+  PS_RC(ps_fd_filter_round_f32(stream, g.cy.data(), B, w.z, w.x, w.s0, w.s1, w.yt_hi, w.yt_lo, w.params, max_deg, d, b,
+                               (int64_t)B * d, w.cy_ws, 1024, &which));
+  g.filter_steps += max_deg > 1 ? max_deg - 1 : 0;
+  float* src = which == 0 ? w.x : (which == 1 ? w.s0 : w.s1);
+  if (src != w.x)
+    PS_HIP(hipMemcpyAsync(w.x, src, (size_t)B * d * b * sizeof(float), hipMemcpyDeviceToDevice, g.st));
+  PS_RC(ps_fd_round_f32(stream, &g.rd));
+  ++g.outer;
+  return fd_run_post_round(g);
+}
+
+int fd_run_finish(FdRun& g) {
+  const ps_fd_update_desc* u = &g.u;
+  const int B = u->batch, d = u->d, r = u->rank, b = g.b;
+  FdCarve& w = g.w;
+  // (w.tmp, the rounds' [B][d][b] temporary, is free now: the column norms' partial sums go there)
+  hipLaunchKernelGGL(fd_colnorm_part_kernel, dim3(FD_NP, B), dim3(256), 0, g.st, w.x, w.tmp, d, b, r);
+  const size_t lds = (size_t)((r + 1) + 4 * r) * sizeof(float);
+  hipLaunchKernelGGL(fd_finish_kernel, dim3(FD_NS, B), dim3(256), lds, g.st, w.theta, w.x, u->prev, w.tmp, u->out, d, b,
+                     r, u->p, u->decay);
+  PS_LAUNCH_CHECK();
+  PS_HIP(hipMemcpyAsync(u->converged, w.conv, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, g.st));
+  return PS_OK;
+}
+
+// factors of the first group when a call of B factors runs as two (0: one group)
+inline int fd_split(int B) {
+  const int want = psh::resolve(nullptr).fd_groups;
+  return (want >= 2 && B >= 4) ? (B + 1) / 2 : 0;
+}
+ps_fd_update_desc fd_sub_desc(const ps_fd_update_desc* u, int j0, int Bg, int b) {
+  ps_fd_update_desc s = *u;
+  const size_t d = (size_t)u->d, pd = (size_t)u->rank + 2;
+  s.batch = Bg;
+  s.new_grad = u->new_grad + j0;
+  s.prev = u->prev + (size_t)j0 * d * pd;
+  s.out = u->out + (size_t)j0 * d * pd;
+  s.x0 = u->x0 + (size_t)j0 * d * (size_t)b;
+  s.converged = u->converged + j0;
+  return s;
+}
+}  // namespace
+
 extern "C" size_t ps_fd_update_workspace_bytes(const ps_fd_update_desc* u) {
   int b = 0;
   if (fd_update_supported(u, &b) != PS_OK) return 0;
   size_t pb[10], eb = 0;
-  return fd_update_sizes(u, b, pb, &eb);
+  const size_t one = fd_update_sizes(u, b, pb, &eb);
+  const int B1 = fd_split(u->batch);
+  if (B1 == 0) return one;
+  const ps_fd_update_desc u1 = fd_sub_desc(u, 0, B1, b), u2 = fd_sub_desc(u, B1, u->batch - B1, b);
+  const size_t two = psh::align_up(fd_update_sizes(&u1, b, pb, &eb), 4096) + fd_update_sizes(&u2, b, pb, &eb);
+  return two > one ? two : one;
 }
 
 extern "C" int ps_fd_update_batched_f32(void* stream, const ps_fd_update_desc* u, int32_t* info_host) {
@@ -292,100 +454,61 @@ extern "C" int ps_fd_update_batched_f32(void* stream, const ps_fd_update_desc* u
   int rc = fd_update_supported(u, &b);
   if (rc != PS_OK) return rc;
   if (!u->new_grad || !u->prev || !u->out || !u->converged || !u->x0 || !u->workspace) return PS_EINVAL;
-  const int B = u->batch, d = u->d, r = u->rank, k = r + 1;
-  const int degree = u->degree > 0 ? u->degree : 12, max_outer = u->max_outer > 0 ? u->max_outer : 14;
-  const float tol = u->tol > 0.f ? u->tol : 1e-5f;
+  if (u->workspace_bytes < ps_fd_update_workspace_bytes(u)) return PS_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  size_t pb[10], eb = 0;
-  const size_t need = fd_update_sizes(u, b, pb, &eb);
-  if (u->workspace_bytes < need) return PS_EWORKSPACE;
-  psh::Arena ar(u->workspace, u->workspace_bytes);
-  FdCarve w;
-  fd_carve(ar, &w, B, d, r, b, u->input_is_factor != 0, pb, eb);
-  if (ar.overflow) return PS_EWORKSPACE;
-  for (int j = 0; j < B; ++j) if (!u->new_grad[j]) return PS_EINVAL;
-
-  std::vector<ps_gemm_desc> ds[9];
-  fd_descs(ds, w, B, d, r, b);
-  ps_gemm_plan* plans[8] = {};
-  struct PlanGuard { ps_gemm_plan** p; ~PlanGuard() { for (int i = 0; i < 8; ++i) if (p[i]) (void)ps_gemm_grouped_plan_destroy(p[i]); } } guard{plans};
-
-  // ---- prepare: C = sym(decay W W^T + Gram), bf16 planes ----------------------------------------
-  hipLaunchKernelGGL(fd_prep_kernel, dim3(64, B), dim3(256), 0, st, u->prev, w.weighted, d, r, u->ridge_epsilon,
-                     u->error_tolerance, u->relative_matrix_epsilon);
-  PS_LAUNCH_CHECK();
-  PS_RC(ps_gemm_grouped_f32(stream, ds[8].data(), B, w.plan_ws[8], w.plan_ws_bytes[8]));
-  std::vector<const float*> grams(B);
-  if (u->input_is_factor) {   // Gram = R R^T (the reference's statistics slot holds R, DS:1497-1505)
-    std::vector<ps_gemm_desc> gd(B);
-    for (int j = 0; j < B; ++j) {
-      ps_gemm_desc g; g.a = u->new_grad[j]; g.b = u->new_grad[j]; g.c = w.gram + (size_t)j * d * d;
-      g.m = d; g.n = d; g.k = d; g.transa = 0; g.transb = 1; g.lda = d; g.ldb = d; g.ldc = d;
-      gd[j] = g; grams[j] = g.c;
-    }
-    PS_RC(ps_gemm_grouped_f32(stream, gd.data(), B, w.plan_ws[9], w.plan_ws_bytes[9]));
+  static thread_local int32_t* h_sum = nullptr;   // 2 x 4 words, pinned
+  static thread_local hipEvent_t evs[4] = {};      // per group: behind the summary copy; fork; join
+  if (!h_sum && hipHostMalloc((void**)&h_sum, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return PS_EINTERNAL;
+  for (int i = 0; i < 4; ++i)
+    if (!evs[i] && hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) != hipSuccess) return PS_EINTERNAL;
+  const int B1 = fd_split(u->batch);
+  const int ngroups = B1 > 0 ? 2 : 1;
+  hipStream_t side = ngroups == 2 ? psh::side_stream(0) : nullptr;
+  if (ngroups == 2 && !side) return PS_EINTERNAL;
+  FdRun run[2];
+  size_t woff[2] = {0, 0}, wbytes[2] = {u->workspace_bytes, 0};
+  if (ngroups == 2) {
+    size_t pb[10], eb = 0;
+    run[0].u = fd_sub_desc(u, 0, B1, b);
+    run[1].u = fd_sub_desc(u, B1, u->batch - B1, b);
+    wbytes[0] = psh::align_up(fd_update_sizes(&run[0].u, b, pb, &eb), 4096);
+    woff[1] = wbytes[0];
+    wbytes[1] = u->workspace_bytes - wbytes[0];
   } else {
-    for (int j = 0; j < B; ++j) grams[j] = u->new_grad[j];
+    run[0].u = *u;
   }
-  PS_RC(ps_fd_cov_update_f32(stream, w.c, grams.data(), B, d, u->decay));
-  std::vector<const void*> p0(B), p1(B), p2(B);
-  for (int j = 0; j < B; ++j) {
-    p0[j] = (uint16_t*)w.planes[0] + (size_t)j * d * d;
-    p1[j] = (uint16_t*)w.planes[1] + (size_t)j * d * d;
-    p2[j] = (uint16_t*)w.planes[2] + (size_t)j * d * d;
-    PS_RC(ps_convert_f32_to_bf16x3_frag(stream, w.c + (size_t)j * d * d, (void*)p0[j], (void*)p1[j], (void*)p2[j],
-                                        d, d, d));
+  for (int q = 0; q < ngroups; ++q) {
+    FdRun& g = run[q];
+    g.st = q == 0 ? st : side;
+    g.b = b;
+    g.degree = u->degree > 0 ? u->degree : 12;
+    g.max_outer = u->max_outer > 0 ? u->max_outer : 14;
+    g.tol = u->tol > 0.f ? u->tol : 1e-5f;
+    g.h_sum = h_sum + 4 * q;
+    g.ev = evs[q];
   }
-  PS_HIP(hipMemcpyAsync(w.x, u->x0, (size_t)B * d * b * sizeof(float), hipMemcpyDeviceToDevice, st));
-
-  // ---- iterate ------------------------------------------------------------------------------------
-  for (int q = 0; q < 8; ++q)
-    if (q != 4) PS_RC(ps_gemm_grouped_plan_create(stream, ds[q].data(), B, w.plan_ws[q], w.plan_ws_bytes[q], &plans[q]));
-  ps_fd_round_desc rd;
-  memset(&rd, 0, sizeof(rd));
-  rd.gram_x = plans[0]; rd.xm = plans[1]; rd.gram_t = plans[2]; rd.pol = plans[3]; rd.cx = nullptr;
-  rd.xtz = plans[5]; rd.xy = plans[6]; rd.zy = plans[7];
-  rd.c0 = p0.data(); rd.c1 = p1.data(); rd.c2 = p2.data();
-  rd.xt0 = w.xt[0]; rd.xt1 = w.xt[1]; rd.xt2 = w.xt[2];
-  rd.x = w.x; rd.z = w.z; rd.tmp = w.tmp;
-  rd.gram = w.g; rd.m = w.m; rd.polish = w.polish; rd.t = w.t; rd.y = w.y; rd.sym = w.sym;
-  rd.evals = w.evals; rd.evecs = w.evecs; rd.theta = w.theta; rd.res = w.res;
-  rd.eigh_workspace = w.eigh_ws; rd.eigh_workspace_bytes = w.eigh_ws_bytes;
-  rd.params = w.params; rd.converged = w.conv; rd.summary = w.summary;
-  rd.batch = B; rd.n = d; rd.b = b; rd.k = k; rd.degree = degree; rd.orthonormalize = 1; rd.tol = tol;
-  std::vector<ps_gemm_bf16_desc> cy(B);
-  for (int j = 0; j < B; ++j) {
-    memset(&cy[j], 0, sizeof(cy[j]));
-    cy[j].a_hi = p0[j]; cy[j].a_lo = p1[j]; cy[j].lda = d; cy[j].a_tiled = 2;
-    cy[j].b_hi = (uint16_t*)w.yt_hi + (size_t)j * d; cy[j].b_lo = (uint16_t*)w.yt_lo + (size_t)j * d;
-    cy[j].c = w.z + (size_t)j * d * b;
-    cy[j].m = d; cy[j].n = b; cy[j].k = d; cy[j].ldb = (int64_t)B * d; cy[j].ldc = b;
+  if (ngroups == 2) {   // the side stream starts behind everything queued on the caller's
+    PS_HIP(hipEventRecord(evs[2], st));
+    PS_HIP(hipStreamWaitEvent(side, evs[2], 0));
   }
-  static thread_local int32_t* h_sum = nullptr;
-  if (!h_sum && hipHostMalloc((void**)&h_sum, 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return PS_EINTERNAL;
-  int outer = 0, filter_steps = 0;
-  PS_RC(ps_fd_round_f32(stream, &rd));
-  for (outer = 1; outer <= max_outer; ++outer) {
-    PS_HIP(hipMemcpyAsync(h_sum, w.summary, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PS_HIP(hipStreamSynchronize(st));   // the one host read of a round
-    if (h_sum[0]) break;
-    const int max_deg = h_sum[1];
-    int32_t which = -1;
-    PS_RC(ps_fd_filter_round_f32(stream, cy.data(), B, w.z, w.x, w.s0, w.s1, w.yt_hi, w.yt_lo, w.params, max_deg, d, b,
-                                 (int64_t)B * d, w.cy_ws, 1024, &which));
-    filter_steps += max_deg > 1 ? max_deg - 1 : 0;
-    float* src = which == 0 ? w.x : (which == 1 ? w.s0 : w.s1);
-    if (src != w.x) PS_HIP(hipMemcpyAsync(w.x, src, (size_t)B * d * b * sizeof(float), hipMemcpyDeviceToDevice, st));
-    PS_RC(ps_fd_round_f32(stream, &rd));
+  for (int q = 0; q < ngroups && rc == PS_OK; ++q)
+    rc = fd_run_begin(run[q], (char*)u->workspace + woff[q], wbytes[q]);
+  while (rc == PS_OK && !(run[0].done && (ngroups == 1 || run[1].done))) {
+    for (int q = 0; q < ngroups && rc == PS_OK; ++q)
+      if (!run[q].done) rc = fd_run_step(run[q]);
   }
-  // ---- finish ---------------------------------------------------------------------------------------
-  // (w.tmp, the rounds' [B][d][b] temporary, is free now: the column norms' partial sums go there)
-  hipLaunchKernelGGL(fd_colnorm_part_kernel, dim3(FD_NP, B), dim3(256), 0, st, w.x, w.tmp, d, b, r);
-  const size_t lds = (size_t)((r + 1) + 4 * r) * sizeof(float);
-  hipLaunchKernelGGL(fd_finish_kernel, dim3(FD_NS, B), dim3(256), lds, st, w.theta, w.x, u->prev, w.tmp, u->out, d, b, r,
-                     u->p, u->decay);
-  PS_LAUNCH_CHECK();
-  PS_HIP(hipMemcpyAsync(u->converged, w.conv, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-  if (info_host) { info_host[0] = outer; info_host[1] = filter_steps; info_host[2] = b; }
+  for (int q = 0; q < ngroups && rc == PS_OK; ++q) rc = fd_run_finish(run[q]);
+  if (ngroups == 2) {   // the caller's stream continues behind the side stream (also on an error: nothing of this
+    (void)hipEventRecord(evs[3], side);   // call may still be running when the workspace is reused)
+    (void)hipStreamWaitEvent(st, evs[3], 0);
+  }
+  if (rc != PS_OK) return rc;
+  if (info_host) {
+    info_host[0] = run[0].outer; info_host[1] = run[0].filter_steps; info_host[2] = b;
+    if (ngroups == 2) {
+      if (run[1].outer > info_host[0]) info_host[0] = run[1].outer;
+      if (run[1].filter_steps > info_host[1]) info_host[1] = run[1].filter_steps;
+    }
+  }
   return PS_OK;
 }

@@ -64,6 +64,7 @@ struct Options {
   float eigh_td_defl_eps = 1e-8f;  // PS_EIGH_TD_DEFL_EPS: deflation tolerance of the divide and conquer (x 8 ||T||)
   int eigh_td_streams = 4;         // PS_EIGH_TD_STREAMS: stream groups of the reduction
   int eigh_td_tail = 192;          // PS_EIGH_TD_TAIL: last columns of a block reduced inside LDS (0: off; <= 192)
+  int fd_groups = 1;               // PS_FD_GROUPS: 2 = a Frequent-Directions update of >= 4 factors runs as two groups on two streams (dev A/B: measured +-0)
   int quant_strip = 1;             // PS_QUANT_STRIP: quantize matrices of 64 ... 4096 rows (and small tensors) from registers in one read (0 = the two-pass kernels)
   int quant_flat = 1;              // PS_QUANT_FLAT: chunks of consecutive elements for contiguous tensors (0 = 64 x 256 tiles for all)
   int eigh_td_force = 0;           // eigh_solver TRIDIAGONAL (PS_EIGH_TD_FORCE): every block keeps the fast path's result

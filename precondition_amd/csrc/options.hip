@@ -76,6 +76,7 @@ void ps_dev_env_overrides(Options& o) {
   geti("PS_EIGH_TD_ACCURATE", o.eigh_td_accurate);
   geti("PS_QUANT_FLAT", o.quant_flat);
   geti("PS_QUANT_STRIP", o.quant_strip);
+  geti("PS_FD_GROUPS", o.fd_groups);
 }
 
 }  // namespace

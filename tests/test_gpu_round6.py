@@ -334,3 +334,39 @@ def test_quantize_tall_strips_next_to_a_busy_stream(device):
       assert torch.isfinite(b).all()
       assert np.array_equal(b.cpu().numpy().view(np.uint32), np.asarray(ob, np.float32).view(np.uint32))
       assert np.array_equal(q.cpu().numpy(), oq)
+
+
+def test_fd_update_two_interleaved_groups_do_not_change_a_bit(device, monkeypatch):
+  """ps_fd_update_batched_f32 runs a call as resumable per-group runs (begin / step / finish); with the developer
+  switch PS_FD_GROUPS=2 a call of >= 4 factors becomes two groups on two streams whose rounds interleave.  Factors
+  are independent: the packed sketches and convergence flags are bit-identical to the one-group run, on two chained
+  updates of five factors (groups of 3 + 2)."""
+  d, rank, bsz = 1024, 24, 5
+  rng = np.random.default_rng(77)
+  grams = []
+  for t in range(2):
+    gs = []
+    for j in range(bsz):
+      g = rng.standard_normal((d, 2 * d)).astype(np.float32)
+      g[:rank + 2] *= np.linspace(6.0, 2.0, rank + 2)[:, None].astype(np.float32)
+      gt = torch.tensor(g, device=device)
+      gs.append(K().matmul(gt, gt, transb=True))
+    grams.append(gs)
+  b = int(K().lib().ps_fd_block_columns(rank, d))
+  x0 = torch.randn((bsz, d, b), generator=torch.Generator(device="cpu").manual_seed(1729)).to(device)
+  outs = {}
+  for groups in ("1", "2"):
+    monkeypatch.setenv("PS_FD_GROUPS", groups)
+    prev = torch.zeros((bsz, d, rank + 2), dtype=torch.float32, device=device)
+    chain = []
+    for t in range(2):
+      res = K().fd_update_batched(grams[t], prev, 4, rank, 0.999, 1e-6, 1e-6, True, x0)
+      assert res is not None
+      out, conv, info = res
+      chain.append((out.cpu().numpy().copy(), conv.cpu().numpy().copy()))
+      prev = out.clone()
+    outs[groups] = chain
+  monkeypatch.delenv("PS_FD_GROUPS")
+  for (o1, c1), (o2, c2) in zip(outs["1"], outs["2"]):
+    assert np.array_equal(c1, c2)
+    assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32))
