@@ -392,7 +392,8 @@ __device__ __forceinline__ QsStrip qs_strip(const QTensor* ts, const int* cmap, 
   s.c0 = strip * QS_COLS;
   s.extract = qs_uni(t->extract); s.bits = qs_uni(t->bits);
   s.diag = qs_uni(t->diag); s.bucket = qs_uni(t->bucket);
-  s.colmax = qs_uni(t->colmax); s.arrive = qs_uni(t->sarrive) + strip;
+  s.colmax = qs_uni(t->colmax);
+  s.arrive = s.team > 1 ? qs_uni(t->sarrive) + strip : nullptr;
   s.lb = reinterpret_cast<const char*>(qs_uni(t->fin) + (long long)(s.r_off + 4 * wave) * s.cols + s.c0);
   s.cb = reinterpret_cast<char*>(qs_uni(t->codes)) +
          ((long long)(s.r_off + 4 * wave) * s.cols + s.c0) * (s.bits == 16 ? 2 : 1);
