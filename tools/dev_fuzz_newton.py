@@ -45,7 +45,13 @@ for rnd in range(int(os.environ.get("ROUNDS", "12"))):
     ok = True
     why = ""
     if not np.isfinite(h).all() or not np.isfinite(got).all():
-      ok = (np.isnan(h) == np.isnan(got)).all() or (mm["inverse_pth_root_errors"] != mm["inverse_pth_root_errors"]) == (met[i, 0] != met[i, 0])
+      # non-finite roots: the failure select (DS:2936-2943: isnan(err) or err >= threshold) must decide alike; WHICH
+      # non-finite value comes out may differ (an all-zero 1 x 1 statistic: the reference blends 0 * (-inf) + inf = NaN
+      # with error inf; here old_mat_h is selected (inf) and the error is NaN through inf * 0 of the tile padding)
+      fail_ref = not (mm["inverse_pth_root_errors"] < 0.1)
+      fail_got = not (met[i, 0] < 0.1)
+      ok = ((np.isnan(h) == np.isnan(got)).all() or (mm["inverse_pth_root_errors"] != mm["inverse_pth_root_errors"]) == (met[i, 0] != met[i, 0])
+            or (fail_ref and fail_got))
       why = f"nan pattern: ref err {mm['inverse_pth_root_errors']} got err {met[i,0]} a={m.ravel()[:4]} ref={h.ravel()[:3]} got={got.ravel()[:3]}"
     else:
       den = max(np.linalg.norm(h), 1e-30)
