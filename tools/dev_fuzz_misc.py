@@ -68,3 +68,41 @@ for shape, bs in (((70, 33), 32), ((5, 6, 7), 4), ((3, 130, 9), 64), ((2, 3, 4, 
     if not np.allclose(got, ref, rtol=2e-5, atol=1e-4 * max(np.abs(ref).max(), 1)):
       bad2 += 1; print("STATS MISMATCH", shape, bs, axis, np.abs(got - ref).max())
 print("stats fuzz done, mismatches", bad2)
+
+# ---- quantization (QU:45-113): every kernel family of csrc/quant.hip in mixed grouped calls ----------------------
+from oracle import quantization_oracle as qorc
+rng = np.random.default_rng(int(os.environ.get("SEED", "0")) + 3)
+bad3 = 0
+cases3 = 0
+row_choices = [1, 2, 3, 17, 63, 64, 65, 100, 197, 512, 768, 1000, 1024, 1025, 1500, 2048, 3072, 4096, 4097, 5000]
+col_choices = [1, 2, 3, 4, 7, 64, 66, 100, 128, 197, 256, 260, 768, 1000, 1024, 2048, 2050, 3072, 9000]
+for rnd in range(int(os.environ.get("QROUNDS", "16"))):
+  bits = int(rng.choice([8, 16]))
+  extract = bool(rng.uniform() < 0.4)
+  xs = []
+  for _ in range(int(rng.integers(3, 12))):
+    r = int(rng.choice(row_choices)); c = r if extract else int(rng.choice(col_choices))
+    if r * c > 6_000_000:
+      c = max(1, 6_000_000 // r)
+      if extract: r = c = min(r, 2048)
+    x = (rng.standard_normal((r, c)) * np.exp(rng.uniform(-10, 10, size=c))).astype(np.float32)
+    if extract: x = (x + x.T).astype(np.float32)
+    x[rng.uniform(size=x.shape) < 0.03] = 0.0
+    if c > 2 and rng.uniform() < 0.5: x[:, int(rng.integers(0, c))] = 0.0
+    xs.append(np.ascontiguousarray(x))
+  tq = torch.int8 if bits == 8 else torch.int16
+  npdt = np.int8 if bits == 8 else np.int16
+  ts = [torch.tensor(x, device=dev) for x in xs]
+  out = K.quantize_grouped(ts, tq, extract)
+  fl = K.dequantize_grouped(out)
+  for x, (q, d, b), f in zip(xs, out, fl):
+    cases3 += 1
+    oq, od, ob = qorc.quantize(x, npdt, extract)
+    of = qorc.to_float(oq, od, ob, npdt, extract)
+    ok = (np.array_equal(q.cpu().numpy(), oq) and
+          np.array_equal(b.cpu().numpy().view(np.uint32), np.asarray(ob, np.float32).view(np.uint32)) and
+          (not extract or np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))) and
+          np.array_equal(f.cpu().numpy().view(np.uint32), of.view(np.uint32)))
+    if not ok:
+      bad3 += 1; print("QUANT MISMATCH", x.shape, bits, extract)
+print("quant fuzz done, cases", cases3, "mismatches", bad3)
