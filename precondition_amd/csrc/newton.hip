@@ -734,6 +734,31 @@ __global__ __launch_bounds__(256) void newton_final_kernel(const NewtonBlock* bl
       const int row = e / nf, col = e % nf;
       out[(int64_t)row * nb->ldo + col] = 0.f;
     }
+  } else if ((nf & 3) == 0 && (nb->ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && nf <= 16384) {
+    // float4 rows (H's stride npad is a multiple of 128, its base 256-byte aligned), 32-bit index arithmetic, four
+    // float4 in flight per thread: the element-wise loop below ran at 3.5 TB/s (a 64-bit division per element)
+    const float* H = nb->H[st->result_sel];
+    const int q = nf >> 2, total = q * nf, npad = nb->npad;
+    const int64_t ldo = nb->ldo;
+    for (int e0 = tid; e0 < total; e0 += 4 * nth) {
+      f32x4 v[4];
+      int row[4], col[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * nth;
+        row[u] = e / q; col[u] = 4 * (e - row[u] * q);
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e < total && row[u] < n) {
+          if (col[u] + 3 < n) v[u] = gload4(H + (int64_t)row[u] * npad + col[u]);
+          else
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (col[u] + k < n) v[u][k] = gload1(H + (int64_t)row[u] * npad + col[u] + k);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + u * nth < total) *(f32x4 PS_GLOBAL*)(out + (int64_t)row[u] * ldo + col[u]) = v[u];
+    }
   } else {
     const float* H = nb->H[st->result_sel];
     for (int64_t e = tid; e < (int64_t)nf * nf; e += nth) {

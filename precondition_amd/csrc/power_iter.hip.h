@@ -92,6 +92,29 @@ static __global__ __launch_bounds__(256) void sym_check_kernel(const PiBlock* bl
   for (int sub = 0; sub < 4; ++sub) {
     const int r0 = te.I * PT + 64 * (sub >> 1), c0 = te.J * PT + 64 * (sub & 1);
     if (r0 >= n || c0 >= n || (te.I == te.J && r0 > c0)) continue;  // uniform
+    if (pb->vec_ok && r0 + 64 <= n && c0 + 64 <= n) {
+      // interior 64 x 64 pair: both blocks as float4 rows, all eight loads of a thread in flight (the scalar
+      // loops below ran the check at 1.9 TB/s: 0.13 ms of a 14 ms recompute)
+      const int rr = tid >> 4, c4 = (tid & 15) * 4;       // rows rr + 16 u, columns c4 .. c4 + 3
+      f32x4 t[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        t[u] = gload4(a + (int64_t)(c0 + rr + 16 * u) * lda + r0 + c4);   // block (J, I)
+        x[u] = gload4(a + (int64_t)(r0 + rr + 16 * u) * lda + c0 + c4);   // block (I, J)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tb[rr + 16 * u][c4 + k] = t[u][k];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (!(x[u][k] == tb[c4 + k][rr + 16 * u])) bad = 1;   // a NaN counts as asymmetric
+      __syncthreads();
+      continue;
+    }
     for (int e = tid; e < 64 * 64; e += 256) {
       const int rr = e >> 6, cc = e & 63;
       const int gr = c0 + rr, gc = r0 + cc;
