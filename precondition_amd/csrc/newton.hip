@@ -447,12 +447,26 @@ __device__ inline void newton_init1_tile(const NewtonBlock* nb, float ridge_try,
   const int n = nb->n, tid = threadIdx.x;
   float ss = 0.f;
   const int tpr = nb->npad / TILE;
-  for (int e = tid; e < TILE * TILE; e += 256) {
-    const int row = tm * TILE + e / TILE, col = tn * TILE + e % TILE;
-    if (row < n && col < n) {
-      float d = gload1(nb->a + (int64_t)row * nb->lda + col);
-      if (row == col) d = __fadd_rn(d, ridge_try);
-      ss += d * d;
+  // a thread's 64 elements (column tid % 128, every second row) in the same order as ever -- the sum's rounding is
+  // part of z -- but eight loads in flight per trip
+  const float* a = nb->a;
+  const int64_t lda = nb->lda;
+  const int col = tn * TILE + (tid & 127), rbase = tm * TILE + (tid >> 7);
+  for (int k0 = 0; k0 < TILE / 2; k0 += 8) {
+    float d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = rbase + 2 * (k0 + u);
+      d[u] = (row < n && col < n) ? gload1(a + (int64_t)row * lda + col) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = rbase + 2 * (k0 + u);
+      if (row < n && col < n) {
+        float x = d[u];
+        if (row == col) x = __fadd_rn(x, ridge_try);
+        ss += x * x;
+      }
     }
   }
   ss = wave_sum_f32(ss);
@@ -480,11 +494,23 @@ __device__ inline void newton_init2_tile(const NewtonBlock* nb, NewtonState* st,
   float* H1 = nb->H[cur ^ 1];
   float* Mi = mi_buf(nb, cur);
   unsigned emax = 0;
-  for (int e = tid; e < TILE * TILE; e += 256) {
-    const int row = tm * TILE + e / TILE, col = tn * TILE + e % TILE;
+  // (eight loads in flight per trip: behind the stores of the trip before, the compiler issues them one at a time)
+  const float* a = nb->a;
+  const int64_t lda = nb->lda;
+  const int col = tn * TILE + (tid & 127), rbase = tm * TILE + (tid >> 7);
+  for (int k0 = 0; k0 < TILE / 2; k0 += 8) {
+    float dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = rbase + 2 * (k0 + u);
+      dv[u] = (row < n && col < n) ? gload1(a + (int64_t)row * lda + col) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+    const int row = rbase + 2 * (k0 + u);
     float m = 0.f, mi = 0.f, h = 0.f, h1 = 0.f;
     if (row < n && col < n) {
-      float d = gload1(nb->a + (int64_t)row * nb->lda + col);
+      float d = dv[u];
       const float ident = row == col ? 1.f : 0.f;
       if (row == col) d = __fadd_rn(d, rt);                 // DS:869
       m = __fmul_rn(d, z);                                   // DS:871
@@ -502,6 +528,7 @@ __device__ inline void newton_init2_tile(const NewtonBlock* nb, NewtonState* st,
     tstore1<WT>(Mi + o, mi);
     tstore1<WT>(H0 + o, h);
     tstore1<WT>(H1 + o, h1);
+    }
   }
   emax = wave_max_u32(emax);
   if ((tid & 63) == 0) red[tid >> 6] = emax;
