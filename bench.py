@@ -109,22 +109,17 @@ class Workload:
     return m
 
   def split_point(self):
-    """First-part size of the two-phase step.  A Newton stage launches T(T+1)/2 tiles per block
-    on 512 resident workgroup slots (2 per CU): both parts should be close to a whole number
-    of rounds (half of cfg2's 256 blocks = 1280 tiles = 2.5 rounds would waste a sixth of its
-    last round), and the second part -- whose all-gather is NOT hidden -- should be the smaller
-    one.  Falls back to the middle."""
+    """First-part size of the two-phase step.  Only the SECOND part's all-gather is exposed, so it should be small,
+    but not below one full round of tiles on the 512 resident workgroup slots of a stage launch (T(T+1)/2 tiles per
+    block), nor below a tenth of the batch.  Measured on cfg2 (tools/dev_r6_two_phase_cost.py, roots of both parts
+    without the power iteration): 128 / 128 13.5 ms, 192 / 64 13.75, 204 / 52 13.6, 230 / 26 13.8 -- the position
+    costs +-0.2 ms, the exposed share of a ~4.5 ms gather at world 8 far more."""
     t = (self.n + 127) // 128
     tpb = t * (t + 1) // 2
-    best, best_cost = self.nb // 2, None
-    for h in range(max(1, (2 * self.nb) // 5), max(2, (3 * self.nb) // 4) + 1):
-      if h >= self.nb:
-        break
-      waste = sum((-(x * tpb)) % 512 for x in (h, self.nb - h)) / 512.0   # idle slot-rounds
-      cost = waste + 0.5 * (self.nb - h) / self.nb                          # + exposed gather share
-      if best_cost is None or cost < best_cost - 1e-9:
-        best, best_cost = h, cost
-    return best
+    second = max(-(-512 // tpb), self.nb // 10, 1)
+    if second > self.nb // 2:
+      second = self.nb // 2
+    return max(1, self.nb - second)
 
   def compute(self):
     """This rank's roots only (no collective)."""
