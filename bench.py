@@ -72,6 +72,7 @@ def make_blocks(name, rank, dev):
 
 
 class Workload:
+  _hi_stream = None   # high-priority stream of the first part of the N > 1 step (created once per process)
 
   def __init__(self, name, rank, world, dev, multi=None):
     self.name = name
@@ -148,8 +149,9 @@ class Workload:
     if not self.name.startswith("eigh"):
       lam, _ = K.power_iteration_batched(list(self.stats.unbind(0)),
                                          padding_starts=[self.n] * self.nb)
-    for k, (lo, hi) in enumerate(((0, h), (h, self.nb))):
-      ms.append(self._roots(lo, hi, None if lam is None else lam[lo:hi]))
+    parts = ((0, h), (h, self.nb))
+
+    def gather(lo, hi):
       off = self.world * lo * per   # parts are laid out one after the other: [part][rank][block]
       out = g[off: off + self.world * (hi - lo) * per]
       inp = self.roots[lo:hi].reshape(-1)
@@ -159,6 +161,49 @@ class Workload:
         out.copy_(tmp)
       else:
         handles.append(dist.all_gather_into_tensor(out, inp, async_op=True))
+
+    side_by_side = (lam is not None and self.stats.is_cuda and dist.get_backend() != "gloo" and
+                    not os.environ.get("PS_BENCH_SEQUENTIAL_PARTS"))
+    if side_by_side:
+      # The two parts as two root calls SIDE BY SIDE: part 2 from a second host thread on a second stream (the
+      # library's calls release the GIL and keep their host state per thread), part 1 on a high-priority stream so that
+      # it finishes first -- its kernels' tails and ramps are filled by part 2's, its all-gather runs under the rest of
+      # part 2.  One after the other the two calls cost 2 ms more than one call of the whole batch (a second set of
+      # setup / ramps / host work: tools/dev_r6_two_phase_cost.py).  Collectives stay on this thread, in a fixed order.
+      import threading
+      # ONE extra stream per process (live streams share ~4 hardware queues: every further one can put two of the
+      # eigh path's stream groups on one queue -- its leg read 211 instead of 173 ms behind two extra streams here)
+      if Workload._hi_stream is None:
+        Workload._hi_stream = torch.cuda.Stream(priority=-1)
+      s1, s2 = Workload._hi_stream, torch.cuda.current_stream()
+      ready = torch.cuda.Event(); ready.record()          # behind the power iteration
+      res, err = [None, None], []
+
+      def run(k, stream):
+        try:
+          lo, hi = parts[k]
+          with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+            res[k] = self._roots(lo, hi, lam[lo:hi])
+        except Exception as e:  # pylint: disable=broad-except
+          err.append(e)
+
+      t2 = threading.Thread(target=run, args=(1, s2))
+      t2.start()
+      run(0, s1)
+      with torch.cuda.stream(s1):
+        gather(*parts[0])
+      t2.join()
+      if err:
+        raise err[0]
+      with torch.cuda.stream(s2):
+        gather(*parts[1])
+      s2.wait_stream(s1)
+      ms = res
+    else:
+      for lo, hi in parts:
+        ms.append(self._roots(lo, hi, None if lam is None else lam[lo:hi]))
+        gather(lo, hi)
     for w in handles:
       w.wait()
     self.metrics = torch.cat(ms, dim=0)

@@ -31,7 +31,15 @@ h = w.split_point()
 lam, _ = K.power_iteration_batched(list(w.stats.unbind(0)), padding_starts=[w.n] * w.nb)
 print("  roots of part 1 (%d blocks)     %.2f ms" % (h, t(lambda: w._roots(0, h, lam[0:h]))), flush=True)
 print("  roots of part 2 (%d blocks)     %.2f ms" % (w.nb - h, t(lambda: w._roots(h, w.nb, lam[h:w.nb]))), flush=True)
-print("two-phase step with all-gathers   %.2f ms" % t(w.step), flush=True)
+w.compute(); torch.cuda.synchronize(); ref = w.roots.clone(); refm = w.metrics.clone()
+print("two-phase step, parts side by side %.2f ms" % t(w.step), flush=True)
+torch.cuda.synchronize()
+print("  roots bit-identical to the one call:", bool(torch.equal(ref, w.roots)), " metrics:", bool(torch.equal(refm, w.metrics)),
+      " gathered order:", w.check_gathered_order(0), flush=True)
+os.environ["PS_BENCH_SEQUENTIAL_PARTS"] = "1"
+print("two-phase step, parts one by one   %.2f ms" % t(w.step), flush=True)
+del os.environ["PS_BENCH_SEQUENTIAL_PARTS"]
+print("two-phase step, parts side by side %.2f ms" % t(w.step), flush=True)
 for hh in (96, 128, 153, 160, 179, 192, 204, 218, 230):
   t1 = t(lambda: w._roots(0, hh, lam[0:hh]), 6); t2 = t(lambda: w._roots(hh, w.nb, lam[hh:w.nb]), 6)
   print("  split %3d / %3d: %.2f + %.2f = %.2f ms" % (hh, w.nb - hh, t1, t2, t1 + t2), flush=True)
