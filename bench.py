@@ -72,7 +72,6 @@ def make_blocks(name, rank, dev):
 
 
 class Workload:
-  _hi_stream = None   # high-priority stream of the first part of the N > 1 step (created once per process)
 
   def __init__(self, name, rank, world, dev, multi=None):
     self.name = name
@@ -170,12 +169,9 @@ class Workload:
       # it finishes first -- its kernels' tails and ramps are filled by part 2's, its all-gather runs under the rest of
       # part 2.  One after the other the two calls cost 2 ms more than one call of the whole batch (a second set of
       # setup / ramps / host work: tools/dev_r6_two_phase_cost.py).  Collectives stay on this thread, in a fixed order.
-      import threading
-      # ONE extra stream per process (live streams share ~4 hardware queues: every further one can put two of the
-      # eigh path's stream groups on one queue -- its leg read 211 instead of 173 ms behind two extra streams here)
-      if Workload._hi_stream is None:
-        Workload._hi_stream = torch.cuda.Stream(priority=-1)
-      s1, s2 = Workload._hi_stream, torch.cuda.current_stream()
+      # (ONE extra stream and ONE persistent side thread per process, shared with the optimizer's exchange: comm.py)
+      from precondition_amd import comm
+      s1, s2 = comm.high_priority_stream(self.stats.device), torch.cuda.current_stream()
       ready = torch.cuda.Event(); ready.record()          # behind the power iteration
       res, err = [None, None], []
 
@@ -188,12 +184,11 @@ class Workload:
         except Exception as e:  # pylint: disable=broad-except
           err.append(e)
 
-      t2 = threading.Thread(target=run, args=(1, s2))
-      t2.start()
+      t2 = comm.side_worker().submit(run, 1, s2)
       run(0, s1)
       with torch.cuda.stream(s1):
         gather(*parts[0])
-      t2.join()
+      t2.result()
       if err:
         raise err[0]
       with torch.cuda.stream(s2):

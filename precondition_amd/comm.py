@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -104,6 +106,32 @@ def ownership_table(sizes: Sequence[int], exponents: Sequence[int], world: int,
   if ownership == "lpt":
     return cost_balanced_ownership(sizes, exponents, world, iters_hint)
   raise ValueError(f"unknown ownership {ownership!r}")
+
+
+_HI_STREAM = {}
+
+
+def high_priority_stream(device):
+  """ONE high-priority stream per device and process (the first phase of a two-phase exchange, bench.py's
+  weak-scaling step): live streams share about four hardware queues, and every further one can put two of the
+  eigh path's stream groups on one queue (measured: its cfg3 step 211 instead of 173 ms behind two extra streams)."""
+  key = str(device)
+  if key not in _HI_STREAM:
+    _HI_STREAM[key] = torch.cuda.Stream(device=device, priority=-1)
+  return _HI_STREAM[key]
+
+
+_WORKER = []
+
+
+def side_worker():
+  """ONE persistent host thread per process for the call that runs beside the caller's (the second phase of the
+  exchange).  Persistent, because the library keeps per-thread host state (pinned status rings, events) for the
+  life of a thread: a new thread per step would allocate it anew every step."""
+  if not _WORKER:
+    from concurrent.futures import ThreadPoolExecutor
+    _WORKER.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix="ps-side"))
+  return _WORKER[0]
 
 
 def _collective_in_flight(delta: int) -> int:
@@ -261,78 +289,149 @@ def sharded_inverse_pth_roots(
     lam_of = {i: k for k, i in enumerate(all_mine)}
   gathered, gathered_metrics, handles = [], [], []
   in_flight = 0
+
+  # ---- one phase = its send buffers, the root call of this rank's statistics in it, its all-gather --------------
+  def _prepare(ph):
+    buf_elems = max(max(fill[ph]), 1)
+    max_count = max(max(count[ph]), 1)
+    send = torch.empty((buf_elems,), dtype=torch.float32, device=dev)
+    mine = [i for i in range(n_stats) if owner[i] == rank and phase_of[i] == ph]
+    send_metrics = torch.zeros((max_count, metrics_cols), dtype=torch.float32, device=dev)
+    outs = [send[offsets[i]:offsets[i] + elems[i]] for i in mine]
+    if not raw:
+      outs = [o.view(sizes[i], cols[i]) for o, i in zip(outs, mine)]
+    return dict(buf_elems=buf_elems, max_count=max_count, send=send, mine=mine, send_metrics=send_metrics, outs=outs)
+
+  def _root(P, lam_):
+    mine, outs = P["mine"], P["outs"]
+    extra = {}
+    if options or iters_hint is not None or eigh_skip_hint is not None:
+      o = dict(options or {})
+      if iters_hint is not None and not eigh:
+        o["iters_hint"] = np.asarray([iters_hint[i] for i in mine], dtype=np.float32)
+      if eigh_skip_hint is not None and eigh:
+        # the blocks' condition numbers at the last recompute: far above the keep rule = no attempt
+        o["iters_hint"] = np.asarray([eigh_skip_hint[i] for i in mine], dtype=np.float32)
+      extra["options"] = o
+    kw = dict(extra)
+    if lam_of is not None:
+      kw["max_ev"] = lam_[[lam_of[i] for i in mine]]
+    return root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
+                   [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
+                   relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
+                   out=outs, **kw)[1]
+
+  def _gather(P):
+    nonlocal in_flight
+    buf_elems, max_count, send, send_metrics = P["buf_elems"], P["max_count"], P["send"], P["send_metrics"]
+    if group is None:
+      gathered.append(send.unsqueeze(0))
+      gathered_metrics.append(send_metrics.unsqueeze(0))
+      return
+    import torch.distributed as dist
+    # flat outputs (concatenation form) are accepted by both RCCL and gloo
+    g = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
+    gm = torch.empty((world * max_count * metrics_cols,), dtype=torch.float32, device=dev)
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+      # gloo has no device all-gather: stage through the host (functional fallback
+      # for single-GPU debugging; the production backend is RCCL)
+      g_h = torch.empty(g.shape, dtype=torch.float32)
+      m_h = torch.empty(gm.shape, dtype=torch.float32)
+      dist.all_gather_into_tensor(g_h, send.cpu(), group=group)
+      dist.all_gather_into_tensor(m_h, send_metrics.reshape(-1).cpu(), group=group)
+      g.copy_(g_h)
+      gm.copy_(m_h)
+    elif n_phases == 2 and send.is_cuda:
+      in_flight += _collective_in_flight(+1)
+      handles.append(dist.all_gather_into_tensor(g, send, group=group, async_op=True))
+      handles.append(dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group,
+                                                 async_op=True))
+      handles.append((send, send_metrics))  # keep the send buffers alive until wait()
+    else:
+      dist.all_gather_into_tensor(g, send, group=group)
+      dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group)
+    gathered.append(g.view(world, buf_elems))
+    gathered_metrics.append(gm.view(world, max_count, metrics_cols))
+
+  # Two phases of the plain HIP Newton root run SIDE BY SIDE: the second phase's root call from a second host thread
+  # on the caller's stream, the first on a high-priority stream, so that it finishes first and its all-gather runs
+  # under the rest of the second; the two calls' kernels fill each other's tails and ramps (one after the other the
+  # halves of a rank's share are each too small to fill the chip: bench.py's weak-scaling step 16.4 -> 14.6 ms).
+  # Collectives are issued by THIS thread, in phase order, on every rank.  The library keeps its host state per
+  # thread and releases the GIL while it waits for the GPU.
+  side_by_side = False
+  if (n_phases == 2 and hip_root and compute_fn is None and not eigh and lam_of is not None and
+      dev is not None and dev.type == "cuda" and not os.environ.get("PS_SHARDED_SEQUENTIAL")):
+    import torch.distributed as dist
+    side_by_side = dist.get_backend(group) != "gloo"
   try:
-    for ph in range(n_phases):
-      buf_elems = max(max(fill[ph]), 1)
-      max_count = max(max(count[ph]), 1)
-      send = torch.empty((buf_elems,), dtype=torch.float32, device=dev)
-      mine = [i for i in range(n_stats) if owner[i] == rank and phase_of[i] == ph]
-      send_metrics = torch.zeros((max_count, metrics_cols), dtype=torch.float32, device=dev)
-      if mine:
-        outs = [send[offsets[i]:offsets[i] + elems[i]] for i in mine]
-        if not raw:
-          outs = [o.view(sizes[i], cols[i]) for o, i in zip(outs, mine)]
-        if compute_fn is not None:
-          m = compute_fn(mine, outs)
-        else:
-          extra = {}
-          if options or iters_hint is not None or eigh_skip_hint is not None:
-            o = dict(options or {})
-            if iters_hint is not None and not eigh:
-              o["iters_hint"] = np.asarray([iters_hint[i] for i in mine], dtype=np.float32)
-            if eigh_skip_hint is not None and eigh:
-              # the blocks' condition numbers at the last recompute: far above the keep rule = no attempt
-              o["iters_hint"] = np.asarray([eigh_skip_hint[i] for i in mine], dtype=np.float32)
-            extra["options"] = o
+    if side_by_side:
+      P = [_prepare(0), _prepare(1)]
+      cur = torch.cuda.current_stream(dev)
+      hi = high_priority_stream(dev)
+      ready = torch.cuda.Event()
+      ready.record(cur)                      # behind the power iteration and whatever produced the statistics
+      res, err = [None, None], []
 
-          def _root():
-            kw = dict(extra)
-            if lam_of is not None:
-              kw["max_ev"] = lam[[lam_of[i] for i in mine]]
-            return root_fn([statistics[i] for i in mine], [exponents[i] for i in mine],
-                           [sizes[i] for i in mine], ridge_epsilon=ridge_epsilon,
-                           relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
-                           out=outs, **kw)
+      def _run(ph, stream):
+        try:
+          if P[ph]["mine"]:
+            with torch.cuda.stream(stream):
+              stream.wait_event(ready)
+              res[ph] = _root(P[ph], lam)
+        except Exception as e:  # pylint: disable=broad-except
+          err.append(e)
 
-          _, m = _root()
-          if pi_expired_before is not None:
-            if (options or {}).get("execution") == "persistent" and statistics[0].is_cuda:
-              # the persistent execution only enqueues: the resident power iteration (queued before
-              # it) may still be running, and its expiry counter with it
-              torch.cuda.current_stream(statistics[0].device).synchronize()
-            if _expired_waits() != pi_expired_before:
-              lam = _power_iteration()     # streaming execution now (ps_power_iteration_health)
-              _, m = _root()
-            pi_expired_before = None       # checked once: later phases reuse the repaired `lam`
-        send_metrics[:len(mine)] = m
-      if group is None:
-        gathered.append(send.unsqueeze(0))
-        gathered_metrics.append(send_metrics.unsqueeze(0))
-        continue
-      import torch.distributed as dist
-      # flat outputs (concatenation form) are accepted by both RCCL and gloo
-      g = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
-      gm = torch.empty((world * max_count * metrics_cols,), dtype=torch.float32, device=dev)
-      if dist.get_backend(group) == "gloo" and send.is_cuda:
-        # gloo has no device all-gather: stage through the host (functional fallback
-        # for single-GPU debugging; the production backend is RCCL)
-        g_h = torch.empty(g.shape, dtype=torch.float32)
-        m_h = torch.empty(gm.shape, dtype=torch.float32)
-        dist.all_gather_into_tensor(g_h, send.cpu(), group=group)
-        dist.all_gather_into_tensor(m_h, send_metrics.reshape(-1).cpu(), group=group)
-        g.copy_(g_h)
-        gm.copy_(m_h)
-      elif n_phases == 2 and send.is_cuda:
-        in_flight += _collective_in_flight(+1)
-        handles.append(dist.all_gather_into_tensor(g, send, group=group, async_op=True))
-        handles.append(dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group,
-                                                   async_op=True))
-        handles.append((send, send_metrics))  # keep the send buffers alive until wait()
+      t2 = side_worker().submit(_run, 1, cur)
+      _run(0, hi)
+      redo = False
+      if pi_expired_before is not None and not err:
+        # (the first root call waited on the host for GPU progress: the power iteration has finished)
+        redo = _expired_waits() != pi_expired_before
+        pi_expired_before = None
+      if redo or err:
+        t2.result()
+        if err:
+          raise err[0]
+        cur.wait_stream(hi)
+        lam = _power_iteration()             # streaming execution now (ps_power_iteration_health)
+        for ph in range(2):
+          if P[ph]["mine"]:
+            res[ph] = _root(P[ph], lam)
+          if res[ph] is not None:
+            P[ph]["send_metrics"][:len(P[ph]["mine"])] = res[ph]
+          _gather(P[ph])
       else:
-        dist.all_gather_into_tensor(g, send, group=group)
-        dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group)
-      gathered.append(g.view(world, buf_elems))
-      gathered_metrics.append(gm.view(world, max_count, metrics_cols))
+        with torch.cuda.stream(hi):
+          if res[0] is not None:
+            P[0]["send_metrics"][:len(P[0]["mine"])] = res[0]
+          _gather(P[0])
+        t2.result()
+        if err:
+          raise err[0]
+        if res[1] is not None:
+          P[1]["send_metrics"][:len(P[1]["mine"])] = res[1]
+        _gather(P[1])
+        cur.wait_stream(hi)
+    else:
+      for ph in range(n_phases):
+        P = _prepare(ph)
+        if P["mine"]:
+          if compute_fn is not None:
+            m = compute_fn(P["mine"], P["outs"])
+          else:
+            m = _root(P, lam if lam_of is not None else None)
+            if pi_expired_before is not None:
+              if (options or {}).get("execution") == "persistent" and statistics[0].is_cuda:
+                # the persistent execution only enqueues: the resident power iteration (queued before
+                # it) may still be running, and its expiry counter with it
+                torch.cuda.current_stream(statistics[0].device).synchronize()
+              if _expired_waits() != pi_expired_before:
+                lam = _power_iteration()     # streaming execution now (ps_power_iteration_health)
+                m = _root(P, lam)
+              pi_expired_before = None       # checked once: later phases reuse the repaired `lam`
+          P["send_metrics"][:len(P["mine"])] = m
+        _gather(P)
   finally:
     # also on an exception from a root / compute call or a later all-gather: outstanding
     # gathers are waited for and the library's in-flight count is restored (a count left above

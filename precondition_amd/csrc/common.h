@@ -60,10 +60,15 @@ inline int bind_device() {
 // process that had run a mixed Newton call (1 side stream) and then an eigh call (3 more) held 5 streams,
 // two of the eigh groups shared a hardware queue and serialised -- cfg3 measured 219 ms inside the full
 // bench against 172 ms standalone.  Streams are created on first use and live as long as the thread.
+// (process-wide, not per thread: a host that runs two calls side by side from two threads -- the two phases of the
+// exchange, comm.sharded_inverse_pth_roots -- must not double the number of live streams, nor leak a pool per
+// short-lived thread; two calls that share a side stream are merely ordered on it.)
 constexpr int PS_MAX_SIDE_STREAMS = 7;
 inline hipStream_t side_stream(int k) {
-  static thread_local hipStream_t pool[PS_MAX_SIDE_STREAMS] = {};
+  static hipStream_t pool[PS_MAX_SIDE_STREAMS] = {};
+  static std::mutex mu;
   if (k < 0 || k >= PS_MAX_SIDE_STREAMS) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
   if (!pool[k] && hipStreamCreateWithFlags(&pool[k], hipStreamNonBlocking) != hipSuccess) pool[k] = nullptr;
   return pool[k];
 }
