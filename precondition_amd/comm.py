@@ -321,17 +321,29 @@ def sharded_inverse_pth_roots(
                    relative_matrix_epsilon=relative_matrix_epsilon, eigh=eigh,
                    out=outs, **kw)[1]
 
-  def _gather(P):
+  def _gather(P, on_stream=None):
+    """All-gather of a phase.  on_stream: the collectives are ordered behind (and issued under) that stream, but
+    the receive buffers are allocated on the CALLER's stream, where the roots (views of them) are used afterwards:
+    a block of another stream's pool could be handed out again while the caller's kernels still read it."""
     nonlocal in_flight
     buf_elems, max_count, send, send_metrics = P["buf_elems"], P["max_count"], P["send"], P["send_metrics"]
     if group is None:
       gathered.append(send.unsqueeze(0))
       gathered_metrics.append(send_metrics.unsqueeze(0))
       return
+    import contextlib
     import torch.distributed as dist
     # flat outputs (concatenation form) are accepted by both RCCL and gloo
     g = torch.empty((world * buf_elems,), dtype=torch.float32, device=dev)
     gm = torch.empty((world * max_count * metrics_cols,), dtype=torch.float32, device=dev)
+    with (torch.cuda.stream(on_stream) if on_stream is not None else contextlib.nullcontext()):
+      _gather_into(P, g, gm, dist)
+    gathered.append(g.view(world, buf_elems))
+    gathered_metrics.append(gm.view(world, max_count, metrics_cols))
+
+  def _gather_into(P, g, gm, dist):
+    nonlocal in_flight
+    send, send_metrics = P["send"], P["send_metrics"]
     if dist.get_backend(group) == "gloo" and send.is_cuda:
       # gloo has no device all-gather: stage through the host (functional fallback
       # for single-GPU debugging; the production backend is RCCL)
@@ -350,8 +362,6 @@ def sharded_inverse_pth_roots(
     else:
       dist.all_gather_into_tensor(g, send, group=group)
       dist.all_gather_into_tensor(gm, send_metrics.reshape(-1), group=group)
-    gathered.append(g.view(world, buf_elems))
-    gathered_metrics.append(gm.view(world, max_count, metrics_cols))
 
   # Two phases of the plain HIP Newton root run SIDE BY SIDE: the second phase's root call from a second host thread
   # on the caller's stream, the first on a high-priority stream, so that it finishes first and its all-gather runs
@@ -402,10 +412,10 @@ def sharded_inverse_pth_roots(
             P[ph]["send_metrics"][:len(P[ph]["mine"])] = res[ph]
           _gather(P[ph])
       else:
-        with torch.cuda.stream(hi):
-          if res[0] is not None:
+        if res[0] is not None:
+          with torch.cuda.stream(hi):
             P[0]["send_metrics"][:len(P[0]["mine"])] = res[0]
-          _gather(P[0])
+        _gather(P[0], on_stream=hi)
         t2.result()
         if err:
           raise err[0]
