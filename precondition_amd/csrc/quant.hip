@@ -581,12 +581,20 @@ __global__ __launch_bounds__(QS_THREADS) void quant_strip_kernel(const QTensor* 
       // waiting one holds exactly one (it takes its next item after the wait): every team but the one at the queue's
       // head is complete among the running workgroups, and that one is completed by the next workgroup to finish
       // an item or to start.  The wait is bounded (10 s); on expiry the part publishes NaN bucket sizes.
+      // The merges must be PERFORMED before this part counts itself in.  They are returning atomics whose results are
+      // consumed (the wave waits for the values, which come back from the point of coherence); a workgroup-scope
+      // release fence is not enough -- outside tgsplit mode the compiler emits no vmcnt wait for it, and the arrival
+      // (another address, another channel) could become visible first: a team mate then read a stale maximum
+      // (seen as one wrong bucket size in ~30 runs of the tall-matrix tests).
       if (g == 0 && col_in) {
+        unsigned seen = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (amax[j]) __hip_atomic_fetch_max(cur.colmax + col + j, amax[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (amax[j])
+            seen |= __hip_atomic_fetch_max(cur.colmax + col + j, amax[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" :: "v"(seen));
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the atomics acknowledged (s_waitcnt), no cache write-back
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
         __hip_atomic_fetch_add(cur.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -370,3 +370,24 @@ def test_fd_update_two_interleaved_groups_do_not_change_a_bit(device, monkeypatc
   for (o1, c1), (o2, c2) in zip(outs["1"], outs["2"]):
     assert np.array_equal(c1, c2)
     assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32))
+
+
+def test_quantize_tall_strips_repeated_calls_never_read_a_stale_maximum(device):
+  """The parts of a tall strip merge their column maxima with atomics and then count themselves in; a part that
+  counted itself in before its merges were PERFORMED let a team mate read a stale maximum (wrong codes in ~1 % of
+  the calls until the merges became returning atomics whose results are awaited).  600 grouped calls of tall
+  matrices, every one against the oracle's codes and bucket sizes."""
+  from oracle import quantization_oracle as qorc
+  rng = np.random.default_rng(68)
+  shapes = [(2048, 2048), (2500, 1000), (3072, 768), (1025, 128)]
+  xs = [np.ascontiguousarray((rng.standard_normal(s) * np.exp(rng.uniform(-4, 4, size=s[1]))).astype(np.float32))
+        for s in shapes]
+  ts = [torch.tensor(x, device=device) for x in xs]
+  ref = [qorc.quantize(x, np.int16, False) for x in xs]
+  refq = [torch.tensor(r[0], device=device) for r in ref]
+  refb = [torch.tensor(np.asarray(r[2], np.float32), device=device) for r in ref]
+  bad = 0
+  for _ in range(600):
+    for i, (q, d, b) in enumerate(K().quantize_grouped(ts, torch.int16, False)):
+      bad += int(not (torch.equal(q, refq[i]) and torch.equal(b.view(torch.int32), refb[i].view(torch.int32))))
+  assert bad == 0, bad
